@@ -1,0 +1,324 @@
+"""ORACLE tooling (build container only): record golden vectors from the REFERENCE's own Python.
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+Inputs are regenerated from seeds by ``tests/golden/cases.py``; the fixtures hold only what the
+reference computed for them (plus bit-packed masks).  The reference is imported under the stand-in
+modules of ``oracle/ref_import.py``; nothing of it is copied or shipped.
+
+Fixture ids follow SURVEY.md 8c (G1..G13).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import cases  # noqa: E402
+import ref_import  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def save(name, **arrays):
+    arrays = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    print(f"  wrote {name}.npz  ({os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024:.1f} KiB)")
+
+
+def warped_mask_512(R, mask, coords):
+    """U/editor.py:147-149 with text_embeddings fp16 (GPU path): coords rounded through fp16."""
+    gt, wu = R.generic_torch, R.warp_utils
+    image_mask = torch.from_numpy(mask[None]).tile((2, 1, 1))
+    t = gt.reshape_transform_coords(torch.from_numpy(coords), in_mat_shape=image_mask.shape).tile(2, 1, 1, 1)
+    t = t.half().float()
+    out = wu.warp_grid_edit(image_mask[:, None], t, padding_mode="zeros", align_corners=True, mode="bilinear")
+    return gt.binarize_tensor(out).float()          # [2,1,512,512]
+
+
+def g_masks_and_warp(R):
+    mask = cases.ellipse_mask()
+    packs = {}
+    for kind in ("translate", "rotate", "scale"):
+        coords = cases.make_coords(kind, mask)
+        m = warped_mask_512(R, mask, coords)
+        assert torch.equal(m[0], m[1])
+        packs[kind] = np.packbits(m[1, 0].numpy().astype(np.uint8))
+        print(f"  warped mask {kind}: area {int(m[1].sum())} (input {int(mask.sum())})")
+    save("G0_warped_mask_512", **packs)
+    return packs
+
+
+def unpack_mask(bits):
+    m = np.unpackbits(bits)[: 512 * 512].reshape(512, 512).astype(np.float32)
+    return torch.from_numpy(m)[None, None].tile(2, 1, 1, 1)
+
+
+def g1_compute_attention(R):
+    q, k, _ = cases.make_qkv(1, 1, 4, 64, 77, 16, spike=False)
+    q, k = torch.from_numpy(q), torch.from_numpy(k)
+    a = R.attention_sharing.compute_attention(q, k, 0.25)
+    m1 = torch.zeros(1, 1, 8, 8); m1[..., 2:5, 2:5] = 1
+    m2 = torch.zeros(1, 1, 8, 8); m2[..., 4:7, 1:4] = 1
+    q2, k2, _ = cases.make_qkv(2, 1, 4, 64, 64, 16)
+    q2, k2 = torch.from_numpy(q2), torch.from_numpy(k2)
+    a_nomask = R.attention_sharing.compute_attention(q2, k2, 0.25)
+    a_mask = R.attention_sharing.compute_attention(q2, k2, 0.25, None, fg_mask_warp=m1, fg_mask=m2, inpaint_mask=1 - m1)
+    assert torch.equal(a_nomask, a_mask), "mask arguments are expected to be no-ops (SURVEY F2)"
+    save("G1_compute_attention", attn=a, attn_self=a_nomask, mask_args_noop=np.array(1))
+
+
+def g3_masks(R, packs):
+    ap, gt = R.attention_processors, R.generic_torch
+    mask = cases.ellipse_mask()
+    out = {}
+    for kind in ("translate", "rotate"):
+        coords = torch.from_numpy(cases.make_coords(kind, mask))
+        mnw = unpack_mask(packs[kind])
+        amodal = gt.torch_erode(torch.from_numpy(cases.amodal_input(mask)))
+        for S in (64, 32, 16, 8):
+            f = 2
+            q_base = torch.zeros(1, f, S * S, 4)
+            q_img = torch.zeros(f, 4, S, S)
+            image_mask = torch.from_numpy(mask[None]).tile((2, 1, 1))
+            res = ap.process_and_cache_masks({}, S, image_mask, mnw, amodal, coords, q_base, q_img)
+            names = ["mask_new_warped", "mask_warp", "amodal_mask", "mask_intersection", "mask_1_empty", "mask_wo_edit", "t_coords_q"]
+            for n, t in zip(names, res[2:]):
+                out[f"{kind}_{S}_{n}"] = t[:1] if n == "t_coords_q" else t
+    save("G3_process_masks", **out)
+
+
+def g5_interpolate(R):
+    S, f, D = 32, 2, 8
+    mask = cases.ellipse_mask()
+    m = torch.from_numpy(mask)[None, None]
+    m_s = (R.generic_torch.reshape_attention_mask(m, in_mat_shape=(1, S)) > 0.5) * 1.0
+    fg = m_s[0, 0].reshape(-1)[None, None, :, None]
+    feats = torch.from_numpy(cases.make_qkv(5, 1, f, S * S, S * S, D)[2])[None]
+    dist = R.attention_processors.DISTANCE_CLASS.get_coord_distance(S, device="cpu")
+    interp, w = R.attention_sharing.interpolate_from_mask(feats, fg, dist)
+    sm = R.generic_torch.smooth_attention_features(feats)
+    save("G5_interpolate", interp=interp, weights=w, smooth=sm, dist_row0=dist[0, 0], dist_row517=dist[0, 517])
+
+
+def _make_controller(R, case, packs):
+    ap, gt = R.attention_processors, R.generic_torch
+    mask = cases.ellipse_mask()
+    cls = ap.AttentionGeometryEdit if case["kind"] == "edit" else ap.AttentionGeometryRemover
+    c = cls(["", ""], cases.NUM_STEPS, {"default_": 0.95}, cases.SELF_REPLACE, image_mask=mask,
+            obj_edit_step=cases.OBJ_EDIT_STEP, device="cpu")
+    c.amodal_mask = gt.torch_erode(torch.from_numpy(cases.amodal_input(mask)))
+    c.mask_new_warped = unpack_mask(packs[case["coords"]])
+    c.num_att_layers = 32
+    c.cur_step = case["cur_step"]
+    if case["cfg"]:
+        c.coords_base, c.coords_edit, c.use_cfg = (2, 3), (3, 4), True
+    else:
+        c.coords_base, c.coords_edit, c.use_cfg = (0, 1), (1, 2), False
+    return c
+
+
+def g6_controller(R, packs):
+    ap = R.attention_processors
+    mask = cases.ellipse_mask()
+    orig_rtc = ap.reshape_transform_coords
+    for name, case in cases.CONTROLLER_CASES.items():
+        print(" case", name)
+        # ".type_as(q)" rounds the resampled coordinates through fp16 on the GPU path
+        # (U/attention_processors.py:363); reproduce it on this fp32 CPU run when quant=True.
+        if case["quant"]:
+            ap.reshape_transform_coords = lambda *a, **k: orig_rtc(*a, **k).half().float()
+        else:
+            ap.reshape_transform_coords = orig_rtc
+        c = _make_controller(R, case, packs)
+        S, f, D = case["S"], case["f"], case["D"]
+        N = S * S
+        M = 77 if case["cross"] else N
+        B = 4 if case["cfg"] else 2
+        q, k, v = (torch.from_numpy(a) for a in cases.make_qkv(case["seed"], B, f, N, M, D))
+        coords = torch.from_numpy(cases.make_coords(case["coords"], mask))
+        grad_mode = not case["cfg"]
+        if grad_mode:
+            q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+        with torch.set_grad_enabled(grad_mode):
+            out = c(q, k, v, is_cross=case["cross"], place_in_unet="up", transform_coords=coords, scale=D ** -0.5)
+        rec = dict(out=out.detach(), cur_att_layer=np.array(c.cur_att_layer), cur_step=np.array(c.cur_step))
+        if grad_mode:
+            g_out = torch.from_numpy(np.random.default_rng(case["seed"] + 1000).standard_normal(tuple(out.shape), dtype=np.float32)) * 0.01
+            total = (out * g_out).sum()
+            if torch.is_tensor(c.loss):
+                total = total + c.loss
+                rec["loss"] = c.loss.detach()
+                kind = "cross" if case["cross"] else "self"
+                for key, val in c.loss_log_dict[kind].items():
+                    rec["log_" + key] = val.detach() if torch.is_tensor(val) else np.array(val)
+                rec["num_layers"] = np.array(c.loss_log_dict["num_layers"])
+            dq, dk, dv = torch.autograd.grad(total, [q, k, v], allow_unused=True)
+            rec.update(dq=dq, dk=dk if dk is not None else torch.zeros_like(k), dv=dv if dv is not None else torch.zeros_like(v))
+        save("G6_" + name, **rec)
+    ap.reshape_transform_coords = orig_rtc
+
+
+def g7_counters(R, packs):
+    case = dict(cases.CONTROLLER_CASES["edit_self_late_16"])
+    c = _make_controller(R, case, packs)
+    c.num_att_layers = 4
+    c.cur_step = 46
+    S, f, D = 8, 1, 8
+    coords = torch.from_numpy(cases.make_coords("translate", cases.ellipse_mask()))
+    trace = []
+    with torch.no_grad():
+        for call in range(14):
+            q, k, v = (torch.from_numpy(a) for a in cases.make_qkv(70 + call, 4, f, S * S, S * S, D))
+            c(q, k, v, is_cross=False, place_in_unet="mid", transform_coords=coords, scale=D ** -0.5)
+            if call == 7:
+                c.cur_step -= 1          # the driver's undo after an optimisation pass, U/editor.py:307
+            trace.append((c.cur_att_layer, c.cur_step))
+    save("G7_counters", trace=np.array(trace))
+
+
+def g8_update_latent(R):
+    rng = np.random.default_rng(8)
+    lat = torch.from_numpy(rng.standard_normal((2, 4, 64, 64), dtype=np.float32))
+    ctx = torch.from_numpy(rng.standard_normal((4, 77, 32), dtype=np.float32))
+    wl = torch.from_numpy(rng.standard_normal((2, 4, 64, 64), dtype=np.float32))
+    wc = torch.from_numpy(rng.standard_normal((4, 77, 32), dtype=np.float32))
+    lat.requires_grad_(True); ctx.requires_grad_(True)
+    loss = (lat * wl).sum() + (ctx * wc).pow(2).sum()
+    mask = torch.from_numpy(cases.ellipse_mask())[None]          # controller.mask_new_warped[:1] has shape [1,1,H,W]; [:1] of [2,1,H,W]
+    lat_o, ctx_o = R.optimization._update_latent(lat, loss, 0.37, mask[None][0], ctx)
+    save("G8_update_latent", latents=lat_o.detach(), context=ctx_o.detach())
+
+
+def g9_adaptive(R):
+    opt = R.optimization
+    import contextlib, io
+
+    def run(fn, seq, weights):
+        c = types.SimpleNamespace()
+        c.default_loss_weights = {k: dict(v) for k, v in weights.items()}
+        c.loss_weight_dict = c.default_loss_weights
+        c.initialize_default_loss_weights = lambda c=c: setattr(c, "loss_weight_dict", c.default_loss_weights)
+        traj = []
+        for i, val in seq:
+            with contextlib.redirect_stdout(io.StringIO()):
+                fn(c, i, 2, {"self": {"removal": val}}, num_ddim_steps=50, removal_loss_value_in=-1.5)
+            traj.append(c.loss_weight_dict["self"]["removal"])
+        return np.array(traj)
+
+    seq = [(0, -0.01), (2, -0.02), (4, -0.5), (6, -3.0), (8, -0.9), (10, -1.2), (12, -0.4), (14, -2.0), (16, -1.0),
+           (18, -1.4), (20, -1.0), (22, -1.9), (24, -1.6), (26, -2.0), (28, -1.0), (30, -1.85), (32, -1.7), (40, -1.0), (44, 0.0)]
+    w_e = {"self": {"sim": 55, "movement": 30.5, "removal": 2.6, "smoothness": 30, "amodal": 80.5},
+           "cross": {"sim": 45, "movement": 30.34, "removal": 2.6, "smoothness": 15, "amodal": 3.5}}
+    w_r = {"self": {"sim": 55, "removal": 4.6, "smoothness": 30}, "cross": {"sim": 45, "removal": 4.6, "smoothness": 15}}
+    save("G9_adaptive", seq=np.array(seq), edit=run(opt.adaptive_optimization_step_editing, seq, w_e),
+         remover=run(opt.adaptive_optimization_step_remover, seq, w_r))
+
+
+def g10_ddim(R):
+    import GeoDiffuser.utils.inversion as inv
+    sys.path.insert(0, HERE)
+    import ref_cpu
+    ac = ref_cpu.alphas_cumprod()
+    fake = types.SimpleNamespace()
+    fake.scheduler = types.SimpleNamespace(config=types.SimpleNamespace(num_train_timesteps=1000), num_inference_steps=50,
+                                           alphas_cumprod=ac, final_alpha_cumprod=ac[0])
+    rng = np.random.default_rng(10)
+    x = torch.from_numpy(rng.standard_normal((1, 4, 8, 8), dtype=np.float32))
+    e = torch.from_numpy(rng.standard_normal((1, 4, 8, 8), dtype=np.float32))
+    prev = torch.stack([inv.NullInversion.prev_step(fake, e, int(t), x) for t in range(980, -1, -20)])
+    nxt = torch.stack([inv.NullInversion.next_step(fake, e, int(t), x) for t in range(0, 1000, 20)])
+    save("G10_ddim", prev=prev, next=nxt, alphas_cumprod=ac)
+
+
+def g11_geometry(R):
+    import GeoDiffuser.utils.vis_utils as vis
+    size = 64
+    mask = cases.ellipse_mask(cx=30, cy=33, ax=11, ay=9, size=size)
+    v, u = np.mgrid[0:size, 0:size].astype(np.float32)
+    depth = np.where(mask > 0.5, 0.5 + 0.2 * (u / size - 0.5), 0.9).astype(np.float32)
+    image = np.zeros((size, size, 3), dtype=np.float32)
+    out = {}
+    tf = {"translate": vis.translateMatrix(0.1, -0.05, 0.02),
+          "rotate": vis.rotateAxis(25.0, 1).float(),
+          "mixed": (vis.translateMatrix(0.05, 0.0, 0.05) @ vis.rotateAxis(-15.0, 1).float() @ vis.rotateAxis(10.0, 2).float())}
+    for name, T in tf.items():
+        t_coords, _ = vis.get_transform_coordinates(image, depth.copy(), mask, transform_in=T.float(), focal_length=550 * size / 512.0, return_mesh=False)
+        out[name] = t_coords
+        out[name + "_T"] = T.numpy()
+    const = np.ones((size, size), dtype=np.float32) * 0.5
+    t_coords, _ = vis.get_transform_coordinates(image, const, mask, transform_in=vis.translateMatrix(0.1, 0, 0), focal_length=550 * size / 512.0, return_mesh=False)
+    out["const_depth"] = t_coords
+    save("G11_geometry", **out)
+
+
+def g13_resample(R):
+    gt = R.generic_torch
+    mask = cases.ellipse_mask()
+    coords = torch.from_numpy(cases.make_coords("rotate", mask))
+    out = {}
+    for S in (64, 8):
+        out[f"coords_{S}"] = gt.reshape_transform_coords(coords, in_mat_shape=(1, 1, S, S))
+        out[f"mask_{S}"] = gt.reshape_attention_mask(torch.from_numpy(mask)[None, None], in_mat_shape=(1, S))
+    blk = torch.zeros(1, 1, 9, 9); blk[..., 3:6, 3:6] = 1
+    out["erode3"] = gt.torch_erode(blk, 3); out["dilate3"] = gt.torch_dilate(blk, 3); out["dilate5"] = gt.torch_dilate(blk, 5)
+    out["gauss_w"] = gt.GAUSSIAN_FEATURE_SMOOTHER.weight[0, 0]
+    save("G13_resample", **out)
+
+
+def g4_losses(R, packs):
+    """Loss values and d/d(replace_out), d/d(replace_att) on seeded features (S=32, f=2, D=8)."""
+    ap, ls = R.attention_processors, R.loss
+    S, f, D = 32, 2, 8
+    N = S * S
+    rng = np.random.default_rng(4)
+    eo = torch.from_numpy(rng.standard_normal((1, f, N, D), dtype=np.float32))
+    ro = torch.from_numpy(rng.standard_normal((1, f, N, D), dtype=np.float32)).requires_grad_(True)
+    m_edit = torch.from_numpy((rng.random((1, 1, N, 1)) > 0.8).astype(np.float32) * rng.choice([0.25, 0.5, 1.0], size=(1, 1, N, 1)).astype(np.float32))
+    m_wo = torch.from_numpy((rng.random((1, 1, N, 1)) > 0.4).astype(np.float32))
+    m_inp = torch.zeros(1, 1, N, 1); m_inp[0, 0, 300:340] = 1
+    m_amo = torch.from_numpy((rng.random((1, 1, N, 1)) > 0.9).astype(np.float32))
+    dist = ap.DISTANCE_CLASS.get_coord_distance(S, device="cpu")
+    a_e = torch.softmax(torch.from_numpy(rng.standard_normal((f, N, N), dtype=np.float32)) * 2, -1).requires_grad_(True)
+    a_b = torch.softmax(torch.from_numpy(rng.standard_normal((f, N, N), dtype=np.float32)) * 2, -1)
+    l_bg = ap.background_preservation_loss(eo, ro, m_wo)
+    l_mv = ap.object_placement_loss_geodiff(eo, ro, m_edit)
+    l_am = ap.amodal_loss_geodiff(eo, ro, m_edit, dist, m_amo)
+    l_sm, _, _ = ls.get_smoothness_loss(ro)
+    l_rm = ap.removal_loss_geodiff(a_e, a_b, m_inp, m_wo, dist, f)
+    g = {}
+    for nm, l in (("bg", l_bg), ("mv", l_mv), ("am", l_am), ("sm", l_sm)):
+        g["d_" + nm] = torch.autograd.grad(l, ro, retain_graph=True)[0]
+    d_rm = torch.autograd.grad(l_rm, a_e)[0]
+    save("G4_losses", bg=l_bg.detach(), mv=l_mv.detach(), am=l_am.detach(), sm=l_sm.detach(), rm=l_rm.detach(),
+         d_rm_rows=d_rm[:, 300:340], **g)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    R = ref_import.import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    print("G0 warped masks"); packs = g_masks_and_warp(R)
+    print("G1"); g1_compute_attention(R)
+    print("G3"); g3_masks(R, packs)
+    print("G4"); g4_losses(R, packs)
+    print("G5"); g5_interpolate(R)
+    print("G6"); g6_controller(R, packs)
+    print("G7"); g7_counters(R, packs)
+    print("G8"); g8_update_latent(R)
+    print("G9"); g9_adaptive(R)
+    print("G10"); g10_ddim(R)
+    print("G11"); g11_geometry(R)
+    print("G13"); g13_resample(R)
+
+
+if __name__ == "__main__":
+    main()

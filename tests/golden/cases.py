@@ -1,0 +1,139 @@
+"""Seeded synthetic inputs shared by ``oracle/gen_golden.py`` (which records what the reference
+computes for them) and the tests (which regenerate the same inputs and compare).
+
+Only IEEE elementwise numpy arithmetic and ``np.random.default_rng`` are used, so the inputs are
+bit-identical wherever they are regenerated; the fixtures therefore store OUTPUTS only.
+Nothing here is reference code.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+IMG = 512
+FOCAL = 550.0
+
+
+def ellipse_mask(cx=236.0, cy=262.0, ax=70.0, ay=58.0, size=IMG) -> np.ndarray:
+    v, u = np.mgrid[0:size, 0:size].astype(np.float32)
+    return ((((u - cx) / ax) ** 2 + ((v - cy) / ay) ** 2) <= 1.0).astype(np.float32)
+
+
+def coords_translate(dx_px=64.0, dy_px=-24.0, z=0.5, size=IMG) -> np.ndarray:
+    """2-D translation on constant depth: t_coords[v,u] = (x_ndc, y_ndc, Z) (align-corners NDC)."""
+    v, u = np.mgrid[0:size, 0:size].astype(np.float32)
+    x = np.float32(2.0) * (u + np.float32(dx_px)) / np.float32(size - 1) - np.float32(1.0)
+    y = np.float32(2.0) * (v + np.float32(dy_px)) / np.float32(size - 1) - np.float32(1.0)
+    zz = np.full_like(x, np.float32(z))
+    return np.stack([x, y, zz], -1)[None].astype(np.float32)
+
+
+def _centroid(mask: np.ndarray):
+    """Exact (integer-sum) centroid of a binary mask, as float32 (cu, cv)."""
+    vs, us = np.nonzero(mask > 0.5)
+    n = max(int(us.size), 1)
+    return np.float32(int(us.sum()) / n), np.float32(int(vs.sum()) / n)
+
+
+def coords_rotate_y(deg=20.0, mask=None, size=IMG) -> np.ndarray:
+    """Rotation about the vertical axis through the object's centre pixel on a tilted depth plane
+    (elementwise float32 arithmetic only, so it regenerates bit-identically)."""
+    import math
+    v, u = np.mgrid[0:size, 0:size].astype(np.float32)
+    if mask is None:
+        mask = ellipse_mask(size=size)
+    cu, cv = _centroid(mask)
+
+    def cam(uu, vv):
+        d = np.float32(0.55) + np.float32(0.2) * (uu / np.float32(size) - np.float32(0.5))
+        return ((uu - np.float32(size / 2)) / np.float32(FOCAL) * d,
+                (vv - np.float32(size / 2)) / np.float32(FOCAL) * d, d)
+
+    cx, cy, cz = cam(u, v)
+    c = cam(cu, cv)
+    co = np.float32(math.cos(math.radians(deg)))
+    si = np.float32(math.sin(math.radians(deg)))
+    x0, y0, z0 = cx - c[0], cy - c[1], cz - c[2]
+    px = co * x0 + si * z0 + c[0]
+    py = y0 + c[1]
+    pz = np.maximum(-si * x0 + co * z0 + c[2], np.float32(1e-3))
+    uu = np.float32(FOCAL) * px / pz + np.float32(size / 2)
+    vv = np.float32(FOCAL) * py / pz + np.float32(size / 2)
+    x = np.float32(2.0) * uu / np.float32(size - 1) - np.float32(1.0)
+    y = np.float32(2.0) * vv / np.float32(size - 1) - np.float32(1.0)
+    return np.stack([x, y, pz], -1)[None].astype(np.float32)
+
+
+def coords_scale(s=0.8, z=0.5, mask=None, size=IMG) -> np.ndarray:
+    """Uniform in-plane scaling about the mask centroid (many-to-one splat: deep pixel queues)."""
+    v, u = np.mgrid[0:size, 0:size].astype(np.float32)
+    if mask is None:
+        mask = ellipse_mask(size=size)
+    cu, cv = _centroid(mask)
+    uu = (u - cu) * np.float32(s) + cu
+    vv = (v - cv) * np.float32(s) + cv
+    x = np.float32(2.0) * uu / np.float32(size - 1) - np.float32(1.0)
+    y = np.float32(2.0) * vv / np.float32(size - 1) - np.float32(1.0)
+    zz = (np.float32(z) + np.float32(0.1) * (v / np.float32(size))).astype(np.float32)
+    return np.stack([x, y, zz], -1)[None].astype(np.float32)
+
+
+def make_coords(kind: str, mask: np.ndarray) -> np.ndarray:
+    if kind == "translate":
+        return coords_translate()
+    if kind == "rotate":
+        return coords_rotate_y(mask=mask)
+    if kind == "scale":
+        return coords_scale(mask=mask)
+    raise ValueError(kind)
+
+
+def amodal_input(mask: np.ndarray, dx=64, dy=-24) -> np.ndarray:
+    """A synthetic 'projected amodal mask' input [1,1,H,W]: the mask shifted by the translation and
+    grown by 6 px (stands in for the mesh coverage; it is only an INPUT of the path under test)."""
+    m = np.roll(np.roll(mask, dy, axis=0), dx, axis=1)
+    g = np.zeros_like(m)
+    for oy in range(-6, 7):
+        for ox in range(-6, 7):
+            if ox * ox + oy * oy <= 36:
+                g = np.maximum(g, np.roll(np.roll(m, oy, axis=0), ox, axis=1))
+    return g[None, None].astype(np.float32)
+
+
+def half_round(a: np.ndarray) -> np.ndarray:
+    return a.astype(np.float16).astype(np.float32)
+
+
+def make_qkv(seed: int, B: int, f: int, N: int, M: int, D: int, spike: bool = True):
+    """q [B*f,N,D], k/v [B*f,M,D]; values rounded through fp16 so the same numbers can be fed to the
+    fp16 HIP path exactly.  A mild structure (shared low-rank term) keeps the softmax peaky enough
+    that the removal-loss arg-max is well separated."""
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((B * f, N, D), dtype=np.float32)
+    k = rng.standard_normal((B * f, M, D), dtype=np.float32)
+    v = rng.standard_normal((B * f, M, D), dtype=np.float32)
+    if spike and M == N:
+        pos = rng.standard_normal((1, N, D), dtype=np.float32)
+        q = q + np.float32(1.5) * pos
+        k = k + np.float32(1.5) * pos
+    return half_round(q * np.float32(1.2)), half_round(k * np.float32(1.2)), half_round(v)
+
+
+# Controller-forward golden cases (G6).  name -> parameters
+CONTROLLER_CASES = {
+    # name:            kind      S   f  D   cross  cfg    cur_step  coords       quant
+    "edit_self_opt_32":   dict(kind="edit", S=32, f=2, D=16, cross=False, cfg=False, cur_step=3, coords="translate", quant=True, seed=11),
+    "edit_cross_opt_32":  dict(kind="edit", S=32, f=2, D=16, cross=True, cfg=False, cur_step=3, coords="translate", quant=True, seed=12),
+    "edit_self_cfg_32":   dict(kind="edit", S=32, f=2, D=16, cross=False, cfg=True, cur_step=3, coords="rotate", quant=True, seed=13),
+    "edit_cross_cfg_32":  dict(kind="edit", S=32, f=2, D=16, cross=True, cfg=True, cur_step=46, coords="rotate", quant=True, seed=14),
+    "edit_self_late_16":  dict(kind="edit", S=16, f=2, D=16, cross=False, cfg=True, cur_step=48, coords="translate", quant=True, seed=15),
+    "edit_self_opt_64":   dict(kind="edit", S=64, f=1, D=8, cross=False, cfg=False, cur_step=0, coords="rotate", quant=True, seed=16),
+    "edit_cross_opt_64":  dict(kind="edit", S=64, f=1, D=8, cross=True, cfg=False, cur_step=0, coords="scale", quant=True, seed=17),
+    "edit_self_opt_32_noquant": dict(kind="edit", S=32, f=2, D=16, cross=False, cfg=False, cur_step=3, coords="scale", quant=False, seed=18),
+    "rem_self_opt_32":    dict(kind="remover", S=32, f=2, D=16, cross=False, cfg=False, cur_step=3, coords="translate", quant=False, seed=21),
+    "rem_cross_opt_32":   dict(kind="remover", S=32, f=2, D=16, cross=True, cfg=False, cur_step=3, coords="translate", quant=False, seed=22),
+    "rem_self_cfg_past_32": dict(kind="remover", S=32, f=2, D=16, cross=False, cfg=True, cur_step=46, coords="translate", quant=False, seed=23),
+    "rem_cross_cfg_16":   dict(kind="remover", S=16, f=2, D=16, cross=True, cfg=True, cur_step=10, coords="translate", quant=False, seed=24),
+}
+NUM_STEPS = 50
+SELF_REPLACE = 0.95
+OBJ_EDIT_STEP = 0.9

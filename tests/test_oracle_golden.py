@@ -1,0 +1,240 @@
+"""Pins the CPU oracle (oracle/ref_cpu.py) against golden vectors recorded from the reference's own
+Python (oracle/gen_golden.py).  CPU only.  fp32-vs-fp32: tolerance 1e-5 relative (max-norm), exact
+for integers / masks / counters."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import ref_cpu as O
+from _util import case_gout, case_inputs, load, rel_err, warped_mask
+
+TOL = 1e-5
+
+
+def test_g1_compute_attention():
+    g = load("G1_compute_attention")
+    q, k, _ = cases.make_qkv(1, 1, 4, 64, 77, 16, spike=False)
+    a = O.compute_attention(torch.from_numpy(q), torch.from_numpy(k), 0.25)
+    assert rel_err(a, g["attn"]) < TOL
+    q2, k2, _ = cases.make_qkv(2, 1, 4, 64, 64, 16)
+    a2 = O.compute_attention(torch.from_numpy(q2), torch.from_numpy(k2), 0.25)
+    assert rel_err(a2, g["attn_self"]) < TOL
+    assert int(g["mask_args_noop"]) == 1          # SURVEY F2 recorded at generation time
+
+
+@pytest.mark.parametrize("kind", ["translate", "rotate"])
+def test_g3_process_masks(kind):
+    g = load("G3_process_masks")
+    mask = cases.ellipse_mask()
+    coords = torch.from_numpy(cases.make_coords(kind, mask))
+    amodal = O.torch_erode(torch.from_numpy(cases.amodal_input(mask)))
+    image_mask = torch.from_numpy(mask[None]).tile((2, 1, 1))
+    for S in (64, 32, 16, 8):
+        r = O.process_masks(image_mask, warped_mask(kind), amodal, coords, S, 2, coords_quant=None)
+        for n in ("mask_new_warped", "mask_warp", "amodal_mask", "mask_intersection", "mask_1_empty", "mask_wo_edit"):
+            assert np.array_equal(r[n].numpy(), g[f"{kind}_{S}_{n}"]), (S, n)
+        assert np.array_equal(r["t_coords_q"][:1].numpy(), g[f"{kind}_{S}_t_coords_q"]), S
+        # resampled binary masks only take values in {0, 1/4, 1/2, 3/4, 1}
+        assert set(np.unique(r["mask_new_warped"].numpy())) <= {0.0, 0.25, 0.5, 0.75, 1.0}
+
+
+def test_g4_losses():
+    g = load("G4_losses")
+    S, f, D = 32, 2, 8
+    N = S * S
+    rng = np.random.default_rng(4)
+    eo = torch.from_numpy(rng.standard_normal((1, f, N, D), dtype=np.float32))
+    ro = torch.from_numpy(rng.standard_normal((1, f, N, D), dtype=np.float32)).requires_grad_(True)
+    m_edit = torch.from_numpy((rng.random((1, 1, N, 1)) > 0.8).astype(np.float32) * rng.choice([0.25, 0.5, 1.0], size=(1, 1, N, 1)).astype(np.float32))
+    m_wo = torch.from_numpy((rng.random((1, 1, N, 1)) > 0.4).astype(np.float32))
+    m_inp = torch.zeros(1, 1, N, 1); m_inp[0, 0, 300:340] = 1
+    m_amo = torch.from_numpy((rng.random((1, 1, N, 1)) > 0.9).astype(np.float32))
+    dist = O.coord_distance(S)
+    a_e = torch.softmax(torch.from_numpy(rng.standard_normal((f, N, N), dtype=np.float32)) * 2, -1).requires_grad_(True)
+    a_b = torch.softmax(torch.from_numpy(rng.standard_normal((f, N, N), dtype=np.float32)) * 2, -1)
+    vals = dict(bg=O.background_preservation_loss(eo, ro, m_wo), mv=O.object_placement_loss(eo, ro, m_edit),
+                am=O.amodal_loss(eo, ro, m_edit, dist, m_amo), sm=O.smoothness_loss(ro),
+                rm=O.removal_loss(a_e, a_b, m_inp, m_wo, dist, f))
+    for k_, v_ in vals.items():
+        assert abs(float(v_) - float(g[k_])) <= TOL * max(1.0, abs(float(g[k_]))), k_
+    for k_ in ("bg", "mv", "am", "sm"):
+        d = torch.autograd.grad(vals[k_], ro, retain_graph=True)[0]
+        assert rel_err(d, g["d_" + k_]) < TOL, k_
+    d_rm = torch.autograd.grad(vals["rm"], a_e)[0]
+    assert rel_err(d_rm[:, 300:340], g["d_rm_rows"]) < TOL
+    assert float(d_rm[:, :300].abs().max()) == 0.0
+
+
+def test_g5_interpolate_and_smooth():
+    g = load("G5_interpolate")
+    S, f, D = 32, 2, 8
+    mask = cases.ellipse_mask()
+    m_s = (O.reshape_attention_mask(torch.from_numpy(mask)[None, None], S) > 0.5) * 1.0
+    fg = m_s[0, 0].reshape(-1)[None, None, :, None]
+    feats = torch.from_numpy(cases.make_qkv(5, 1, f, S * S, S * S, D)[2])[None]
+    dist = O.coord_distance(S)
+    interp, w = O.interpolate_from_mask(feats, fg, dist)
+    assert rel_err(interp, g["interp"]) < TOL
+    assert rel_err(w, g["weights"]) < TOL
+    assert rel_err(O.smooth_attention_features(feats), g["smooth"]) < TOL
+    assert np.array_equal(dist[0, 0].numpy(), g["dist_row0"])
+    assert np.array_equal(dist[0, 517].numpy(), g["dist_row517"])
+
+
+def _run_oracle_case(case):
+    q, k, v, mask, coords = case_inputs(case)
+    cls = O.GeometryEditOracle if case["kind"] == "edit" else O.GeometryRemoverOracle
+    c = cls(mask, cases.NUM_STEPS, cases.SELF_REPLACE, cases.OBJ_EDIT_STEP,
+            coords_quant=torch.float16 if case["quant"] else None)
+    c.amodal_mask = O.torch_erode(torch.from_numpy(cases.amodal_input(mask)))
+    c.mask_new_warped = warped_mask(case["coords"])
+    c.num_att_layers = 32
+    c.cur_step = case["cur_step"]
+    if case["cfg"]:
+        c.coords_base, c.coords_edit, c.use_cfg = (2, 3), (3, 4), True
+    else:
+        c.coords_base, c.coords_edit, c.use_cfg = (0, 1), (1, 2), False
+    grad = not case["cfg"]
+    if grad:
+        q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+    with torch.set_grad_enabled(grad):
+        out = c(q, k, v, case["cross"], "up", transform_coords=coords, scale=case["D"] ** -0.5)
+    return c, q, k, v, out
+
+
+@pytest.mark.parametrize("name", list(cases.CONTROLLER_CASES))
+def test_g6_controller_forward(name):
+    case = cases.CONTROLLER_CASES[name]
+    g = load("G6_" + name)
+    c, q, k, v, out = _run_oracle_case(case)
+    assert rel_err(out, g["out"]) < TOL
+    assert (c.cur_att_layer, c.cur_step) == (int(g["cur_att_layer"]), int(g["cur_step"]))
+    if not case["cfg"]:
+        total = (out * case_gout(case, out.shape)).sum()
+        if "loss" in g:
+            assert abs(float(c.loss) - float(g["loss"])) <= TOL * max(1.0, abs(float(g["loss"])))
+            kind = "cross" if case["cross"] else "self"
+            for key, val in c.loss_log_dict[kind].items():
+                assert abs(float(val) - float(g["log_" + key])) <= TOL * max(1.0, abs(float(g["log_" + key]))), key
+            assert c.loss_log_dict["num_layers"] == int(g["num_layers"])
+            total = total + c.loss
+        dq, dk, dv = torch.autograd.grad(total, [q, k, v], allow_unused=True)
+        assert rel_err(dq, g["dq"]) < 5 * TOL
+        assert rel_err(dk if dk is not None else torch.zeros_like(k), g["dk"]) < 5 * TOL
+        assert rel_err(dv if dv is not None else torch.zeros_like(v), g["dv"]) < 5 * TOL
+
+
+def test_g7_counters():
+    g = load("G7_counters")
+    case = dict(cases.CONTROLLER_CASES["edit_self_late_16"])
+    mask = cases.ellipse_mask()
+    c = O.GeometryEditOracle(mask, cases.NUM_STEPS, cases.SELF_REPLACE, cases.OBJ_EDIT_STEP)
+    c.amodal_mask = O.torch_erode(torch.from_numpy(cases.amodal_input(mask)))
+    c.mask_new_warped = warped_mask("translate")
+    c.num_att_layers, c.cur_step = 4, 46
+    coords = torch.from_numpy(cases.make_coords("translate", mask))
+    trace = []
+    with torch.no_grad():
+        for call in range(14):
+            q, k, v = (torch.from_numpy(a) for a in cases.make_qkv(70 + call, 4, 1, 64, 64, 8))
+            c(q, k, v, False, "mid", transform_coords=coords, scale=8 ** -0.5)
+            if call == 7:
+                c.cur_step -= 1
+            trace.append((c.cur_att_layer, c.cur_step))
+    assert np.array_equal(np.array(trace), g["trace"])
+
+
+def test_g8_update_latent():
+    g = load("G8_update_latent")
+    rng = np.random.default_rng(8)
+    lat = torch.from_numpy(rng.standard_normal((2, 4, 64, 64), dtype=np.float32))
+    ctx = torch.from_numpy(rng.standard_normal((4, 77, 32), dtype=np.float32))
+    wl = torch.from_numpy(rng.standard_normal((2, 4, 64, 64), dtype=np.float32))
+    wc = torch.from_numpy(rng.standard_normal((4, 77, 32), dtype=np.float32))
+    gl, gc = wl, 2 * ctx * wc * wc
+    mask = torch.from_numpy(cases.ellipse_mask())[None, None]
+    lo, co = O.update_latent(lat, gl, 0.37, mask[0, 0], ctx, gc)
+    assert rel_err(lo, g["latents"]) < TOL
+    assert rel_err(co, g["context"]) < TOL
+
+
+def test_g9_adaptive():
+    g = load("G9_adaptive")
+    w_e = {"self": {"sim": 55, "movement": 30.5, "removal": 2.6, "smoothness": 30, "amodal": 80.5},
+           "cross": {"sim": 45, "movement": 30.34, "removal": 2.6, "smoothness": 15, "amodal": 3.5}}
+    w_r = {"self": {"sim": 55, "removal": 4.6, "smoothness": 30}, "cross": {"sim": 45, "removal": 4.6, "smoothness": 15}}
+    for key, w, remover in (("edit", w_e, False), ("remover", w_r, True)):
+        class C:
+            pass
+        c = C()
+        c.default_loss_weights = {k: dict(v) for k, v in w.items()}
+        c.loss_weight_dict = c.default_loss_weights
+        c.initialize_default_loss_weights = lambda c=c: setattr(c, "loss_weight_dict", c.default_loss_weights)
+        traj = []
+        for i, val in g["seq"]:
+            O.adaptive_step(c, int(i), 2, float(val), 50, -1.5, remover=remover)
+            traj.append(c.loss_weight_dict["self"]["removal"])
+        assert np.allclose(np.array(traj), g[key], rtol=1e-12, atol=0), key
+
+
+def test_g10_ddim_closed_forms():
+    g = load("G10_ddim")
+    ac = O.alphas_cumprod()
+    assert np.array_equal(ac.numpy(), g["alphas_cumprod"])
+    rng = np.random.default_rng(10)
+    x = torch.from_numpy(rng.standard_normal((1, 4, 8, 8), dtype=np.float32))
+    e = torch.from_numpy(rng.standard_normal((1, 4, 8, 8), dtype=np.float32))
+    prev = torch.stack([O.prev_step(e, int(t), x, ac, 50) for t in range(980, -1, -20)])
+    nxt = torch.stack([O.next_step(e, int(t), x, ac, 50) for t in range(0, 1000, 20)])
+    assert rel_err(prev, g["prev"]) < TOL
+    assert rel_err(nxt, g["next"]) < TOL
+    assert list(O.ddim_timesteps(50)) == list(range(980, -1, -20))
+    # t = 0 inversion step is the identity (both alphas are alphas_cumprod[0])
+    assert rel_err(nxt[0], x) < 1e-6
+
+
+def test_g11_geometry_prepass():
+    g = load("G11_geometry")
+    size = 64
+    mask = cases.ellipse_mask(cx=30, cy=33, ax=11, ay=9, size=size)
+    v, u = np.mgrid[0:size, 0:size].astype(np.float32)
+    depth = np.where(mask > 0.5, 0.5 + 0.2 * (u / size - 0.5), 0.9).astype(np.float32)
+    for name in ("translate", "rotate", "mixed"):
+        t, _ = O.get_transform_coordinates(depth.copy(), mask, torch.from_numpy(g[name + "_T"]).float(), focal_length=550 * size / 512.0)
+        assert rel_err(t, g[name]) < 2e-5, name
+    const = np.ones((size, size), dtype=np.float32) * 0.5
+    T = torch.eye(4); T[0, 3] = 0.1
+    t, _ = O.get_transform_coordinates(const, mask, T, focal_length=550 * size / 512.0)
+    assert rel_err(t, g["const_depth"]) < 2e-5
+    # the reference's documented example: tx = 0.1 on depth 0.5 is a pure shift of f*tx/Z pixels
+    shift_px = (t[..., 0] - (2 * u / (size - 1) - 1)) * (size - 1) / 2
+    assert np.allclose(shift_px, 550 * size / 512.0 * 0.1 / 0.5, atol=1e-3)
+
+
+def test_g13_resample_and_morphology():
+    g = load("G13_resample")
+    mask = cases.ellipse_mask()
+    coords = torch.from_numpy(cases.make_coords("rotate", mask))
+    for S in (64, 8):
+        assert np.array_equal(O.reshape_transform_coords(coords, S).numpy(), g[f"coords_{S}"])
+        assert np.array_equal(O.reshape_attention_mask(torch.from_numpy(mask)[None, None], S).numpy(), g[f"mask_{S}"])
+    blk = torch.zeros(1, 1, 9, 9); blk[..., 3:6, 3:6] = 1
+    assert np.array_equal(O.torch_erode(blk, 3).numpy(), g["erode3"])
+    assert np.array_equal(O.torch_dilate(blk, 3).numpy(), g["dilate3"])
+    assert np.array_equal(O.torch_dilate(blk, 5).numpy(), g["dilate5"])
+    assert rel_err(O.gaussian_kernel_5x5(), g["gauss_w"]) < 1e-6
+    assert abs(float(O.gaussian_kernel_5x5()[2, 2]) - 0.18102) < 1e-4
+
+
+def test_rasterizer_boxes_match_bruteforce():
+    """The candidate-box rasterizer equals the every-pixel-visits-every-point form (small sizes)."""
+    rng = np.random.default_rng(3)
+    for S, P, K, rpx in ((16, 256, 4, 1.3), (24, 900, 15, 2.7), (8, 64, 2, 0.6)):
+        pts = rng.uniform(-1.2, 1.2, size=(2, P, 3)).astype(np.float32)
+        pts[..., 2] = np.round(rng.uniform(-0.1, 1.0, size=(2, P)) * 8) / 8      # many z ties + some z<0
+        pts = torch.from_numpy(pts)
+        a = O.rasterize_points(pts, S, rpx / S * 2.0, K)
+        b = O.rasterize_points(pts, S, rpx / S * 2.0, K, bruteforce=True)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)

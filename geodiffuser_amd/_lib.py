@@ -1,0 +1,94 @@
+"""ctypes binding of libgeodiff_hip.so — the C ABI declared in include/geodiff_hip.h.
+
+There is deliberately NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libgeodiff_hip.so")
+
+GD_F16, GD_BF16, GD_F32 = 0, 1, 2
+GD_TOKEN_MAJOR, GD_CHANNEL_MAJOR = 0, 1
+GD_ATTN_MAX_SEGS = 4
+
+
+class GdAttnSeg(Structure):
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("lse", c_void_p),
+                ("bh", c_int32), ("pad_", c_int32)]
+
+
+class GeodiffError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); every symbol of include/geodiff_hip.h must be listed here
+SIGNATURES = {
+    "gd_version": (c_int, []),
+    "gd_last_error": (c_char_p, []),
+    "gd_error_string": (c_char_p, [c_int]),
+    "gd_rasterize_workspace_bytes": (c_size_t, [c_int, c_int, c_float]),
+    "gd_rasterize_points": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
+    "gd_splat_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "gd_splat_composite": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_int, c_void_p]),
+    "gd_attn_fwd": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "gd_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                            c_float, c_void_p, c_void_p, c_int, c_void_p]),
+    "gd_attn_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_float, c_void_p, c_int, c_void_p]),
+    "gd_removal_corr_max": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "gd_removal_loss_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                       c_void_p, c_void_p]),
+    "gd_removal_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                               c_void_p, c_void_p, c_int, c_void_p]),
+    "gd_amodal_target": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                 c_int, c_void_p]),
+    "gd_edit_losses_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "gd_edit_losses_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   POINTER(c_float), c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "gd_blend_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "gd_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int64, c_int, c_void_p]),
+    "gd_masked_latent_update": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p]),
+    "gd_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "gd_norm_rescale": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load(path: str = LIB_PATH) -> ctypes.CDLL:
+    """Load the library and bind every declared symbol (raises if the .so or a symbol is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise GeodiffError(
+            f"{path} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -m geodiffuser_amd.build` (needs hipcc).")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GeodiffError(f"libgeodiff_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gd_version() != 1:
+        raise GeodiffError(f"ABI version mismatch: library {lib.gd_version()} != binding 1")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        lib = load()
+        raise GeodiffError(f"{what} failed ({code}: {lib.gd_error_string(code).decode()}): "
+                           f"{lib.gd_last_error().decode()}")

@@ -1,0 +1,220 @@
+// Attention backward for the edit path (gfx950 MFMA), D = 64.
+//
+// Reference: torch.autograd through compute_attention + torch.bmm (GeoDiffuser/utils/attention_sharing.py:30-47,
+// GeoDiffuser/utils/attention_processors.py:432-433,555-557) as driven by torch.autograd.grad in
+// GeoDiffuser/utils/optimization.py:182.  On this path only q_edit (always) and k_edit (cross-attention)
+// carry gradient; k_base / v_base are detached (U/attention_sharing.py:242, U/attention_processors.py:433,555-557).
+//
+//   k_attn_bwd_dq : same swapped geometry as the forward.  S^T = K Q^T and dP^T = V dO^T have the query on the
+//                   lane, so P, dS = P o (dP - delta) stay lane-local and dS (16-bit) is directly the B operand
+//                   of dQ^T += K^T dS^T (K^T by hardware-transposed LDS read).  No atomics, no [N,N] traffic.
+//   k_attn_bwd_dk : cross-attention only (M <= 128 keys): one thread pair per key, queries broadcast from LDS,
+//                   fp32 atomics into dk_f32.  0.6 GFLOP per 64^2 layer — VALU is plenty.
+// MFMA-bound (dq): algorithmic FLOPs = 6 * BH * N * M * D.
+#include "attn_common.hpp"
+
+struct BwdArgs {
+    const void* q; const void* k; const void* v; const void* o; const float* lse; const void* dout;
+    void* dq; float* dk;
+    int N, M, tiles, nwg;
+    float c, scale, l2e;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_attn_bwd_dq(const BwdArgs a) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    __shared__ __attribute__((aligned(16))) char lds[2][2][ATT_TILE_BYTES];   // [buf][K|V]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int wg = xcd_remap(blockIdx.x, a.nwg);
+    const int bh = wg / a.tiles, tile = wg - bh * a.tiles;
+    const int N = a.N, M = a.M;
+    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * ATT_D;
+    const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * ATT_D;
+    const T* __restrict__ vp = (const T*)a.v + (size_t)bh * M * ATT_D;
+    const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * ATT_D;
+    const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * ATT_D;
+
+    const int qrow = tile * ATT_BM + wave * 32 + (lane & 31);
+    const int qld = qrow < N ? qrow : N - 1;
+    V8 qf[4], gf[4];
+    float dpart = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = *(const V8*)(qp + (size_t)qld * ATT_D + 16 * s + 8 * h);
+        gf[s] = *(const V8*)(gp + (size_t)qld * ATT_D + 16 * s + 8 * h);
+        const V8 of = *(const V8*)(op + (size_t)qld * ATT_D + 16 * s + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dpart = __builtin_fmaf(TR::to_f32(gf[s][j]), TR::to_f32(of[j]), dpart);
+    }
+    const float delta = dpart + __shfl_xor(dpart, 32, 64);         // rowsum(dO o O)
+    const float lse2 = a.lse[(size_t)bh * N + qld] * a.l2e;
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
+
+    const int T_tiles = (M + ATT_BN - 1) / ATT_BN;
+    u32x4 kr[2], vr[2];
+    tile_load<T>(kp, 0, M, tid, kr);
+    tile_load<T>(vp, 0, M, tid, vr);
+    tile_store(lds[0][0], tid, kr);
+    tile_store(lds[0][1], tid, vr);
+    __syncthreads();
+
+    for (int t = 0; t < T_tiles; ++t) {
+        const int cur = t & 1;
+        const bool more = (t + 1) < T_tiles;
+        if (more) {
+            tile_load<T>(kp, (t + 1) * ATT_BN, M, tid, kr);
+            tile_load<T>(vp, (t + 1) * ATT_BN, M, tid, vr);
+        }
+        const char* lk = lds[cur][0];
+        const char* lv = lds[cur][1];
+        const int kv0 = t * ATT_BN;
+        V8 dsf[4];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            f32x16 s_acc, p_acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s_acc[i] = 0.f; p_acc[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(read_row_frag<T>(lk, blk, s, lane), qf[s], s_acc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) p_acc = TR::mfma32(read_row_frag<T>(lv, blk, s, lane), gf[s], p_acc);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], a.c, -lse2));
+                if (kv0 + blk * 32 + acc_key(i, h) >= M) p = 0.f;
+                s_acc[i] = p * (p_acc[i] - delta);
+            }
+            dsf[2 * blk] = acc_to_frag<T>(s_acc, 0);
+            dsf[2 * blk + 1] = acc_to_frag<T>(s_acc, 1);
+        }
+        // dQ^T += K^T dS^T
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dq[dblk] = TR::mfma32(read_tr_frag<T>(lk, dblk, ks, lane), dsf[ks], dq[dblk]);
+
+        if (more) {
+            tile_store(lds[cur ^ 1][0], tid, kr);
+            tile_store(lds[cur ^ 1][1], tid, vr);
+        }
+        __syncthreads();
+    }
+    if (qrow < N) {
+        T* __restrict__ dp = (T*)a.dq + ((size_t)bh * N + qrow) * ATT_D;
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typename TR::vec4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = TR::from_f32(dq[dblk][4 * g + j] * a.scale);
+                *(typename TR::vec4*)(dp + dblk * 32 + 8 * g + 4 * h) = w;
+            }
+    }
+}
+
+// ---- dK for cross-attention (few keys) -------------------------------------------------------------
+#define DK_QCHUNK 64
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_attn_bwd_dk(const BwdArgs a) {
+    using TR = elem_traits<T>;
+    __shared__ float sq[DK_QCHUNK][ATT_D + 1];
+    __shared__ float sg[DK_QCHUNK][ATT_D + 1];
+    __shared__ float slse[DK_QCHUNK], sdelta[DK_QCHUNK];
+    const int tid = threadIdx.x;
+    const int bh = blockIdx.y, q0 = blockIdx.x * DK_QCHUNK;
+    const int N = a.N, M = a.M;
+    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * ATT_D;
+    const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * ATT_D;
+    const T* __restrict__ vp = (const T*)a.v + (size_t)bh * M * ATT_D;
+    const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * ATT_D;
+    const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * ATT_D;
+
+    // stage 64 queries: thread (qq = tid/4, part = tid%4) handles 16 features
+    {
+        const int qq = tid >> 2, part = tid & 3;
+        const int qi = q0 + qq;
+        float d = 0.f;
+        for (int j = 0; j < 16; ++j) {
+            const int dd = part * 16 + j;
+            float qv = 0.f, gv = 0.f, ov = 0.f;
+            if (qi < N) {
+                qv = TR::to_f32(qp[(size_t)qi * ATT_D + dd]);
+                gv = TR::to_f32(gp[(size_t)qi * ATT_D + dd]);
+                ov = TR::to_f32(op[(size_t)qi * ATT_D + dd]);
+            }
+            sq[qq][dd] = qv; sg[qq][dd] = gv;
+            d = __builtin_fmaf(gv, ov, d);
+        }
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        if (part == 0) {
+            sdelta[qq] = d;
+            slse[qq] = qi < N ? a.lse[(size_t)bh * N + qi] : INFINITY;     // exp(-inf) = 0 for padding queries
+        }
+    }
+    __syncthreads();
+    const int key = tid >> 1, half = tid & 1;       // 128 keys x 2 feature halves
+    const bool valid = key < M;
+    float kreg[32], vreg[32], acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        kreg[j] = valid ? TR::to_f32(kp[(size_t)key * ATT_D + half * 32 + j]) : 0.f;
+        vreg[j] = valid ? TR::to_f32(vp[(size_t)key * ATT_D + half * 32 + j]) : 0.f;
+        acc[j] = 0.f;
+    }
+    for (int qq = 0; qq < DK_QCHUNK; ++qq) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            s = __builtin_fmaf(sq[qq][half * 32 + j], kreg[j], s);
+            dp = __builtin_fmaf(sg[qq][half * 32 + j], vreg[j], dp);
+        }
+        s += __shfl_xor(s, 1, 64);
+        dp += __shfl_xor(dp, 1, 64);
+        const float p = __expf(s * a.scale - slse[qq]);
+        const float ds = p * (dp - sdelta[qq]) * a.scale;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[j] = __builtin_fmaf(ds, sq[qq][half * 32 + j], acc[j]);
+    }
+    if (valid) {
+        float* dst = a.dk + ((size_t)bh * M + key) * ATT_D + half * 32;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) atomicAdd(dst + j, acc[j]);
+    }
+}
+
+extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
+                           const void* dout, int BH, int N, int M, int D, float scale,
+                           void* dq, float* dk_f32, int dtype, void* stream) {
+    GD_REQUIRE(q && k && v && out && lse && dout && dq, GD_EINVAL, "gd_attn_bwd: null pointer");
+    GD_REQUIRE(D == ATT_D, GD_EUNSUPPORTED, "gd_attn_bwd: head dim %d unsupported (only 64)", D);
+    GD_REQUIRE(BH > 0 && N > 0 && M > 0, GD_EINVAL, "gd_attn_bwd: bad sizes");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_bwd: dtype must be f16/bf16");
+    GD_REQUIRE(!dk_f32 || M <= 128, GD_EUNSUPPORTED, "gd_attn_bwd: dK is only implemented for M <= 128 keys (cross-attention); M=%d", M);
+    BwdArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = out; a.lse = lse; a.dout = dout; a.dq = dq; a.dk = dk_f32;
+    a.N = N; a.M = M;
+    a.tiles = (N + ATT_BM - 1) / ATT_BM;
+    a.nwg = a.tiles * BH;
+    a.scale = scale;
+    a.c = scale * 1.4426950408889634f;
+    a.l2e = 1.4426950408889634f;
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16) k_attn_bwd_dq<f16_t><<<a.nwg, 256, 0, st>>>(a);
+    else k_attn_bwd_dq<bf16_t><<<a.nwg, 256, 0, st>>>(a);
+    if (dk_f32) {
+        dim3 grid((N + DK_QCHUNK - 1) / DK_QCHUNK, BH);
+        if (dtype == GD_F16) k_attn_bwd_dk<f16_t><<<grid, 256, 0, st>>>(a);
+        else k_attn_bwd_dk<bf16_t><<<grid, 256, 0, st>>>(a);
+    }
+    GD_CHECK_LAUNCH("gd_attn_bwd");
+    return GD_OK;
+}

@@ -1,0 +1,99 @@
+// Tile helpers shared by the attention forward / backward / probs kernels (D = 64, 16-bit storage).
+//
+// Geometry (gfx950, wave = 64 lanes, v_mfma_f32_32x32x16_{f16,bf16}):
+//   workgroup = 4 waves = 128 query rows (32 per wave); key/value tile = 64 keys.
+//   S^T = K Q^T is computed "swapped": A = K tile (key rows), B = Q^T, so the accumulator has the QUERY
+//   on the lane (col = lane & 31) and the 32 keys of a block in its 16 registers x 2 lane halves:
+//       key(reg, h) = (reg & 3) + 8 * (reg >> 2) + 4 * h,   h = lane >> 5.
+//   Row max / sum are then lane-local plus one exchange with lane ^ 32, and the accumulator converted
+//   to 16-bit IS the B operand of the next product (O^T += V^T P^T, dQ^T += K^T dS^T) with no lane
+//   movement; the matching A operand (V^T / K^T) is read from the row-major LDS tile with
+//   ds_read_b64_tr_b16 (hardware transpose).
+//
+// LDS image (bytes; one tile = 64 rows x 128 B): the 16-B chunk c of row r is stored at
+//       r*128 + ((c ^ g((r >> 1) & 7)) << 4),     g = swap bit0 <-> bit2 of a 3-bit value.
+//   * read as an A operand with key rows (ds_read_b128, 16-lane groups cover all 16 combinations of
+//     (r & 1, (r >> 1) & 7)): g is a bijection, so the 16 lanes hit 16 distinct 16-B slots of the 256-B bank row;
+//   * read transposed (ds_read_b64_tr_b16, 4 key rows x 16 columns per 16 lanes): bit2 of g(.) = (r >> 1) & 1
+//     sends rows q and q+2 of a block to different 64-B windows, rows q and q+1 differ in r & 1 (128 B apart),
+//     so the four rows of a block land in four distinct 64-B bank windows.
+//   One image therefore serves both kinds of read (K in the backward is read both ways).
+#pragma once
+#include "common.hpp"
+
+#define ATT_D 64
+#define ATT_BM 128   // query rows per workgroup
+#define ATT_BN 64    // keys per tile
+#define ATT_TILE_BYTES (ATT_BN * ATT_D * 2)
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ int img_off(int r, int c) {
+    const int x = (r >> 1) & 7;
+    const int g = (x & 2) | ((x & 1) << 2) | ((x >> 2) & 1);
+    return r * 128 + ((c ^ g) << 4);
+}
+
+// global -> registers: this thread's two 16-B chunks of a 64 x 64 tile (rows tid/8 and tid/8 + 32)
+template <typename T>
+__device__ __forceinline__ void tile_load(const T* __restrict__ base, int row0, int nrows, int tid, u32x4 (&r)[2]) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = row0 + (tid >> 3) + 32 * i;
+        row = row < nrows ? row : nrows - 1;                 // clamp; out-of-range keys are masked later
+        r[i] = *(const u32x4*)(base + (size_t)row * ATT_D + c * 8);
+    }
+}
+
+__device__ __forceinline__ void tile_store(char* lds, int tid, const u32x4 (&r)[2]) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        *(u32x4*)(lds + img_off(row, c)) = r[i];
+    }
+}
+
+// A operand (32 key rows x 16 d) of k-step s; key row = blk*32 + (lane & 31)
+template <typename T>
+__device__ __forceinline__ typename elem_traits<T>::vec8 read_row_frag(const char* lds, int blk, int s, int lane) {
+    const int r = blk * 32 + (lane & 31);
+    const int c = 2 * s + (lane >> 5);
+    return *(const typename elem_traits<T>::vec8*)(lds + img_off(r, c));
+}
+
+// A operand (32 d rows x 16 keys) = transposed tile (hardware transpose read).
+//   dblk: which 32 of the 64 feature columns;  ks: 16-key step (0..3)
+//   element j of lane (r = lane & 31, h = lane >> 5) = tile[key = 16*ks + 8*(j>>2) + 4*h + (j&3)][d = 32*dblk + r]
+template <typename T>
+__device__ __forceinline__ typename elem_traits<T>::vec8 read_tr_frag(const char* lds, int dblk, int ks, int lane) {
+    const int h = lane >> 5, g1 = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+    union { s16x4 v[2]; typename elem_traits<T>::vec8 f; } u;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int key = 16 * ks + 8 * hh + 4 * h + q;
+        const int c = dblk * 4 + g1 * 2 + (p >> 1);
+        const int off = img_off(key, c) + (p & 1) * 8;
+        u.v[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off));
+    }
+    return u.f;
+}
+
+// accumulator registers 8*s .. 8*s+7 -> 16-bit B fragment of k-step s (k order matches read_tr_frag)
+template <typename T>
+__device__ __forceinline__ typename elem_traits<T>::vec8 acc_to_frag(const f32x16& a, int s) {
+    typename elem_traits<T>::vec8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = elem_traits<T>::from_f32(a[8 * s + j]);
+    return f;
+}
+
+__device__ __forceinline__ int acc_key(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// bijective XCD-aware remap of a 1-D grid: blocks that land on one XCD (id % 8) get a contiguous chunk
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}

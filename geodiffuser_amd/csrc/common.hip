@@ -1,0 +1,25 @@
+// Error plumbing + version for libgeodiff_hip.so (include/geodiff_hip.h).
+#include "common.hpp"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void gd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int gd_version(void) { return GD_ABI_VERSION; }
+extern "C" const char* gd_last_error(void) { return g_err; }
+extern "C" const char* gd_error_string(int code) {
+    switch (code) {
+        case GD_OK: return "ok";
+        case GD_EINVAL: return "invalid argument";
+        case GD_EWORKSPACE: return "workspace too small";
+        case GD_ELAUNCH: return "kernel launch failed";
+        case GD_EUNSUPPORTED: return "unsupported configuration";
+        default: return "unknown error";
+    }
+}

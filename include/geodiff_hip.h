@@ -1,0 +1,209 @@
+/*
+ * geodiff_hip.h — C ABI of libgeodiff_hip.so (hand-written HIP kernels for gfx950 / MI355X).
+ *
+ * Drop-in boundary for GeoDiffuser's geometry-guided attention-sharing hot path.  The reference has
+ * no FFI of its own (it is pure Python on torch + pytorch3d); each entry point below replaces the
+ * torch / pytorch3d op sequence cited next to it (paths relative to the reference root,
+ * U/ = GeoDiffuser/utils/).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns GD_OK (0) or a negative GD_E* code; nothing throws across the ABI;
+ *     gd_last_error() gives a thread-local message for the last failure on this thread.
+ *   - all buffers are CALLER-OWNED DEVICE pointers (e.g. torch Tensor.data_ptr()), contiguous in the
+ *     documented layout; the library never allocates, never frees and never synchronises.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Calls are asynchronous,
+ *     stateless and re-entrant per stream, and are safe to capture in a hipGraph.
+ *   - `dtype` selects the 16-bit storage type of feature tensors: GD_F16 or GD_BF16 (GD_F32 where
+ *     noted).  Accumulation is always binary32.
+ */
+#ifndef GEODIFF_HIP_H
+#define GEODIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GD_ABI_VERSION 1
+
+enum { GD_F16 = 0, GD_BF16 = 1, GD_F32 = 2 };
+enum { GD_TOKEN_MAJOR = 0 /* [B, P, C] */, GD_CHANNEL_MAJOR = 1 /* [B, C, P] */ };
+
+enum {
+    GD_OK = 0,
+    GD_EINVAL = -1,      /* bad argument (null pointer, unsupported size / dtype) */
+    GD_EWORKSPACE = -2,  /* workspace too small */
+    GD_ELAUNCH = -3,     /* HIP launch failure (message in gd_last_error) */
+    GD_EUNSUPPORTED = -4
+};
+
+int gd_version(void);
+const char* gd_last_error(void);
+const char* gd_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * R3  point splat.   Replaces pytorch3d rasterize_points + compositing.alpha_composite as called by
+ *     RasterizePointsXYsBlending.forward (U/warp_utils.py:72-176) / warp_grid_edit (:798-825).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Bytes of scratch gd_rasterize_points needs for P points on an S x S grid. */
+size_t gd_rasterize_workspace_bytes(int P, int S, float radius_ndc);
+
+/*
+ * U/warp_utils.py:111  rasterize_points(Pointclouds(pts), S, radius_ndc, K) for ONE cloud.
+ *   pts   [P,3] f32  (x,y,z) in the rasterizer's convention (x,y already negated, :90-91)
+ *   idx   [S,S,K] i32  point index or -1       (the bit-exact "integer warp-index grid")
+ *   zbuf  [S,S,K] f32  (may be NULL)           dist2 [S,S,K] f32
+ * Semantics: pixel (row,col) centre at NDC (1-(2col+1)/S, 1-(2row+1)/S); hit iff dist2 < r^2 and
+ * z >= 0; K nearest in z, ascending, ties as documented in DESIGN.md ("Splat semantics" A1-A7).
+ */
+int gd_rasterize_points(const float* pts, int P, int S, float radius_ndc, int K,
+                        int32_t* idx, float* zbuf, float* dist2,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * U/warp_utils.py:131-140 + the compositor's transmittance:  alpha_k = (1-clamp(d2/r^rad_pow,1e-3,1)^.5)^tau,
+ *   w[pix,k] = alpha_k * prod_{j<k}(1-alpha_j)   (0 for empty slots).   w [npix,K] f32.
+ */
+int gd_splat_weights(const int32_t* idx, const float* dist2, int npix, int K,
+                     float radius_ndc, float rad_pow, float tau, float* w, void* stream);
+
+/*
+ * U/warp_utils.py:156-176 (alpha_composite, result rounded through fp16) fused with the blend of
+ * U/attention_processors.py:424,544:
+ *     out = src * (1 - m) + m * half(sum_k w[pix,k] * src[idx[pix,k]])        (m == NULL: out = half(sum))
+ *   src/out: B clouds that share ONE idx/w table; layout GD_TOKEN_MAJOR [B,P,C] (attention queries,
+ *   P == npix) or GD_CHANNEL_MAJOR [B,C,P] (latents / masks / images).  m [npix] f32.
+ */
+int gd_splat_composite(const void* src, const int32_t* idx, const float* w, const float* m,
+                       int B, int P, int C, int npix, int K, int layout, void* out, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * R5/R6/R7  attention.  Replaces compute_attention (baddbmm + softmax, U/attention_sharing.py:30-47)
+ *     followed by torch.bmm(attn, v) (U/attention_processors.py:428,433,549,557,644,647) without ever
+ *     materialising the [BH,N,M] map.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* q;   /* [bh, N, D] */
+    const void* k;   /* [bh, M, D] */
+    const void* v;   /* [bh, M, D] */
+    void* out;       /* [bh, N, D] */
+    float* lse;      /* [bh, N]  natural-log sum-exp of the scaled scores (may be NULL) */
+    int32_t bh;      /* batch*heads entries in this segment */
+    int32_t pad_;
+} gd_attn_seg_t;
+
+#define GD_ATTN_MAX_SEGS 4
+
+/* out = softmax(scale * q k^T) v for up to GD_ATTN_MAX_SEGS independent segments in ONE launch
+ * (vanilla rows, edit_out with warped queries, replace_out) that share N, M, D.  D must be 64. */
+int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int dtype, void* stream);
+
+/*
+ * Backward of out = softmax(scale q k^T) v w.r.t. q (always) and k (dk_f32 != NULL).
+ *   dout [BH,N,D] 16-bit; lse from the forward; dq [BH,N,D] 16-bit (overwritten);
+ *   dk_f32 [BH,M,D] f32, ACCUMULATED into (caller zeroes) — used by cross-attention where k_edit
+ *   carries gradient (U/attention_processors.py:432).  v never receives gradient on this path
+ *   (v_base.detach(), :433,557).
+ */
+int gd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
+                const void* dout, int BH, int N, int M, int D, float scale,
+                void* dq, float* dk_f32, int dtype, void* stream);
+
+/* P[bh, r, m] = exp(scale * q[bh, rows[r]] . k[bh, m] - lse[bh, rows[r]])   (rows == NULL: r = row)
+ * The opt-pass materialisation of base_att / replace_att rows that removal_loss_geodiff consumes
+ * (U/attention_processors.py:250, 307-317).  P is 16-bit [BH, R, Mpad], Mpad = multiple of 8 >= M,
+ * padding columns are written as 0. */
+int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t* rows,
+                  int BH, int N, int R, int M, int Mpad, int D, float scale, void* P, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * R8  losses.
+ * ---------------------------------------------------------------------------------------------- */
+
+/*
+ * removal_loss_geodiff forward (U/attention_processors.py:248-268):
+ *   corr[h,r,j] = sum_m Pe[h,r,m] * Pb[h,j,m];  (p_in,j_in) = max_j corr*m_inp[j];  (p_wo,j_wo) = max_j corr*m_wo[j]
+ * Pe [H,R,Mpad], Pb [H,N,Mpad] 16-bit; m_inp, m_wo [N] f32; outputs p_in,p_wo [H,R] f32, j_in,j_wo [H,R] i32
+ * (first index on ties).  The scalar loss is assembled by gd_removal_loss_reduce.
+ */
+int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo,
+                        int H, int R, int N, int Mpad, float* p_in, int32_t* j_in, float* p_wo, int32_t* j_wo,
+                        int dtype, void* stream);
+
+/* loss_acc[0] += sum_{h,r} exp(-dist(rows[r], j_wo)) * (-log(p_wo+1e-4) + log(p_in+1e-4));  also writes
+ * wgt[h,r] = exp(-dist) (f32) for the backward.  dist = CoordinateDistances (U/generic_torch.py:126-140)
+ * evaluated analytically on the S x S grid. */
+int gd_removal_loss_reduce(const float* p_in, const float* p_wo, const int32_t* j_wo, const int32_t* rows,
+                           int H, int R, int S, float* wgt, float* loss_acc, void* stream);
+
+/*
+ * Backward of the removal loss through replace_att rows into q (and k for cross):
+ *   dA[h,r,m] = coef * wgt[h,r] * ( -Pb[h,j_wo,m] * m_wo[j_wo]/(p_wo+1e-4) + Pb[h,j_in,m] * m_inp[j_in]/(p_in+1e-4) )
+ *   dS = A o (dA - rowsum(A o dA));  dq[h,rows[r]] += scale * dS K;  dk_f32[h] += scale * dS^T q   (dk_f32 may be NULL)
+ * dq_f32 [H,N,D] f32 accumulated (caller zeroes).
+ */
+int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
+                   const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
+                   const float* wgt, const float* m_inp, const float* m_wo, float coef,
+                   int H, int R, int N, int M, int Mpad, int D, float scale,
+                   float* dq_f32, float* dk_f32, int dtype, void* stream);
+
+/*
+ * interpolate_from_mask + overwrite + 5x5 gaussian (U/attention_sharing.py:67-105,
+ * U/attention_processors.py:291-293, U/generic_torch.py:145-154): the amodal-loss target.
+ *   eo [H,N,D] 16-bit; nn_idx [N,4] i32, nn_w [N,4] f32 (precomputed from the mask per edit);
+ *   fg [N] f32 (mask_edit > 0.5 rows keep eo); tmp, target [H,N,D] f32.
+ */
+int gd_amodal_target(const void* eo, const int32_t* nn_idx, const float* nn_w, const float* fg,
+                     int H, int S, int D, float* tmp, float* target, int dtype, void* stream);
+
+/*
+ * The four feature losses in one pass (U/attention_processors.py:231-246,283-305; U/loss.py:29-41).
+ * sums[0] += sum |eo-ro| m_wo      sums[1] += sum |eo-ro| m_edit      sums[2] += sum |tgt-ro| w_am m_amodal
+ * sums[3] += sum |ro[y+1]-ro[y]|   sums[4] += sum |ro[x+1]-ro[x]|      (tgt/w_am/m_amodal may be NULL)
+ */
+int gd_edit_losses_fwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
+                       const float* w_am, const float* m_amodal, int H, int S, int D, float* sums, int dtype, void* stream);
+
+/*
+ * d(loss)/d(ro) for the weighted sum of those losses plus the blend path:
+ *   g = c[0]*(-sgn(eo-ro)) m_wo + c[1]*(-sgn(eo-ro)) m_edit + c[2]*(-sgn(tgt-ro)) w_am m_amodal
+ *     + c[3]*d|D_h| + c[4]*d|D_w| + gout * (blend ? (1-m_edit) : 1)
+ * c[5] host coefficients (loss weight * upstream grad / denominator); gout [H,N,D] 16-bit (may be NULL);
+ * dro [H,N,D] 16-bit.
+ */
+int gd_edit_losses_bwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
+                       const float* w_am, const float* m_amodal, const void* gout, const float* c, int blend,
+                       int H, int S, int D, void* dro, int dtype, void* stream);
+
+/* out = a*m + b*(1-m) per token (U/attention_processors.py:504,619); m [N] f32; a,b,out [H,N,D]. */
+int gd_blend_tokens(const void* a, const void* b, const float* m, int H, int N, int D, void* out, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * R10-R12  scheduler / latent arithmetic (f32 or 16-bit latents, n elements).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* eps = eps_u + g*(eps_c-eps_u) (U/diffusion.py:45-46) then the DDIM closed form (U/inversion.py:47-65):
+ *   x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t);  out = sqrt(a_to) x0 + sqrt(1-a_to) eps.
+ * a_t/a_to are the alphas_cumprod at the source / destination timestep (denoise: t -> t-20; invert: t-20 -> t).
+ * eps_c == NULL: eps = eps_u (no CFG). */
+int gd_ddim_step(const void* x, const void* eps_u, const void* eps_c, float guidance, float a_t, float a_to,
+                 void* out, int64_t n, int dtype, void* stream);
+
+/* U/optimization.py:228-231: x1 <- x1 - step*(1+m)*nan_to_num(g)  (the two chained updates), m [hw] f32
+ * broadcast over C channels; x, g, out f32 [C*hw]. */
+int gd_masked_latent_update(const float* x, const float* g, const float* m, float step, int C, int hw,
+                            float* out, void* stream);
+
+/* U/editor.py:219,316: sumsq[0] += sum x^2 (f32, caller zeroes);  gd_scale: out = x * s[0]/s[1] style rescale is
+ * done by the host from two sumsq results: out = x * sqrt(num[0]+1e-12)/sqrt(den[0]+1e-12). */
+int gd_sumsq(const float* x, int64_t n, float* sumsq, void* stream);
+int gd_norm_rescale(const float* x, const float* num_sumsq, const float* den_sumsq, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEODIFF_HIP_H */

@@ -1,0 +1,496 @@
+"""Attention processors and the geometry-edit controllers — the drop-in boundary of the hot path.
+
+Mirror of the reference's GeoDiffuser/utils/attention_processors.py: same class names (the driver dispatches on
+``type(controller).__name__``), constructor signatures, public state (``loss``, ``loss_log_dict``,
+``loss_weight_dict``, ``default_loss_weights``, ``mask_new_warped``, ``amodal_mask``, ``image_mask``, ``cur_step``,
+``num_att_layers``, ``coords_base``, ``coords_edit``, ``use_cfg``, ``store_attention_maps``) and the diffusers
+attention-processor protocol.  The arithmetic of one hooked layer call —
+
+    vanilla rows, q_warp = blend(q_base, splat(q_base)), edit_out, replace_out, the five losses, the blend —
+
+runs as a handful of HIP launches inside one ``torch.autograd.Function`` (``_EditLayer``), so the UNet's own autograd
+graph stays in PyTorch while no ``[f, N, N]`` map, correlation tensor or per-loss temporary is created.
+
+Exactness notes (all derived from the reference's own code):
+  * the reference rows never receive gradient: everything taken from them is detached before it enters a loss
+    (attention_sharing.py:242, attention_processors.py:428,433,549,555-557,250,309), and their vanilla output feeds
+    only their own sample, so d loss / d(reference rows) is exactly zero in the reference too;
+  * the point rasterisation is cached per resolution (the reference recomputes an identical result on every call,
+    SURVEY.md F3), the 4-NN table of the amodal loss per edit (it depends on the mask only).
+"""
+from __future__ import annotations
+
+import abc
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from . import warp_utils
+from ._lib import GD_TOKEN_MAJOR
+from .attention_sharing import AttentionStore, attention, compute_attention, get_base_edit_qkv
+from .generic_torch import (CoordinateDistances, binarize_tensor, reshape_attention_mask,
+                            reshape_transform_coords, torch_dilate)
+
+try:  # pragma: no cover - diffusers is optional (absent in the build image)
+    from diffusers.models.attention_processor import USE_PEFT_BACKEND
+except Exception:  # noqa: BLE001
+    USE_PEFT_BACKEND = False
+
+DISTANCE_CLASS = CoordinateDistances()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# registration (attention_processors.py:26-67)
+# ---------------------------------------------------------------------------------------------------------
+def register_attention_control_diffusers(model, controller, transform_coords=None):
+    attn_procs = {}
+    cross_att_count = 0
+    for name in model.unet.attn_processors.keys():
+        if name.startswith("mid_block"):
+            place_in_unet = "mid"
+        elif name.startswith("up_blocks"):
+            place_in_unet = "up"
+        elif name.startswith("down_blocks"):
+            place_in_unet = "down"
+        else:
+            continue
+        cross_att_count += 1
+        attn_procs[name] = EditProcessor(transform_coords, controller, place_in_unet)
+    model.unet.set_attn_processor(attn_procs)
+    controller.num_att_layers = cross_att_count
+
+
+def set_attn_processor_for_edit(model, perform_edit=True, coords_base=(2, 3), coords_edit=(3, 4), use_cfg=True):
+    for name in model.unet.attn_processors.keys():
+        proc = model.unet.attn_processors[name]
+        proc.perform_edit = perform_edit
+        proc.controller.coords_base = coords_base
+        proc.controller.coords_edit = coords_edit
+        proc.controller.use_cfg = use_cfg
+
+
+def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale):
+    """Shared front half of both processors (attention_processors.py:85-120 / :165-203)."""
+    args = () if USE_PEFT_BACKEND else (scale,)
+    if getattr(attn, "spatial_norm", None) is not None:
+        hidden_states = attn.spatial_norm(hidden_states, temb)
+    input_ndim = hidden_states.ndim
+    shape4 = None
+    if input_ndim == 4:
+        shape4 = hidden_states.shape
+        b, c, hh, ww = shape4
+        hidden_states = hidden_states.view(b, c, hh * ww).transpose(1, 2)
+    if getattr(attn, "group_norm", None) is not None:
+        hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
+    lin_args = args if getattr(attn, "linear_takes_scale", False) else ()
+    query = attn.to_q(hidden_states, *lin_args)
+    is_cross = True
+    if encoder_hidden_states is None:
+        encoder_hidden_states = hidden_states
+        is_cross = False
+    elif getattr(attn, "norm_cross", None):
+        encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
+    key = attn.to_k(encoder_hidden_states, *lin_args)
+    value = attn.to_v(encoder_hidden_states, *lin_args)
+    query = attn.head_to_batch_dim(query).contiguous()
+    key = attn.head_to_batch_dim(key).contiguous()
+    value = attn.head_to_batch_dim(value).contiguous()
+    return query, key, value, is_cross, shape4, lin_args
+
+
+def _finish(attn, hidden_states, residual, shape4, lin_args):
+    hidden_states = attn.batch_to_head_dim(hidden_states)
+    hidden_states = attn.to_out[0](hidden_states, *lin_args)
+    hidden_states = attn.to_out[1](hidden_states)
+    if shape4 is not None:
+        b, c, hh, ww = shape4
+        hidden_states = hidden_states.transpose(-1, -2).reshape(b, c, hh, ww)
+    if getattr(attn, "residual_connection", False):
+        hidden_states = hidden_states + residual
+    return hidden_states / getattr(attn, "rescale_output_factor", 1.0)
+
+
+class VanillaAttentionProcessor:
+    """attention_processors.py:69-139 (used for inversion and after an edit)."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale: float = 1.0):
+        residual = hidden_states
+        q, k, v, _, shape4, lin_args = _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale)
+        out = attention(q, k, v, attn.scale)
+        return _finish(attn, out, residual, shape4, lin_args)
+
+
+class EditProcessor:
+    """attention_processors.py:141-228."""
+
+    def __init__(self, transform_coords, controller, place_in_unet="down", perform_edit=True, coords_base=(2, 3),
+                 coords_edit=(3, 4), use_cfg=True):
+        self.transform_coords = transform_coords
+        self.place_in_unet = place_in_unet
+        self.perform_edit = perform_edit
+        self.controller = controller
+        self.controller.use_cfg = use_cfg
+        self.controller.coords_base = coords_base
+        self.controller.coords_edit = coords_edit
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale: float = 1.0):
+        residual = hidden_states
+        q, k, v, is_cross, shape4, lin_args = _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale)
+        if self.perform_edit:
+            out = self.controller(q, k, v, is_cross=is_cross, place_in_unet=self.place_in_unet,
+                                  transform_coords=self.transform_coords, scale=attn.scale, mask=None)
+        else:
+            out = attention(q, k, v, attn.scale)
+        return _finish(attn, out, residual, shape4, lin_args)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# masks (attention_processors.py:319-373)
+# ---------------------------------------------------------------------------------------------------------
+def process_and_cache_masks(masks_cache_dict, h, image_mask, mask_new_warped, amodal_mask, transform_coords, q_base,
+                            q_edit_base, coords_dtype=None):
+    """Same contract as the reference.  ``coords_dtype``: dtype the resampled coordinates are rounded through
+    (the reference's ``.type_as(q_edit_base)`` — fp16 on its GPU path); default = dtype of ``q_edit_base``."""
+    names = ["mask_new_warped", "mask_warp", "amodal_mask", "mask_intersection", "mask_1_empty", "mask_wo_edit", "t_coords_q"]
+    if h in masks_cache_dict:
+        c = masks_cache_dict[h]
+        return (masks_cache_dict, image_mask, *[c[n].detach() for n in names])
+    masks_cache_dict[h] = {}
+    dev = q_base.device
+    S = int(np.sqrt(q_base.shape[2]))
+    image_mask = image_mask.to(dev).float().detach()
+    amodal_mask = amodal_mask.to(dev).float().detach()
+    mask_new_warped = mask_new_warped.to(dev).float()
+    mask_warp = binarize_tensor(image_mask)[:, None]
+    mask_new_warped = reshape_attention_mask(mask_new_warped, in_mat_shape=(1, S))[1:]
+    mask_warp = reshape_attention_mask(mask_warp, in_mat_shape=(1, S))[1:]
+    amodal_mask = reshape_attention_mask(amodal_mask, in_mat_shape=(1, S))
+    amodal_mask = binarize_tensor(amodal_mask - mask_new_warped).detach()
+    mask_intersection = binarize_tensor((mask_new_warped + amodal_mask) * mask_warp, 0.5)
+    mask_1_empty = binarize_tensor(mask_warp - mask_intersection, 0.5)
+    mask_wo_edit = binarize_tensor(torch.ones_like(mask_new_warped) - (mask_1_empty + mask_new_warped))
+    cd = coords_dtype if coords_dtype is not None else q_edit_base.dtype
+    t_coords_q = reshape_transform_coords(transform_coords.to(dev).float(), in_mat_shape=q_edit_base.shape)
+    t_coords_q = t_coords_q.to(cd).tile(q_edit_base.shape[0], 1, 1, 1)
+    vals = [mask_new_warped, mask_warp, amodal_mask, mask_intersection, mask_1_empty, mask_wo_edit, t_coords_q]
+    for n, t in zip(names, vals):
+        masks_cache_dict[h][n] = t.detach()
+    return (masks_cache_dict, image_mask, *vals)
+
+
+def _flat(m: torch.Tensor) -> torch.Tensor:
+    return m[0, 0].reshape(-1).float().contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the fused layer
+# ---------------------------------------------------------------------------------------------------------
+class _EditLayer(torch.autograd.Function):
+    """One hooked attention call of AttentionGeometryEdit / AttentionGeometryRemover (forward :633-664 / :931-959 with
+    replace_{self,cross}_attention inlined).  Returns (out [(cb+1)*f, N, D], layer_loss [] f32, terms [5] f32)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, ctrl, is_cross, scale, c):
+        f = c["f"]
+        remover = ctrl._is_remover
+        (b0, b1), (e0, e1) = ctrl.coords_base, ctrl.coords_edit
+        cb = ctrl.coords_base[-1] * f
+        N, D = q.shape[1], q.shape[2]
+        S = c["S"]
+        dev, dt = q.device, q.dtype
+        grad_mode = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        want_losses = (N >= 32 ** 2) and (not ctrl.use_cfg)
+        blend = ctrl.cur_step < int(ctrl.num_steps * ctrl.obj_edit_step)
+
+        q_base, k_base, v_base = q[b0 * f:b1 * f], k[b0 * f:b1 * f], v[b0 * f:b1 * f]
+        q_edit, k_edit, v_edit = q[e0 * f:e1 * f], k[e0 * f:e1 * f], v[e0 * f:e1 * f]
+        out_full = torch.empty(cb + f, N, D, dtype=dt, device=dev)
+        lse_van = torch.empty(cb, N, dtype=torch.float32, device=dev) if want_losses else None
+        segs = [(q[:cb], k[:cb], v[:cb], out_full[:cb], lse_van)]
+        replace_out = torch.empty(f, N, D, dtype=dt, device=dev)
+        lse_e = torch.empty(f, N, dtype=torch.float32, device=dev) if (grad_mode or want_losses) else None
+        ident_out = None
+        if not remover:
+            # q_warp = q_base*(1-m) + m*splat(q_base)                       (:424,544)
+            q_warp = ops.splat_composite(q_base, c["idx"], c["w"], c["m_edit"], GD_TOKEN_MAJOR)
+            edit_out = torch.empty(f, N, D, dtype=dt, device=dev)
+            segs.append((q_warp, k_base, v_base, edit_out, None))           # :427-428,548-549
+            K = k_edit if is_cross else k_base                              # :432 / :555
+        else:
+            edit_out = None                                                 # :786,879 vanilla reference output (below)
+            K = k_base                                                      # :790,882
+            if not blend:                                                   # :793-796,886-888
+                ident_out = torch.empty(f, N, D, dtype=dt, device=dev)
+                segs.append((q_edit, k_edit, v_edit, ident_out, None))
+        segs.append((q_edit, K, v_base, replace_out, lse_e))                # :433,557 / :791,883
+        ops.attn_fwd(segs, scale)
+        if remover:
+            edit_out = out_full[b0 * f:b1 * f].clone() if want_losses else out_full[b0 * f:b1 * f]
+
+        terms = torch.zeros(5, dtype=torch.float32, device=dev)            # sim, movement, removal, smoothness, amodal
+        loss = torch.zeros((), dtype=torch.float32, device=dev)
+        Pe = Pb = aux = tgt = None
+        coefs = [0.0] * 5
+        rm_coef = 0.0
+        if want_losses:
+            kind = "cross" if is_cross else "self"
+            lw = ctrl.loss_weight_dict[kind]
+            R = c["rows"].numel()
+            rm = torch.zeros(1, dtype=torch.float32, device=dev)
+            if R > 0:
+                Pb = ops.attn_probs(q_base, k_base, lse_van[b0 * f:b1 * f], None, scale)     # base_att (:307-317)
+                Pe = ops.attn_probs(q_edit, K, lse_e, c["rows"], scale)                      # replace_att[:, inpaint rows]
+                aux, rm = ops.removal_fwd(Pe, Pb, c["m_inp"], c["m_wo"], c["rows"], S)
+                ctrl._last_removal_aux = aux          # diagnostics: arg-max indices / values of this layer
+            use_amodal = (not remover) and N > 32 ** 2                                       # :479-480,596-597
+            if use_amodal:
+                tgt = ops.amodal_target(edit_out, c["nn_idx"], c["nn_w"], c["m_edit"], S)    # :291-293
+            m_edit_l = c["m_edit"] if not remover else c["zeros"]
+            sums = ops.edit_losses_fwd(edit_out, replace_out, tgt, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), S)
+            den_sim = f * D * c["s_wo"] + 1e-8
+            den_mov = f * D * c["s_edit"] + 1e-8
+            den_amo = f * D * c.get("s_am", 0.0) + 1e-8
+            cnt = float(f * S * (S - 1) * D)
+            den_rm = c["s_inp"] * f + 1e-8
+            inv = torch.tensor([1.0 / den_sim, 1.0 / den_mov, 1.0 / den_amo, 1.0 / cnt, 1.0 / cnt], dtype=torch.float32, device=dev)
+            t5 = sums * inv
+            l_rm = rm[0] / den_rm
+            terms = torch.stack([t5[0], t5[1], l_rm, t5[3] + t5[4], t5[2] if use_amodal else t5[1] * 0.0])
+            w_sim, w_rm, w_smo = float(lw["sim"]), float(lw["removal"]), float(lw["smoothness"])
+            w_mov = float(lw.get("movement", 0.0)) if not remover else 0.0
+            w_amo = float(lw.get("amodal", 0.0)) if not remover else 0.0
+            wv = torch.tensor([w_sim, w_mov, w_rm, w_smo, w_amo], dtype=torch.float32, device=dev)
+            loss = (terms * wv).sum()
+            coefs = [w_sim / den_sim, w_mov / den_mov, (w_amo / den_amo) if use_amodal else 0.0, w_smo / cnt, w_smo / cnt]
+            rm_coef = w_rm / den_rm
+
+        # output (:502-508,617-624 / :831-834,922-925)
+        if not remover:
+            if blend:
+                ops.blend_tokens(edit_out, replace_out, c["m_edit"], out=out_full[cb:])
+            else:
+                out_full[cb:].copy_(replace_out)
+        else:
+            if blend:
+                out_full[cb:].copy_(replace_out)            # ro*m_inp + ro*m_wo == ro for complementary binary masks
+            else:
+                ops.blend_tokens(ident_out, replace_out, c["m_inp"], out=out_full[cb:])
+
+        if grad_mode:
+            ctx.save_for_backward(q_edit, K, v_base, replace_out, lse_e, edit_out if want_losses else None, tgt, Pe, Pb)
+            ctx.aux, ctx.c, ctx.coefs, ctx.rm_coef = aux, c, coefs, rm_coef
+            ctx.meta = dict(f=f, cb=cb, e0=e0, e1=e1, is_cross=is_cross, scale=scale, remover=remover, blend=blend,
+                            want_losses=want_losses, q_shape=q.shape, k_shape=k.shape, S=S)
+        ctx.mark_non_differentiable(terms)
+        return out_full, loss, terms
+
+    @staticmethod
+    def backward(ctx, g_out, g_loss, _g_terms):
+        q_edit, K, v_base, replace_out, lse_e, edit_out, tgt, Pe, Pb = ctx.saved_tensors
+        m, c = ctx.meta, ctx.c
+        f, cb, S = m["f"], m["cb"], m["S"]
+        dev, dt = q_edit.device, q_edit.dtype
+        if m["remover"] and not m["blend"]:
+            raise NotImplementedError("gradient through the remover's identity attention (cur_step >= obj_edit_step) is "
+                                      "never taken by the reference driver (optimize_steps <= obj_edit_step)")
+        gout = g_out[cb:].contiguous() if g_out is not None else None
+        gscale = g_loss.reshape(1).float().contiguous() if (m["want_losses"] and g_loss is not None) else None
+        have_loss = m["want_losses"] and gscale is not None
+        eo = edit_out if edit_out is not None else replace_out
+        m_edit_l = c["m_edit"] if not m["remover"] else c["zeros"]
+        dro = ops.edit_losses_bwd(eo, replace_out, tgt if have_loss else None, c["m_wo"], m_edit_l, c.get("w_dist"),
+                                  c.get("m_amodal"), gout, ctx.coefs if have_loss else [0.0] * 5, gscale,
+                                  blend=(m["blend"] and not m["remover"]), S=S)
+        dq16, dk32 = ops.attn_bwd(q_edit, K, v_base, replace_out, lse_e, dro, m["scale"], need_dk=m["is_cross"] and not m["remover"])
+        dq = dq16
+        if have_loss and Pe is not None:
+            dq32 = torch.zeros(q_edit.shape, dtype=torch.float32, device=dev)
+            ops.removal_bwd(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], ctx.rm_coef, gscale, m["scale"], dq32, dk32)
+            dq = (dq16.float() + dq32).to(dt)
+        grad_q = torch.zeros(m["q_shape"], dtype=dt, device=dev)
+        grad_q[m["e0"] * f:m["e1"] * f] = dq
+        grad_k = None
+        if dk32 is not None:
+            grad_k = torch.zeros(m["k_shape"], dtype=dt, device=dev)
+            grad_k[m["e0"] * f:m["e1"] * f] = dk32.to(dt)
+        return grad_q, grad_k, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# controllers
+# ---------------------------------------------------------------------------------------------------------
+class _GeometryControllerBase(AttentionStore, abc.ABC):
+    _is_remover = False
+
+    def step_callback(self, x_t, transform_coords=None):
+        if self.local_blend is not None:
+            x_t = self.local_blend(x_t, self.attention_store, transform_coords)
+        return x_t
+
+    def initialize_default_loss_weights(self):
+        # aliases rather than copies, as the reference does (:667-668): the adaptive schedule's in-place updates
+        # therefore also change the "defaults"
+        self.loss_weight_dict = self.default_loss_weights
+
+    def _common_init(self, prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend, controller,
+                     empty_scale, use_all, obj_edit_step, mode):
+        self.mode = mode
+        self.prev_controller = controller
+        self.last_cross_mask = None
+        self.thre = 0.00001
+        self.empty_scale = empty_scale
+        self.use_all = use_all
+        self.loss = 0.0
+        self.batch_size = len(prompts)
+        # get_time_words_attention_alpha (ptp_utils.py:110-128): only its shape/indexing is consumed
+        alpha = torch.zeros(num_steps + 1, len(prompts) - 1, 1, 1, 77)
+        bounds = cross_replace_steps["default_"] if isinstance(cross_replace_steps, dict) else cross_replace_steps
+        if isinstance(bounds, float):
+            bounds = (0.0, bounds)
+        alpha[int(bounds[0] * (num_steps + 1)):int(bounds[1] * (num_steps + 1))] = 1
+        self.cross_replace_alpha = alpha
+        if type(self_replace_steps) is float:
+            self_replace_steps = 0, self_replace_steps
+        self.num_self_replace = int(num_steps * self_replace_steps[0]), int(num_steps * self_replace_steps[1])
+        self.local_blend = local_blend
+        self.mask_inpaint = None
+        self.obj_edit_step = obj_edit_step
+        self.num_steps = num_steps
+        self.mask_new_warped = None
+        self.mask_wo_edit = None
+        self.mask_1_empty = None
+        self.amodal_mask = None
+        self.coords_base = (2, 3)
+        self.coords_edit = (3, 4)
+        self.use_cfg = True
+        self.loss_log_dict = None
+        self.loss_weight_dict = None
+        self.store_attention_maps = False
+        self.masks_cache_dict: Dict[int, dict] = {}
+        # dtype the resampled warp coordinates are rounded through (".type_as(q)" in the reference, whose q is fp16)
+        self.coords_dtype = torch.float16
+
+    # -- per-resolution device tables --------------------------------------------------------------------
+    def _tables(self, S: int, f: int, q: torch.Tensor, transform_coords):
+        c = self.masks_cache_dict.get(S)
+        if c is not None and "f" in c:
+            return c
+        dev = q.device
+        N = S * S
+        q_base_like = torch.empty(1, f, N, 1, device=dev, dtype=q.dtype)
+        q_img_like = torch.empty(f, 1, S, S, device=dev, dtype=q.dtype)
+        if not self._is_remover:
+            if self.mask_new_warped is None:                                   # :390-396,520-526
+                t_m = reshape_transform_coords(transform_coords.to(dev).float(), in_mat_shape=self.image_mask.shape)
+                t_m = t_m.tile(self.image_mask.shape[0], 1, 1, 1).to(self.coords_dtype)
+                self.mask_new_warped = binarize_tensor(
+                    warp_utils.warp_grid_edit(self.image_mask[:, None].to(dev).float(), t_m)).detach()
+            res = process_and_cache_masks(self.masks_cache_dict, S, self.image_mask, self.mask_new_warped.detach(),
+                                          self.amodal_mask, transform_coords, q_base_like, q_img_like,
+                                          coords_dtype=self.coords_dtype)
+            self.masks_cache_dict, self.image_mask = res[0], res[1]
+            m_new, mask_warp, amodal, inter, m_empty, m_wo, t_q = res[2:]
+            c = self.masks_cache_dict[S]
+            c["m_edit"] = _flat(m_new)
+            c["m_amodal"] = _flat(amodal)
+            c["idx"], c["w"] = warp_utils.SPLATTER.tables(t_q[0].reshape(-1, 3))
+        else:
+            self.image_mask = self.image_mask.to(dev).float().detach()         # :758,852
+            mask_warp = binarize_tensor(self.image_mask)[:, None]
+            mask_warp = reshape_attention_mask(mask_warp, in_mat_shape=(1, S))[1:]
+            m_empty = binarize_tensor(mask_warp, 0.5)                          # :765,858
+            m_wo = binarize_tensor(torch.ones_like(mask_warp) - m_empty)       # :775,867
+            c = self.masks_cache_dict.setdefault(S, {})
+            c["mask_1_empty"], c["mask_wo_edit"] = m_empty, m_wo
+        c["m_inp"] = _flat(m_empty)
+        c["m_wo"] = _flat(m_wo)
+        c["zeros"] = torch.zeros(N, dtype=torch.float32, device=dev)
+        c["rows"] = torch.nonzero(c["m_inp"] > 0.5).reshape(-1).to(torch.int32).contiguous()
+        sums = [c["m_wo"].sum(), c["m_inp"].sum()]
+        if not self._is_remover:
+            sums.append(c["m_edit"].sum())
+            if N > 32 ** 2:
+                c["nn_idx"], c["nn_w"], c["w_dist"] = ops.nn_table(c["m_edit"], S)
+                sums.append((c["w_dist"] * c["m_amodal"]).sum())
+        host = torch.stack(sums).tolist()                                      # one sync per resolution per edit
+        c["s_wo"], c["s_inp"] = host[0], host[1]
+        c["s_edit"] = host[2] if len(host) > 2 else 0.0
+        c["s_am"] = host[3] if len(host) > 3 else 0.0
+        c["S"], c["f"] = S, f
+        if N >= 32 ** 2:                                                       # :413-415,575-576 / :778-780
+            self.mask_wo_edit = m_wo.detach()
+            self.mask_1_empty = m_empty.detach()
+            self.mask_inpaint = m_empty[0, 0].detach().clone()
+        return c
+
+    def forward(self, q, k, v, is_cross: bool, place_in_unet: str, transform_coords=None, scale=None, mask=None):
+        nb = 2 * self.batch_size if self.use_cfg else self.batch_size
+        f = q.shape[0] // nb
+        active = is_cross or (self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1])
+        if not active:
+            return attention(q, k, v, scale)                                   # :646-647
+        if is_cross:
+            _ = self.cross_replace_alpha[self.cur_step]                        # :654 (indexing only; value unused)
+        S = int(math.isqrt(q.shape[1]))
+        c = self._tables(S, f, q, transform_coords)
+        out, loss, terms = _EditLayer.apply(q.contiguous(), k.contiguous(), v.contiguous(), self, is_cross, float(scale), c)
+        if (q.shape[1] >= 32 ** 2) and (not self.use_cfg):
+            kind = "cross" if is_cross else "self"
+            self.loss = self.loss + loss                                       # :494,604 / :822,914
+            log = self.loss_log_dict[kind]
+            named = {"sim": terms[0], "movement": terms[1], "removal": terms[2], "smoothness": terms[3]}
+            for key in log:                                                    # generic.py:34-39
+                log[key] = log[key] + named[key]
+            self.loss_log_dict["num_layers"] += 1
+        return out
+
+
+class AttentionGeometryEdit(_GeometryControllerBase):
+    """attention_processors.py:377-736."""
+
+    def initialize_loss_log_dict(self):
+        self.loss_log_dict = {"self": {"sim": 0.0, "movement": 0.0, "removal": 0.0, "smoothness": 0.0},
+                              "cross": {"sim": 0.0, "movement": 0.0, "removal": 0.0, "smoothness": 0.0},
+                              "num_layers": 0}
+
+    def __init__(self, prompts, num_steps: int, cross_replace_steps, self_replace_steps, equalizer=None, local_blend=None,
+                 controller=None, image_mask=None, empty_scale=0.2, use_all=True, obj_edit_step=0.0, tokenizer=None,
+                 device="cuda:0", mode="bilinear"):
+        super().__init__()
+        self._common_init(prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend, controller,
+                          empty_scale, use_all, obj_edit_step, mode)
+        if image_mask is not None:
+            image_mask = torch.from_numpy(np.asarray(image_mask)[None])
+            self.image_mask = image_mask.tile((len(prompts), 1, 1))
+        self.default_loss_weights = {"self": {"sim": 110, "movement": 13.5, "removal": 1.67, "smoothness": 35.0, "amodal": 80.5},
+                                     "cross": {"sim": 60, "movement": 6.34, "removal": 1.6, "smoothness": 20.0, "amodal": 3.5}}
+        self.initialize_loss_log_dict()
+        self.initialize_default_loss_weights()
+
+
+class AttentionGeometryRemover(_GeometryControllerBase):
+    """attention_processors.py:741-1023."""
+
+    _is_remover = True
+
+    def initialize_loss_log_dict(self):
+        self.loss_log_dict = {"self": {"sim": 0.0, "removal": 0.0, "smoothness": 0.0},
+                              "cross": {"sim": 0.0, "removal": 0.0, "smoothness": 0.0},
+                              "num_layers": 0}
+
+    def __init__(self, prompts, num_steps: int, cross_replace_steps, self_replace_steps, equalizer=None, local_blend=None,
+                 controller=None, image_mask=None, empty_scale=0.2, use_all=True, obj_edit_step=0.0, tokenizer=None,
+                 device="cuda:0", mode="bilinear"):
+        super().__init__()
+        self._common_init(prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend, controller,
+                          empty_scale, use_all, obj_edit_step, mode)
+        if image_mask is not None:
+            image_mask = torch.from_numpy(np.asarray(image_mask)[None]).tile((len(prompts), 1, 1))
+            self.image_mask = torch_dilate(image_mask[:, None].float(), 5)[:, 0]               # :986
+        self.default_loss_weights = {"self": {"sim": 110.0, "removal": 3.6, "smoothness": 35.0},
+                                     "cross": {"sim": 60.0, "removal": 3.6, "smoothness": 20.0}}
+        self.initialize_default_loss_weights()
+        self.initialize_loss_log_dict()

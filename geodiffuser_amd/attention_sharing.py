@@ -1,0 +1,159 @@
+"""AttentionControl / AttentionStore base classes and attention helpers.
+
+Mirror of the reference's GeoDiffuser/utils/attention_sharing.py (same class / function names and counter
+semantics); the arithmetic runs in the HIP flash-attention kernels, so no [B*f, N, M] map is
+materialised unless a caller explicitly asks for one.
+"""
+from __future__ import annotations
+
+import abc
+from typing import Optional
+
+import torch
+
+from . import ops
+
+LOW_RESOURCE = False
+
+
+class _VanillaAttention(torch.autograd.Function):
+    """out = softmax(scale q k^T) v through gd_attn_fwd / gd_attn_bwd.
+
+    Backward returns dQ (and dK for few-key cross-attention).  dV and self-attention dK are not produced:
+    on the GeoDiffuser path every tensor that would receive them is detached (v_base.detach(), k_base.detach(),
+    attention_sharing.py:242; attention_processors.py:433,555-557), so asking for them raises instead of
+    silently returning zeros."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        out = torch.empty_like(q)
+        lse = torch.empty(q.shape[0], q.shape[1], dtype=torch.float32, device=q.device)
+        ops.attn_fwd([(q, k, v, out, lse)], scale)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, out, lse = ctx.saved_tensors
+        need_dk = ctx.needs_input_grad[1]
+        if ctx.needs_input_grad[2]:
+            raise NotImplementedError("gradient w.r.t. v is never needed on the GeoDiffuser path (v is detached)")
+        dq, dk = ops.attn_bwd(q, k, v, out, lse, g.contiguous(), ctx.scale, need_dk)
+        return dq, (dk.to(k.dtype) if dk is not None else None), None, None
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+    """softmax(scale q k^T) v, [BH,N,D] x [BH,M,D] -> [BH,N,D] (HIP, flash-style)."""
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad):
+        return _VanillaAttention.apply(q, k, v.detach(), scale)
+    out = torch.empty_like(q)
+    ops.attn_fwd([(q, k, v, out, None)], scale)
+    return out
+
+
+def compute_attention(q, k, scale, mask=None, fg_mask_warp=None, fg_mask=None, inpaint_mask=None):
+    """attention_sharing.py:30-47: the materialised probability map softmax(scale q k^T), fp32 like the reference's
+    autocast softmax.  The mask arguments are accepted and ignored — they are no-ops in the reference (the masked
+    assignment goes to a temporary).  Only for callers that really want the map (AttentionStore at
+    N <= 16^2); the hot path never calls this."""
+    q, k = q.contiguous(), k.contiguous()
+    BH, N, D = q.shape
+    out = torch.empty_like(q)
+    lse = torch.empty(BH, N, dtype=torch.float32, device=q.device)
+    ops.attn_fwd([(q, k, k, out, lse)], scale)          # only lse is needed; k stands in for v
+    P = ops.attn_probs(q, k, lse, None, scale)
+    return P[:, :, : k.shape[1]].float()
+
+
+def get_base_edit_qkv(q, k, v, batch_size, coords_base=None, coords_edit=None, use_cfg=True):
+    """attention_sharing.py:210-242: [B*f, N, D] -> ([1,f,N,D] base (detached), edit) views."""
+    nb = 2 * batch_size if use_cfg else batch_size
+    h = q.shape[0] // nb
+    q = q.reshape(nb, h, *q.shape[1:])
+    k = k.reshape(nb, h, *k.shape[1:])
+    v = v.reshape(nb, h, *v.shape[1:])
+    q_base, k_base, v_base = (t[coords_base[0]:coords_base[1]] for t in (q, k, v))
+    q_edit, k_edit, v_edit = (t[coords_edit[0]:coords_edit[1]] for t in (q, k, v))
+    return q_base.detach(), k_base.detach(), v_base.detach(), q_edit, k_edit, v_edit
+
+
+class AttentionControl(abc.ABC):
+    """attention_sharing.py:110-153 — layer counter -> step counter, reproduced exactly: ``cur_step`` gates the
+    self-replace window and obj_edit_step, and the driver undoes an optimisation pass with ``cur_step -= 1``."""
+
+    def step_callback(self, x_t, transform_coords):
+        return x_t
+
+    def between_steps(self):
+        return
+
+    @property
+    def num_uncond_att_layers(self):
+        return self.num_att_layers if LOW_RESOURCE else 0
+
+    @abc.abstractmethod
+    def forward(self, q, k, v, is_cross: bool, place_in_unet: str, transform_coords=None, scale=None, mask=None):
+        raise NotImplementedError
+
+    def __call__(self, q, k, v, is_cross: bool, place_in_unet: str, transform_coords=None, scale=None, mask=None):
+        if self.cur_att_layer >= self.num_uncond_att_layers:
+            out = self.forward(q, k, v, is_cross, place_in_unet, transform_coords=transform_coords, scale=scale, mask=mask)
+        self.cur_att_layer += 1
+        if self.cur_att_layer == self.num_att_layers + self.num_uncond_att_layers:
+            self.cur_att_layer = 0
+            self.cur_step += 1
+            self.between_steps()
+        return out
+
+    def reset(self):
+        self.cur_step = 0
+        self.cur_att_layer = 0
+
+    def __init__(self):
+        self.cur_step = 0
+        self.num_att_layers = -1
+        self.cur_att_layer = 0
+
+
+class AttentionStore(AttentionControl):
+    """attention_sharing.py:158-207.  Maps are kept only for N <= 16^2 ("to avoid memory overhead")."""
+
+    @staticmethod
+    def get_empty_store():
+        return {"down_cross": [], "mid_cross": [], "up_cross": [], "down_self": [], "mid_self": [], "up_self": []}
+
+    def forward(self, q, k, v, is_cross: bool, place_in_unet: str, transform_coords=None, scale=None, mask=None):
+        key = f"{place_in_unet}_{'cross' if is_cross else 'self'}"
+        if q.shape[1] <= 16 ** 2:
+            self.step_store[key].append(compute_attention(q.detach(), k.detach(), scale))
+        return attention(q, k, v, scale)
+
+    def attn_store(self, attn, is_cross: bool, place_in_unet: str):
+        key = f"{place_in_unet}_{'cross' if is_cross else 'self'}"
+        if attn.shape[1] <= 16 ** 2:
+            self.step_store[key].append(attn.detach())
+
+    def between_steps(self):
+        if len(self.attention_store) == 0:
+            self.attention_store = self.step_store
+        else:
+            for key in self.step_store:
+                self.attention_store[key] = self.attention_store[key] + self.step_store[key]
+                if self.cur_step == 1:
+                    self.attention_store["length_" + key] = len(self.step_store[key])
+        self.step_store = self.get_empty_store()
+
+    def get_average_attention(self):
+        return {key: [item / self.cur_step for item in self.attention_store[key]] for key in self.attention_store}
+
+    def reset(self):
+        super().reset()
+        self.step_store = self.get_empty_store()
+        self.attention_store = {}
+
+    def __init__(self):
+        super().__init__()
+        self.step_store = self.get_empty_store()
+        self.attention_store = {}

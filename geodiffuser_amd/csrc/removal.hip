@@ -1,0 +1,255 @@
+// R8 — removal loss (the largest single contraction of the path) and its sparse backward.
+//
+// Replaces removal_loss_geodiff (GeoDiffuser/utils/attention_processors.py:248-280):
+//     corr = bmm(replace_att[:, inpaint rows], base_att^T);  masked row-max x 2;  distance-weighted log ratio.
+// The reference materialises corr [f, n_inp, N] and two masked copies; here corr lives only in MFMA accumulators:
+//   k_corr_max : C^T[j, r] = sum_m Pb[j, m] Pe[r, m] with the inpaint row r on the LANE, so the masked running
+//                max/arg-max over j is lane-local; tiles are combined with one 64-bit atomicMax per (row, mask) on
+//                (value bits << 32 | ~j)  => larger value wins, first index wins ties (torch.max on CPU).
+//   k_reduce   : unpack, exp(-dist) weight from the analytic pixel-centre distance, scalar loss.
+//   k_bwd      : only the two arg-max rows of Pb carry gradient (U/attention_processors.py:259-268); softmax
+//                backward of the n_inp rows and the rank-1 updates of dq / dk.
+// MFMA-bound (k_corr_max): algorithmic FLOPs = 2 * H * R * N * M.
+#include "attn_common.hpp"
+
+#define CM_T 128   // rows of each operand tile
+#define CM_K 64    // k per chunk
+
+struct CorrArgs {
+    const void* Pe; const void* Pb; const float* m_inp; const float* m_wo; unsigned long long* best;
+    int H, R, N, Mpad, rtiles, jtiles;
+};
+
+template <typename T>
+__device__ __forceinline__ void cm_load(const T* __restrict__ base, int row0, int nrows, int k0, int Mpad, int tid, u32x4 (&r)[4]) {
+    const int c = tid & 7;
+    const bool kin = (k0 + c * 8) < Mpad;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = row0 + (tid >> 3) + 32 * i;
+        row = row < nrows ? row : nrows - 1;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        r[i] = kin ? *(const u32x4*)(base + (size_t)row * Mpad + k0 + c * 8) : z;
+    }
+}
+__device__ __forceinline__ void cm_store(char* lds, int tid, const u32x4 (&r)[4]) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4*)(lds + img_off((tid >> 3) + 32 * i, c)) = r[i];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_corr_max(const CorrArgs a) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    __shared__ __attribute__((aligned(16))) char lds[2][2][CM_T * 128];      // [buf][A = Pb rows (j) | B = Pe rows (r)]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int wj = wave >> 1, wr = wave & 1;
+    const int hd = blockIdx.y;
+    const int jt = blockIdx.x / a.rtiles, rt = blockIdx.x - jt * a.rtiles;
+    const int j0 = jt * CM_T, r0 = rt * CM_T;
+    const T* __restrict__ pb = (const T*)a.Pb + (size_t)hd * a.N * a.Mpad;
+    const T* __restrict__ pe = (const T*)a.Pe + (size_t)hd * a.R * a.Mpad;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[x][y][i] = 0.f;
+
+    const int KC = (a.Mpad + CM_K - 1) / CM_K;
+    u32x4 ar[4], br[4];
+    cm_load<T>(pb, j0, a.N, 0, a.Mpad, tid, ar);
+    cm_load<T>(pe, r0, a.R, 0, a.Mpad, tid, br);
+    cm_store(lds[0][0], tid, ar);
+    cm_store(lds[0][1], tid, br);
+    __syncthreads();
+    for (int kc = 0; kc < KC; ++kc) {
+        const int cur = kc & 1;
+        const bool more = (kc + 1) < KC;
+        if (more) {
+            cm_load<T>(pb, j0, a.N, (kc + 1) * CM_K, a.Mpad, tid, ar);
+            cm_load<T>(pe, r0, a.R, (kc + 1) * CM_K, a.Mpad, tid, br);
+        }
+        const char* la = lds[cur][0];
+        const char* lb = lds[cur][1];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            V8 af[2], bf[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                af[x] = read_row_frag<T>(la, wj * 2 + x, s, lane);
+                bf[x] = read_row_frag<T>(lb, wr * 2 + x, s, lane);
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = TR::mfma32(af[x], bf[y], acc[x][y]);
+        }
+        if (more) {
+            cm_store(lds[cur ^ 1][0], tid, ar);
+            cm_store(lds[cur ^ 1][1], tid, br);
+        }
+        __syncthreads();
+    }
+    // masked running max over j (lane-local), r on the lane
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        float b_in = -1.f, b_wo = -1.f;
+        int ji = 0, jw = 0;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int j = j0 + wj * 64 + x * 32 + acc_key(i, h);
+                if (j < a.N) {
+                    const float v = acc[x][y][i];
+                    const float vi = v * a.m_inp[j], vw = v * a.m_wo[j];
+                    if (vi > b_in) { b_in = vi; ji = j; }
+                    if (vw > b_wo) { b_wo = vw; jw = j; }
+                }
+            }
+        unsigned long long pi = b_in >= 0.f ? (((unsigned long long)__float_as_uint(b_in) << 32) | (0xFFFFFFFFu - (unsigned)ji)) : 0ull;
+        unsigned long long pw = b_wo >= 0.f ? (((unsigned long long)__float_as_uint(b_wo) << 32) | (0xFFFFFFFFu - (unsigned)jw)) : 0ull;
+        const unsigned long long oi = __shfl_xor(pi, 32, 64), ow = __shfl_xor(pw, 32, 64);
+        pi = pi > oi ? pi : oi;
+        pw = pw > ow ? pw : ow;
+        const int r = r0 + wr * 64 + y * 32 + (lane & 31);
+        if (h == 0 && r < a.R) {
+            unsigned long long* dst = a.best + ((size_t)hd * a.R + r) * 2;
+            atomicMax(dst, pi);
+            atomicMax(dst + 1, pw);
+        }
+    }
+}
+
+extern "C" int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo,
+                                   int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream) {
+    GD_REQUIRE(Pe && Pb && m_inp && m_wo && best, GD_EINVAL, "gd_removal_corr_max: null pointer");
+    GD_REQUIRE(H > 0 && R > 0 && N > 0 && Mpad > 0 && (Mpad & 7) == 0, GD_EINVAL, "gd_removal_corr_max: bad sizes");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_corr_max: dtype must be f16/bf16");
+    CorrArgs a;
+    a.Pe = Pe; a.Pb = Pb; a.m_inp = m_inp; a.m_wo = m_wo; a.best = best;
+    a.H = H; a.R = R; a.N = N; a.Mpad = Mpad;
+    a.rtiles = (R + CM_T - 1) / CM_T;
+    a.jtiles = (N + CM_T - 1) / CM_T;
+    hipStream_t st = as_stream(stream);
+    (void)hipMemsetAsync(best, 0, (size_t)H * R * 2 * sizeof(unsigned long long), st);
+    dim3 grid(a.rtiles * a.jtiles, H);
+    if (dtype == GD_F16) k_corr_max<f16_t><<<grid, 256, 0, st>>>(a);
+    else k_corr_max<bf16_t><<<grid, 256, 0, st>>>(a);
+    GD_CHECK_LAUNCH("gd_removal_corr_max");
+    return GD_OK;
+}
+
+// pixel-centre distance of CoordinateDistances (U/generic_torch.py:126-140): centres (2i+1)/S - 1
+__device__ __forceinline__ float pix_dist(int a, int b, int S) {
+    const int ya = a / S, xa = a - ya * S, yb = b / S, xb = b - yb * S;
+    const float dx = (float)(2 * (xa - xb)) / (float)S, dy = (float)(2 * (ya - yb)) / (float)S;
+    return sqrtf(dx * dx + dy * dy + 1e-12f);
+}
+
+__global__ void k_removal_reduce(const unsigned long long* __restrict__ best, const int32_t* __restrict__ rows, int H, int R, int S,
+                                 float* __restrict__ p_in, int32_t* __restrict__ j_in, float* __restrict__ p_wo,
+                                 int32_t* __restrict__ j_wo, float* __restrict__ wgt, float* __restrict__ loss_acc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float term = 0.f;
+    if (i < H * R) {
+        const unsigned long long bi = best[(size_t)i * 2], bw = best[(size_t)i * 2 + 1];
+        const float pi = __uint_as_float((unsigned)(bi >> 32)), pw = __uint_as_float((unsigned)(bw >> 32));
+        const int ji = (int)(0xFFFFFFFFu - (unsigned)(bi & 0xFFFFFFFFu)), jw = (int)(0xFFFFFFFFu - (unsigned)(bw & 0xFFFFFFFFu));
+        const int r = i % R;
+        const float w = __expf(-pix_dist(rows[r], jw, S));
+        p_in[i] = pi; j_in[i] = ji; p_wo[i] = pw; j_wo[i] = jw; wgt[i] = w;
+        term = w * (-__logf(pw + 1e-4f) + __logf(pi + 1e-4f));
+    }
+    term = wave_sum(term);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss_acc, term);
+}
+
+extern "C" int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, int H, int R, int S,
+                                      float* p_in, int32_t* j_in, float* p_wo, int32_t* j_wo, float* wgt,
+                                      float* loss_acc, void* stream) {
+    GD_REQUIRE(best && rows && p_in && j_in && p_wo && j_wo && wgt && loss_acc, GD_EINVAL, "gd_removal_loss_reduce: null pointer");
+    GD_REQUIRE(H > 0 && R > 0 && S > 0, GD_EINVAL, "gd_removal_loss_reduce: bad sizes");
+    k_removal_reduce<<<(H * R + 255) / 256, 256, 0, as_stream(stream)>>>(best, rows, H, R, S, p_in, j_in, p_wo, j_wo, wgt, loss_acc);
+    GD_CHECK_LAUNCH("gd_removal_loss_reduce");
+    return GD_OK;
+}
+
+// ---- backward ------------------------------------------------------------------------------------------
+struct RmBwdArgs {
+    const void* Pe; const void* Pb; const void* q; const void* k; const int32_t* rows;
+    const float* p_in; const int32_t* j_in; const float* p_wo; const int32_t* j_wo; const float* wgt;
+    const float* m_inp; const float* m_wo; float coef; const float* gscale;
+    int H, R, N, M, Mpad; float scale; float* dq; float* dk;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_removal_bwd(const RmBwdArgs a) {
+    using TR = elem_traits<T>;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per (head, inpaint row)
+    if (row >= a.H * a.R) return;
+    const int hd = row / a.R, r = row - hd * a.R;
+    const int qrow = a.rows[r];
+    const int ji = a.j_in[row], jw = a.j_wo[row];
+    const float cf = a.gscale ? a.coef * a.gscale[0] : a.coef;
+    const float cw = -cf * a.wgt[row] * a.m_wo[jw] / (a.p_wo[row] + 1e-4f);
+    const float ci = cf * a.wgt[row] * a.m_inp[ji] / (a.p_in[row] + 1e-4f);
+    const T* __restrict__ pe = (const T*)a.Pe + ((size_t)hd * a.R + r) * a.Mpad;
+    const T* __restrict__ pbw = (const T*)a.Pb + ((size_t)hd * a.N + jw) * a.Mpad;
+    const T* __restrict__ pbi = (const T*)a.Pb + ((size_t)hd * a.N + ji) * a.Mpad;
+    const T* __restrict__ kp = (const T*)a.k + (size_t)hd * a.M * ATT_D;
+    // dot = sum_m A dA
+    float dot = 0.f;
+    for (int m = lane; m < a.M; m += 64) {
+        const float A = TR::to_f32(pe[m]);
+        const float dA = cw * TR::to_f32(pbw[m]) + ci * TR::to_f32(pbi[m]);
+        dot = __builtin_fmaf(A, dA, dot);
+    }
+    dot = wave_sum(dot);
+    const float qd = a.dk ? TR::to_f32(((const T*)a.q)[((size_t)hd * a.N + qrow) * ATT_D + lane]) : 0.f;
+    float acc = 0.f;                                               // lane = feature d
+    for (int m0 = 0; m0 < a.M; m0 += 64) {
+        const int m = m0 + lane;
+        float ds = 0.f;
+        if (m < a.M) {
+            const float A = TR::to_f32(pe[m]);
+            const float dA = cw * TR::to_f32(pbw[m]) + ci * TR::to_f32(pbi[m]);
+            ds = A * (dA - dot) * a.scale;
+        }
+        const int lim = (a.M - m0) < 64 ? (a.M - m0) : 64;
+        for (int mm = 0; mm < lim; ++mm) {
+            const float dsm = __shfl(ds, mm, 64);
+            acc = __builtin_fmaf(dsm, TR::to_f32(kp[(size_t)(m0 + mm) * ATT_D + lane]), acc);
+            if (a.dk) atomicAdd(a.dk + ((size_t)hd * a.M + m0 + mm) * ATT_D + lane, dsm * qd);
+        }
+    }
+    a.dq[((size_t)hd * a.N + qrow) * ATT_D + lane] += acc;
+}
+
+extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
+                              const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
+                              const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
+                              int H, int R, int N, int M, int Mpad, int D, float scale,
+                              float* dq_f32, float* dk_f32, int dtype, void* stream) {
+    GD_REQUIRE(Pe && Pb && q && k && rows && p_in && j_in && p_wo && j_wo && wgt && m_inp && m_wo && dq_f32, GD_EINVAL,
+               "gd_removal_bwd: null pointer");
+    GD_REQUIRE(D == ATT_D, GD_EUNSUPPORTED, "gd_removal_bwd: head dim %d unsupported (only 64)", D);
+    GD_REQUIRE(H > 0 && R > 0 && N > 0 && M > 0 && Mpad >= M, GD_EINVAL, "gd_removal_bwd: bad sizes");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_bwd: dtype must be f16/bf16");
+    RmBwdArgs a;
+    a.Pe = Pe; a.Pb = Pb; a.q = q; a.k = k; a.rows = rows; a.p_in = p_in; a.j_in = j_in; a.p_wo = p_wo; a.j_wo = j_wo;
+    a.wgt = wgt; a.m_inp = m_inp; a.m_wo = m_wo; a.coef = coef; a.gscale = gscale_dev; a.H = H; a.R = R; a.N = N; a.M = M; a.Mpad = Mpad;
+    a.scale = scale; a.dq = dq_f32; a.dk = dk_f32;
+    const int blocks = (H * R + 3) / 4;
+    if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, as_stream(stream)>>>(a);
+    else k_removal_bwd<bf16_t><<<blocks, 256, 0, as_stream(stream)>>>(a);
+    GD_CHECK_LAUNCH("gd_removal_bwd");
+    return GD_OK;
+}

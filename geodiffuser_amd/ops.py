@@ -1,0 +1,276 @@
+"""Thin torch <-> C-ABI glue: every function takes/returns CUDA(HIP) tensors and launches one entry point of
+libgeodiff_hip.so on torch's current stream.  No arithmetic happens here; there is no CPU fallback — a CPU
+tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GD_BF16, GD_CHANNEL_MAJOR, GD_F16, GD_F32, GD_TOKEN_MAJOR, GdAttnSeg, check
+
+_DT = {torch.float16: GD_F16, torch.bfloat16: GD_BF16, torch.float32: GD_F32}
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t: torch.Tensor, name: str, dtype=None):
+    if not t.is_cuda:
+        raise _lib.GeodiffError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback), got {t.device}")
+    if not t.is_contiguous():
+        raise _lib.GeodiffError(f"{name}: tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.GeodiffError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _dt16(t: torch.Tensor, name: str) -> int:
+    if t.dtype not in (torch.float16, torch.bfloat16):
+        raise _lib.GeodiffError(f"{name}: expected float16/bfloat16, got {t.dtype}")
+    return _DT[t.dtype]
+
+
+# ---------------------------------------------------------------------------------------------------
+# R3 splat
+# ---------------------------------------------------------------------------------------------------
+def rasterize_points(pts: torch.Tensor, S: int, radius_ndc: float, K: int, want_zbuf: bool = False):
+    """pts [P,3] f32 (x,y negated already) -> idx [S,S,K] i32, dist2 [S,S,K] f32 (, zbuf)."""
+    lib = _lib.load()
+    _need(pts, "pts", torch.float32)
+    P = pts.shape[0]
+    idx = torch.empty(S, S, K, dtype=torch.int32, device=pts.device)
+    dist2 = torch.empty(S, S, K, dtype=torch.float32, device=pts.device)
+    zbuf = torch.empty(S, S, K, dtype=torch.float32, device=pts.device) if want_zbuf else None
+    nbytes = lib.gd_rasterize_workspace_bytes(P, S, radius_ndc)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+    check(lib.gd_rasterize_points(_p(pts), P, S, radius_ndc, K, _p(idx), _p(zbuf), _p(dist2), _p(ws), nbytes, _stream()),
+          "gd_rasterize_points")
+    return (idx, dist2, zbuf) if want_zbuf else (idx, dist2)
+
+
+def splat_weights(idx: torch.Tensor, dist2: torch.Tensor, radius_ndc: float, rad_pow: float = 2.0, tau: float = 1.0):
+    lib = _lib.load()
+    _need(idx, "idx", torch.int32); _need(dist2, "dist2", torch.float32)
+    K = idx.shape[-1]
+    npix = idx.numel() // K
+    w = torch.empty(npix, K, dtype=torch.float32, device=idx.device)
+    check(lib.gd_splat_weights(_p(idx), _p(dist2), npix, K, radius_ndc, rad_pow, tau, _p(w), _stream()), "gd_splat_weights")
+    return w
+
+
+def splat_composite(src: torch.Tensor, idx: torch.Tensor, w: torch.Tensor, m: Optional[torch.Tensor], layout: int,
+                    out: Optional[torch.Tensor] = None):
+    """src [B,P,C] (token-major) or [B,C,P] (channel-major); returns the same shape with P -> npix."""
+    lib = _lib.load()
+    _need(src, "src"); _need(idx, "idx", torch.int32); _need(w, "w", torch.float32)
+    if m is not None:
+        _need(m, "m", torch.float32)
+    K = idx.shape[-1]
+    npix = idx.numel() // K
+    if layout == GD_TOKEN_MAJOR:
+        B, P, C = src.shape
+        shape = (B, npix, C)
+    else:
+        B, C, P = src.shape
+        shape = (B, C, npix)
+    if out is None:
+        out = torch.empty(shape, dtype=src.dtype, device=src.device)
+    check(lib.gd_splat_composite(_p(src), _p(idx), _p(w), _p(m), B, P, C, npix, K, layout, _p(out), _DT[src.dtype], _stream()),
+          "gd_splat_composite")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# R5-R7 attention
+# ---------------------------------------------------------------------------------------------------
+def attn_fwd(segs: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]],
+             scale: float) -> None:
+    """segs: list of (q [bh,N,D], k [bh,M,D], v [bh,M,D], out [bh,N,D], lse [bh,N] | None); one launch."""
+    lib = _lib.load()
+    n = len(segs)
+    arr = (GdAttnSeg * n)()
+    q0, k0 = segs[0][0], segs[0][1]
+    N, D, M = q0.shape[1], q0.shape[2], k0.shape[1]
+    dt = _dt16(q0, "q")
+    for i, (q, k, v, o, lse) in enumerate(segs):
+        for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "out")):
+            _need(t, nm, q0.dtype)
+        if q.shape[1:] != (N, D) or k.shape[1:] != (M, D) or v.shape != k.shape or o.shape != q.shape or k.shape[0] != q.shape[0]:
+            raise _lib.GeodiffError("attn_fwd: segment shapes disagree")
+        if lse is not None:
+            _need(lse, "lse", torch.float32)
+        arr[i] = GdAttnSeg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 0 if lse is None else lse.data_ptr(),
+                           q.shape[0], 0)
+    check(lib.gd_attn_fwd(arr, n, N, M, D, scale, dt, _stream()), "gd_attn_fwd")
+
+
+def attn_bwd(q, k, v, out, lse, dout, scale: float, need_dk: bool):
+    lib = _lib.load()
+    dt = _dt16(q, "q")
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
+        _need(t, nm, q.dtype)
+    _need(lse, "lse", torch.float32)
+    BH, N, D = q.shape
+    M = k.shape[1]
+    dq = torch.empty_like(q)
+    dk = torch.zeros(BH, M, D, dtype=torch.float32, device=q.device) if need_dk else None
+    check(lib.gd_attn_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), BH, N, M, D, scale, _p(dq), _p(dk), dt, _stream()),
+          "gd_attn_bwd")
+    return dq, dk
+
+
+def attn_probs(q, k, lse, rows: Optional[torch.Tensor], scale: float):
+    """-> P [BH, R, Mpad] 16-bit, Mpad = ceil8(M)."""
+    lib = _lib.load()
+    dt = _dt16(q, "q")
+    _need(q, "q"); _need(k, "k", q.dtype); _need(lse, "lse", torch.float32)
+    BH, N, D = q.shape
+    M = k.shape[1]
+    Mpad = (M + 7) // 8 * 8
+    R = N if rows is None else rows.numel()
+    if rows is not None:
+        _need(rows, "rows", torch.int32)
+    P = torch.empty(BH, R, Mpad, dtype=q.dtype, device=q.device)
+    check(lib.gd_attn_probs(_p(q), _p(k), _p(lse), _p(rows), BH, N, R, M, Mpad, D, scale, _p(P), dt, _stream()), "gd_attn_probs")
+    return P
+
+
+# ---------------------------------------------------------------------------------------------------
+# R8 losses
+# ---------------------------------------------------------------------------------------------------
+def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int):
+    """-> dict(p_in, j_in, p_wo, j_wo, wgt [H,R]) and loss_sum [1] f32 (un-normalised)."""
+    lib = _lib.load()
+    dt = _dt16(Pe, "Pe")
+    _need(Pe, "Pe"); _need(Pb, "Pb", Pe.dtype); _need(m_inp, "m_inp", torch.float32); _need(m_wo, "m_wo", torch.float32)
+    _need(rows, "rows", torch.int32)
+    H, R, Mpad = Pe.shape
+    N = Pb.shape[1]
+    dev = Pe.device
+    best = torch.empty(H, R, 2, dtype=torch.int64, device=dev)
+    check(lib.gd_removal_corr_max(_p(Pe), _p(Pb), _p(m_inp), _p(m_wo), H, R, N, Mpad, _p(best), dt, _stream()), "gd_removal_corr_max")
+    p_in = torch.empty(H, R, dtype=torch.float32, device=dev); p_wo = torch.empty_like(p_in); wgt = torch.empty_like(p_in)
+    j_in = torch.empty(H, R, dtype=torch.int32, device=dev); j_wo = torch.empty_like(j_in)
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    check(lib.gd_removal_loss_reduce(_p(best), _p(rows), H, R, S, _p(p_in), _p(j_in), _p(p_wo), _p(j_wo), _p(wgt), _p(loss), _stream()),
+          "gd_removal_loss_reduce")
+    return dict(p_in=p_in, j_in=j_in, p_wo=p_wo, j_wo=j_wo, wgt=wgt), loss
+
+
+def removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, scale: float, dq_f32, dk_f32):
+    lib = _lib.load()
+    dt = _dt16(Pe, "Pe")
+    H, R, Mpad = Pe.shape
+    N, D = q.shape[1], q.shape[2]
+    M = k.shape[1]
+    _need(dq_f32, "dq_f32", torch.float32)
+    check(lib.gd_removal_bwd(_p(Pe), _p(Pb), _p(q), _p(k), _p(rows), _p(aux["p_in"]), _p(aux["j_in"]), _p(aux["p_wo"]),
+                             _p(aux["j_wo"]), _p(aux["wgt"]), _p(m_inp), _p(m_wo), coef, _p(gscale), H, R, N, M, Mpad, D, scale,
+                             _p(dq_f32), _p(dk_f32), dt, _stream()), "gd_removal_bwd")
+
+
+def nn_table(fg, S: int):
+    """fg [N] f32 -> nn_idx [N,4] i32, nn_w [N,4] f32, w_dist [N] f32 (deterministic 4-nearest-foreground table)."""
+    lib = _lib.load()
+    _need(fg, "fg", torch.float32)
+    N = S * S
+    nn_idx = torch.empty(N, 4, dtype=torch.int32, device=fg.device)
+    nn_w = torch.empty(N, 4, dtype=torch.float32, device=fg.device)
+    w_dist = torch.empty(N, dtype=torch.float32, device=fg.device)
+    check(lib.gd_nn_table(_p(fg), S, _p(nn_idx), _p(nn_w), _p(w_dist), _stream()), "gd_nn_table")
+    return nn_idx, nn_w, w_dist
+
+
+def amodal_target(eo, nn_idx, nn_w, fg, S: int):
+    lib = _lib.load()
+    dt = _dt16(eo, "eo")
+    _need(eo, "eo"); _need(nn_idx, "nn_idx", torch.int32); _need(nn_w, "nn_w", torch.float32); _need(fg, "fg", torch.float32)
+    H, N, D = eo.shape
+    tmp = torch.empty(H, N, D, dtype=torch.float32, device=eo.device)
+    tgt = torch.empty_like(tmp)
+    check(lib.gd_amodal_target(_p(eo), _p(nn_idx), _p(nn_w), _p(fg), H, S, D, _p(tmp), _p(tgt), dt, _stream()), "gd_amodal_target")
+    return tgt
+
+
+def edit_losses_fwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int):
+    lib = _lib.load()
+    dt = _dt16(eo, "eo")
+    _need(eo, "eo"); _need(ro, "ro", eo.dtype)
+    H, N, D = eo.shape
+    sums = torch.zeros(5, dtype=torch.float32, device=eo.device)
+    check(lib.gd_edit_losses_fwd(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), H, S, D, _p(sums), dt, _stream()),
+          "gd_edit_losses_fwd")
+    return sums
+
+
+def edit_losses_bwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs: Sequence[float], gscale, blend: bool, S: int):
+    lib = _lib.load()
+    dt = _dt16(eo, "eo")
+    H, N, D = eo.shape
+    dro = torch.empty_like(ro)
+    c = (ctypes.c_float * 5)(*[float(x) for x in coefs])
+    check(lib.gd_edit_losses_bwd(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), _p(gout), c, _p(gscale), int(blend),
+                                 H, S, D, _p(dro), dt, _stream()), "gd_edit_losses_bwd")
+    return dro
+
+
+def blend_tokens(a, b, m, out=None):
+    lib = _lib.load()
+    dt = _dt16(a, "a")
+    _need(a, "a"); _need(b, "b", a.dtype); _need(m, "m", torch.float32)
+    H, N, D = a.shape
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.gd_blend_tokens(_p(a), _p(b), _p(m), H, N, D, _p(out), dt, _stream()), "gd_blend_tokens")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# R10-R12 scheduler / latent arithmetic
+# ---------------------------------------------------------------------------------------------------
+def ddim_step(x, eps_u, eps_c, guidance: float, a_t: float, a_to: float, out=None):
+    lib = _lib.load()
+    _need(x, "x"); _need(eps_u, "eps_u", x.dtype)
+    if eps_c is not None:
+        _need(eps_c, "eps_c", x.dtype)
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.gd_ddim_step(_p(x), _p(eps_u), _p(eps_c), guidance, a_t, a_to, _p(out), x.numel(), _DT[x.dtype], _stream()), "gd_ddim_step")
+    return out
+
+
+def masked_latent_update(x, g, m, step: float):
+    """x, g [C,h,w] f32; m [h*w] f32."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32); _need(g, "g", torch.float32); _need(m, "m", torch.float32)
+    C = x.shape[-3]
+    hw = x.shape[-1] * x.shape[-2]
+    out = torch.empty_like(x)
+    check(lib.gd_masked_latent_update(_p(x), _p(g), _p(m), step, C * (x.numel() // (C * hw)), hw, _p(out), _stream()),
+          "gd_masked_latent_update")
+    return out
+
+
+def sumsq(x):
+    lib = _lib.load()
+    _need(x, "x", torch.float32)
+    acc = torch.zeros(1, dtype=torch.float32, device=x.device)
+    check(lib.gd_sumsq(_p(x), x.numel(), _p(acc), _stream()), "gd_sumsq")
+    return acc
+
+
+def norm_rescale(x, num_sumsq, den_sumsq):
+    lib = _lib.load()
+    _need(x, "x", torch.float32)
+    out = torch.empty_like(x)
+    check(lib.gd_norm_rescale(_p(x), _p(num_sumsq), _p(den_sumsq), x.numel(), _p(out), _stream()), "gd_norm_rescale")
+    return out

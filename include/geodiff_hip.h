@@ -126,30 +126,40 @@ int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t*
 /*
  * removal_loss_geodiff forward (U/attention_processors.py:248-268):
  *   corr[h,r,j] = sum_m Pe[h,r,m] * Pb[h,j,m];  (p_in,j_in) = max_j corr*m_inp[j];  (p_wo,j_wo) = max_j corr*m_wo[j]
- * Pe [H,R,Mpad], Pb [H,N,Mpad] 16-bit; m_inp, m_wo [N] f32; outputs p_in,p_wo [H,R] f32, j_in,j_wo [H,R] i32
- * (first index on ties).  The scalar loss is assembled by gd_removal_loss_reduce.
+ * Pe [H,R,Mpad], Pb [H,N,Mpad] 16-bit (gd_attn_probs); m_inp, m_wo [N] f32.
+ * best [H,R,2] u64 scratch: (value bits << 32 | ~j) for the inpaint / wo-edit mask (first index wins ties);
+ * it is cleared by the call and unpacked by gd_removal_loss_reduce.
  */
 int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo,
-                        int H, int R, int N, int Mpad, float* p_in, int32_t* j_in, float* p_wo, int32_t* j_wo,
-                        int dtype, void* stream);
+                        int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream);
 
-/* loss_acc[0] += sum_{h,r} exp(-dist(rows[r], j_wo)) * (-log(p_wo+1e-4) + log(p_in+1e-4));  also writes
- * wgt[h,r] = exp(-dist) (f32) for the backward.  dist = CoordinateDistances (U/generic_torch.py:126-140)
- * evaluated analytically on the S x S grid. */
-int gd_removal_loss_reduce(const float* p_in, const float* p_wo, const int32_t* j_wo, const int32_t* rows,
-                           int H, int R, int S, float* wgt, float* loss_acc, void* stream);
+/* Unpacks best -> p_in,p_wo [H,R] f32, j_in,j_wo [H,R] i32, writes wgt[h,r] = exp(-dist(rows[r], j_wo)) and
+ * loss_acc[0] += sum_{h,r} wgt * (-log(p_wo+1e-4) + log(p_in+1e-4))      (U/attention_processors.py:262-268).
+ * dist = CoordinateDistances (U/generic_torch.py:126-140) evaluated analytically on the S x S grid. */
+int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, int H, int R, int S,
+                           float* p_in, int32_t* j_in, float* p_wo, int32_t* j_wo, float* wgt,
+                           float* loss_acc, void* stream);
 
 /*
  * Backward of the removal loss through replace_att rows into q (and k for cross):
  *   dA[h,r,m] = coef * wgt[h,r] * ( -Pb[h,j_wo,m] * m_wo[j_wo]/(p_wo+1e-4) + Pb[h,j_in,m] * m_inp[j_in]/(p_in+1e-4) )
  *   dS = A o (dA - rowsum(A o dA));  dq[h,rows[r]] += scale * dS K;  dk_f32[h] += scale * dS^T q   (dk_f32 may be NULL)
- * dq_f32 [H,N,D] f32 accumulated (caller zeroes).
+ * dq_f32 [H,N,D] f32 accumulated (caller zeroes).  gscale_dev: optional DEVICE scalar multiplied into coef (the
+ * upstream gradient of the loss, so that no host sync is needed to read it).
  */
 int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
                    const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
-                   const float* wgt, const float* m_inp, const float* m_wo, float coef,
+                   const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
                    int H, int R, int N, int M, int Mpad, int D, float scale,
                    float* dq_f32, float* dk_f32, int dtype, void* stream);
+
+/*
+ * The mask-only half of interpolate_from_mask (U/attention_sharing.py:81-83,103), once per edit and resolution:
+ * for every pixel of the S x S grid the 4 foreground pixels (fg > 0.5) with the largest 1/(dist*256 + 1e5*bg + 1e-4),
+ * ties resolved (value desc, index asc).  nn_idx [N,4] i32, nn_w [N,4] f32 (those inverse distances),
+ * w_dist [N] f32 = exp(-(1/max_i nn_w)/5).
+ */
+int gd_nn_table(const float* fg, int S, int32_t* nn_idx, float* nn_w, float* w_dist, void* stream);
 
 /*
  * interpolate_from_mask + overwrite + 5x5 gaussian (U/attention_sharing.py:67-105,
@@ -172,12 +182,13 @@ int gd_edit_losses_fwd(const void* eo, const void* ro, const float* tgt, const f
  * d(loss)/d(ro) for the weighted sum of those losses plus the blend path:
  *   g = c[0]*(-sgn(eo-ro)) m_wo + c[1]*(-sgn(eo-ro)) m_edit + c[2]*(-sgn(tgt-ro)) w_am m_amodal
  *     + c[3]*d|D_h| + c[4]*d|D_w| + gout * (blend ? (1-m_edit) : 1)
- * c[5] host coefficients (loss weight * upstream grad / denominator); gout [H,N,D] 16-bit (may be NULL);
+ * c[5] host coefficients (loss weight / denominator), all multiplied by the optional DEVICE scalar gscale_dev[0]
+ * (upstream gradient of the loss); gout [H,N,D] 16-bit (may be NULL);
  * dro [H,N,D] 16-bit.
  */
 int gd_edit_losses_bwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
-                       const float* w_am, const float* m_amodal, const void* gout, const float* c, int blend,
-                       int H, int S, int D, void* dro, int dtype, void* stream);
+                       const float* w_am, const float* m_amodal, const void* gout, const float* c, const float* gscale_dev,
+                       int blend, int H, int S, int D, void* dro, int dtype, void* stream);
 
 /* out = a*m + b*(1-m) per token (U/attention_processors.py:504,619); m [N] f32; a,b,out [H,N,D]. */
 int gd_blend_tokens(const void* a, const void* b, const float* m, int H, int N, int D, void* out, int dtype, void* stream);

@@ -1,0 +1,372 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against the CPU oracle / a torch fp32 reference
+of the same op on the same seeded inputs.
+
+Bars: bit-exact for the integer warp-index grid and every index output; floating point within
+    rel = max|a-b| / max|b|  <=  1e-3  for fp16 storage (the north-star tolerance),  8e-3 for bf16 storage.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import ref_cpu as O
+from _util import rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL16 = 1e-3
+TOLBF = 8e-3
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from geodiffuser_amd import ops as _ops
+    from geodiffuser_amd import _lib
+    _lib.load()
+    return _ops
+
+
+def tol(dtype):
+    return TOL16 if dtype == torch.float16 else TOLBF
+
+
+# ------------------------------------------------------------------------------------------------ R3 raster
+def _raster_both(ops, pts_np, S, rpx, K):
+    r = rpx / S * 2.0
+    ri, rz, rd = O.rasterize_points(torch.from_numpy(pts_np)[None], S, r, K)
+    idx, d2, zb = ops.rasterize_points(torch.from_numpy(pts_np).to(DEV), S, r, K, want_zbuf=True)
+    torch.cuda.synchronize()
+    return (ri[0], rz[0], rd[0]), (idx.cpu(), zb.cpu(), d2.cpu())
+
+
+@pytest.mark.parametrize("S,rpx,K", [(8, 1.3, 15), (16, 2.7, 4), (32, 1.3, 15), (64, 1.3, 15), (48, 1.3, 15), (64, 0.6, 2), (24, 3.9, 32)])
+def test_rasterizer_bit_exact_random_clouds(ops, S, rpx, K):
+    rng = np.random.default_rng(S * 31 + K)
+    P = S * S
+    pts = rng.uniform(-1.15, 1.15, size=(P, 3)).astype(np.float32)
+    pts[:, 2] = np.round(rng.uniform(-0.05, 1.0, size=P) * 16) / 16          # many z ties, some z < 0
+    ref, got = _raster_both(ops, pts, S, rpx, K)
+    for a, b, name in zip(ref, got, ("idx", "zbuf", "dist2")):
+        assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("kind", ["translate", "rotate", "scale"])
+@pytest.mark.parametrize("S", [64, 32, 16, 8])
+def test_rasterizer_bit_exact_on_edit_grids(ops, kind, S):
+    """The grids the controller actually rasterises: 512^2 coords -> bilinear S^2 -> fp16 round trip."""
+    mask = cases.ellipse_mask()
+    coords = torch.from_numpy(cases.make_coords(kind, mask))
+    t = O.reshape_transform_coords(coords, S).half().float()[0].reshape(-1, 3).clone()
+    t[:, :2] = -t[:, :2]
+    ref, got = _raster_both(ops, t.numpy(), S, 1.3, 15)
+    for a, b, name in zip(ref, got, ("idx", "zbuf", "dist2")):
+        assert torch.equal(a, b), name
+    assert int((ref[0] >= 0).sum()) > 0
+
+
+def test_rasterizer_full_size_512_and_degenerate(ops):
+    """BASELINE full size: P = 262144 points on a 512^2 grid (the one-off mask / image warp)."""
+    mask = cases.ellipse_mask()
+    t = torch.from_numpy(cases.make_coords("scale", mask)).half().float()[0].reshape(-1, 3).clone()
+    t[:, :2] = -t[:, :2]
+    ref, got = _raster_both(ops, t.numpy(), 512, 1.3, 15)
+    for a, b, name in zip(ref, got, ("idx", "zbuf", "dist2")):
+        assert torch.equal(a, b), name
+    # degenerate: every point on one pixel (long candidate list -> heap-sort path), and an empty result
+    S = 16
+    pts = np.zeros((S * S, 3), np.float32); pts[:, 2] = np.linspace(1, 0.1, S * S, dtype=np.float32)
+    ref, got = _raster_both(ops, pts, S, 1.3, 15)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    pts[:, 2] = -1.0
+    ref, got = _raster_both(ops, pts, S, 1.3, 15)
+    assert torch.equal(ref[0], got[0]) and int((got[0] >= 0).sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ R3 composite
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_splat_composite_token_major_and_blend(ops, dtype):
+    S, f, D = 32, 3, 64
+    N = S * S
+    mask = cases.ellipse_mask()
+    coords = torch.from_numpy(cases.make_coords("rotate", mask))
+    t = O.reshape_transform_coords(coords, S).half().float()                      # [1,S,S,3]
+    q = torch.from_numpy(cases.make_qkv(3, 1, f, N, N, D)[0]).to(dtype)           # [f,N,D]
+    # oracle: src [f, D, S, S] channel-major, f identical clouds
+    src = q.float().permute(0, 2, 1).reshape(f, D, S, S)
+    ref = O.warp_grid_edit(src, t.tile(f, 1, 1, 1))                               # [f,D,S,S], fp16-rounded
+    pts = t[0].reshape(-1, 3).clone(); pts[:, :2] = -pts[:, :2]
+    r = 1.3 / S * 2.0
+    idx, d2 = ops.rasterize_points(pts.to(DEV), S, r, 15)
+    w = ops.splat_weights(idx, d2, r, 2.0, 1.0)
+    from geodiffuser_amd._lib import GD_TOKEN_MAJOR, GD_CHANNEL_MAJOR
+    out = ops.splat_composite(q.to(DEV), idx, w, None, GD_TOKEN_MAJOR)            # [f,N,D]
+    ref_tok = ref.reshape(f, D, N).permute(0, 2, 1)
+    assert rel_err(out.float().cpu(), ref_tok) < tol(dtype)
+    # fused blend q*(1-m) + m*splat
+    m = O.reshape_attention_mask(torch.from_numpy(mask)[None, None], S)[0, 0].reshape(-1)
+    outb = ops.splat_composite(q.to(DEV), idx, w, m.to(DEV), GD_TOKEN_MAJOR)
+    refb = q.float() * (1 - m)[None, :, None] + m[None, :, None] * ref_tok
+    assert rel_err(outb.float().cpu(), refb) < tol(dtype)
+    # channel-major f32 (latent / mask warp)
+    lat = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 4, N), dtype=np.float32))
+    outc = ops.splat_composite(lat.to(DEV), idx, w, None, GD_CHANNEL_MAJOR)
+    refc = O.warp_grid_edit(lat.reshape(2, 4, S, S), t.tile(2, 1, 1, 1)).reshape(2, 4, N)
+    assert rel_err(outc.cpu(), refc) < 1e-3
+
+
+def test_warp_grid_edit_mask_512(ops):
+    """The one-off 512^2 mask warp of U/editor.py:147-149 reproduces the fixture bit for bit."""
+    from geodiffuser_amd.warp_utils import warp_grid_edit
+    from geodiffuser_amd.generic_torch import binarize_tensor
+    from _util import warped_mask
+    mask = cases.ellipse_mask()
+    for kind in ("translate", "scale"):
+        coords = torch.from_numpy(cases.make_coords(kind, mask))
+        image_mask = torch.from_numpy(mask[None]).tile((2, 1, 1))
+        t = coords.tile(2, 1, 1, 1).half()
+        out = binarize_tensor(warp_grid_edit(image_mask[:, None].to(DEV), t.to(DEV))).float().cpu()
+        assert torch.equal(out, warped_mask(kind)), kind
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _ref_attn(q, k, v, scale):
+    s = torch.einsum("bnd,bmd->bnm", q.double(), k.double()) * scale
+    p = torch.softmax(s, -1)
+    return torch.einsum("bnm,bmd->bnd", p, v.double()), torch.logsumexp(s, -1), p
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("BH,N,M", [(2, 128, 64), (3, 256, 256), (2, 1024, 77), (2, 100, 77), (1, 64, 64), (2, 576, 576), (1, 144, 1)])
+def test_attention_forward(ops, dtype, BH, N, M):
+    torch.manual_seed(N + M)
+    q = (torch.randn(BH, N, 64) * 1.5).to(dtype); k = (torch.randn(BH, M, 64) * 1.5).to(dtype); v = torch.randn(BH, M, 64).to(dtype)
+    out = torch.empty(BH, N, 64, dtype=dtype, device=DEV); lse = torch.empty(BH, N, device=DEV)
+    ops.attn_fwd([(q.to(DEV), k.to(DEV), v.to(DEV), out, lse)], 0.125)
+    ro, rl, _ = _ref_attn(q, k, v, 0.125)
+    assert rel_err(out.float().cpu(), ro) < tol(dtype)
+    assert float((lse.cpu().double() - rl).abs().max()) < 1e-4
+
+
+def test_attention_forward_full_size_and_segments(ops):
+    """BASELINE full size (64^2 tokens, 5 heads) checked against the reference on a row sample, plus a size-independent
+    property: three segments in one launch equal three separate launches bit for bit."""
+    torch.manual_seed(1)
+    f, N = 5, 4096
+    mk = lambda b, n: (torch.randn(b, n, 64, device=DEV) * 1.3).half()
+    q1, q2, q3, k1, k2, v1 = mk(3 * f, N), mk(f, N), mk(f, N), mk(3 * f, N), mk(f, N), mk(3 * f, N)
+    o1 = torch.empty_like(q1); o2 = torch.empty_like(q2); o3 = torch.empty_like(q3)
+    l1 = torch.empty(3 * f, N, device=DEV); l3 = torch.empty(f, N, device=DEV)
+    ops.attn_fwd([(q1, k1, v1, o1, l1), (q2, k2, v1[:f], o2, None), (q3, k2, v1[:f], o3, l3)], 0.125)
+    s1 = torch.empty_like(q1); s2 = torch.empty_like(q2); s3 = torch.empty_like(q3)
+    ops.attn_fwd([(q1, k1, v1, s1, None)], 0.125); ops.attn_fwd([(q2, k2, v1[:f], s2, None)], 0.125); ops.attn_fwd([(q3, k2, v1[:f], s3, None)], 0.125)
+    assert torch.equal(o1, s1) and torch.equal(o2, s2) and torch.equal(o3, s3)
+    rows = torch.arange(7, N, 97)
+    ro, rl, _ = _ref_attn(q1[:, rows].cpu(), k1.cpu(), v1.cpu(), 0.125)
+    assert rel_err(o1[:, rows].float().cpu(), ro) < TOL16
+    assert float((l1[:, rows].cpu().double() - rl).abs().max()) < 1e-4
+    # softmax rows are convex combinations: every output lies inside the value range
+    assert float(o2.float().abs().max()) <= float(v1[:f].float().abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("BH,N,M,need_dk", [(2, 256, 256, False), (2, 1024, 77, True), (1, 200, 77, True), (2, 576, 576, False)])
+def test_attention_backward(ops, dtype, BH, N, M, need_dk):
+    torch.manual_seed(N * 3 + M)
+    q = (torch.randn(BH, N, 64) * 1.2).to(dtype); k = (torch.randn(BH, M, 64) * 1.2).to(dtype); v = torch.randn(BH, M, 64).to(dtype)
+    g = (torch.randn(BH, N, 64) * 0.1).to(dtype)
+    qd, kd, vd, gd = (t.to(DEV) for t in (q, k, v, g))
+    out = torch.empty_like(qd); lse = torch.empty(BH, N, device=DEV)
+    ops.attn_fwd([(qd, kd, vd, out, lse)], 0.125)
+    dq, dk = ops.attn_bwd(qd, kd, vd, out, lse, gd, 0.125, need_dk)
+    q64 = q.double().requires_grad_(True); k64 = k.double().requires_grad_(True)
+    s = torch.einsum("bnd,bmd->bnm", q64, k64) * 0.125
+    o = torch.einsum("bnm,bmd->bnd", torch.softmax(s, -1), v.double())
+    rq, rk = torch.autograd.grad((o * g.double()).sum(), [q64, k64])
+    assert rel_err(dq.float().cpu(), rq) < 3 * tol(dtype)
+    if need_dk:
+        assert rel_err(dk.cpu(), rk) < 3 * tol(dtype)
+
+
+def test_attention_probs(ops):
+    torch.manual_seed(3)
+    for BH, N, M in ((2, 256, 256), (2, 1024, 77), (1, 300, 77)):
+        q = (torch.randn(BH, N, 64) * 1.3).half(); k = (torch.randn(BH, M, 64) * 1.3).half(); v = torch.randn(BH, M, 64).half()
+        qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+        out = torch.empty_like(qd); lse = torch.empty(BH, N, device=DEV)
+        ops.attn_fwd([(qd, kd, vd, out, lse)], 0.125)
+        rows = torch.arange(5, N, 3, dtype=torch.int32)
+        P = ops.attn_probs(qd, kd, lse, rows.to(DEV), 0.125)
+        _, _, p = _ref_attn(q, k, v, 0.125)
+        assert rel_err(P[:, :, :M].float().cpu(), p[:, rows.long()]) < TOL16
+        assert float(P[:, :, M:].float().abs().sum()) == 0.0
+        Pall = ops.attn_probs(qd, kd, lse, None, 0.125)
+        assert rel_err(Pall[:, :, :M].float().cpu(), p) < TOL16
+        # rows of a probability map sum to one
+        assert float((Pall.float().sum(-1) - 1).abs().max()) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def _loss_inputs(S, f, D, seed):
+    N = S * S
+    rng = np.random.default_rng(seed)
+    eo = torch.from_numpy(rng.standard_normal((1, f, N, D), dtype=np.float32)).half().float()
+    ro = torch.from_numpy(rng.standard_normal((1, f, N, D), dtype=np.float32)).half().float()
+    m_edit = torch.from_numpy((rng.random((1, 1, N, 1)) > 0.8).astype(np.float32) * rng.choice([0.25, 0.5, 1.0], size=(1, 1, N, 1)).astype(np.float32))
+    m_wo = torch.from_numpy((rng.random((1, 1, N, 1)) > 0.4).astype(np.float32))
+    m_amo = torch.from_numpy((rng.random((1, 1, N, 1)) > 0.9).astype(np.float32))
+    return eo, ro, m_edit, m_wo, m_amo
+
+
+def test_feature_losses_forward_backward(ops):
+    S, f, D = 32, 2, 64
+    N = S * S
+    eo, ro, m_edit, m_wo, m_amo = _loss_inputs(S, f, D, 7)
+    ro.requires_grad_(True)
+    dist = O.coord_distance(S)
+    l_bg = O.background_preservation_loss(eo, ro, m_wo)
+    l_mv = O.object_placement_loss(eo, ro, m_edit)
+    l_am = O.amodal_loss(eo, ro, m_edit, dist, m_amo)
+    l_sm = O.smoothness_loss(ro)
+    gout = torch.from_numpy(np.random.default_rng(8).standard_normal((1, f, N, D), dtype=np.float32)).half().float() * 0.01
+    wts = (3.0, 2.0, 5.0, 7.0)
+    blend = eo * m_edit + ro * (1 - m_edit)
+    total = wts[0] * l_bg + wts[1] * l_mv + wts[2] * l_am + wts[3] * l_sm + (blend * gout).sum()
+    g_ref = torch.autograd.grad(total, ro)[0]
+
+    fl = lambda m: m.reshape(-1).float().contiguous().to(DEV)
+    eo_d, ro_d = eo[0].half().to(DEV), ro.detach()[0].half().to(DEV)
+    # deterministic 4-nearest-foreground table: exact integer distances, (distance asc, index asc)
+    nn_idx, nn_w, w_dist = ops.nn_table(fl(m_edit), S)
+    yy, xx = np.divmod(np.arange(N), S)
+    r2 = (yy[:, None] - yy[None]) ** 2 + (xx[:, None] - xx[None]) ** 2
+    bgk = (m_edit.reshape(-1).numpy() <= 0.5).astype(np.int64)
+    key = (bgk[None, :] << 40) | (r2.astype(np.int64) << 20) | np.arange(N)[None, :]
+    expect = np.argsort(key, axis=1)[:, :4]
+    assert np.array_equal(nn_idx.cpu().numpy(), expect)
+    # ... which is torch.topk's choice up to equidistant alternatives: the kept inverse distances agree
+    d_new = dist * 512 / 2.0 + 100000 * (1.0 - (m_edit[:1, :1, :, 0] > 0.5) * 1.0)
+    top = torch.topk(1.0 / (d_new + 1e-4), k=4, dim=-1, largest=True, sorted=False)
+    assert rel_err(nn_w.cpu().sort(-1).values, top.values[0].sort(-1).values) < 1e-5
+    # the kernels below are checked with the oracle's own table (the tie choice is an input here)
+    nn_idx, nn_w = top.indices[0].to(torch.int32).contiguous().to(DEV), top.values[0].contiguous().to(DEV)
+    tgt = ops.amodal_target(eo_d, nn_idx, nn_w, fl(m_edit), S)
+    w_dist = w_dist.cpu()
+    interp, w_ref = O.interpolate_from_mask(eo, m_edit, dist)
+    fg = m_edit[0, 0, :, 0] > 0.5
+    interp[:, :, fg] = eo[:, :, fg]
+    tgt_ref = O.smooth_attention_features(interp)
+    assert rel_err(tgt.cpu(), tgt_ref[0]) < 1e-4
+    assert rel_err(w_dist, w_ref[0, 0]) < 1e-6
+    sums = ops.edit_losses_fwd(eo_d, ro_d, tgt, fl(m_wo), fl(m_edit), w_dist.to(DEV), fl(m_amo), S).cpu()
+    den = [f * D * float(m_wo.sum()) + 1e-8, f * D * float(m_edit.sum()) + 1e-8, f * D * float((w_dist * m_amo.reshape(-1)).sum()) + 1e-8]
+    cnt = f * S * (S - 1) * D
+    got = [float(sums[0]) / den[0], float(sums[1]) / den[1], float(sums[2]) / den[2], float(sums[3]) / cnt + float(sums[4]) / cnt]
+    for a, b in zip(got, (l_bg, l_mv, l_am, l_sm)):
+        assert abs(a - float(b)) <= 1e-4 * max(1.0, abs(float(b)))
+    coefs = [wts[0] / den[0], wts[1] / den[1], wts[2] / den[2], wts[3] / cnt, wts[3] / cnt]
+    gscale = torch.ones(1, device=DEV)
+    dro = ops.edit_losses_bwd(eo_d, ro_d, tgt, fl(m_wo), fl(m_edit), w_dist.to(DEV), fl(m_amo), gout[0].half().to(DEV), coefs, gscale, True, S)
+    # sgn() of an L1 term whose argument is below fp16 resolution may flip on isolated elements: L2 metric
+    assert rel_l2(dro.float().cpu(), g_ref[0]) < 2e-3
+    # linearity in the upstream gradient (size-independent property)
+    dro2 = ops.edit_losses_bwd(eo_d, ro_d, tgt, fl(m_wo), fl(m_edit), w_dist.to(DEV), fl(m_amo), None, coefs, gscale * 2, True, S)
+    dro1 = ops.edit_losses_bwd(eo_d, ro_d, tgt, fl(m_wo), fl(m_edit), w_dist.to(DEV), fl(m_amo), None, coefs, gscale, True, S)
+    assert rel_err(dro2.float().cpu(), 2 * dro1.float().cpu()) < 2e-3
+    # blend kernel
+    out = ops.blend_tokens(eo_d, ro_d, fl(m_edit)).float().cpu()
+    assert rel_err(out, blend[0].detach()) < TOL16
+
+
+@pytest.mark.parametrize("M", [1024, 77])
+def test_removal_loss_forward_backward(ops, M):
+    """corr / masked arg-max / loss / sparse backward vs the oracle's removal_loss under autograd."""
+    S, f, D = 32, 2, 64
+    N = S * S
+    q, k, v = (torch.from_numpy(a) for a in cases.make_qkv(31 + M, 2, f, N, M, D))
+    scale = 0.125
+    qb, qe = q[:f], q[f:]
+    kb = k[:f]
+    ke = (k[f:] if M == 77 else kb)
+    rng = np.random.default_rng(9)
+    m_inp = torch.zeros(N); m_inp[torch.from_numpy(rng.choice(N, 70, replace=False))] = 1
+    m_wo = torch.from_numpy((rng.random(N) > 0.3).astype(np.float32)) * (1 - m_inp)
+    rows = torch.nonzero(m_inp > 0.5).reshape(-1).to(torch.int32)
+    # oracle (fp64 for the arg-max to be unambiguous)
+    qe64 = qe.double().requires_grad_(True); ke64 = ke.double().requires_grad_(True)
+    a_e = torch.softmax(torch.einsum("bnd,bmd->bnm", qe64, ke64) * scale, -1)
+    a_b = torch.softmax(torch.einsum("bnd,bmd->bnm", qb.double(), kb.double()) * scale, -1)
+    loss_ref, aux_ref = O.removal_loss(a_e, a_b, m_inp[None, None, :, None].double(), m_wo[None, None, :, None].double(),
+                                       O.coord_distance(S).double(), f, return_aux=True)
+    dq_ref, dk_ref = torch.autograd.grad(loss_ref, [qe64, ke64])
+    # HIP
+    d = lambda t: t.half().to(DEV).contiguous()
+    qe_d, ke_d, qb_d, kb_d = d(qe), d(ke), d(qb), d(kb)
+    o = torch.empty_like(qe_d); lse_e = torch.empty(f, N, device=DEV); lse_b = torch.empty(f, N, device=DEV)
+    vv = d(v[:f])
+    ops.attn_fwd([(qe_d, ke_d, vv, o, lse_e)], scale); ops.attn_fwd([(qb_d, kb_d, vv, o, lse_b)], scale)
+    Pb = ops.attn_probs(qb_d, kb_d, lse_b, None, scale)
+    Pe = ops.attn_probs(qe_d, ke_d, lse_e, rows.to(DEV), scale)
+    aux, rm = ops.removal_fwd(Pe, Pb, m_inp.to(DEV), m_wo.to(DEV), rows.to(DEV), S)
+    den = float(m_inp.sum()) * f + 1e-8
+    # arg-max indices: exact, except where the reference's own top two candidates are closer than the 16-bit storage
+    # precision of the probabilities (then either index is a maximiser at that precision)
+    corr = torch.bmm(a_e[:, rows.long()].detach(), a_b.permute(0, 2, 1))
+    for key_j, key_p, mk in (("j_in", "p_in", m_inp), ("j_wo", "p_wo", m_wo)):
+        jh = aux[key_j].cpu().long()
+        same = jh == aux_ref[key_j]
+        at_h = torch.gather(corr * mk.double(), 2, jh[..., None])[..., 0]
+        assert bool(((at_h >= aux_ref[key_p] * (1 - 2e-3)) | same).all()), key_j
+        if M == N:
+            assert float(same.double().mean()) > 0.98, key_j
+    assert rel_err(aux["p_in"].cpu(), aux_ref["p_in"]) < 2e-3 and rel_err(aux["p_wo"].cpu(), aux_ref["p_wo"]) < 2e-3
+    assert abs(float(rm) / den - float(loss_ref)) <= 2e-3 * max(1.0, abs(float(loss_ref)))
+    dq32 = torch.zeros(f, N, D, device=DEV); dk32 = torch.zeros(f, M, D, device=DEV)
+    ops.removal_bwd(Pe, Pb, qe_d, ke_d, rows.to(DEV), aux, m_inp.to(DEV), m_wo.to(DEV), 1.0 / den, None, scale, dq32, dk32 if M == 77 else None)
+    exact = torch.equal(aux["j_in"].cpu().long(), aux_ref["j_in"]) and torch.equal(aux["j_wo"].cpu().long(), aux_ref["j_wo"])
+    if exact:
+        assert rel_err(dq32.cpu(), dq_ref) < 5e-3
+        if M == 77:
+            assert rel_err(dk32.cpu(), dk_ref) < 5e-3
+    assert float(dq32.cpu()[:, (m_inp < 0.5)].abs().max()) == 0.0           # only inpaint rows receive gradient
+
+
+# ------------------------------------------------------------------------------------------------ scheduler arithmetic
+def test_ddim_and_latent_update(ops):
+    ac = O.alphas_cumprod()
+    rng = np.random.default_rng(10)
+    x = torch.from_numpy(rng.standard_normal((2, 4, 64, 64), dtype=np.float32))
+    eu = torch.from_numpy(rng.standard_normal((2, 4, 64, 64), dtype=np.float32))
+    ec = torch.from_numpy(rng.standard_normal((2, 4, 64, 64), dtype=np.float32))
+    for t in (980, 500, 20, 0):
+        eps = O.cfg_combine(eu, ec, 3.0)
+        ref = O.prev_step(eps, t, x, ac, 50)
+        a_t, a_p = float(ac[t]), float(ac[t - 20] if t >= 20 else ac[0])
+        got = ops.ddim_step(x.to(DEV), eu.to(DEV), ec.to(DEV), 3.0, a_t, a_p).cpu()
+        assert rel_err(got, ref) < 1e-5
+        refn = O.next_step(eps, t, x, ac, 50)
+        a_c = float(ac[t - 20] if t >= 20 else ac[0])
+        gotn = ops.ddim_step(x.to(DEV), eu.to(DEV), ec.to(DEV), 3.0, a_c, float(ac[t])).cpu()
+        assert rel_err(gotn, refn) < 1e-5
+    # invert then denoise with the same eps is the identity (round-trip property)
+    xn = ops.ddim_step(x.to(DEV), eu.to(DEV), None, 1.0, float(ac[480]), float(ac[500]))
+    xb = ops.ddim_step(xn, eu.to(DEV), None, 1.0, float(ac[500]), float(ac[480])).cpu()
+    assert rel_err(xb, x) < 1e-5
+    # 16-bit latents
+    got16 = ops.ddim_step(x.half().to(DEV), eu.half().to(DEV), ec.half().to(DEV), 3.0, float(ac[500]), float(ac[480])).float().cpu()
+    assert rel_err(got16, O.prev_step(O.cfg_combine(eu.half().float(), ec.half().float(), 3.0), 500, x.half().float(), ac, 50)) < TOL16
+    # masked latent step (U/optimization.py:228-231) incl. nan_to_num
+    g = torch.from_numpy(rng.standard_normal((2, 4, 64, 64), dtype=np.float32)); g[1, 0, 0, 0] = float("nan"); g[1, 1, 2, 3] = float("inf")
+    mask512 = torch.from_numpy(cases.ellipse_mask())
+    ref_l, _ = O.update_latent(x, g, 0.37, mask512, torch.zeros(2, 1, 1), torch.zeros(2, 1, 1))
+    m64 = O.reshape_attention_mask(mask512[None, None], 64)[0, 0].reshape(-1)
+    got_l = ops.masked_latent_update(x[1].to(DEV).contiguous(), g[1].to(DEV).contiguous(), m64.to(DEV), 0.37).cpu()
+    assert rel_err(got_l, ref_l[1]) < 1e-6
+    # norm preservation (U/editor.py:219,316)
+    n0 = ops.sumsq(x[1].to(DEV).contiguous()); n1 = ops.sumsq(got_l.to(DEV))
+    out = ops.norm_rescale(got_l.to(DEV), n0, n1).cpu()
+    ref = got_l * float(O.norm_tensor(x[1])) / float(O.norm_tensor(got_l))
+    assert rel_err(out, ref) < 1e-5

@@ -36,6 +36,7 @@ SIGNATURES = {
     "gd_splat_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
     "gd_splat_composite": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_int, c_void_p]),
+    "gd_mesh_coverage": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gd_attn_fwd": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "gd_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_float, c_void_p, c_void_p, c_int, c_void_p]),

@@ -1,0 +1,98 @@
+"""Multi-GPU: one process per GPU, independent edits sharded round-robin, no collective in the step.
+
+The reference is single-process / single-GPU (README.md:88); an edit is a self-contained ~117-UNet-pass job on a batch of
+two latents, so the path shards naturally by edit.  The only collectives are one broadcast of the model
+weights from rank 0 at start-up (RCCL over xGMI on GPUs, gloo on CPU for tests) and the barrier / max-reduce of the
+benchmark's timing.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Sequence, TypeVar
+
+import torch
+import torch.distributed as dist
+
+T = TypeVar("T")
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend: str = None) -> tuple:
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard(items: Sequence[T], rank: int, world: int) -> List[T]:
+    """edit j -> rank j mod world."""
+    return [x for j, x in enumerate(items) if j % world == rank]
+
+
+@torch.no_grad()
+def broadcast_model(modules: Iterable[torch.nn.Module], src: int = 0, bucket_bytes: int = 256 << 20) -> int:
+    """One-off weight broadcast from ``src`` in large flat buckets (xGMI is point-to-point: few, large transfers).
+    Returns the number of bytes sent."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    total = 0
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size, total
+        if not bucket:
+            return
+        flat = torch.cat([p.reshape(-1) for p in bucket])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            p.copy_(flat[off:off + n].reshape(p.shape))
+            off += n
+        total += flat.numel() * flat.element_size()
+        bucket, size = [], 0
+
+    by_dtype = {}
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            by_dtype.setdefault(t.dtype, []).append(t.data)
+    for dt, tensors in by_dtype.items():
+        for t in tensors:
+            bucket.append(t)
+            size += t.numel() * t.element_size()
+            if size >= bucket_bytes:
+                flush()
+        flush()
+    return total
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(x: float, device=None) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(x: float, device=None) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

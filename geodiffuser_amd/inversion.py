@@ -1,0 +1,115 @@
+"""DDIM inversion.  Mirror of GeoDiffuser/utils/inversion.py (``NullInversion``: ``invert`` :261-277, ``ddim_loop``
+:131-196, ``prev_step`` / ``next_step`` :47-65, ``init_prompt`` :113-128).  Null-text optimisation (:213-259) is switched
+off in every reference driver (``perform_inversion=False``) and is not implemented."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .attention_processors import VanillaAttentionProcessor
+from .scheduler import DDIMInverseScheduler, DDIMScheduler
+
+
+class NullInversion:
+    def prev_step(self, model_output, timestep: int, sample):
+        """inversion.py:47-55 (closed form, executed by gd_ddim_step)."""
+        return self.scheduler.step(model_output, timestep, sample, eta=0.0)["prev_sample"]
+
+    def next_step(self, model_output, timestep: int, sample):
+        """inversion.py:57-65."""
+        return self._inverse.step(model_output, timestep, sample)["prev_sample"]
+
+    @torch.no_grad()
+    def latent2image(self, latents, return_type="np"):
+        latents = latents.detach() / self.model.vae.config.scaling_factor
+        image = self.model.vae.decode(latents)["sample"]
+        if return_type == "np":
+            image = (image.float() / 2 + 0.5).clamp(0, 1)
+            image = image.cpu().permute(0, 2, 3, 1).numpy()[0]
+            image = (image * 255).astype(np.uint8)
+        return image
+
+    @torch.no_grad()
+    def image2latent(self, image):
+        if type(image) is torch.Tensor and image.dim() == 4:
+            return image
+        image = torch.from_numpy(np.asarray(image)).float() / 127.5 - 1
+        image = image.permute(2, 0, 1).unsqueeze(0).to(self.device)
+        latents = self.model.vae.encode(image)["latent_dist"].mean
+        return latents * self.model.vae.config.scaling_factor
+
+    @torch.no_grad()
+    def init_prompt(self, prompt: str):
+        tok = self.model.tokenizer
+        uncond_input = tok([self.uncond_text], padding="max_length", max_length=tok.model_max_length, return_tensors="pt")
+        uncond_embeddings = self.model.text_encoder(uncond_input.input_ids.to(self.model.device))[0]
+        text_input = tok([prompt], padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt")
+        text_embeddings = self.model.text_encoder(text_input.input_ids.to(self.model.device))[0]
+        self.context = torch.cat([uncond_embeddings, text_embeddings])
+        self.prompt = prompt
+
+    @torch.no_grad()
+    def ddim_loop(self, latent, latent_2=None):
+        """inversion.py:131-196: 50 batch-2 (CFG) UNet passes with the vanilla processor; CFG uses the SAME guidance scale
+        as editing (:187)."""
+        self.model.unet.set_attn_processor(VanillaAttentionProcessor())
+        if latent_2 is not None:
+            latent = torch.cat([latent, latent_2], 0)
+        all_latent = [latent]
+        all_noise = [latent]
+        latents = latent.clone().detach()
+        inv = self._inverse
+        inv.set_timesteps(self.num_ddim_steps, device=self.device)
+        context_in = self.context
+        if latent_2 is not None:
+            uncond_e, cond_e = context_in.chunk(2)
+            context_in = torch.cat([uncond_e, uncond_e, cond_e, cond_e], 0)
+        for i, t in enumerate(inv.timesteps):
+            if self.progress_bar is not None:
+                self.progress_bar(i / self.num_ddim_steps, desc="Performing DDIM Inversion")
+            latent_model_input = torch.cat([latents] * 2)
+            noise_pred = self.model.unet(latent_model_input, t, encoder_hidden_states=context_in, return_dict=False)[0]
+            noise_pred_uncond, noise_pred_cond = noise_pred.chunk(2)
+            latents = inv.step(noise_pred_uncond, t, latents, eps_cond=noise_pred_cond, guidance_scale=self.guidance_scale,
+                               return_dict=False)[0]
+            all_latent.append(latents.detach())
+            all_noise.append(noise_pred_cond.detach())
+        return all_latent, all_noise
+
+    @property
+    def scheduler(self):
+        return self.model.scheduler
+
+    @torch.no_grad()
+    def ddim_inversion(self, image, image_2=None):
+        latent = self.image2latent(image)
+        image_rec = None                      # the reference decodes a reconstruction here and never uses it (:205)
+        latent_2 = self.image2latent(image_2) if image_2 is not None else None
+        ddim_latents, ddim_noise = self.ddim_loop(latent, latent_2)
+        return image_rec, ddim_latents, ddim_noise
+
+    def invert(self, image_gt, prompt: str, offsets=(0, 0, 0, 0), num_inner_steps=10, early_stop_epsilon=1e-5, verbose=False,
+               t_coords=None, perform_inversion=True, image_2=None):
+        """inversion.py:261-277."""
+        self.init_prompt(prompt)
+        image_rec, ddim_latents, ddim_noise = self.ddim_inversion(image_gt, image_2)
+        if perform_inversion:
+            raise NotImplementedError("null-text optimisation is off in every reference driver (large_scale_editor.py:208, "
+                                      "ui_utils.py:596,626); call with perform_inversion=False")
+        return (image_gt, image_rec), ddim_latents[-1], None, ddim_latents, ddim_noise
+
+    def __init__(self, model, num_ddim_steps=50, uncond_text="", device="cuda:0", progress_bar=None, guidance_scale=3.0):
+        self.guidance_scale = guidance_scale
+        self.progress_bar = progress_bar
+        self.device = device
+        self.num_ddim_steps = num_ddim_steps
+        self.uncond_text = uncond_text
+        self.model = model
+        self.tokenizer = self.model.tokenizer
+        self.model.scheduler.set_timesteps(self.num_ddim_steps)
+        self._inverse = DDIMInverseScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                             clip_sample=False, set_alpha_to_one=False)
+        self._inverse.set_timesteps(self.num_ddim_steps)
+        self.prompt = None
+        self.context = None
+        self.controller = None

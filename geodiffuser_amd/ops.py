@@ -89,6 +89,18 @@ def splat_composite(src: torch.Tensor, idx: torch.Tensor, w: torch.Tensor, m: Op
     return out
 
 
+def mesh_coverage(verts, faces, S: int):
+    """verts [V,3] f32, faces [F,3] i32 -> coverage [S,S] f32 in {0,1}."""
+    lib = _lib.load()
+    _need(verts, "verts", torch.float32)
+    if faces.numel():
+        _need(faces, "faces", torch.int32)
+    out = torch.empty(S, S, dtype=torch.float32, device=verts.device)
+    check(lib.gd_mesh_coverage(_p(verts), _p(faces) if faces.numel() else None, verts.shape[0], faces.shape[0], S, _p(out), _stream()),
+          "gd_mesh_coverage")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # R5-R7 attention
 # ---------------------------------------------------------------------------------------------------

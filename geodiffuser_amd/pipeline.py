@@ -1,0 +1,177 @@
+"""Model container with the members the reference reads from a diffusers ``StableDiffusionPipeline``
+(``unet``, ``vae``, ``text_encoder``, ``tokenizer``, ``scheduler``, ``device``, ``progress_bar``): enough of
+SD2.1-base's *shape* to make edits/sec measurable when diffusers and the weights are not available (no network in the
+build / benchmark environment).  VAE and text encoder are stock PyTorch modules (plumbing around the hot path, SURVEY.md
+8f N2); all UNet attention runs through the HIP processors.
+
+Random-init weights are seeded; throughput does not depend on weight values.
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+import zlib
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .scheduler import DDIMScheduler
+from .unet_sd21 import UNet2DConditionModel, tiny_unet
+
+
+# ------------------------------------------------------------------------------------------------ tokenizer
+class SimpleTokenizer:
+    """Stand-in for the CLIP BPE tokenizer (vocabulary files are not available offline): BOS, hashed word ids, EOS,
+    pad 0 — exact for the empty prompt every reference driver uses for the unconditional branch."""
+
+    model_max_length = 77
+    bos, eos, pad = 49406, 49407, 0
+
+    def __call__(self, texts, padding="max_length", max_length=None, truncation=True, return_tensors="pt"):
+        if isinstance(texts, str):
+            texts = [texts]
+        L = max_length or self.model_max_length
+        ids = torch.full((len(texts), L), self.pad, dtype=torch.long)
+        for i, t in enumerate(texts):
+            toks = [self.bos] + [1000 + (zlib.crc32(w.encode()) % 40000) for w in t.lower().split()][: L - 2] + [self.eos]
+            ids[i, : len(toks)] = torch.tensor(toks)
+        return SimpleNamespace(input_ids=ids)
+
+
+class _TextLayer(nn.Module):
+    def __init__(self, d, heads):
+        super().__init__()
+        self.ln1, self.ln2 = nn.LayerNorm(d), nn.LayerNorm(d)
+        self.attn = nn.MultiheadAttention(d, heads, batch_first=True)
+        self.fc1, self.fc2 = nn.Linear(d, 4 * d), nn.Linear(4 * d, d)
+
+    def forward(self, x, mask):
+        h = self.ln1(x)
+        x = x + self.attn(h, h, h, attn_mask=mask, need_weights=False)[0]
+        return x + self.fc2(F.gelu(self.fc1(self.ln2(x))))
+
+
+class TextEncoder(nn.Module):
+    """OpenCLIP ViT-H text tower shape: width 1024, 23 layers, 16 heads, 77 positions (causal)."""
+
+    def __init__(self, width=1024, layers=23, heads=16, vocab=49408, max_len=77):
+        super().__init__()
+        self.tok = nn.Embedding(vocab, width)
+        self.pos = nn.Parameter(torch.randn(max_len, width) * 0.01)
+        self.layers = nn.ModuleList([_TextLayer(width, heads) for _ in range(layers)])
+        self.ln_f = nn.LayerNorm(width)
+
+    def forward(self, input_ids):
+        x = self.tok(input_ids) + self.pos[: input_ids.shape[1]].to(self.tok.weight.dtype)
+        L = x.shape[1]
+        mask = torch.full((L, L), float("-inf"), device=x.device, dtype=x.dtype).triu(1)
+        for l in self.layers:
+            x = l(x, mask)
+        return (self.ln_f(x),)
+
+
+# ------------------------------------------------------------------------------------------------ VAE
+class _VRes(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.n1, self.c1 = nn.GroupNorm(32, cin, eps=1e-6), nn.Conv2d(cin, cout, 3, padding=1)
+        self.n2, self.c2 = nn.GroupNorm(32, cout, eps=1e-6), nn.Conv2d(cout, cout, 3, padding=1)
+        self.sc = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x):
+        h = self.c1(F.silu(self.n1(x)))
+        h = self.c2(F.silu(self.n2(h)))
+        return (self.sc(x) if self.sc is not None else x) + h
+
+
+class _VAttn(nn.Module):
+    """Single-head 512-dim spatial attention of the VAE mid block (once per encode/decode; not the hot path)."""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.q, self.k, self.v, self.o = (nn.Linear(ch, ch) for _ in range(4))
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        t = self.norm(x).reshape(b, c, h * w).transpose(1, 2)
+        a = F.scaled_dot_product_attention(self.q(t)[:, None], self.k(t)[:, None], self.v(t)[:, None])[:, 0]
+        return x + self.o(a).transpose(1, 2).reshape(b, c, h, w)
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self, ch=(128, 256, 512, 512), latent=4, scaling_factor=0.18215):
+        super().__init__()
+        self.config = SimpleNamespace(scaling_factor=scaling_factor)
+        enc = [nn.Conv2d(3, ch[0], 3, padding=1)]
+        cin = ch[0]
+        for i, c in enumerate(ch):
+            enc += [_VRes(cin, c), _VRes(c, c)]
+            if i < len(ch) - 1:
+                enc.append(nn.Conv2d(c, c, 3, stride=2, padding=1))
+            cin = c
+        enc += [_VRes(cin, cin), _VAttn(cin), _VRes(cin, cin)]
+        self.encoder = nn.Sequential(*enc)
+        self.enc_out = nn.Sequential(nn.GroupNorm(32, cin, eps=1e-6), nn.SiLU(), nn.Conv2d(cin, 2 * latent, 3, padding=1))
+        self.quant_conv = nn.Conv2d(2 * latent, 2 * latent, 1)
+        self.post_quant_conv = nn.Conv2d(latent, latent, 1)
+        dec = [nn.Conv2d(latent, cin, 3, padding=1), _VRes(cin, cin), _VAttn(cin), _VRes(cin, cin)]
+        for i, c in enumerate(reversed(ch)):
+            dec += [_VRes(cin, c), _VRes(c, c), _VRes(c, c)]
+            if i < len(ch) - 1:
+                dec += [nn.Upsample(scale_factor=2.0, mode="nearest"), nn.Conv2d(c, c, 3, padding=1)]
+            cin = c
+        self.decoder = nn.Sequential(*dec)
+        self.dec_out = nn.Sequential(nn.GroupNorm(32, cin, eps=1e-6), nn.SiLU(), nn.Conv2d(cin, 3, 3, padding=1))
+
+    @property
+    def dtype(self):
+        return self.quant_conv.weight.dtype
+
+    def encode(self, x):
+        moments = self.quant_conv(self.enc_out(self.encoder(x.to(self.dtype))))
+        mean = moments.chunk(2, dim=1)[0]
+        return {"latent_dist": SimpleNamespace(mean=mean)}
+
+    def decode(self, z):
+        return {"sample": self.dec_out(self.decoder(self.post_quant_conv(z.to(self.dtype))))}
+
+
+# ------------------------------------------------------------------------------------------------ pipeline
+class StableDiffusionPipeline:
+    def __init__(self, unet, vae, text_encoder, tokenizer, scheduler, device):
+        self.unet, self.vae, self.text_encoder, self.tokenizer, self.scheduler = unet, vae, text_encoder, tokenizer, scheduler
+        self.device = torch.device(device)
+
+    @contextlib.contextmanager
+    def progress_bar(self, total=None):
+        yield SimpleNamespace(update=lambda *a, **k: None)
+
+    def parameters(self):
+        for m in (self.unet, self.vae, self.text_encoder):
+            yield from m.parameters()
+
+
+def build_random_sd21(device="cuda:0", dtype=torch.float16, seed=1234, tiny=False) -> StableDiffusionPipeline:
+    """Seeded random-init SD2.1-base-shaped model.  ``tiny``: same topology, narrow (for smoke tests)."""
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        if tiny:
+            unet = tiny_unet(ctx_dim=64)
+            vae = AutoencoderKL(ch=(32, 32, 64, 64))
+            te = TextEncoder(width=64, layers=2, heads=2)
+        else:
+            unet = UNet2DConditionModel()
+            vae = AutoencoderKL()
+            te = TextEncoder()
+    finally:
+        torch.random.set_rng_state(g)
+    for m in (unet, vae, te):
+        m.to(device=device, dtype=dtype).eval()
+        for p in m.parameters():
+            p.requires_grad_(False)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)
+    return StableDiffusionPipeline(unet, vae, te, SimpleTokenizer(), sched, device)

@@ -1,0 +1,323 @@
+"""SD2.1-base-shaped UNet harness (plain PyTorch-ROCm modules).
+
+diffusers is not installable in the build image, and the benchmark needs *a* UNet2DConditionModel of the public
+``stabilityai/stable-diffusion-2-1-base`` shape to host the attention processors.  This module
+reproduces that architecture's module tree and names (``down_blocks.0.attentions.1.transformer_blocks.0.attn1`` ...),
+the ``attn_processors`` / ``set_attn_processor`` members the reference drives (GeoDiffuser/utils/attention_processors.py:30,52,58-64)
+and the ``Attention`` members its processors touch (``to_q/to_k/to_v/to_out``, ``head_to_batch_dim``, ``batch_to_head_dim``,
+``scale``, ...).  When diffusers IS importable the same processors attach to the real model instead.
+
+Convolutions / linears / norms are stock PyTorch-ROCm (MIOpen / rocBLAS) — plumbing, not the accelerated path; every
+attention goes through a processor and therefore through the HIP kernels.  Weights are random-init (seeded) or loaded
+from a diffusers-format state dict (the parameter names match).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class UNetOutput(dict):
+    """``out["sample"]`` / ``out.sample`` / ``out[0]`` like diffusers' UNet2DConditionOutput."""
+
+    @property
+    def sample(self):
+        return self["sample"]
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return list(self.values())[k]
+        return super().__getitem__(k)
+
+
+class Attention(nn.Module):
+    def __init__(self, query_dim: int, cross_attention_dim: Optional[int], heads: int, dim_head: int):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.is_cross_attention = cross_attention_dim is not None
+        kv_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(kv_dim, inner, bias=False)
+        self.to_v = nn.Linear(kv_dim, inner, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(0.0)])
+        self.spatial_norm = None
+        self.group_norm = None
+        self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+        self.processor = None
+
+    def set_processor(self, processor):
+        self.processor = processor
+
+    def head_to_batch_dim(self, t: torch.Tensor) -> torch.Tensor:
+        b, n, c = t.shape
+        h = self.heads
+        return t.reshape(b, n, h, c // h).permute(0, 2, 1, 3).reshape(b * h, n, c // h)
+
+    def batch_to_head_dim(self, t: torch.Tensor) -> torch.Tensor:
+        bh, n, d = t.shape
+        h = self.heads
+        return t.reshape(bh // h, h, n, d).permute(0, 2, 1, 3).reshape(bh // h, n, h * d)
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size):
+        return attention_mask
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask, **kw)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        x, gate = self.proj(x).chunk(2, dim=-1)
+        return x * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim)])
+
+    def forward(self, x):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, dim_head, cross_attention_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, None, heads, dim_head)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, cross_attention_dim, heads, dim_head)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, ctx):
+        x = self.attn1(self.norm1(x)) + x
+        x = self.attn2(self.norm2(x), encoder_hidden_states=ctx) + x
+        x = self.ff(self.norm3(x)) + x
+        return x
+
+
+class Transformer2DModel(nn.Module):
+    """use_linear_projection=True variant (SD2.x)."""
+
+    def __init__(self, channels, heads, dim_head, cross_attention_dim):
+        super().__init__()
+        self.norm = nn.GroupNorm(32, channels, eps=1e-6)
+        self.proj_in = nn.Linear(channels, channels)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(channels, heads, dim_head, cross_attention_dim)])
+        self.proj_out = nn.Linear(channels, channels)
+
+    def forward(self, x, ctx):
+        b, c, h, w = x.shape
+        res = x
+        x = self.norm(x)
+        x = x.permute(0, 2, 3, 1).reshape(b, h * w, c)
+        x = self.proj_in(x)
+        for blk in self.transformer_blocks:
+            x = blk(x, ctx)
+        x = self.proj_out(x)
+        x = x.reshape(b, h, w, c).permute(0, 3, 1, 2)
+        return x + res
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_ch=1280):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, cin, eps=1e-5)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_ch, cout)
+        self.norm2 = nn.GroupNorm(32, cout, eps=1e-5)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x, temb):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        return x + h
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=1)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, heads, ctx_dim, n_layers=2, attn=True, down=True, temb_ch=1280):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_ch) for i in range(n_layers)])
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cout // heads, ctx_dim) for _ in range(n_layers)]) if attn else None
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if down else None
+
+    def forward(self, x, temb, ctx):
+        outs = []
+        for i, r in enumerate(self.resnets):
+            x = r(x, temb)
+            if self.attentions is not None:
+                x = self.attentions[i](x, ctx)
+            outs.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+            outs.append(x)
+        return x, outs
+
+
+class MidBlock(nn.Module):
+    def __init__(self, ch, heads, ctx_dim, temb_ch=1280):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb_ch), ResnetBlock2D(ch, ch, temb_ch)])
+        self.attentions = nn.ModuleList([Transformer2DModel(ch, heads, ch // heads, ctx_dim)])
+
+    def forward(self, x, temb, ctx):
+        x = self.resnets[0](x, temb)
+        x = self.attentions[0](x, ctx)
+        return self.resnets[1](x, temb)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin, cout, prev, heads, ctx_dim, n_layers=3, attn=True, up=True, temb_ch=1280):
+        super().__init__()
+        res = []
+        for i in range(n_layers):
+            skip = cin if i == n_layers - 1 else cout
+            r_in = prev if i == 0 else cout
+            res.append(ResnetBlock2D(r_in + skip, cout, temb_ch))
+        self.resnets = nn.ModuleList(res)
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cout // heads, ctx_dim) for _ in range(n_layers)]) if attn else None
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if up else None
+
+    def forward(self, x, skips, temb, ctx):
+        for i, r in enumerate(self.resnets):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = r(x, temb)
+            if self.attentions is not None:
+                x = self.attentions[i](x, ctx)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """diffusers Timesteps(flip_sin_to_cos=True, downscale_freq_shift=0)."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(cin, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class UNet2DConditionModel(nn.Module):
+    """SD2.1-base: block_out_channels (320,640,1280,1280), heads (5,10,20,20) (head dim 64), ctx 1024, 32 attention
+    processors (16 transformer blocks x {attn1, attn2})."""
+
+    def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), heads=(5, 10, 20, 20),
+                 cross_attention_dim=1024, layers_per_block=2):
+        super().__init__()
+        ch = block_out_channels
+        self.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(ch[0], ch[0] * 4)
+        self.down_blocks = nn.ModuleList()
+        cin = ch[0]
+        for i, cout in enumerate(ch):
+            last = i == len(ch) - 1
+            self.down_blocks.append(DownBlock(cin, cout, heads[i], cross_attention_dim, layers_per_block, attn=not last, down=not last, temb_ch=ch[0] * 4))
+            cin = cout
+        self.mid_block = MidBlock(ch[-1], heads[-1], cross_attention_dim, temb_ch=ch[0] * 4)
+        self.up_blocks = nn.ModuleList()
+        rev, rheads = list(reversed(ch)), list(reversed(heads))
+        prev = rev[0]
+        for i, cout in enumerate(rev):
+            cin_skip = rev[min(i + 1, len(ch) - 1)]
+            last = i == len(ch) - 1
+            self.up_blocks.append(UpBlock(cin_skip, cout, prev, rheads[i], cross_attention_dim, layers_per_block + 1, attn=i > 0, up=not last, temb_ch=ch[0] * 4))
+            prev = cout
+        self.conv_norm_out = nn.GroupNorm(32, ch[0], eps=1e-5)
+        self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
+        self.t_dim = ch[0]
+        from .attention_processors import VanillaAttentionProcessor
+        self.set_attn_processor(VanillaAttentionProcessor())
+
+    # -- the two members the reference drives -----------------------------------------------------------
+    @property
+    def attn_processors(self) -> Dict[str, object]:
+        procs = {}
+        for name, m in self.named_modules():
+            if isinstance(m, Attention):
+                procs[f"{name}.processor"] = m.processor
+        return procs
+
+    def set_attn_processor(self, processor: Union[object, Dict[str, object]]):
+        for name, m in self.named_modules():
+            if isinstance(m, Attention):
+                m.set_processor(processor[f"{name}.processor"] if isinstance(processor, dict) else processor)
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, return_dict=True, **kw):
+        dt = self.dtype
+        x = sample.to(dt)
+        ctx = encoder_hidden_states.to(dt)
+        t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep], device=x.device)
+        t = t.reshape(-1).to(x.device).expand(x.shape[0])
+        temb = self.time_embedding(timestep_embedding(t, self.t_dim).to(dt))
+        x = self.conv_in(x)
+        skips = [x]
+        for blk in self.down_blocks:
+            x, outs = blk(x, temb, ctx)
+            skips.extend(outs)
+        x = self.mid_block(x, temb, ctx)
+        for blk in self.up_blocks:
+            x = blk(x, skips, temb, ctx)
+        x = self.conv_out(F.silu(self.conv_norm_out(x)))
+        if not return_dict:
+            return (x,)
+        return UNetOutput(sample=x)
+
+
+def tiny_unet(ctx_dim=64) -> UNet2DConditionModel:
+    """A small model with the same topology (head dim 64) for smoke tests."""
+    return UNet2DConditionModel(block_out_channels=(64, 128, 128, 128), heads=(1, 2, 2, 2), cross_attention_dim=ctx_dim)

@@ -80,6 +80,12 @@ int gd_splat_weights(const int32_t* idx, const float* dist2, int npix, int K,
 int gd_splat_composite(const void* src, const int32_t* idx, const float* w, const float* m,
                        int B, int P, int C, int npix, int K, int layout, void* out, int dtype, void* stream);
 
+/*
+ * Setup (once per edit), U/warp_utils.py:235-298 splatter_mesh: coverage of the transformed object surface mesh.
+ *   verts [V,3] f32 (x,y in the rasterizer's NDC convention, z depth), faces [F,3] i32, out [S,S] f32 in {0,1}.
+ */
+int gd_mesh_coverage(const float* verts, const int32_t* faces, int V, int F, int S, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * R5/R6/R7  attention.  Replaces compute_attention (baddbmm + softmax, U/attention_sharing.py:30-47)
  *     followed by torch.bmm(attn, v) (U/attention_processors.py:428,433,549,557,644,647) without ever

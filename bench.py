@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark: geometry edits/sec (512^2, 50-step DDIM, SD2.1) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete edit through run_geodiffuser(): geometry pre-pass, 50-step DDIM inversion, 50 denoising steps
+with 17 optimisation passes (UNet forward+backward through the fused edit layers), VAE encode/decode, histogram
+post-process — BASELINE.json configs[1]: single 512x512 image, 3-D rotation edit, 50-step inversion + edit, SD2.1-base
+shape, 16-bit, one GPU per edit.  Inputs are synthetic (seeded image / elliptical mask / tilted-plane depth / random
+rotation) and the weights are seeded random-init of the SD2.1-base architecture: there is no network for datasets or
+checkpoints.  Edits are independent, so N ranks run N different edits concurrently (weak scaling, no collective in the step;
+the model is broadcast once from rank 0 over RCCL at start-up).
+
+Besides the contract's fields the JSON line carries
+  roofline     : the dominant kernel (k_attn_fwd, MFMA-bound) — algorithmic FLOPs / launch duration measured live with
+                 HIP events on the launch stream during the timed region, for the 64^2 self-attention launches;
+  cpu_baseline : the oracle (CPU restatement of the reference's formulation) timed on this box's host cores on a bounded
+                 sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_MFMA_16BIT = 2.5e15     # dense bf16/fp16 MFMA peak of MI355X, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+class AttnTimer:
+    """Wraps ops.attn_fwd: HIP events around every launch of the dominant shape (N = M = (size/8)^2) on torch's current
+    stream — the stream the kernel is launched on."""
+
+    def __init__(self, n_tokens):
+        self.n = n_tokens
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        from geodiffuser_amd import ops
+        self._orig = ops.attn_fwd
+        timer = self
+
+        def wrapped(segs, scale):
+            q0, k0 = segs[0][0], segs[0][1]
+            if timer.enabled and q0.shape[1] == timer.n and k0.shape[1] == timer.n:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                timer._orig(segs, scale)
+                e1.record()
+                bh = sum(s[0].shape[0] for s in segs)
+                timer.records.append((e0, e1, 4.0 * bh * q0.shape[1] * k0.shape[1] * q0.shape[2]))
+            else:
+                timer._orig(segs, scale)
+
+        ops.attn_fwd = wrapped
+
+    def summary(self):
+        if not self.records:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return dict(launches=len(self.records), avg_us=1e3 * ms / len(self.records), flops_per_launch=fl / len(self.records),
+                    achieved=fl / (ms * 1e-3))
+
+
+def cpu_baseline(budget_s=45.0):
+    """Oracle timed on the host cores: hooked attention-layer calls of one optimisation pass + one CFG pass at SD2.1-base
+    token counts (32^2 level: N=1024, D=64, measured with f=2 of its 10 heads; self + cross), i.e. the reference's formulation (materialised maps, per-call
+    rasterisation, unfused losses, autograd).  Extrapolated to a whole edit by call counts with the measured 64^2/32^2
+    cost ratio of the formulation (N^2 scaling); the UNet conv/GEMM part is NOT included (it would only lower the CPU number)."""
+    import cases
+    import ref_cpu as O
+    from _util import warped_mask
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    mask = cases.ellipse_mask()
+    coords = torch.from_numpy(cases.make_coords("rotate", mask))
+
+    def ctrl(cfg):
+        c = O.GeometryEditOracle(mask, 50, 0.95, 0.9, coords_quant=torch.float16)
+        c.amodal_mask = O.torch_erode(torch.from_numpy(cases.amodal_input(mask)))
+        c.mask_new_warped = warped_mask("rotate")
+        c.num_att_layers, c.cur_step = 32, 3
+        if cfg:
+            c.coords_base, c.coords_edit, c.use_cfg = (2, 3), (3, 4), True
+        else:
+            c.coords_base, c.coords_edit, c.use_cfg = (0, 1), (1, 2), False
+        return c
+
+    f, S, D = 2, 32, 64
+    head_scale = 10 / f                         # the 32^2 level has 10 heads; cost is linear in heads
+    N = S * S
+    t_used = 0.0
+    times = {}
+    for name, cfg, cross in (("opt_self", False, False), ("opt_cross", False, True), ("cfg_self", True, False), ("cfg_cross", True, True)):
+        if t_used > budget_s:
+            break
+        B = 4 if cfg else 2
+        q, k, v = (torch.from_numpy(a) for a in cases.make_qkv(5, B, f, N, 77 if cross else N, D))
+        c = ctrl(cfg)
+        c._masks(S, f, coords)                      # mask cache is per edit in the reference too; not timed
+        t0 = time.perf_counter()
+        if not cfg:
+            q.requires_grad_(True); k.requires_grad_(True)
+            with torch.enable_grad():
+                c(q, k, v, cross, "up", transform_coords=coords, scale=0.125)
+                torch.autograd.grad(c.loss, [q, k], allow_unused=True)
+        else:
+            with torch.no_grad():
+                c(q, k, v, cross, "up", transform_coords=coords, scale=0.125)
+        dt_ = time.perf_counter() - t0
+        t_used += dt_
+        times[name] = dt_ * head_scale
+    if len(times) < 4:
+        return None
+    # per UNet pass: 5 blocks at each of 64^2 (f=5), 32^2 (f=10), 16^2 (f=20) and 1 at 8^2; self cost ~ f*N^2:
+    # 64^2 = 8x the 32^2 layer, 16^2 = 1/8; cross cost ~ f*N*77: 64^2 = 2x, 16^2 = 1/2.
+    self_mult = 5 * (8.0 + 1.0 + 0.125) + 0.03
+    cross_mult = 5 * (2.0 + 1.0 + 0.5) + 0.25
+    opt_pass = times["opt_self"] * self_mult + times["opt_cross"] * cross_mult
+    cfg_pass = times["cfg_self"] * self_mult + times["cfg_cross"] * cross_mult
+    inv_pass = cfg_pass * 0.4                       # vanilla attention only (2 of the 5 maps of a CFG pass)
+    edit_s = 17 * opt_pass + 50 * cfg_pass + 50 * inv_pass
+    return dict(value=1.0 / edit_s, unit="edits/sec", cores=cores, kind="port",
+                sample=("oracle controller calls at SD2.1-base 32^2 shapes (N=1024, D=64; 2 of 10 heads timed, x5): "
+                        + ", ".join(f"{k}={v:.2f}s" for k, v in times.items())
+                        + f"; extrapolated by call counts to 17 opt + 50 CFG + 50 inversion passes = {edit_s:.0f} s/edit, attention path only"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--kind", default="rotate", choices=["rotate", "translate", "mixed"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="narrow model (debug only; the result is not a benchmark number)")
+    args = ap.parse_args()
+
+    from geodiffuser_amd import dist as gdist
+    rank, world, local = gdist.init()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    from geodiffuser_amd import _lib, editor
+    from geodiffuser_amd.diffusion import load_model
+    from geodiffuser_amd.synthetic import editor_kwargs, make_edit
+    _lib.load()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    editor.DEVICE = torch.device(dev)
+    pipe, tok, sched = load_model(device=dev, dtype=dtype, tiny=args.tiny)
+    nbytes = gdist.broadcast_model([pipe.unet, pipe.vae, pipe.text_encoder], src=0)
+
+    timer = AttnTimer((args.size // 8) ** 2)
+    timer.install()
+    kw = editor_kwargs()
+    kw.update(num_ddim_steps=args.ddim_steps, ldm_stable_model=pipe, tokenizer_model=tok, scheduler_in=sched)
+
+    def one_edit(j):
+        image, depth, mask, T = make_edit(j * world + rank, size=args.size, kind=args.kind)
+        return editor.run_geodiffuser(image, depth, mask, T, **kw)
+
+    for j in range(args.warmup):
+        one_edit(1000 + j)
+    torch.cuda.synchronize()
+    gdist.barrier()
+    timer.enabled = rank == 0
+    t0 = time.perf_counter()
+    for j in range(args.steps):
+        one_edit(j)
+    torch.cuda.synchronize()
+    gdist.barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    elapsed = gdist.max_over_ranks(elapsed, device=dev)
+
+    if rank == 0:
+        value = args.steps * world / elapsed
+        roof = timer.summary()
+        line = {
+            "metric": "geometry edits/sec (512^2, 50-step DDIM, SD2.1)", "value": value, "unit": "edits/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"configs[1]: single {args.size}x{args.size} image, 3-D {args.kind} edit, {args.ddim_steps}-step DDIM "
+                                   f"inversion + edit (17 optimisation passes), SD2.1-base-shaped UNet/VAE/text-encoder, random-init, "
+                                   f"one edit per GPU", "edits_per_min": 60.0 * value, "weights_broadcast_bytes": nbytes,
+                       "tiny_debug_model": bool(args.tiny)},
+        }
+        if roof:
+            line["roofline"] = {"kernel": "k_attn_fwd (64^2 self-attention launches)", "bound": "mfma", "achieved": roof["achieved"] / 1e12,
+                                "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s", "frac": roof["achieved"] / PEAK_MFMA_16BIT,
+                                "traffic": None, "launches": roof["launches"], "avg_launch_us": roof["avg_us"],
+                                "flops_per_launch": roof["flops_per_launch"]}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

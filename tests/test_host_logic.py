@@ -1,0 +1,158 @@
+"""CPU tests of the host-side mirror of the reference interface (no kernels are launched):
+adaptive schedule (golden G9), scheduler tables, UNet harness topology / processor registration, loss-log handling,
+multi-process sharding + weight broadcast over gloo (world size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import ref_cpu as O
+from _util import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_adaptive_schedule_matches_golden():
+    from geodiffuser_amd.optimization import adaptive_optimization_step_editing, adaptive_optimization_step_remover
+    g = load("G9_adaptive")
+    w_e = {"self": {"sim": 55, "movement": 30.5, "removal": 2.6, "smoothness": 30, "amodal": 80.5},
+           "cross": {"sim": 45, "movement": 30.34, "removal": 2.6, "smoothness": 15, "amodal": 3.5}}
+    w_r = {"self": {"sim": 55, "removal": 4.6, "smoothness": 30}, "cross": {"sim": 45, "removal": 4.6, "smoothness": 15}}
+    for key, w, fn in (("edit", w_e, adaptive_optimization_step_editing), ("remover", w_r, adaptive_optimization_step_remover)):
+        class C:
+            pass
+        c = C()
+        c.default_loss_weights = {k: dict(v) for k, v in w.items()}
+        c.loss_weight_dict = c.default_loss_weights
+        c.initialize_default_loss_weights = lambda c=c: setattr(c, "loss_weight_dict", c.default_loss_weights)
+        traj = []
+        for i, val in g["seq"]:
+            fn(c, int(i), 2, {"self": {"removal": float(val)}}, num_ddim_steps=50, removal_loss_value_in=-1.5)
+            traj.append(c.loss_weight_dict["self"]["removal"])
+        assert np.allclose(np.array(traj), g[key], rtol=1e-12, atol=0), key
+
+
+def test_scheduler_tables():
+    from geodiffuser_amd.scheduler import DDIMInverseScheduler, DDIMScheduler
+    g = load("G10_ddim")
+    s = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)
+    assert np.array_equal(s.alphas_cumprod.numpy(), g["alphas_cumprod"])
+    s.set_timesteps(50)
+    assert s.timesteps.tolist() == list(range(980, -1, -20))
+    assert float(s.final_alpha_cumprod) == float(g["alphas_cumprod"][0])
+    inv = DDIMInverseScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)
+    inv.set_timesteps(50)
+    assert inv.timesteps.tolist() == list(range(0, 1000, 20))
+    s.set_timesteps(20)
+    assert s.timesteps.tolist() == list(range(950, -1, -50))
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler(clip_sample=True)
+
+
+def test_unet_harness_topology_and_registration():
+    from geodiffuser_amd.attention_processors import (AttentionGeometryEdit, EditProcessor, VanillaAttentionProcessor,
+                                                      register_attention_control_diffusers, set_attn_processor_for_edit)
+    from geodiffuser_amd.unet_sd21 import UNet2DConditionModel
+    with torch.device("meta"):
+        unet = UNet2DConditionModel()
+    assert sum(p.numel() for p in unet.parameters()) == 865910724          # public SD2.1-base UNet parameter count
+    names = list(unet.attn_processors)
+    assert len(names) == 32
+    assert names[0] == "down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor"
+    assert sum(n.startswith("down_blocks") for n in names) == 12 and sum(n.startswith("mid_block") for n in names) == 2
+    heads = {n: m.heads for n, m in unet.named_modules() if hasattr(m, "heads")}
+    assert set(heads.values()) == {5, 10, 20}
+    assert all(abs(m.scale - 0.125) < 1e-12 for m in unet.modules() if hasattr(m, "scale"))
+
+    class Model:
+        pass
+    model = Model(); model.unet = unet
+    mask = np.zeros((512, 512), np.float32); mask[200:300, 200:300] = 1
+    ctrl = AttentionGeometryEdit(["", ""], 50, {"default_": 0.95}, 0.95, image_mask=mask, obj_edit_step=0.9)
+    register_attention_control_diffusers(model, ctrl, transform_coords=None)
+    assert ctrl.num_att_layers == 32
+    procs = unet.attn_processors
+    assert all(isinstance(p, EditProcessor) for p in procs.values())
+    places = [p.place_in_unet for p in procs.values()]
+    assert places.count("down") == 12 and places.count("mid") == 2 and places.count("up") == 18
+    set_attn_processor_for_edit(model, coords_base=(0, 1), coords_edit=(1, 2), use_cfg=False)
+    assert ctrl.coords_base == (0, 1) and ctrl.coords_edit == (1, 2) and ctrl.use_cfg is False
+    assert ctrl.num_self_replace == (0, 47) and type(ctrl).__name__ == "AttentionGeometryEdit"
+    # aliasing of the default weights (reference behaviour)
+    ctrl.loss_weight_dict["self"]["removal"] *= 2
+    ctrl.initialize_default_loss_weights()
+    assert ctrl.loss_weight_dict["self"]["removal"] == 1.67 * 2
+    unet.set_attn_processor(VanillaAttentionProcessor())
+    assert all(isinstance(p, VanillaAttentionProcessor) for p in unet.attn_processors.values())
+
+
+def test_loss_log_helpers_and_errors():
+    from geodiffuser_amd import editor
+    from geodiffuser_amd.attention_processors import AttentionGeometryRemover
+    mask = np.zeros((512, 512), np.float32); mask[100:140, 100:140] = 1
+    c = AttentionGeometryRemover(["", ""], 50, {"default_": 0.9}, 0.9, image_mask=mask, obj_edit_step=1.0)
+    assert float(c.image_mask[0].sum()) == 44 * 44                           # 5x5 dilation at construction (:986)
+    assert set(c.loss_log_dict["self"]) == {"sim", "removal", "smoothness"}
+    c.loss_log_dict["self"]["sim"] = torch.tensor(1.5)
+    out = editor.convert_loss_log_to_numpy(c.loss_log_dict)
+    assert out["self"]["sim"] == 1.5 and out["cross"]["removal"] == 0.0 and out["num_layers"] == 0
+    c.loss = torch.tensor(3.0)
+    editor.clear_controller_loss(c)
+    assert c.loss == 0.0 and c.loss_log_dict["self"]["sim"] == 0.0
+    with pytest.raises(NameError):                                            # same failure as the reference (editor.py:618-621)
+        editor.perform_geometric_edit(np.zeros((8, 8, 3), np.uint8), np.ones((8, 8), np.float32), np.ones((8, 8), np.float32),
+                                      torch.eye(4), edit_type="geometry_stitch")
+
+
+def test_histogram_matching_properties():
+    from geodiffuser_amd.image_processing import masked_histogram_matching
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)
+    m = np.ones((64, 64), np.float32)
+    out = masked_histogram_matching(src, src, m, m)
+    assert np.allclose(out, src)                                              # matching an image to itself is the identity
+    tmpl = (src // 2).astype(np.uint8)
+    out = masked_histogram_matching(src, tmpl, m, m)
+    assert out.shape == src.shape
+    # the mapping is a per-channel monotone look-up table
+    for ch in range(3):
+        order = np.argsort(src[..., ch].reshape(-1), kind="stable")
+        assert np.all(np.diff(out[..., ch].reshape(-1)[order]) >= -1e-9)
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+from geodiffuser_amd import dist as gd
+rank, world, local = gd.init(backend="gloo")
+assert world == 2
+torch.manual_seed(100 + rank)                       # different weights per rank before the broadcast
+m = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Linear(32, 8)).half()
+sent = gd.broadcast_model([m], src=0, bucket_bytes=256)
+torch.manual_seed(100)
+ref = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Linear(32, 8)).half()
+for a, b in zip(m.parameters(), ref.parameters()):
+    assert torch.equal(a, b)
+mine = gd.shard(list(range(7)), rank, world)
+assert mine == [j for j in range(7) if j %% 2 == rank]
+t = gd.max_over_ranks(1.0 + rank)
+n = gd.sum_over_ranks(float(len(mine)))
+gd.barrier()
+assert t == 2.0 and n == 7.0 and sent > 0
+print("rank", rank, "ok")
+'''
+
+
+def test_two_process_gloo_shard_and_broadcast(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29612", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o

@@ -220,8 +220,23 @@ def perform_geometric_edit(image, depth, image_mask, transform_in, prompt="", ld
     """editor.py:428-710.  Returns ``images`` (2 uint8 [H,W,3]: reference reconstruction, edit)
     ``[, loss_log_dict][, attention_store]``; ``return_latents=True`` (extension for parity tests) appends the final
     latents [2,4,h,w]."""
-    global SEED, TOKENIZER, LDM_STABLE, SCHEDULER, PROGRESS_BAR, GUIDANCE_SCALE, SKIP_OPTIM_STEPS, NUM_DDIM_STEPS, UNET_NAME
+    # the reference switches autograd off globally and never restores it (editor.py:467); the previous mode is restored here
+    prev_grad = torch.is_grad_enabled()
     torch.set_grad_enabled(False)
+    try:
+        return _perform_geometric_edit(**{k: v for k, v in locals().items() if k != "prev_grad"})
+    finally:
+        torch.set_grad_enabled(prev_grad)
+
+
+def _perform_geometric_edit(image, depth, image_mask, transform_in, prompt, ldm_stable_model, tokenizer_model, scheduler_in,
+                            cross_replace_steps, self_replace_steps, optimize_steps, lr, latent_replace, optimize_embeddings,
+                            optimize_latents, obj_edit_step, perform_inversion, guidance_scale, skip_optim_steps, num_ddim_steps,
+                            splatting_radius, edit_type, image_stitch, progress, fast_start_steps, num_first_optim_steps,
+                            loss_weights_dict, return_loss_log_dict, splatting_tau, splatting_points_per_pixel,
+                            use_adaptive_optimization, return_attention_maps, unet_path, use_optimizer, removal_loss_value_in,
+                            return_latents):
+    global SEED, TOKENIZER, LDM_STABLE, SCHEDULER, PROGRESS_BAR, GUIDANCE_SCALE, SKIP_OPTIM_STEPS, NUM_DDIM_STEPS, UNET_NAME
     torch.manual_seed(SEED)
     torch.cuda.manual_seed_all(SEED)
     max_opt = max(self_replace_steps, cross_replace_steps["default_"])

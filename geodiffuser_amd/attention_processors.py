@@ -63,13 +63,16 @@ def register_attention_control_diffusers(model, controller, transform_coords=Non
     controller.num_att_layers = cross_att_count
 
 
-def set_attn_processor_for_edit(model, perform_edit=True, coords_base=(2, 3), coords_edit=(3, 4), use_cfg=True):
+def set_attn_processor_for_edit(model, perform_edit=True, coords_base=(2, 3), coords_edit=(3, 4), use_cfg=True, n_batch=None):
+    """attention_processors.py:56-67.  ``n_batch`` (extension): number of batch entries of the next UNet pass when it differs
+    from the reference's 2*len(prompts) / len(prompts) — used by the driver to drop the CFG pass's unused ``uncond_ref`` row."""
     for name in model.unet.attn_processors.keys():
         proc = model.unet.attn_processors[name]
         proc.perform_edit = perform_edit
         proc.controller.coords_base = coords_base
         proc.controller.coords_edit = coords_edit
         proc.controller.use_cfg = use_cfg
+        proc.controller.n_batch = n_batch
 
 
 def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale):
@@ -427,7 +430,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         return c
 
     def forward(self, q, k, v, is_cross: bool, place_in_unet: str, transform_coords=None, scale=None, mask=None):
-        nb = 2 * self.batch_size if self.use_cfg else self.batch_size
+        nb = getattr(self, "n_batch", None) or (2 * self.batch_size if self.use_cfg else self.batch_size)
         f = q.shape[0] // nb
         active = is_cross or (self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1])
         if not active:

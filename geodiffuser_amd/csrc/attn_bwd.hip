@@ -21,7 +21,7 @@ struct BwdArgs {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_attn_bwd_dq(const BwdArgs a) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;

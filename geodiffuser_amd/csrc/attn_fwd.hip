@@ -20,8 +20,94 @@ struct FwdArgs {
     float scale;
 };
 
+// Per-lane LDS byte offsets of the fragment reads, computed once (the swizzle term does not depend on the k-step /
+// key block, which therefore become immediates): krd[s] for the row fragments, vrd[dblk][hh] for the transposed ones.
+struct FragOffs { int krd[4]; int vrd[2][2]; };
+
+__device__ __forceinline__ FragOffs make_frag_offs(int lane) {
+    FragOffs f;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f.krd[s] = img_off(r, 2 * s + h);
+    const int g1 = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+#pragma unroll
+    for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            f.vrd[dblk][hh] = img_off(8 * hh + 4 * h + q, dblk * 4 + g1 * 2 + (p >> 1)) + (p & 1) * 8;
+    return f;
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ typename elem_traits<T>::vec8 rd_row(const char* lds, const FragOffs& f, int blk, int s) {
+    return *(const typename elem_traits<T>::vec8*)(lds + f.krd[s] + blk * 4096);
+}
+template <typename T>
+__device__ __forceinline__ typename elem_traits<T>::vec8 rd_tr(const char* lds, const FragOffs& f, int dblk, int ks) {
+    union { s16x4 v[2]; typename elem_traits<T>::vec8 x; } u;
+    u.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + f.vrd[dblk][0] + ks * 2048));
+    u.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + f.vrd[dblk][1] + ks * 2048));
+    return u.x;
+}
+
+// log2-domain slack before the running maximum is raised: while a row's maximum grows by less than this, the
+// accumulators are NOT rescaled (probabilities then reach at most 2^RESCALE_SLACK, harmless in f32 / 16-bit)
+#define RESCALE_SLACK 6.0f
+
+// one 64-key tile, processed as two 32-key half steps (S^T = K Q^T, online softmax, O^T += V^T P^T).  Half steps keep
+// only 16 score + 8 probability registers live, which fits 4 waves per SIMD (<= 128 VGPRs): on this kernel latency
+// hiding by occupancy is worth more than the few extra max/rescale checks.
+template <typename T, bool MASKED>
+__device__ __forceinline__ void fwd_tile(const char* lk, const char* lv, const FragOffs& fo, const typename elem_traits<T>::vec8 (&qf)[4],
+                                         f32x16 (&o)[2], float& m_run, float& l_run, float c, int kv0, int M, int h) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        f32x16 s_acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(rd_row<T>(lk, fo, blk, s), qf[s], s_acc);
+        if (MASKED) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (kv0 + blk * 32 + acc_key(i, h) >= M) s_acc[i] = -INFINITY;
+        }
+        float mx = s_acc[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s_acc[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // raise the running maximum only when some row of the wave outgrew it by more than the slack (wave-uniform branch)
+        if (__builtin_amdgcn_ballot_w64((mx - m_run) * c > RESCALE_SLACK) != 0) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        }
+        const float mc = m_run * c;
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], c, -mc));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i + 1], c, -mc));
+            s_acc[i] = p0; s_acc[i + 1] = p1;
+            ps0 += p0; ps1 += p1;
+        }
+        l_run += ps0 + ps1;
+        const V8 pf0 = acc_to_frag<T>(s_acc, 0), pf1 = acc_to_frag<T>(s_acc, 1);
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk) {
+            o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 2 * blk), pf0, o[dblk]);
+            o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 2 * blk + 1), pf1, o[dblk]);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
 k_attn_fwd(const FwdArgs a) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
@@ -47,12 +133,14 @@ k_attn_fwd(const FwdArgs a) {
     V8 qf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *(const V8*)(qp + (size_t)qld * ATT_D + 16 * s + 8 * h);
+    const FragOffs fo = make_frag_offs(lane);
 
     f32x16 o[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
+    const int T_full = M / ATT_BN;                     // tiles without a key tail
     const int T_tiles = (M + ATT_BN - 1) / ATT_BN;
     u32x4 kr[2], vr[2];
     tile_load<T>(kp, 0, M, tid, kr);
@@ -60,72 +148,31 @@ k_attn_fwd(const FwdArgs a) {
     tile_store(lds[0][0], tid, kr);
     tile_store(lds[0][1], tid, vr);
     __syncthreads();
+    // this thread's chunk of the NEXT tile (rows tid/8 and tid/8 + 32 of tile 1); advanced by one tile per iteration
+    const T* kq = kp + (size_t)(ATT_BN + (tid >> 3)) * ATT_D + (tid & 7) * 8;
+    const T* vq = vp + (size_t)(ATT_BN + (tid >> 3)) * ATT_D + (tid & 7) * 8;
 
-    for (int t = 0; t < T_tiles; ++t) {
+#pragma unroll 1
+    for (int t = 0; t < T_full; ++t) {
         const int cur = t & 1;
         const bool more = (t + 1) < T_tiles;
-        if (more) {
+        if (t + 1 < T_full) {                      // next tile is full: no clamping
+            kr[0] = *(const u32x4*)kq; kr[1] = *(const u32x4*)(kq + 32 * ATT_D);
+            vr[0] = *(const u32x4*)vq; vr[1] = *(const u32x4*)(vq + 32 * ATT_D);
+            kq += ATT_BN * ATT_D; vq += ATT_BN * ATT_D;
+        } else if (more) {
             tile_load<T>(kp, (t + 1) * ATT_BN, M, tid, kr);
             tile_load<T>(vp, (t + 1) * ATT_BN, M, tid, vr);
         }
-        const char* lk = lds[cur][0];
-        const char* lv = lds[cur][1];
-
-        // S^T tile: 64 keys x 32 queries per wave
-        f32x16 s_acc[2];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s_acc[blk][i] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) s_acc[blk] = TR::mfma32(read_row_frag<T>(lk, blk, s, lane), qf[s], s_acc[blk]);
-        }
-        const int kv0 = t * ATT_BN;
-        if (kv0 + ATT_BN > M) {
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (kv0 + blk * 32 + acc_key(i, h) >= M) s_acc[blk][i] = -INFINITY;
-        }
-        float mx = s_acc[0][0];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s_acc[blk][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * a.c);
-        const float mc = m_new * a.c;
-        float ps = 0.f;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[blk][i], a.c, -mc));
-                s_acc[blk][i] = p;
-                ps += p;
-            }
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-
-        // O^T += V^T P^T
-        V8 pf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) pf[ks] = acc_to_frag<T>(s_acc[ks >> 1], ks & 1);
-#pragma unroll
-        for (int dblk = 0; dblk < 2; ++dblk)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) o[dblk] = TR::mfma32(read_tr_frag<T>(lv, dblk, ks, lane), pf[ks], o[dblk]);
-
+        fwd_tile<T, false>(lds[cur][0], lds[cur][1], fo, qf, o, m_run, l_run, a.c, t * ATT_BN, M, h);
         if (more) {
             tile_store(lds[cur ^ 1][0], tid, kr);
             tile_store(lds[cur ^ 1][1], tid, vr);
         }
         __syncthreads();
     }
+    if (T_full < T_tiles)        // key tail (M % 64 != 0): one masked tile
+        fwd_tile<T, true>(lds[T_full & 1][0], lds[T_full & 1][1], fo, qf, o, m_run, l_run, a.c, T_full * ATT_BN, M, h);
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -183,7 +230,7 @@ struct ProbsArgs {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_attn_probs(const ProbsArgs a) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;

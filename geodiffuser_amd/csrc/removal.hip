@@ -39,7 +39,7 @@ __device__ __forceinline__ void cm_store(char* lds, int tid, const u32x4 (&r)[4]
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_corr_max(const CorrArgs a) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;

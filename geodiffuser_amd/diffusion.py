@@ -14,10 +14,21 @@ from .scheduler import DDIMScheduler
 
 
 def diffusion_step(model, controller, latents, context, t, guidance_scale, low_resource=False, transform_coords=None,
-                   use_cfg=True, return_noise=False):
+                   use_cfg=True, return_noise=False, skip_uncond_ref=False):
     """diffusion.py:39-59: UNet -> (CFG combine) -> scheduler.step(eta=0) -> controller.step_callback.
     The CFG combine is fused into the DDIM kernel (gd_ddim_step) unless the caller asks for the combined noise."""
-    if use_cfg:
+    if use_cfg and skip_uncond_ref:
+        # The reference latent is overwritten by the inversion trajectory after every step (editor.py:375-377), so the
+        # reference rows' noise prediction is never used; `cond_ref` is still needed for its per-layer q/k/v, `uncond_ref`
+        # is not (vanilla attention, per-sample norms => no influence on other rows).  Batch [uncond_edit, cond_ref, cond_edit].
+        latents_input = torch.cat([latents[1:2], latents[0:1], latents[1:2]])
+        ctx3 = torch.cat([context[1:2], context[2:3], context[3:4]])
+        noise_pred = model.unet(latents_input, t, encoder_hidden_states=ctx3)["sample"]
+        edit_out = model.scheduler.step(noise_pred[0:1], t, latents[1:2], eta=0.0, eps_cond=noise_pred[2:3],
+                                        guidance_scale=guidance_scale)["prev_sample"]
+        latents_out = torch.cat([latents[0:1].to(edit_out.dtype), edit_out])
+        noise_pred_out = None
+    elif use_cfg:
         latents_input = torch.cat([latents] * 2)
         noise_pred = model.unet(latents_input, t, encoder_hidden_states=context)["sample"]
         noise_pred_uncond, noise_prediction_text = noise_pred.chunk(2)

@@ -42,6 +42,7 @@ SCHEDULER = None
 TOKENIZER = None
 UNET_NAME = None
 PROGRESS_BAR = None
+SKIP_UNCOND_REF = True      # drop the CFG pass's unused `uncond_ref` batch row (identical edit output)
 
 
 def clear_controller_loss(controller):
@@ -121,6 +122,17 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
             warp_grid_edit(controller.image_mask[:, None].to(model.device).float(), t_coords_m)).type_as(text_embeddings)
 
     is_geo = type(controller).__name__.startswith("AttentionGeometry")
+    # parity-preserving saving: with an inversion trajectory the CFG pass runs 3 batch rows, not 4
+    skip_ref = ddim_latents is not None and batch_size == 2 and SKIP_UNCOND_REF
+
+    def cfg_pass(lat, ctx, tt):
+        if skip_ref:
+            set_attn_processor_for_edit(model, coords_base=(1, 2), coords_edit=(2, 3), use_cfg=True, n_batch=3)
+            return diffusion_step(model, controller, lat, ctx, tt, guidance_scale, transform_coords=transform_coordinates,
+                                  skip_uncond_ref=True)
+        set_attn_processor_for_edit(model, coords_base=(2, 3), coords_edit=(3, 4), use_cfg=True)           # :343,366
+        return diffusion_step(model, controller, lat, ctx, tt, guidance_scale, transform_coords=transform_coordinates)
+
     for i, t in enumerate(timesteps):
         if uncond_embeddings_ is None:
             context = torch.cat([uncond_embeddings[i].expand(*text_embeddings.shape), text_embeddings])
@@ -162,15 +174,13 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
             if context_new is not None and optimize_embeddings:                                            # :319-322
                 context = context_new.detach()
                 context_save = context
-            set_attn_processor_for_edit(model, coords_base=(2, 3), coords_edit=(3, 4), use_cfg=True)      # :343
-            latents = diffusion_step(model, controller, latents, context, t, guidance_scale, transform_coords=transform_coordinates)
+            latents = cfg_pass(latents, context, t)                                                          # :343-351
         elif i < fast_start_steps * T:
             pass
         else:
             if context_save is not None:
                 context = context_save
-            set_attn_processor_for_edit(model, coords_base=(2, 3), coords_edit=(3, 4), use_cfg=True)      # :366
-            latents = diffusion_step(model, controller, latents, context, t, guidance_scale, transform_coords=transform_coordinates)
+            latents = cfg_pass(latents, context, t)                                                          # :366-368
 
         if ddim_latents is not None:                                                                       # :375-377
             i_n = len(ddim_latents) - 2 - i

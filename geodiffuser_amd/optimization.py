@@ -49,8 +49,12 @@ def _update_latent(latents: torch.Tensor, loss: torch.Tensor, step_size: float, 
         raise NotImplementedError("the optimizer / GradScaler branches are dead in the reference (SURVEY.md F4)")
     if context is None:
         raise ValueError("context is required (the reference always passes it, editor.py:273)")
-    grads = torch.autograd.grad(loss, [latents, context], retain_graph=False)
-    grad_cond, context_grad = grads[0], grads[1]
+    # In the reference every leaf is graph-reachable through the batched tensors even where its gradient is identically
+    # zero (e.g. the text embedding for the remover, whose replace path uses only detached keys/values); the fused layer
+    # returns no gradient there, hence allow_unused + explicit zeros.
+    grads = torch.autograd.grad(loss, [latents, context], retain_graph=False, allow_unused=True)
+    grad_cond = grads[0] if grads[0] is not None else torch.zeros_like(latents)
+    context_grad = grads[1] if grads[1] is not None else torch.zeros_like(context)
     context_grad = torch.nan_to_num(context_grad, posinf=0.0, neginf=0.0, nan=0.0)
     x1 = latents[-1].detach().float().contiguous()
     g1 = grad_cond[-1].detach().float().contiguous()

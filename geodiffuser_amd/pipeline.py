@@ -169,8 +169,12 @@ def build_random_sd21(device="cuda:0", dtype=torch.float16, seed=1234, tiny=Fals
             te = TextEncoder()
     finally:
         torch.random.set_rng_state(g)
+    import os
+    cl = os.environ.get("GD_CHANNELS_LAST", "1") == "1"
     for m in (unet, vae, te):
         m.to(device=device, dtype=dtype).eval()
+        if cl and m is not te:
+            m.to(memory_format=torch.channels_last)      # MIOpen's igemm kernels are NHWC: avoids per-conv layout transposes
         for p in m.parameters():
             p.requires_grad_(False)
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)

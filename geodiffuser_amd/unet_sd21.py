@@ -304,6 +304,8 @@ class UNet2DConditionModel(nn.Module):
         t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep], device=x.device)
         t = t.reshape(-1).to(x.device).expand(x.shape[0])
         temb = self.time_embedding(timestep_embedding(t, self.t_dim).to(dt))
+        if self.conv_in.weight.is_contiguous(memory_format=torch.channels_last) and not self.conv_in.weight.is_contiguous():
+            x = x.contiguous(memory_format=torch.channels_last)
         x = self.conv_in(x)
         skips = [x]
         for blk in self.down_blocks:

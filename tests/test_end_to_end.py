@@ -1,0 +1,85 @@
+"""GPU end-to-end checks of run_geodiffuser() on a narrow SD-shaped model (same topology, head dim 64):
+the edit runs, is deterministic, and the parity-preserving CFG batch-3 shortcut gives the same edited latents as the
+reference's batch-4 layout."""
+import numpy as np
+import pytest
+import torch
+
+from _util import rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    from geodiffuser_amd.diffusion import load_model
+    return load_model(device="cuda:0", tiny=True, dtype=torch.float16)
+
+
+def _run(pipe, kind="geometry_editor", steps=6, skip=True, seed=0, size=256, lr=0.03):
+    from geodiffuser_amd import editor
+    from geodiffuser_amd.synthetic import editor_kwargs, make_edit
+    p, tok, sched = pipe
+    image, depth, mask, T = make_edit(seed, size=size, kind="translate" if seed % 2 == 0 else "rotate")
+    kw = editor_kwargs(kind)
+    kw.update(lr=lr, num_ddim_steps=steps, ldm_stable_model=p, tokenizer_model=tok, scheduler_in=sched, return_latents=True,
+              return_loss_log_dict=True)
+    editor.SKIP_UNCOND_REF = skip
+    try:
+        images, log, latents = editor.run_geodiffuser(image, depth, mask, T, **kw)
+    finally:
+        editor.SKIP_UNCOND_REF = True
+    torch.cuda.synchronize()
+    return images, log, latents.float().cpu()
+
+
+def test_edit_runs(pipe):
+    images, log, lat = _run(pipe)
+    assert len(images) == 2 and images[0].shape == (256, 256, 3) and images[0].dtype == np.uint8
+    assert torch.isfinite(lat).all() and lat.shape == (2, 4, 32, 32)
+    assert len(log) >= 1 and all(np.isfinite(v) for d in log.values() for v in d["self"].values())
+    assert torch.is_grad_enabled()                        # the edit restores autograd's mode
+    # NOTE: whole edits are not bit-reproducible: PyTorch-ROCm's split-K conv / GEMM kernels accumulate with atomics
+    # (two identical UNet passes differ by ~2e-3), exactly as the reference's cudnn.benchmark path; see the pass-level test.
+
+
+def test_cfg_batch3_equals_batch4(pipe):
+    """One CFG pass with the reference's 4-row batch [uncond_ref, uncond_edit, cond_ref, cond_edit] and with the 3-row batch
+    that drops the unused uncond_ref row give the same edited latent (up to the UNet kernels' own run-to-run noise)."""
+    import cases
+    from geodiffuser_amd.attention_processors import (AttentionGeometryEdit, register_attention_control_diffusers,
+                                                      set_attn_processor_for_edit)
+    from geodiffuser_amd.diffusion import diffusion_step
+    from geodiffuser_amd.generic_torch import torch_erode
+    from _util import warped_mask
+    p, tok, sched = pipe
+    mask = cases.ellipse_mask()
+    coords = torch.from_numpy(cases.make_coords("translate", mask))
+    sched.set_timesteps(50)
+    torch.manual_seed(3)
+    latents = torch.randn(2, 4, 64, 64, device="cuda").half()
+    context = torch.randn(4, 77, 64, device="cuda").half()
+    outs = []
+    for mode in ("b4", "b4", "b3"):
+        c = AttentionGeometryEdit(["", ""], 50, {"default_": 0.95}, 0.95, image_mask=mask, obj_edit_step=0.9, device="cuda:0")
+        c.amodal_mask = torch_erode(torch.from_numpy(cases.amodal_input(mask)))
+        c.mask_new_warped = warped_mask("translate")
+        register_attention_control_diffusers(p, c, coords)
+        with torch.no_grad():
+            if mode == "b4":
+                set_attn_processor_for_edit(p, coords_base=(2, 3), coords_edit=(3, 4), use_cfg=True)
+                o = diffusion_step(p, c, latents, context, 500, 3.0, transform_coords=coords)
+            else:
+                set_attn_processor_for_edit(p, coords_base=(1, 2), coords_edit=(2, 3), use_cfg=True, n_batch=3)
+                o = diffusion_step(p, c, latents, context, 500, 3.0, transform_coords=coords, skip_uncond_ref=True)
+        assert c.cur_step == 1 and c.cur_att_layer == 0
+        outs.append(o.float().cpu())
+    noise = rel_err(outs[1][1], outs[0][1])                 # run-to-run noise of two identical batch-4 passes
+    assert rel_err(outs[2][1], outs[0][1]) < max(5 * noise, 5e-3)
+    from geodiffuser_amd.attention_processors import VanillaAttentionProcessor
+    p.unet.set_attn_processor(VanillaAttentionProcessor())
+
+
+def test_remover_runs(pipe):
+    images, log, lat = _run(pipe, kind="geometry_remover", seed=2)
+    assert torch.isfinite(lat).all() and len(images) == 2

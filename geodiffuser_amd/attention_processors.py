@@ -66,8 +66,7 @@ def register_attention_control_diffusers(model, controller, transform_coords=Non
 def set_attn_processor_for_edit(model, perform_edit=True, coords_base=(2, 3), coords_edit=(3, 4), use_cfg=True, n_batch=None):
     """attention_processors.py:56-67.  ``n_batch`` (extension): number of batch entries of the next UNet pass when it differs
     from the reference's 2*len(prompts) / len(prompts) — used by the driver to drop the CFG pass's unused ``uncond_ref`` row."""
-    for name in model.unet.attn_processors.keys():
-        proc = model.unet.attn_processors[name]
+    for proc in model.unet.attn_processors.values():
         proc.perform_edit = perform_edit
         proc.controller.coords_base = coords_base
         proc.controller.coords_edit = coords_edit
@@ -186,6 +185,23 @@ def process_and_cache_masks(masks_cache_dict, h, image_mask, mask_new_warped, am
 
 def _flat(m: torch.Tensor) -> torch.Tensor:
     return m[0, 0].reshape(-1).float().contiguous()
+
+
+# Device buffers that outlive a controller: a captured hipGraph of a CFG pass reads the per-resolution tables by address, so an
+# edit that wants to reuse the graphs of the previous edit copies its tables INTO these buffers instead of allocating new ones.
+_PERSISTENT_TABLES: Dict[tuple, torch.Tensor] = {}
+
+
+def _persist(enabled: bool, key: tuple, t: torch.Tensor) -> torch.Tensor:
+    if not enabled:
+        return t
+    key = key + (tuple(t.shape), t.dtype, str(t.device))
+    buf = _PERSISTENT_TABLES.get(key)
+    if buf is None:
+        buf = _PERSISTENT_TABLES[key] = t.clone()
+    else:
+        buf.copy_(t)
+    return buf
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -397,9 +413,11 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             self.masks_cache_dict, self.image_mask = res[0], res[1]
             m_new, mask_warp, amodal, inter, m_empty, m_wo, t_q = res[2:]
             c = self.masks_cache_dict[S]
-            c["m_edit"] = _flat(m_new)
+            pt = getattr(self, "persistent_tables", False)
+            c["m_edit"] = _persist(pt, ("m_edit", S), _flat(m_new))
             c["m_amodal"] = _flat(amodal)
-            c["idx"], c["w"] = warp_utils.SPLATTER.tables(t_q[0].reshape(-1, 3))
+            idx_, w_ = warp_utils.SPLATTER.tables(t_q[0].reshape(-1, 3))
+            c["idx"], c["w"] = _persist(pt, ("idx", S), idx_), _persist(pt, ("w", S), w_)
         else:
             self.image_mask = self.image_mask.to(dev).float().detach()         # :758,852
             mask_warp = binarize_tensor(self.image_mask)[:, None]
@@ -408,7 +426,8 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             m_wo = binarize_tensor(torch.ones_like(mask_warp) - m_empty)       # :775,867
             c = self.masks_cache_dict.setdefault(S, {})
             c["mask_1_empty"], c["mask_wo_edit"] = m_empty, m_wo
-        c["m_inp"] = _flat(m_empty)
+        pt = getattr(self, "persistent_tables", False)
+        c["m_inp"] = _persist(pt, ("m_inp", S, self._is_remover), _flat(m_empty))
         c["m_wo"] = _flat(m_wo)
         c["zeros"] = torch.zeros(N, dtype=torch.float32, device=dev)
         c["rows"] = torch.nonzero(c["m_inp"] > 0.5).reshape(-1).to(torch.int32).contiguous()
@@ -428,6 +447,19 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             self.mask_1_empty = m_empty.detach()
             self.mask_inpaint = m_empty[0, 0].detach().clone()
         return c
+
+    def graph_key(self):
+        """Everything a no-grad UNet pass of this controller branches on (the launch sequence is static for a given key)."""
+        active = self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1]
+        blend = self.cur_step < int(self.num_steps * self.obj_edit_step)
+        return (type(self).__name__, active, blend, getattr(self, "n_batch", None), self.coords_base, self.coords_edit,
+                self.use_cfg, self.store_attention_maps)
+
+    def after_graph_replay(self):
+        """A replayed pass ran no Python: advance the counters as its num_att_layers hooked calls would have."""
+        self.cur_att_layer = 0
+        self.cur_step += 1
+        self.between_steps()
 
     def forward(self, q, k, v, is_cross: bool, place_in_unet: str, transform_coords=None, scale=None, mask=None):
         nb = getattr(self, "n_batch", None) or (2 * self.batch_size if self.use_cfg else self.batch_size)

@@ -8,9 +8,24 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import warp_utils
+from . import graphs, warp_utils
 from .pipeline import build_random_sd21
 from .scheduler import DDIMScheduler
+
+
+def _unet_nograd(model, controller, x, t, ctx, tag):
+    """UNet call of a no-grad pass, through a captured hipGraph when the controller's launch sequence is static."""
+    key_fn = getattr(controller, "graph_key", None)
+    if not graphs.ENABLED or torch.is_grad_enabled() or key_fn is None or getattr(controller, "store_attention_maps", False) \
+            or not getattr(controller, "persistent_tables", False):
+        return model.unet(x, t, encoder_hidden_states=ctx)["sample"]
+    runner = model.__dict__.get("_graphed")
+    if runner is None:
+        runner = model.__dict__["_graphed"] = graphs.GraphedUNet(model.unet)
+    out, replayed = runner((tag,) + key_fn(), x, t, ctx)
+    if replayed:
+        controller.after_graph_replay()
+    return out
 
 
 def diffusion_step(model, controller, latents, context, t, guidance_scale, low_resource=False, transform_coords=None,
@@ -23,14 +38,14 @@ def diffusion_step(model, controller, latents, context, t, guidance_scale, low_r
         # is not (vanilla attention, per-sample norms => no influence on other rows).  Batch [uncond_edit, cond_ref, cond_edit].
         latents_input = torch.cat([latents[1:2], latents[0:1], latents[1:2]])
         ctx3 = torch.cat([context[1:2], context[2:3], context[3:4]])
-        noise_pred = model.unet(latents_input, t, encoder_hidden_states=ctx3)["sample"]
+        noise_pred = _unet_nograd(model, controller, latents_input, t, ctx3, "cfg3")
         edit_out = model.scheduler.step(noise_pred[0:1], t, latents[1:2], eta=0.0, eps_cond=noise_pred[2:3],
                                         guidance_scale=guidance_scale)["prev_sample"]
         latents_out = torch.cat([latents[0:1].to(edit_out.dtype), edit_out])
         noise_pred_out = None
     elif use_cfg:
         latents_input = torch.cat([latents] * 2)
-        noise_pred = model.unet(latents_input, t, encoder_hidden_states=context)["sample"]
+        noise_pred = _unet_nograd(model, controller, latents_input, t, context, "cfg4")
         noise_pred_uncond, noise_prediction_text = noise_pred.chunk(2)
         if return_noise:
             noise_pred_out = noise_pred_uncond + guidance_scale * (noise_prediction_text - noise_pred_uncond)

@@ -94,6 +94,8 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
     global_loss_log_dict = {}
     skip_optim_steps = SKIP_OPTIM_STEPS
     batch_size = len(prompt)
+    controller.persistent_tables = True      # lets captured CFG-pass graphs be reused by the next edit (one edit at a time per
+    #                                          process, like the reference's module-level singletons)
     register_attention_control_diffusers(model, controller, transform_coordinates)
     height = width = image_size or IMAGE_SIZE
 

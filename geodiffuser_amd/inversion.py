@@ -6,6 +6,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from . import graphs
 from .attention_processors import VanillaAttentionProcessor
 from .scheduler import DDIMInverseScheduler, DDIMScheduler
 
@@ -68,7 +69,13 @@ class NullInversion:
             if self.progress_bar is not None:
                 self.progress_bar(i / self.num_ddim_steps, desc="Performing DDIM Inversion")
             latent_model_input = torch.cat([latents] * 2)
-            noise_pred = self.model.unet(latent_model_input, t, encoder_hidden_states=context_in, return_dict=False)[0]
+            if graphs.ENABLED and not torch.is_grad_enabled():
+                runner = self.model.__dict__.get("_graphed")
+                if runner is None:
+                    runner = self.model.__dict__["_graphed"] = graphs.GraphedUNet(self.model.unet)
+                noise_pred, _ = runner(("inversion",), latent_model_input, t, context_in)
+            else:
+                noise_pred = self.model.unet(latent_model_input, t, encoder_hidden_states=context_in, return_dict=False)[0]
             noise_pred_uncond, noise_pred_cond = noise_pred.chunk(2)
             latents = inv.step(noise_pred_uncond, t, latents, eps_cond=noise_pred_cond, guidance_scale=self.guidance_scale,
                                return_dict=False)[0]

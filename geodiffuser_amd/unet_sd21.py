@@ -276,18 +276,20 @@ class UNet2DConditionModel(nn.Module):
         self.set_attn_processor(VanillaAttentionProcessor())
 
     # -- the two members the reference drives -----------------------------------------------------------
+    def _attn_modules(self):
+        mods = self.__dict__.get("_attn_mods")
+        if mods is None:                       # the module tree is static: walk it once
+            mods = [(f"{name}.processor", m) for name, m in self.named_modules() if isinstance(m, Attention)]
+            self.__dict__["_attn_mods"] = mods
+        return mods
+
     @property
     def attn_processors(self) -> Dict[str, object]:
-        procs = {}
-        for name, m in self.named_modules():
-            if isinstance(m, Attention):
-                procs[f"{name}.processor"] = m.processor
-        return procs
+        return {name: m.processor for name, m in self._attn_modules()}
 
     def set_attn_processor(self, processor: Union[object, Dict[str, object]]):
-        for name, m in self.named_modules():
-            if isinstance(m, Attention):
-                m.set_processor(processor[f"{name}.processor"] if isinstance(processor, dict) else processor)
+        for name, m in self._attn_modules():
+            m.set_processor(processor[name] if isinstance(processor, dict) else processor)
 
     @property
     def dtype(self):

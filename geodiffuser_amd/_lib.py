@@ -38,8 +38,9 @@ SIGNATURES = {
                                    c_void_p, c_int, c_void_p]),
     "gd_mesh_coverage": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gd_attn_fwd": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "gd_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "gd_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                            c_float, c_void_p, c_void_p, c_int, c_void_p]),
+                            c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "gd_attn_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_float, c_void_p, c_int, c_void_p]),
     "gd_removal_corr_max": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -48,7 +49,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_removal_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                               c_void_p, c_void_p, c_int, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gd_nn_table": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_amodal_target": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_int, c_void_p]),

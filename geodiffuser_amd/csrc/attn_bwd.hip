@@ -15,7 +15,7 @@
 
 struct BwdArgs {
     const void* q; const void* k; const void* v; const void* o; const float* lse; const void* dout;
-    void* dq; float* dk;
+    void* dq; float* dk; float* dk_part;
     int N, M, tiles, nwg;
     float c, scale, l2e;
 };
@@ -121,6 +121,7 @@ k_attn_bwd_dq(const BwdArgs a) {
 
 // ---- dK for cross-attention (few keys) -------------------------------------------------------------
 #define DK_QCHUNK 64
+#define DK_CHUNKS 1      // query chunks per workgroup
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_attn_bwd_dk(const BwdArgs a) {
@@ -129,7 +130,7 @@ k_attn_bwd_dk(const BwdArgs a) {
     __shared__ float sg[DK_QCHUNK][ATT_D + 1];
     __shared__ float slse[DK_QCHUNK], sdelta[DK_QCHUNK];
     const int tid = threadIdx.x;
-    const int bh = blockIdx.y, q0 = blockIdx.x * DK_QCHUNK;
+    const int bh = blockIdx.y;
     const int N = a.N, M = a.M;
     const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * ATT_D;
     const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * ATT_D;
@@ -137,30 +138,6 @@ k_attn_bwd_dk(const BwdArgs a) {
     const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * ATT_D;
     const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * ATT_D;
 
-    // stage 64 queries: thread (qq = tid/4, part = tid%4) handles 16 features
-    {
-        const int qq = tid >> 2, part = tid & 3;
-        const int qi = q0 + qq;
-        float d = 0.f;
-        for (int j = 0; j < 16; ++j) {
-            const int dd = part * 16 + j;
-            float qv = 0.f, gv = 0.f, ov = 0.f;
-            if (qi < N) {
-                qv = TR::to_f32(qp[(size_t)qi * ATT_D + dd]);
-                gv = TR::to_f32(gp[(size_t)qi * ATT_D + dd]);
-                ov = TR::to_f32(op[(size_t)qi * ATT_D + dd]);
-            }
-            sq[qq][dd] = qv; sg[qq][dd] = gv;
-            d = __builtin_fmaf(gv, ov, d);
-        }
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        if (part == 0) {
-            sdelta[qq] = d;
-            slse[qq] = qi < N ? a.lse[(size_t)bh * N + qi] : INFINITY;     // exp(-inf) = 0 for padding queries
-        }
-    }
-    __syncthreads();
     const int key = tid >> 1, half = tid & 1;       // 128 keys x 2 feature halves
     const bool valid = key < M;
     float kreg[32], vreg[32], acc[32];
@@ -170,37 +147,84 @@ k_attn_bwd_dk(const BwdArgs a) {
         vreg[j] = valid ? TR::to_f32(vp[(size_t)key * ATT_D + half * 32 + j]) : 0.f;
         acc[j] = 0.f;
     }
-    for (int qq = 0; qq < DK_QCHUNK; ++qq) {
-        float s = 0.f, dp = 0.f;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            s = __builtin_fmaf(sq[qq][half * 32 + j], kreg[j], s);
-            dp = __builtin_fmaf(sg[qq][half * 32 + j], vreg[j], dp);
+    for (int ch = 0; ch < DK_CHUNKS; ++ch) {
+        const int q0 = (blockIdx.x * DK_CHUNKS + ch) * DK_QCHUNK;
+        if (q0 >= N) break;
+        __syncthreads();
+        // stage 64 queries: thread (qq = tid/4, part = tid%4) handles 16 features
+        {
+            const int qq = tid >> 2, part = tid & 3;
+            const int qi = q0 + qq;
+            float d = 0.f;
+            for (int j = 0; j < 16; ++j) {
+                const int dd = part * 16 + j;
+                float qv = 0.f, gv = 0.f, ov = 0.f;
+                if (qi < N) {
+                    qv = TR::to_f32(qp[(size_t)qi * ATT_D + dd]);
+                    gv = TR::to_f32(gp[(size_t)qi * ATT_D + dd]);
+                    ov = TR::to_f32(op[(size_t)qi * ATT_D + dd]);
+                }
+                sq[qq][dd] = qv; sg[qq][dd] = gv;
+                d = __builtin_fmaf(gv, ov, d);
+            }
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            if (part == 0) {
+                sdelta[qq] = d;
+                slse[qq] = qi < N ? a.lse[(size_t)bh * N + qi] : INFINITY;     // exp(-inf) = 0 for padding queries
+            }
         }
-        s += __shfl_xor(s, 1, 64);
-        dp += __shfl_xor(dp, 1, 64);
-        const float p = __expf(s * a.scale - slse[qq]);
-        const float ds = p * (dp - sdelta[qq]) * a.scale;
+        __syncthreads();
+        for (int qq = 0; qq < DK_QCHUNK; ++qq) {
+            float s_ = 0.f, dp = 0.f;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) acc[j] = __builtin_fmaf(ds, sq[qq][half * 32 + j], acc[j]);
-    }
-    if (valid) {
-        float* dst = a.dk + ((size_t)bh * M + key) * ATT_D + half * 32;
+            for (int j = 0; j < 32; ++j) {
+                s_ = __builtin_fmaf(sq[qq][half * 32 + j], kreg[j], s_);
+                dp = __builtin_fmaf(sg[qq][half * 32 + j], vreg[j], dp);
+            }
+            s_ += __shfl_xor(s_, 1, 64);
+            dp += __shfl_xor(dp, 1, 64);
+            const float p = __expf(s_ * a.scale - slse[qq]);
+            const float ds = p * (dp - sdelta[qq]) * a.scale;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) atomicAdd(dst + j, acc[j]);
+            for (int j = 0; j < 32; ++j) acc[j] = __builtin_fmaf(ds, sq[qq][half * 32 + j], acc[j]);
+        }
     }
+    if (valid) {          // partial dK of this query chunk (plain stores; summed by k_attn_bwd_dk_reduce)
+        float* dst = a.dk_part + (((size_t)bh * gridDim.x + blockIdx.x) * M + key) * ATT_D + half * 32;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) dst[j] = acc[j];
+    }
+}
+
+__global__ void k_attn_bwd_dk_reduce(const float* __restrict__ part, int nchunks, int MD, float* __restrict__ dk) {
+    const int bh = blockIdx.y;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= MD) return;
+    const float* p = part + (size_t)bh * nchunks * MD + o;
+    float acc = 0.f;
+    for (int c = 0; c < nchunks; ++c) acc += p[(size_t)c * MD];
+    dk[(size_t)bh * MD + o] += acc;
+}
+
+extern "C" size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk) {
+    if (!need_dk) return 0;
+    const size_t chunks = (size_t)(N + DK_QCHUNK * DK_CHUNKS - 1) / (DK_QCHUNK * DK_CHUNKS);
+    return (size_t)BH * chunks * M * D * sizeof(float);
 }
 
 extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                            const void* dout, int BH, int N, int M, int D, float scale,
-                           void* dq, float* dk_f32, int dtype, void* stream) {
+                           void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
     GD_REQUIRE(q && k && v && out && lse && dout && dq, GD_EINVAL, "gd_attn_bwd: null pointer");
     GD_REQUIRE(D == ATT_D, GD_EUNSUPPORTED, "gd_attn_bwd: head dim %d unsupported (only 64)", D);
     GD_REQUIRE(BH > 0 && N > 0 && M > 0, GD_EINVAL, "gd_attn_bwd: bad sizes");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_bwd: dtype must be f16/bf16");
     GD_REQUIRE(!dk_f32 || M <= 128, GD_EUNSUPPORTED, "gd_attn_bwd: dK is only implemented for M <= 128 keys (cross-attention); M=%d", M);
     BwdArgs a;
-    a.q = q; a.k = k; a.v = v; a.o = out; a.lse = lse; a.dout = dout; a.dq = dq; a.dk = dk_f32;
+    GD_REQUIRE(!dk_f32 || (workspace && workspace_bytes >= gd_attn_bwd_workspace_bytes(BH, N, M, D, 1)), GD_EWORKSPACE,
+               "gd_attn_bwd: dK needs a workspace of gd_attn_bwd_workspace_bytes() bytes");
+    a.q = q; a.k = k; a.v = v; a.o = out; a.lse = lse; a.dout = dout; a.dq = dq; a.dk = dk_f32; a.dk_part = (float*)workspace;
     a.N = N; a.M = M;
     a.tiles = (N + ATT_BM - 1) / ATT_BM;
     a.nwg = a.tiles * BH;
@@ -211,9 +235,11 @@ extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const vo
     if (dtype == GD_F16) k_attn_bwd_dq<f16_t><<<a.nwg, 256, 0, st>>>(a);
     else k_attn_bwd_dq<bf16_t><<<a.nwg, 256, 0, st>>>(a);
     if (dk_f32) {
-        dim3 grid((N + DK_QCHUNK - 1) / DK_QCHUNK, BH);
+        dim3 grid((N + DK_QCHUNK * DK_CHUNKS - 1) / (DK_QCHUNK * DK_CHUNKS), BH);
         if (dtype == GD_F16) k_attn_bwd_dk<f16_t><<<grid, 256, 0, st>>>(a);
         else k_attn_bwd_dk<bf16_t><<<grid, 256, 0, st>>>(a);
+        dim3 rgrid((M * ATT_D + 255) / 256, BH);
+        k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>((const float*)workspace, (int)grid.x, M * ATT_D, dk_f32);
     }
     GD_CHECK_LAUNCH("gd_attn_bwd");
     return GD_OK;

@@ -181,63 +181,135 @@ extern "C" int gd_removal_loss_reduce(const unsigned long long* best, const int3
 }
 
 // ---- backward ------------------------------------------------------------------------------------------
+
 struct RmBwdArgs {
     const void* Pe; const void* Pb; const void* q; const void* k; const int32_t* rows;
     const float* p_in; const int32_t* j_in; const float* p_wo; const int32_t* j_wo; const float* wgt;
     const float* m_inp; const float* m_wo; float coef; const float* gscale;
-    int H, R, N, M, Mpad; float scale; float* dq; float* dk;
+    int H, R, N, M, Mpad; float scale; float* dq; float* dk; float* ds_ws; const float* rowdot;
 };
+
+// rowdot[h, r] = sum_m A[h,r,m] * dA[h,r,m]   (one wave per inpaint row; feeds the softmax backward below)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_removal_rowdot(const RmBwdArgs a, float* __restrict__ rowdot) {
+    using TR = elem_traits<T>;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.H * a.R) return;
+    const int hd = row / a.R, r = row - hd * a.R;
+    const float cf = a.gscale ? a.coef * a.gscale[0] : a.coef;
+    const int ji = a.j_in[row], jw = a.j_wo[row];
+    const float cw = -cf * a.wgt[row] * a.m_wo[jw] / (a.p_wo[row] + 1e-4f);
+    const float ci = cf * a.wgt[row] * a.m_inp[ji] / (a.p_in[row] + 1e-4f);
+    const T* __restrict__ pe = (const T*)a.Pe + ((size_t)hd * a.R + r) * a.Mpad;
+    const T* __restrict__ pbw = (const T*)a.Pb + ((size_t)hd * a.N + jw) * a.Mpad;
+    const T* __restrict__ pbi = (const T*)a.Pb + ((size_t)hd * a.N + ji) * a.Mpad;
+    float dot = 0.f;
+    for (int m = lane; m < a.M; m += 64)
+        dot = __builtin_fmaf(TR::to_f32(pe[m]), cw * TR::to_f32(pbw[m]) + ci * TR::to_f32(pbi[m]), dot);
+    dot = wave_sum(dot);
+    if (lane == 0) rowdot[row] = dot;
+}
+
+#define RM_RB 8      // inpaint rows per wave: each K row fetched from L2 serves 8 rows
+#define RM_MCH 512   // keys per wave: the key range is split over waves (more parallelism; dq combined with f32 atomics)
 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_removal_bwd(const RmBwdArgs a) {
     using TR = elem_traits<T>;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per (head, inpaint row)
-    if (row >= a.H * a.R) return;
-    const int hd = row / a.R, r = row - hd * a.R;
-    const int qrow = a.rows[r];
-    const int ji = a.j_in[row], jw = a.j_wo[row];
+    const int blocks_per_head = (a.R + RM_RB - 1) / RM_RB;
+    const int msplit = (a.M + RM_MCH - 1) / RM_MCH;
+    int wb = blockIdx.x * 4 + (threadIdx.x >> 6);                 // one wave per (head, block of RM_RB inpaint rows, key chunk)
+    if (wb >= a.H * blocks_per_head * msplit) return;
+    const int mc = wb % msplit; wb /= msplit;
+    const int m_lo = mc * RM_MCH, m_hi = (m_lo + RM_MCH) < a.M ? (m_lo + RM_MCH) : a.M;
+    const int hd = wb / blocks_per_head, r0 = (wb - hd * blocks_per_head) * RM_RB;
     const float cf = a.gscale ? a.coef * a.gscale[0] : a.coef;
-    const float cw = -cf * a.wgt[row] * a.m_wo[jw] / (a.p_wo[row] + 1e-4f);
-    const float ci = cf * a.wgt[row] * a.m_inp[ji] / (a.p_in[row] + 1e-4f);
-    const T* __restrict__ pe = (const T*)a.Pe + ((size_t)hd * a.R + r) * a.Mpad;
-    const T* __restrict__ pbw = (const T*)a.Pb + ((size_t)hd * a.N + jw) * a.Mpad;
-    const T* __restrict__ pbi = (const T*)a.Pb + ((size_t)hd * a.N + ji) * a.Mpad;
     const T* __restrict__ kp = (const T*)a.k + (size_t)hd * a.M * ATT_D;
-    // dot = sum_m A dA
-    float dot = 0.f;
-    for (int m = lane; m < a.M; m += 64) {
-        const float A = TR::to_f32(pe[m]);
-        const float dA = cw * TR::to_f32(pbw[m]) + ci * TR::to_f32(pbi[m]);
-        dot = __builtin_fmaf(A, dA, dot);
+    const T* pe[RM_RB]; const T* pbw[RM_RB]; const T* pbi[RM_RB];
+    float cw[RM_RB], ci[RM_RB], dot[RM_RB], acc[RM_RB];
+    int qrow[RM_RB];
+#pragma unroll
+    for (int i = 0; i < RM_RB; ++i) {
+        const int r = (r0 + i) < a.R ? (r0 + i) : (a.R - 1);
+        const bool live = (r0 + i) < a.R;
+        const int row = hd * a.R + r;
+        const int ji = a.j_in[row], jw = a.j_wo[row];
+        qrow[i] = a.rows[r];
+        cw[i] = live ? -cf * a.wgt[row] * a.m_wo[jw] / (a.p_wo[row] + 1e-4f) : 0.f;
+        ci[i] = live ? cf * a.wgt[row] * a.m_inp[ji] / (a.p_in[row] + 1e-4f) : 0.f;
+        pe[i] = (const T*)a.Pe + ((size_t)hd * a.R + r) * a.Mpad;
+        pbw[i] = (const T*)a.Pb + ((size_t)hd * a.N + jw) * a.Mpad;
+        pbi[i] = (const T*)a.Pb + ((size_t)hd * a.N + ji) * a.Mpad;
+        dot[i] = a.rowdot[row]; acc[i] = 0.f;
     }
-    dot = wave_sum(dot);
-    const float qd = a.dk ? TR::to_f32(((const T*)a.q)[((size_t)hd * a.N + qrow) * ATT_D + lane]) : 0.f;
-    float acc = 0.f;                                               // lane = feature d
-    for (int m0 = 0; m0 < a.M; m0 += 64) {
+    // dq_i[d = lane] = scale * sum_m dS_i[m] K[m][d];   dS (scaled) optionally stored for the dk reduction
+    for (int m0 = m_lo; m0 < m_hi; m0 += 64) {
         const int m = m0 + lane;
-        float ds = 0.f;
-        if (m < a.M) {
-            const float A = TR::to_f32(pe[m]);
-            const float dA = cw * TR::to_f32(pbw[m]) + ci * TR::to_f32(pbi[m]);
-            ds = A * (dA - dot) * a.scale;
+        float ds[RM_RB];
+#pragma unroll
+        for (int i = 0; i < RM_RB; ++i) {
+            ds[i] = 0.f;
+            if (m < m_hi) {
+                const float A = TR::to_f32(pe[i][m]);
+                ds[i] = A * (cw[i] * TR::to_f32(pbw[i][m]) + ci[i] * TR::to_f32(pbi[i][m]) - dot[i]) * a.scale;
+            }
+            if (a.ds_ws && (r0 + i) < a.R && m < m_hi) a.ds_ws[((size_t)hd * a.R + r0 + i) * a.Mpad + m] = ds[i];
         }
-        const int lim = (a.M - m0) < 64 ? (a.M - m0) : 64;
-        for (int mm = 0; mm < lim; ++mm) {
-            const float dsm = __shfl(ds, mm, 64);
-            acc = __builtin_fmaf(dsm, TR::to_f32(kp[(size_t)(m0 + mm) * ATT_D + lane]), acc);
-            if (a.dk) atomicAdd(a.dk + ((size_t)hd * a.M + m0 + mm) * ATT_D + lane, dsm * qd);
+        // 16 key rows of K in flight at a time (a load-use chain per key made this loop latency-bound); keys past the chunk
+        // end have dS = 0, their (clamped) K rows contribute nothing
+#pragma unroll 1
+        for (int mb = 0; mb < 64; mb += 16) {
+            if (m0 + mb >= m_hi) break;
+            float kv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int mk = (m0 + mb + u) < a.M ? (m0 + mb + u) : (a.M - 1);
+                kv[u] = TR::to_f32(kp[(size_t)mk * ATT_D + lane]);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int i = 0; i < RM_RB; ++i)
+                    acc[i] = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ds[i]), mb + u)), kv[u], acc[i]);
         }
     }
-    a.dq[((size_t)hd * a.N + qrow) * ATT_D + lane] += acc;
+#pragma unroll
+    for (int i = 0; i < RM_RB; ++i)
+        if ((r0 + i) < a.R) atomicAdd(&a.dq[((size_t)hd * a.N + qrow[i]) * ATT_D + lane], acc[i]);
+}
+
+// dk[h, m, d] += sum_r dS[h, r, m] * q[h, rows[r], d]   (cross-attention: few keys; one thread per (m, d) of a head)
+template <typename T>
+__global__ void k_removal_dk(const float* __restrict__ ds_ws, const T* __restrict__ q, const int32_t* __restrict__ rows,
+                             int R, int N, int M, int Mpad, float* __restrict__ dk) {
+    const int hd = blockIdx.y;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= M * ATT_D) return;
+    const int m = o / ATT_D, d = o - m * ATT_D;
+    const float* dsh = ds_ws + (size_t)hd * R * Mpad + m;
+    const T* qh = q + (size_t)hd * N * ATT_D + d;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    int r = 0;
+    for (; r + 8 <= R; r += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc[u] = __builtin_fmaf(dsh[(size_t)(r + u) * Mpad], elem_traits<T>::to_f32(qh[(size_t)rows[r + u] * ATT_D]), acc[u]);
+    }
+    for (; r < R; ++r) acc[0] = __builtin_fmaf(dsh[(size_t)r * Mpad], elem_traits<T>::to_f32(qh[(size_t)rows[r] * ATT_D]), acc[0]);
+    dk[((size_t)hd * M + m) * ATT_D + d] += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
 extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
                               const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
                               const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
                               int H, int R, int N, int M, int Mpad, int D, float scale,
-                              float* dq_f32, float* dk_f32, int dtype, void* stream) {
+                              float* dq_f32, float* dk_f32, float* ds_ws, int dtype, void* stream) {
     GD_REQUIRE(Pe && Pb && q && k && rows && p_in && j_in && p_wo && j_wo && wgt && m_inp && m_wo && dq_f32, GD_EINVAL,
                "gd_removal_bwd: null pointer");
     GD_REQUIRE(D == ATT_D, GD_EUNSUPPORTED, "gd_removal_bwd: head dim %d unsupported (only 64)", D);
@@ -246,10 +318,21 @@ extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, con
     RmBwdArgs a;
     a.Pe = Pe; a.Pb = Pb; a.q = q; a.k = k; a.rows = rows; a.p_in = p_in; a.j_in = j_in; a.p_wo = p_wo; a.j_wo = j_wo;
     a.wgt = wgt; a.m_inp = m_inp; a.m_wo = m_wo; a.coef = coef; a.gscale = gscale_dev; a.H = H; a.R = R; a.N = N; a.M = M; a.Mpad = Mpad;
-    a.scale = scale; a.dq = dq_f32; a.dk = dk_f32;
-    const int blocks = (H * R + 3) / 4;
-    if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, as_stream(stream)>>>(a);
-    else k_removal_bwd<bf16_t><<<blocks, 256, 0, as_stream(stream)>>>(a);
+    GD_REQUIRE(ds_ws, GD_EINVAL, "gd_removal_bwd: workspace required: H*R floats (+ H*R*Mpad floats when dk_f32 != NULL)");
+    float* rowdot = ds_ws;
+    a.scale = scale; a.dq = dq_f32; a.dk = dk_f32; a.ds_ws = dk_f32 ? ds_ws + (size_t)H * R : nullptr; a.rowdot = rowdot;
+    const int waves = H * ((R + RM_RB - 1) / RM_RB) * ((M + RM_MCH - 1) / RM_MCH);
+    const int blocks = (waves + 3) / 4;
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16) k_removal_rowdot<f16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rowdot);
+    else k_removal_rowdot<bf16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rowdot);
+    if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, st>>>(a);
+    else k_removal_bwd<bf16_t><<<blocks, 256, 0, st>>>(a);
+    if (dk_f32) {
+        dim3 grid((M * ATT_D + 255) / 256, H);
+        if (dtype == GD_F16) k_removal_dk<f16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const f16_t*)q, rows, R, N, M, Mpad, dk_f32);
+        else k_removal_dk<bf16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const bf16_t*)q, rows, R, N, M, Mpad, dk_f32);
+    }
     GD_CHECK_LAUNCH("gd_removal_bwd");
     return GD_OK;
 }

@@ -55,13 +55,27 @@ __global__ void k_composite_tok(const T* __restrict__ src, const int32_t* __rest
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
-    for (int k = 0; k < K; ++k) {
-        const int p = idx[(size_t)pix * K + k];
-        if (p < 0) continue;
-        const float wk = w[(size_t)pix * K + k];
-        const V8 f = *(const V8*)(sb + (size_t)p * C + ch * 8);
+    // the K gathers of a pixel are independent: fetch the index/weight slots 8 at a time, issue the 8 row loads together
+    // (a dependent idx -> row chain per slot made this kernel latency-bound), then accumulate in slot order
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        int pk[8];
+        float wk[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(wk, TR::to_f32(f[i]), acc[i]);
+        for (int j = 0; j < 8; ++j) {
+            const int kk = k0 + j;
+            const int p = kk < K ? idx[(size_t)pix * K + kk] : -1;
+            pk[j] = p;
+            wk[j] = (kk < K && p >= 0) ? w[(size_t)pix * K + kk] : 0.0f;
+        }
+        V8 f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = *(const V8*)(sb + (size_t)(pk[j] < 0 ? 0 : pk[j]) * C + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (pk[j] >= 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(wk[j], TR::to_f32(f[j][i]), acc[i]);
+            }
     }
     V8 o;
     if (m) {
@@ -96,10 +110,21 @@ __global__ void k_composite_chan(const T* __restrict__ src, const int32_t* __res
     const long long bc = gid / npix;
     const T* sp = src + (size_t)bc * P;
     float acc = 0.0f;
-    for (int k = 0; k < K; ++k) {
-        const int p = idx[(size_t)pix * K + k];
-        if (p < 0) continue;
-        acc = __builtin_fmaf(w[(size_t)pix * K + k], (float)sp[p], acc);
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        int pk[8];
+        float wk[8], fv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = k0 + j;
+            const int p = kk < K ? idx[(size_t)pix * K + kk] : -1;
+            pk[j] = p;
+            wk[j] = (kk < K && p >= 0) ? w[(size_t)pix * K + kk] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fv[j] = (float)sp[pk[j] < 0 ? 0 : pk[j]];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (pk[j] >= 0) acc = __builtin_fmaf(wk[j], fv[j], acc);
     }
     float r = (float)(f16_t)acc;
     if (m) {

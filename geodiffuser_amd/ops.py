@@ -135,8 +135,10 @@ def attn_bwd(q, k, v, out, lse, dout, scale: float, need_dk: bool):
     M = k.shape[1]
     dq = torch.empty_like(q)
     dk = torch.zeros(BH, M, D, dtype=torch.float32, device=q.device) if need_dk else None
-    check(lib.gd_attn_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), BH, N, M, D, scale, _p(dq), _p(dk), dt, _stream()),
-          "gd_attn_bwd")
+    nbytes = lib.gd_attn_bwd_workspace_bytes(BH, N, M, D, int(need_dk))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device) if nbytes else None
+    check(lib.gd_attn_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), BH, N, M, D, scale, _p(dq), _p(dk), _p(ws), nbytes, dt,
+                          _stream()), "gd_attn_bwd")
     return dq, dk
 
 
@@ -185,9 +187,10 @@ def removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, scale
     N, D = q.shape[1], q.shape[2]
     M = k.shape[1]
     _need(dq_f32, "dq_f32", torch.float32)
+    ds_ws = torch.empty(H * R * (1 + (Mpad if dk_f32 is not None else 0)), dtype=torch.float32, device=Pe.device)
     check(lib.gd_removal_bwd(_p(Pe), _p(Pb), _p(q), _p(k), _p(rows), _p(aux["p_in"]), _p(aux["j_in"]), _p(aux["p_wo"]),
                              _p(aux["j_wo"]), _p(aux["wgt"]), _p(m_inp), _p(m_wo), coef, _p(gscale), H, R, N, M, Mpad, D, scale,
-                             _p(dq_f32), _p(dk_f32), dt, _stream()), "gd_removal_bwd")
+                             _p(dq_f32), _p(dk_f32), _p(ds_ws), dt, _stream()), "gd_removal_bwd")
 
 
 def nn_table(fg, S: int):

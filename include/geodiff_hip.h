@@ -112,11 +112,13 @@ int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float 
  *   dout [BH,N,D] 16-bit; lse from the forward; dq [BH,N,D] 16-bit (overwritten);
  *   dk_f32 [BH,M,D] f32, ACCUMULATED into (caller zeroes) — used by cross-attention where k_edit
  *   carries gradient (U/attention_processors.py:432).  v never receives gradient on this path
- *   (v_base.detach(), :433,557).
+ *   (v_base.detach(), :433,557).  workspace: gd_attn_bwd_workspace_bytes() bytes when dk_f32 != NULL (per-chunk partials,
+ *   summed without atomics), else NULL.
  */
+size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk);
 int gd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                 const void* dout, int BH, int N, int M, int D, float scale,
-                void* dq, float* dk_f32, int dtype, void* stream);
+                void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* P[bh, r, m] = exp(scale * q[bh, rows[r]] . k[bh, m] - lse[bh, rows[r]])   (rows == NULL: r = row)
  * The opt-pass materialisation of base_att / replace_att rows that removal_loss_geodiff consumes
@@ -150,14 +152,14 @@ int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, 
  * Backward of the removal loss through replace_att rows into q (and k for cross):
  *   dA[h,r,m] = coef * wgt[h,r] * ( -Pb[h,j_wo,m] * m_wo[j_wo]/(p_wo+1e-4) + Pb[h,j_in,m] * m_inp[j_in]/(p_in+1e-4) )
  *   dS = A o (dA - rowsum(A o dA));  dq[h,rows[r]] += scale * dS K;  dk_f32[h] += scale * dS^T q   (dk_f32 may be NULL)
- * dq_f32 [H,N,D] f32 accumulated (caller zeroes).  gscale_dev: optional DEVICE scalar multiplied into coef (the
+ * dq_f32 [H,N,D] f32 accumulated (caller zeroes).  ds_ws: scratch, H*R floats (+ H*R*Mpad floats when dk_f32 != NULL).  gscale_dev: optional DEVICE scalar multiplied into coef (the
  * upstream gradient of the loss, so that no host sync is needed to read it).
  */
 int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
                    const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
                    const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
                    int H, int R, int N, int M, int Mpad, int D, float scale,
-                   float* dq_f32, float* dk_f32, int dtype, void* stream);
+                   float* dq_f32, float* dk_f32, float* ds_ws, int dtype, void* stream);
 
 /*
  * The mask-only half of interpolate_from_mask (U/attention_sharing.py:81-83,103), once per edit and resolution:

@@ -23,3 +23,14 @@ extern "C" const char* gd_error_string(int code) {
         default: return "unknown error";
     }
 }
+
+__global__ void k_zero_u32(uint32_t* __restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+void gd_zero_async(void* ptr, size_t bytes, hipStream_t st) {
+    const size_t n = (bytes + 3) / 4;                      // all scratch buffers are multiples of 4 bytes
+    if (n == 0) return;
+    k_zero_u32<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((uint32_t*)ptr, n);
+}

@@ -76,3 +76,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+// Zero-fill as a KERNEL node: memset nodes inside a captured hipGraph were observed to race with neighbouring kernel nodes
+// on this stack (memory faults on replay that disappear under AMD_SERIALIZE_KERNEL=3), kernels are ordered correctly.
+void gd_zero_async(void* ptr, size_t bytes, hipStream_t st);

@@ -46,7 +46,7 @@ extern "C" int gd_mesh_coverage(const float* verts, const int32_t* faces, int V,
     GD_REQUIRE(verts && out && S > 0 && V >= 0 && F >= 0, GD_EINVAL, "gd_mesh_coverage: bad argument");
     GD_REQUIRE(F == 0 || faces, GD_EINVAL, "gd_mesh_coverage: null faces");
     hipStream_t st = as_stream(stream);
-    (void)hipMemsetAsync(out, 0, (size_t)S * S * sizeof(float), st);
+    gd_zero_async(out, (size_t)S * S * sizeof(float), st);
     if (F > 0) k_mesh_coverage<<<(F + 127) / 128, 128, 0, st>>>(verts, faces, F, S, out);
     GD_CHECK_LAUNCH("gd_mesh_coverage");
     return GD_OK;

@@ -216,8 +216,8 @@ extern "C" int gd_rasterize_points(const float* pts, int P, int S, float radius_
     int* cursor = (int*)w;           w += align256((npix + 1) * 4);
     int* cand = (int*)w;
     const float r2 = radius_ndc * radius_ndc;
-    (void)hipMemsetAsync(count, 0, (npix + 1) * 4, st);
-    (void)hipMemsetAsync(cursor, 0, (npix + 1) * 4, st);
+    gd_zero_async(count, (npix + 1) * 4, st);
+    gd_zero_async(cursor, (npix + 1) * 4, st);
     const int tp = 256;
     k_count_fill<false><<<(P + tp - 1) / tp, tp, 0, st>>>(pts, P, S, radius_ndc, r2, count, nullptr, nullptr, nullptr);
     k_scan<<<1, 1024, 0, st>>>(count, offset, (int)npix);

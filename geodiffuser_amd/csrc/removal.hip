@@ -137,7 +137,7 @@ extern "C" int gd_removal_corr_max(const void* Pe, const void* Pb, const float* 
     a.rtiles = (R + CM_T - 1) / CM_T;
     a.jtiles = (N + CM_T - 1) / CM_T;
     hipStream_t st = as_stream(stream);
-    (void)hipMemsetAsync(best, 0, (size_t)H * R * 2 * sizeof(unsigned long long), st);
+    gd_zero_async(best, (size_t)H * R * 2 * sizeof(unsigned long long), st);
     dim3 grid(a.rtiles * a.jtiles, H);
     if (dtype == GD_F16) k_corr_max<f16_t><<<grid, 256, 0, st>>>(a);
     else k_corr_max<bf16_t><<<grid, 256, 0, st>>>(a);

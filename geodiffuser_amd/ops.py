@@ -289,3 +289,20 @@ def norm_rescale(x, num_sumsq, den_sumsq):
     out = torch.empty_like(x)
     check(lib.gd_norm_rescale(_p(x), _p(num_sumsq), _p(den_sumsq), x.numel(), _p(out), _stream()), "gd_norm_rescale")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# UNet plumbing: fused GroupNorm (+SiLU), channels-last, no-grad
+# ---------------------------------------------------------------------------------------------------
+def group_norm_nhwc(x, gamma, beta, groups: int, eps: float, silu: bool):
+    """x [B,C,H,W] in channels_last memory format (16-bit) -> same shape / format."""
+    lib = _lib.load()
+    dt = _dt16(x, "x")
+    if not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last):
+        raise _lib.GeodiffError("group_norm_nhwc: expected a channels_last GPU tensor")
+    B, C, H, W = x.shape
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+    check(lib.gd_group_norm_nhwc(_p(x), _p(gamma), _p(beta), B, H * W, C, groups, eps, int(silu), _p(stats), _p(y), dt, _stream()),
+          "gd_group_norm_nhwc")
+    return y

@@ -34,6 +34,20 @@ class UNetOutput(dict):
         return super().__getitem__(k)
 
 
+class GroupNormAct(nn.GroupNorm):
+    """nn.GroupNorm with an optional fused SiLU.  On no-grad passes over channels-last 16-bit GPU activations it runs the fused
+    HIP kernel (gd_group_norm_nhwc: no NCHW round trip, 2 launches); otherwise stock PyTorch (autograd-capable)."""
+
+    def forward(self, x, silu: bool = False):
+        if (not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16)
+                and self.num_channels // self.num_groups >= 8 and x.is_contiguous(memory_format=torch.channels_last)
+                and self.weight.dtype == x.dtype):
+            from . import ops
+            return ops.group_norm_nhwc(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+        y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+        return F.silu(y) if silu else y
+
+
 class Attention(nn.Module):
     def __init__(self, query_dim: int, cross_attention_dim: Optional[int], heads: int, dim_head: int):
         super().__init__()
@@ -116,7 +130,7 @@ class Transformer2DModel(nn.Module):
 
     def __init__(self, channels, heads, dim_head, cross_attention_dim):
         super().__init__()
-        self.norm = nn.GroupNorm(32, channels, eps=1e-6)
+        self.norm = GroupNormAct(32, channels, eps=1e-6)
         self.proj_in = nn.Linear(channels, channels)
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(channels, heads, dim_head, cross_attention_dim)])
         self.proj_out = nn.Linear(channels, channels)
@@ -137,17 +151,17 @@ class Transformer2DModel(nn.Module):
 class ResnetBlock2D(nn.Module):
     def __init__(self, cin, cout, temb_ch=1280):
         super().__init__()
-        self.norm1 = nn.GroupNorm(32, cin, eps=1e-5)
+        self.norm1 = GroupNormAct(32, cin, eps=1e-5)
         self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
         self.time_emb_proj = nn.Linear(temb_ch, cout)
-        self.norm2 = nn.GroupNorm(32, cout, eps=1e-5)
+        self.norm2 = GroupNormAct(32, cout, eps=1e-5)
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, temb):
-        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv1(self.norm1(x, silu=True))
         h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        h = self.conv2(self.norm2(h, silu=True))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return x + h
@@ -269,7 +283,7 @@ class UNet2DConditionModel(nn.Module):
             last = i == len(ch) - 1
             self.up_blocks.append(UpBlock(cin_skip, cout, prev, rheads[i], cross_attention_dim, layers_per_block + 1, attn=i > 0, up=not last, temb_ch=ch[0] * 4))
             prev = cout
-        self.conv_norm_out = nn.GroupNorm(32, ch[0], eps=1e-5)
+        self.conv_norm_out = GroupNormAct(32, ch[0], eps=1e-5)
         self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
         self.t_dim = ch[0]
         from .attention_processors import VanillaAttentionProcessor
@@ -316,7 +330,7 @@ class UNet2DConditionModel(nn.Module):
         x = self.mid_block(x, temb, ctx)
         for blk in self.up_blocks:
             x = blk(x, skips, temb, ctx)
-        x = self.conv_out(F.silu(self.conv_norm_out(x)))
+        x = self.conv_out(self.conv_norm_out(x, silu=True))
         if not return_dict:
             return (x,)
         return UNetOutput(sample=x)

@@ -222,6 +222,13 @@ int gd_masked_latent_update(const float* x, const float* g, const float* m, floa
 int gd_sumsq(const float* x, int64_t n, float* sumsq, void* stream);
 int gd_norm_rescale(const float* x, const float* num_sumsq, const float* den_sumsq, int64_t n, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * UNet plumbing (not a row of the hot path): GroupNorm (+ SiLU) on channels-last 16-bit activations, no-grad passes.
+ * x, y [B, HW, C] (NHWC memory), gamma/beta [C] 16-bit, stats [B,G,2] f32 scratch (cleared by the call).
+ * ---------------------------------------------------------------------------------------------- */
+int gd_group_norm_nhwc(const void* x, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
+                       int silu, float* stats, void* y, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

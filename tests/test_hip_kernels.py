@@ -370,3 +370,22 @@ def test_ddim_and_latent_update(ops):
     out = ops.norm_rescale(got_l.to(DEV), n0, n1).cpu()
     ref = got_l * float(O.norm_tensor(x[1])) / float(O.norm_tensor(got_l))
     assert rel_err(out, ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ UNet plumbing
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H", [(3, 320, 64), (2, 1920, 16), (2, 2560, 8), (3, 960, 32), (1, 640, 24), (2, 1280, 8)])
+def test_group_norm_nhwc(ops, dtype, B, C, H):
+    """Fused channels-last GroupNorm(+SiLU) used by the UNet harness on no-grad passes vs torch's GroupNorm in fp32."""
+    import torch.nn.functional as F
+    torch.manual_seed(C + H)
+    x = (torch.randn(B, C, H, H) * 2 + 0.5).to(dtype)
+    g = (torch.rand(C) + 0.5).to(dtype); bta = (torch.randn(C) * 0.2).to(dtype)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    for silu in (False, True):
+        y = ops.group_norm_nhwc(xd, g.to(DEV), bta.to(DEV), 32, 1e-5, silu)
+        assert y.is_contiguous(memory_format=torch.channels_last)
+        ref = F.group_norm(x.float(), 32, g.float(), bta.float(), 1e-5)
+        if silu:
+            ref = F.silu(ref)
+        assert rel_err(y.float().cpu(), ref) < tol(dtype)

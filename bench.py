@@ -70,8 +70,18 @@ class AttnTimer:
             return None
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
         fl = sum(f for _, _, f in self.records)
+        # HBM traffic of the most frequent launch shape, from the committed PMC run of the same kernel (profiles/)
+        traffic = None
+        try:
+            tab = json.load(open(os.path.join(ROOT, "profiles", "r01_attn_traffic.json")))["bytes_per_launch"]
+            per = 4.0 * self.n * self.n * 64
+            heads = [int(round(f / per)) for _, _, f in self.records]
+            common = max(set(heads), key=heads.count)
+            traffic = tab.get(str(common))
+        except Exception:  # noqa: BLE001
+            pass
         return dict(launches=len(self.records), avg_us=1e3 * ms / len(self.records), flops_per_launch=fl / len(self.records),
-                    achieved=fl / (ms * 1e-3))
+                    achieved=fl / (ms * 1e-3), traffic=traffic)
 
 
 def cpu_baseline(budget_s=45.0):
@@ -204,7 +214,7 @@ def main():
         if roof:
             line["roofline"] = {"kernel": "k_attn_fwd (64^2 self-attention launches)", "bound": "mfma", "achieved": roof["achieved"] / 1e12,
                                 "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s", "frac": roof["achieved"] / PEAK_MFMA_16BIT,
-                                "traffic": None, "launches": roof["launches"], "avg_launch_us": roof["avg_us"],
+                                "traffic": roof["traffic"], "launches": roof["launches"], "avg_launch_us": roof["avg_us"],
                                 "flops_per_launch": roof["flops_per_launch"]}
         if not args.no_cpu_baseline and world == 1:
             try:

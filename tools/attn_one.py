@@ -2,7 +2,7 @@
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from geodiffuser_amd import ops
-BH, N, M = 25, 4096, 4096
+BH, N, M = int(os.environ.get("BH", "32")), 4096, 4096
 torch.manual_seed(0)
 q = (torch.randn(BH, N, 64, device="cuda") * 1.2).bfloat16(); k = (torch.randn(BH, M, 64, device="cuda") * 1.2).bfloat16(); v = torch.randn(BH, M, 64, device="cuda").bfloat16()
 out = torch.empty_like(q); lse = torch.empty(BH, N, device="cuda")

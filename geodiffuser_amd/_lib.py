@@ -18,7 +18,7 @@ GD_ATTN_MAX_SEGS = 4
 
 class GdAttnSeg(Structure):
     _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("lse", c_void_p),
-                ("bh", c_int32), ("pad_", c_int32)]
+                ("bh", c_int32), ("heads", c_int32)]
 
 
 class GeodiffError(RuntimeError):

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import abc
 import math
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -30,7 +31,7 @@ import torch
 from . import ops
 from . import warp_utils
 from ._lib import GD_TOKEN_MAJOR
-from .attention_sharing import AttentionStore, attention, compute_attention, get_base_edit_qkv
+from .attention_sharing import attention_tok, AttentionStore, attention, compute_attention, get_base_edit_qkv
 from .generic_torch import (CoordinateDistances, binarize_tensor, reshape_attention_mask,
                             reshape_transform_coords, torch_dilate)
 
@@ -74,7 +75,7 @@ def set_attn_processor_for_edit(model, perform_edit=True, coords_base=(2, 3), co
         proc.controller.n_batch = n_batch
 
 
-def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale):
+def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_major=False):
     """Shared front half of both processors (attention_processors.py:85-120 / :165-203)."""
     args = () if USE_PEFT_BACKEND else (scale,)
     if getattr(attn, "spatial_norm", None) is not None:
@@ -97,14 +98,29 @@ def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale):
         encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
     key = attn.to_k(encoder_hidden_states, *lin_args)
     value = attn.to_v(encoder_hidden_states, *lin_args)
+    if token_major:
+        # to_q/to_k/to_v output [B, N, heads*D] is consumed in place by the attention kernel's token-major mode: the
+        # reference's head_to_batch_dim / batch_to_head_dim permutes (4 copies per layer) disappear
+        return query.contiguous(), key.contiguous(), value.contiguous(), is_cross, shape4, lin_args
     query = attn.head_to_batch_dim(query).contiguous()
     key = attn.head_to_batch_dim(key).contiguous()
     value = attn.head_to_batch_dim(value).contiguous()
     return query, key, value, is_cross, shape4, lin_args
 
 
-def _finish(attn, hidden_states, residual, shape4, lin_args):
-    hidden_states = attn.batch_to_head_dim(hidden_states)
+TOKEN_MAJOR = os.environ.get("GD_TOKEN_MAJOR", "1") == "1"
+
+
+def _tok_ok(attn, hidden_states) -> bool:
+    """Token-major fast path: no-grad passes with 64-wide heads on the GPU (every SD 2.1 attention layer)."""
+    return (TOKEN_MAJOR and not torch.is_grad_enabled() and hidden_states.is_cuda
+            and hidden_states.dtype in (torch.float16, torch.bfloat16)
+            and attn.to_q.out_features == attn.heads * 64)
+
+
+def _finish(attn, hidden_states, residual, shape4, lin_args, token_major=False):
+    if not token_major:
+        hidden_states = attn.batch_to_head_dim(hidden_states)
     hidden_states = attn.to_out[0](hidden_states, *lin_args)
     hidden_states = attn.to_out[1](hidden_states)
     if shape4 is not None:
@@ -120,9 +136,10 @@ class VanillaAttentionProcessor:
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale: float = 1.0):
         residual = hidden_states
-        q, k, v, _, shape4, lin_args = _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale)
-        out = attention(q, k, v, attn.scale)
-        return _finish(attn, out, residual, shape4, lin_args)
+        tok = _tok_ok(attn, hidden_states)
+        q, k, v, _, shape4, lin_args = _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, tok)
+        out = attention_tok(q, k, v, attn.scale, attn.heads) if tok else attention(q, k, v, attn.scale)
+        return _finish(attn, out, residual, shape4, lin_args, tok)
 
 
 class EditProcessor:
@@ -140,13 +157,22 @@ class EditProcessor:
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale: float = 1.0):
         residual = hidden_states
-        q, k, v, is_cross, shape4, lin_args = _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale)
+        ctrl = self.controller
+        # losses (use_cfg False) and stored maps stay on the head-major path
+        tok = _tok_ok(attn, hidden_states) and (not self.perform_edit or (
+            getattr(ctrl, "supports_token_major", False) and ctrl.use_cfg and not getattr(ctrl, "store_attention_maps", False)))
+        q, k, v, is_cross, shape4, lin_args = _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, tok)
         if self.perform_edit:
-            out = self.controller(q, k, v, is_cross=is_cross, place_in_unet=self.place_in_unet,
-                                  transform_coords=self.transform_coords, scale=attn.scale, mask=None)
+            if tok:
+                ctrl.heads_tok = attn.heads
+            try:
+                out = ctrl(q, k, v, is_cross=is_cross, place_in_unet=self.place_in_unet,
+                           transform_coords=self.transform_coords, scale=attn.scale, mask=None)
+            finally:
+                ctrl.heads_tok = 0
         else:
-            out = attention(q, k, v, attn.scale)
-        return _finish(attn, out, residual, shape4, lin_args)
+            out = attention_tok(q, k, v, attn.scale, attn.heads) if tok else attention(q, k, v, attn.scale)
+        return _finish(attn, out, residual, shape4, lin_args, tok)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -461,10 +487,57 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         self.cur_step += 1
         self.between_steps()
 
+    supports_token_major = True
+    heads_tok = 0
+
+    def _forward_tok(self, q, k, v, is_cross: bool, transform_coords, scale: float, heads: int):
+        """No-grad CFG pass on token-major q/k/v [B, N, heads*64]; the caller (EditProcessor) routes passes that accumulate
+        losses (use_cfg False) through the head-major _EditLayer instead.  Same launches as _EditLayer.forward with batch
+        rows in place of head blocks; the edit attention, whose output only feeds the blend, is skipped when not blending."""
+        (b0, b1), (e0, e1) = self.coords_base, self.coords_edit
+        cb = self.coords_base[-1]
+        S = int(math.isqrt(q.shape[1]))
+        c = self._tables(S, heads, q, transform_coords)
+        remover = self._is_remover
+        blend = self.cur_step < int(self.num_steps * self.obj_edit_step)
+        out_full = torch.empty(cb + 1, q.shape[1], q.shape[2], dtype=q.dtype, device=q.device)
+        q_base, k_base, v_base = q[b0:b1], k[b0:b1], v[b0:b1]
+        q_edit, k_edit, v_edit = q[e0:e1], k[e0:e1], v[e0:e1]
+        segs = [(q[:cb], k[:cb], v[:cb], out_full[:cb], None)]
+        replace_out = out_full[cb:]
+        edit_out = ident_out = None
+        if not remover:
+            K = k_edit if is_cross else k_base
+            if blend:
+                q_warp = ops.splat_composite(q_base, c["idx"], c["w"], c["m_edit"], GD_TOKEN_MAJOR)   # all heads in one row
+                edit_out = torch.empty_like(q_edit)
+                replace_out = torch.empty_like(q_edit)
+                segs.append((q_warp, k_base, v_base, edit_out, None))
+        else:
+            K = k_base
+            if not blend:
+                ident_out = torch.empty_like(q_edit)
+                replace_out = torch.empty_like(q_edit)
+                segs.append((q_edit, k_edit, v_edit, ident_out, None))
+        segs.append((q_edit, K, v_base, replace_out, None))
+        ops.attn_fwd(segs, scale, heads=heads)
+        if edit_out is not None:
+            ops.blend_tokens(edit_out, replace_out, c["m_edit"], out=out_full[cb:])
+        elif ident_out is not None:
+            ops.blend_tokens(ident_out, replace_out, c["m_inp"], out=out_full[cb:])
+        return out_full
+
     def forward(self, q, k, v, is_cross: bool, place_in_unet: str, transform_coords=None, scale=None, mask=None):
         nb = getattr(self, "n_batch", None) or (2 * self.batch_size if self.use_cfg else self.batch_size)
-        f = q.shape[0] // nb
         active = is_cross or (self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1])
+        heads = self.heads_tok
+        if heads:
+            if not active:
+                return attention_tok(q, k, v, scale, heads)
+            if is_cross:
+                _ = self.cross_replace_alpha[self.cur_step]
+            return self._forward_tok(q, k, v, is_cross, transform_coords, float(scale), heads)
+        f = q.shape[0] // nb
         if not active:
             return attention(q, k, v, scale)                                   # :646-647
         if is_cross:

@@ -53,6 +53,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -
     return out
 
 
+def attention_tok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, heads: int) -> torch.Tensor:
+    """No-grad attention on the projections' own layout: q [B,N,heads*64], k/v [B,M,heads*64] -> [B,N,heads*64]."""
+    out = torch.empty_like(q)
+    ops.attn_fwd([(q, k, v, out, None)], scale, heads=heads)
+    return out
+
+
 def compute_attention(q, k, scale, mask=None, fg_mask_warp=None, fg_mask=None, inpaint_mask=None):
     """attention_sharing.py:30-47: the materialised probability map softmax(scale q k^T), fp32 like the reference's
     autocast softmax.  The mask arguments are accepted and ignored — they are no-ops in the reference (the masked

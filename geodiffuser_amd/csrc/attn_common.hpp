@@ -36,13 +36,14 @@ __device__ __forceinline__ int img_off(int r, int c) {
 
 // global -> registers: this thread's two 16-B chunks of a 64 x 64 tile (rows tid/8 and tid/8 + 32)
 template <typename T>
-__device__ __forceinline__ void tile_load(const T* __restrict__ base, int row0, int nrows, int tid, u32x4 (&r)[2]) {
+__device__ __forceinline__ void tile_load(const T* __restrict__ base, int row0, int nrows, int tid, u32x4 (&r)[2],
+                                          int row_stride = ATT_D) {
     const int c = tid & 7;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int row = row0 + (tid >> 3) + 32 * i;
         row = row < nrows ? row : nrows - 1;                 // clamp; out-of-range keys are masked later
-        r[i] = *(const u32x4*)(base + (size_t)row * ATT_D + c * 8);
+        r[i] = *(const u32x4*)(base + (size_t)row * row_stride + c * 8);
     }
 }
 

@@ -123,16 +123,27 @@ k_attn_fwd(const FwdArgs a) {
     const int bh = gbh - (sidx ? a.bh_end[sidx - 1] : 0);
     const gd_attn_seg_t sg = a.seg[sidx];
     const int N = a.N, M = a.M;
-    const T* __restrict__ qp = (const T*)sg.q + (size_t)bh * N * ATT_D;
-    const T* __restrict__ kp = (const T*)sg.k + (size_t)bh * M * ATT_D;
-    const T* __restrict__ vp = (const T*)sg.v + (size_t)bh * M * ATT_D;
+    // row stride / base offsets: head-major [bh, N, 64] or token-major [B, N, heads*64]
+    const int rs = sg.heads > 0 ? sg.heads * ATT_D : ATT_D;
+    size_t qoff, koff;
+    if (sg.heads > 0) {
+        const int b = bh / sg.heads, hh = bh - b * sg.heads;
+        qoff = (size_t)b * N * rs + (size_t)hh * ATT_D;
+        koff = (size_t)b * M * rs + (size_t)hh * ATT_D;
+    } else {
+        qoff = (size_t)bh * N * ATT_D;
+        koff = (size_t)bh * M * ATT_D;
+    }
+    const T* __restrict__ qp = (const T*)sg.q + qoff;
+    const T* __restrict__ kp = (const T*)sg.k + koff;
+    const T* __restrict__ vp = (const T*)sg.v + koff;
 
     // this lane's query (B operand column); lanes l and l^32 share the query, split d / keys
     const int qrow = tile * ATT_BM + wave * 32 + (lane & 31);
     const int qld = qrow < N ? qrow : N - 1;
     V8 qf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const V8*)(qp + (size_t)qld * ATT_D + 16 * s + 8 * h);
+    for (int s = 0; s < 4; ++s) qf[s] = *(const V8*)(qp + (size_t)qld * rs + 16 * s + 8 * h);
     const FragOffs fo = make_frag_offs(lane);
 
     f32x16 o[2];
@@ -143,26 +154,26 @@ k_attn_fwd(const FwdArgs a) {
     const int T_full = M / ATT_BN;                     // tiles without a key tail
     const int T_tiles = (M + ATT_BN - 1) / ATT_BN;
     u32x4 kr[2], vr[2];
-    tile_load<T>(kp, 0, M, tid, kr);
-    tile_load<T>(vp, 0, M, tid, vr);
+    tile_load<T>(kp, 0, M, tid, kr, rs);
+    tile_load<T>(vp, 0, M, tid, vr, rs);
     tile_store(lds[0][0], tid, kr);
     tile_store(lds[0][1], tid, vr);
     __syncthreads();
     // this thread's chunk of the NEXT tile (rows tid/8 and tid/8 + 32 of tile 1); advanced by one tile per iteration
-    const T* kq = kp + (size_t)(ATT_BN + (tid >> 3)) * ATT_D + (tid & 7) * 8;
-    const T* vq = vp + (size_t)(ATT_BN + (tid >> 3)) * ATT_D + (tid & 7) * 8;
+    const T* kq = kp + (size_t)(ATT_BN + (tid >> 3)) * rs + (tid & 7) * 8;
+    const T* vq = vp + (size_t)(ATT_BN + (tid >> 3)) * rs + (tid & 7) * 8;
 
 #pragma unroll 1
     for (int t = 0; t < T_full; ++t) {
         const int cur = t & 1;
         const bool more = (t + 1) < T_tiles;
         if (t + 1 < T_full) {                      // next tile is full: no clamping
-            kr[0] = *(const u32x4*)kq; kr[1] = *(const u32x4*)(kq + 32 * ATT_D);
-            vr[0] = *(const u32x4*)vq; vr[1] = *(const u32x4*)(vq + 32 * ATT_D);
-            kq += ATT_BN * ATT_D; vq += ATT_BN * ATT_D;
+            kr[0] = *(const u32x4*)kq; kr[1] = *(const u32x4*)(kq + (size_t)32 * rs);
+            vr[0] = *(const u32x4*)vq; vr[1] = *(const u32x4*)(vq + (size_t)32 * rs);
+            kq += (size_t)ATT_BN * rs; vq += (size_t)ATT_BN * rs;
         } else if (more) {
-            tile_load<T>(kp, (t + 1) * ATT_BN, M, tid, kr);
-            tile_load<T>(vp, (t + 1) * ATT_BN, M, tid, vr);
+            tile_load<T>(kp, (t + 1) * ATT_BN, M, tid, kr, rs);
+            tile_load<T>(vp, (t + 1) * ATT_BN, M, tid, vr, rs);
         }
         fwd_tile<T, false>(lds[cur][0], lds[cur][1], fo, qf, o, m_run, l_run, a.c, t * ATT_BN, M, h);
         if (more) {
@@ -177,7 +188,7 @@ k_attn_fwd(const FwdArgs a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (qrow < N) {
-        T* __restrict__ op = (T*)sg.out + ((size_t)bh * N + qrow) * ATT_D;
+        T* __restrict__ op = (T*)sg.out + qoff + (size_t)qrow * rs;
 #pragma unroll
         for (int dblk = 0; dblk < 2; ++dblk)
 #pragma unroll

@@ -104,24 +104,31 @@ def mesh_coverage(verts, faces, S: int):
 # ---------------------------------------------------------------------------------------------------
 # R5-R7 attention
 # ---------------------------------------------------------------------------------------------------
-def attn_fwd(segs: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]],
-             scale: float) -> None:
-    """segs: list of (q [bh,N,D], k [bh,M,D], v [bh,M,D], out [bh,N,D], lse [bh,N] | None); one launch."""
+def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0) -> None:
+    """segs: list of (q, k, v, out, lse | None); one launch.
+    heads == 0: q/out [bh,N,D], k/v [bh,M,D] (head-major).  heads > 0: token-major q/out [B,N,heads*D], k/v [B,M,heads*D]
+    exactly as to_q/to_k/to_v produce them (no head_to_batch_dim copies); lse [B*heads, N]."""
     lib = _lib.load()
     n = len(segs)
     arr = (GdAttnSeg * n)()
     q0, k0 = segs[0][0], segs[0][1]
-    N, D, M = q0.shape[1], q0.shape[2], k0.shape[1]
+    D = 64 if heads else q0.shape[2]
+    N, M = q0.shape[1], k0.shape[1]
     dt = _dt16(q0, "q")
     for i, (q, k, v, o, lse) in enumerate(segs):
         for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "out")):
             _need(t, nm, q0.dtype)
-        if q.shape[1:] != (N, D) or k.shape[1:] != (M, D) or v.shape != k.shape or o.shape != q.shape or k.shape[0] != q.shape[0]:
+        if heads:
+            ok = q.shape[1:] == (N, heads * D) and k.shape[1:] == (M, heads * D) and v.shape == k.shape and o.shape == q.shape \
+                and k.shape[0] == q.shape[0]
+        else:
+            ok = q.shape[1:] == (N, D) and k.shape[1:] == (M, D) and v.shape == k.shape and o.shape == q.shape and k.shape[0] == q.shape[0]
+        if not ok:
             raise _lib.GeodiffError("attn_fwd: segment shapes disagree")
         if lse is not None:
             _need(lse, "lse", torch.float32)
-        arr[i] = GdAttnSeg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 0 if lse is None else lse.data_ptr(),
-                           q.shape[0], 0)
+        bh = q.shape[0] * (heads if heads else 1)
+        arr[i] = GdAttnSeg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 0 if lse is None else lse.data_ptr(), bh, heads)
     check(lib.gd_attn_fwd(arr, n, N, M, D, scale, dt, _stream()), "gd_attn_fwd")
 
 

@@ -92,13 +92,14 @@ int gd_mesh_coverage(const float* verts, const int32_t* faces, int V, int F, int
  *     materialising the [BH,N,M] map.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
-    const void* q;   /* [bh, N, D] */
-    const void* k;   /* [bh, M, D] */
-    const void* v;   /* [bh, M, D] */
-    void* out;       /* [bh, N, D] */
+    const void* q;   /* [bh, N, D]            (heads == 0)   or   [B, N, heads*D]  token-major (heads > 0, bh = B*heads) */
+    const void* k;   /* [bh, M, D]                           or   [B, M, heads*D] */
+    const void* v;   /* [bh, M, D]                           or   [B, M, heads*D] */
+    void* out;       /* [bh, N, D]                           or   [B, N, heads*D] */
     float* lse;      /* [bh, N]  natural-log sum-exp of the scaled scores (may be NULL) */
     int32_t bh;      /* batch*heads entries in this segment */
-    int32_t pad_;
+    int32_t heads;   /* 0: head-major (the reference's head_to_batch_dim layout); > 0: token-major as produced by to_q/to_k/to_v,
+                        which saves the four head_to_batch_dim / batch_to_head_dim copies per attention layer */
 } gd_attn_seg_t;
 
 #define GD_ATTN_MAX_SEGS 4

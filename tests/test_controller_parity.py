@@ -220,6 +220,40 @@ def test_amodal_table_choice_is_the_only_difference():
     assert abs(res["loss"] - float(co.loss)) <= 2e-3 * abs(float(co.loss))
 
 
+@pytest.mark.parametrize("kind", ["edit", "remover"])
+@pytest.mark.parametrize("cross", [False, True])
+@pytest.mark.parametrize("step", [3, 45])
+def test_token_major_cfg_pass_equals_head_major(kind, cross, step):
+    """The no-grad CFG pass takes q/k/v in the projections' own [B, N, heads*64] layout (EditProcessor fast path); its output
+    must equal the head-major controller call (the reference's head_to_batch_dim layout) bit for bit, for both
+    controllers, blended (early) and un-blended (late) steps, batch 3 and batch 4."""
+    mask = cases.ellipse_mask()
+    coords = torch.from_numpy(cases.make_coords("translate", mask))
+    H, S = 5, 32
+    N, M = S * S, (77 if cross else S * S)
+    for nb, cbase, cedit in ((4, (2, 3), (3, 4)), (3, (1, 2), (2, 3))):
+        torch.manual_seed(nb + step)
+        q = (torch.randn(nb, N, H * 64, device=DEV) * 1.2).half(); k = (torch.randn(nb, M, H * 64, device=DEV) * 1.2).half()
+        v = torch.randn(nb, M, H * 64, device=DEV).half()
+        h2b = lambda t: t.reshape(t.shape[0], t.shape[1], H, 64).permute(0, 2, 1, 3).reshape(-1, t.shape[1], 64).contiguous()
+        outs = []
+        for tok in (False, True):
+            c = _make_hip_controller(dict(kind=kind, coords="translate", cur_step=step, quant=True, cfg=True), mask)
+            c.num_att_layers, c.cur_step = 32, step
+            c.coords_base, c.coords_edit, c.use_cfg, c.n_batch = cbase, cedit, True, nb
+            with torch.no_grad():
+                if tok:
+                    c.heads_tok = H
+                    o = c(q, k, v, is_cross=cross, place_in_unet="up", transform_coords=coords, scale=0.125)
+                    c.heads_tok = 0
+                    o = h2b(o)
+                else:
+                    o = c(h2b(q), h2b(k), h2b(v), is_cross=cross, place_in_unet="up", transform_coords=coords, scale=0.125)
+            outs.append(o)
+        assert outs[0].shape == outs[1].shape
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_counters_and_inactive_window():
     """AttentionControl bookkeeping on the HIP controller (G7): cur_step gating, the driver's cur_step -= 1."""
     g = load("G7_counters")

@@ -173,6 +173,24 @@ def test_attention_forward_full_size_and_segments(ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,N,M", [(3, 5, 1024, 1024), (2, 10, 256, 77), (1, 20, 100, 100), (2, 5, 64, 1)])
+def test_attention_forward_token_major_is_bit_identical(ops, dtype, B, H, N, M):
+    """heads > 0 mode reads q/k/v as the projections lay them out ([B, N, heads*64]) and writes the output the same way: the
+    result must equal the head-major launch on the permuted copies bit for bit (same arithmetic, different addressing)."""
+    torch.manual_seed(B * N + M)
+    q = (torch.randn(B, N, H * 64, device=DEV) * 1.4).to(dtype); k = (torch.randn(B, M, H * 64, device=DEV) * 1.4).to(dtype)
+    v = torch.randn(B, M, H * 64, device=DEV).to(dtype)
+    h2b = lambda t: t.reshape(t.shape[0], t.shape[1], H, 64).permute(0, 2, 1, 3).reshape(-1, t.shape[1], 64).contiguous()
+    o_tok = torch.empty_like(q); lse_tok = torch.empty(B * H, N, device=DEV)
+    ops.attn_fwd([(q, k, v, o_tok, lse_tok)], 0.125, heads=H)
+    o_hm = torch.empty(B * H, N, 64, dtype=dtype, device=DEV); lse_hm = torch.empty(B * H, N, device=DEV)
+    ops.attn_fwd([(h2b(q), h2b(k), h2b(v), o_hm, lse_hm)], 0.125)
+    assert torch.equal(h2b(o_tok), o_hm) and torch.equal(lse_tok, lse_hm)
+    with pytest.raises(Exception):
+        ops.attn_fwd([(q, k[:, :, :64], v, o_tok, None)], 0.125, heads=H)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("BH,N,M,need_dk", [(2, 256, 256, False), (2, 1024, 77, True), (1, 200, 77, True), (2, 576, 576, False)])
 def test_attention_backward(ops, dtype, BH, N, M, need_dk):
     torch.manual_seed(N * 3 + M)

@@ -56,7 +56,7 @@ SIGNATURES = {
     "gd_edit_losses_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gd_edit_losses_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   POINTER(c_float), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gd_blend_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gd_group_norm_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
                                    c_int, c_void_p]),

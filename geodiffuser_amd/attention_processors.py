@@ -230,6 +230,23 @@ def _persist(enabled: bool, key: tuple, t: torch.Tensor) -> torch.Tensor:
     return buf
 
 
+_CONST: Dict[tuple, torch.Tensor] = {}
+
+
+def _perm5(dev) -> torch.Tensor:
+    k = ("perm5", str(dev))
+    if k not in _CONST:
+        _CONST[k] = torch.tensor([0, 1, 4, 3, 3], dtype=torch.long, device=dev)
+    return _CONST[k]
+
+
+def _zeros5(dev) -> torch.Tensor:
+    k = ("zeros5", str(dev))
+    if k not in _CONST:
+        _CONST[k] = torch.zeros(5, dtype=torch.float32, device=dev)
+    return _CONST[k]
+
+
 # ---------------------------------------------------------------------------------------------------------
 # the fused layer
 # ---------------------------------------------------------------------------------------------------------
@@ -278,11 +295,9 @@ class _EditLayer(torch.autograd.Function):
         terms = torch.zeros(5, dtype=torch.float32, device=dev)            # sim, movement, removal, smoothness, amodal
         loss = torch.zeros((), dtype=torch.float32, device=dev)
         Pe = Pb = aux = tgt = None
-        coefs = [0.0] * 5
-        rm_coef = 0.0
+        coefs = rm_coef = None
         if want_losses:
             kind = "cross" if is_cross else "self"
-            lw = ctrl.loss_weight_dict[kind]
             R = c["rows"].numel()
             rm = torch.zeros(1, dtype=torch.float32, device=dev)
             if R > 0:
@@ -295,22 +310,25 @@ class _EditLayer(torch.autograd.Function):
                 tgt = ops.amodal_target(edit_out, c["nn_idx"], c["nn_w"], c["m_edit"], S)    # :291-293
             m_edit_l = c["m_edit"] if not remover else c["zeros"]
             sums = ops.edit_losses_fwd(edit_out, replace_out, tgt, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), S)
-            den_sim = f * D * c["s_wo"] + 1e-8
-            den_mov = f * D * c["s_edit"] + 1e-8
-            den_amo = f * D * c.get("s_am", 0.0) + 1e-8
-            cnt = float(f * S * (S - 1) * D)
-            den_rm = c["s_inp"] * f + 1e-8
-            inv = torch.tensor([1.0 / den_sim, 1.0 / den_mov, 1.0 / den_amo, 1.0 / cnt, 1.0 / cnt], dtype=torch.float32, device=dev)
-            t5 = sums * inv
-            l_rm = rm[0] / den_rm
+            # Everything that depends on the (adaptive) loss weights stays on the device: a captured hipGraph of the
+            # optimisation pass then follows the schedule without re-capture, and no host->device copy sits in the layer.
+            if "inv5" not in c:
+                cnt = float(f * S * (S - 1) * D)
+                inv = [1.0 / (f * D * c["s_wo"] + 1e-8), 1.0 / (f * D * c["s_edit"] + 1e-8),
+                       1.0 / (f * D * c.get("s_am", 0.0) + 1e-8), 1.0 / cnt, 1.0 / cnt, 1.0 / (c["s_inp"] * f + 1e-8)]
+                t = torch.tensor(inv, dtype=torch.float32, device=dev)
+                c["inv5"], c["inv_rm"] = t[:5].contiguous(), t[5:6].contiguous()
+                tb = t[:5].clone()
+                if not use_amodal:
+                    tb[2] = 0.0
+                c["inv5_bwd"] = tb
+            wv = ctrl.loss_weights_device(kind, dev)                 # [sim, movement, removal, smoothness, amodal]
+            t5 = sums * c["inv5"]
+            l_rm = rm[0] * c["inv_rm"][0]
             terms = torch.stack([t5[0], t5[1], l_rm, t5[3] + t5[4], t5[2] if use_amodal else t5[1] * 0.0])
-            w_sim, w_rm, w_smo = float(lw["sim"]), float(lw["removal"]), float(lw["smoothness"])
-            w_mov = float(lw.get("movement", 0.0)) if not remover else 0.0
-            w_amo = float(lw.get("amodal", 0.0)) if not remover else 0.0
-            wv = torch.tensor([w_sim, w_mov, w_rm, w_smo, w_amo], dtype=torch.float32, device=dev)
             loss = (terms * wv).sum()
-            coefs = [w_sim / den_sim, w_mov / den_mov, (w_amo / den_amo) if use_amodal else 0.0, w_smo / cnt, w_smo / cnt]
-            rm_coef = w_rm / den_rm
+            coefs = wv.index_select(0, _perm5(dev)) * c["inv5_bwd"]   # d(loss)/d(sum_i): sim, movement, amodal, smooth_h, smooth_w
+            rm_coef = wv[2:3] * c["inv_rm"]
 
         # output (:502-508,617-624 / :831-834,922-925)
         if not remover:
@@ -325,8 +343,8 @@ class _EditLayer(torch.autograd.Function):
                 ops.blend_tokens(ident_out, replace_out, c["m_inp"], out=out_full[cb:])
 
         if grad_mode:
-            ctx.save_for_backward(q_edit, K, v_base, replace_out, lse_e, edit_out if want_losses else None, tgt, Pe, Pb)
-            ctx.aux, ctx.c, ctx.coefs, ctx.rm_coef = aux, c, coefs, rm_coef
+            ctx.save_for_backward(q_edit, K, v_base, replace_out, lse_e, edit_out if want_losses else None, tgt, Pe, Pb, coefs, rm_coef)
+            ctx.aux, ctx.c = aux, c
             ctx.meta = dict(f=f, cb=cb, e0=e0, e1=e1, is_cross=is_cross, scale=scale, remover=remover, blend=blend,
                             want_losses=want_losses, q_shape=q.shape, k_shape=k.shape, S=S)
         ctx.mark_non_differentiable(terms)
@@ -334,7 +352,7 @@ class _EditLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, g_loss, _g_terms):
-        q_edit, K, v_base, replace_out, lse_e, edit_out, tgt, Pe, Pb = ctx.saved_tensors
+        q_edit, K, v_base, replace_out, lse_e, edit_out, tgt, Pe, Pb, coefs, rm_coef = ctx.saved_tensors
         m, c = ctx.meta, ctx.c
         f, cb, S = m["f"], m["cb"], m["S"]
         dev, dt = q_edit.device, q_edit.dtype
@@ -347,13 +365,13 @@ class _EditLayer(torch.autograd.Function):
         eo = edit_out if edit_out is not None else replace_out
         m_edit_l = c["m_edit"] if not m["remover"] else c["zeros"]
         dro = ops.edit_losses_bwd(eo, replace_out, tgt if have_loss else None, c["m_wo"], m_edit_l, c.get("w_dist"),
-                                  c.get("m_amodal"), gout, ctx.coefs if have_loss else [0.0] * 5, gscale,
+                                  c.get("m_amodal"), gout, coefs if have_loss else _zeros5(dev), gscale,
                                   blend=(m["blend"] and not m["remover"]), S=S)
         dq16, dk32 = ops.attn_bwd(q_edit, K, v_base, replace_out, lse_e, dro, m["scale"], need_dk=m["is_cross"] and not m["remover"])
         dq = dq16
         if have_loss and Pe is not None:
             dq32 = torch.zeros(q_edit.shape, dtype=torch.float32, device=dev)
-            ops.removal_bwd(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], ctx.rm_coef, gscale, m["scale"], dq32, dk32)
+            ops.removal_bwd(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], 1.0, gscale * rm_coef, m["scale"], dq32, dk32)
             dq = (dq16.float() + dq32).to(dt)
         grad_q = torch.zeros(m["q_shape"], dtype=dt, device=dev)
         grad_q[m["e0"] * f:m["e1"] * f] = dq
@@ -379,6 +397,27 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         # aliases rather than copies, as the reference does (:667-668): the adaptive schedule's in-place updates
         # therefore also change the "defaults"
         self.loss_weight_dict = self.default_loss_weights
+
+    def loss_weights_device(self, kind: str, dev) -> torch.Tensor:
+        """[sim, movement, removal, smoothness, amodal] of ``loss_weight_dict[kind]`` as a device vector with a stable
+        address; re-uploaded only when the host values changed (the adaptive schedule edits the dict in place)."""
+        lw = self.loss_weight_dict[kind]
+        rem = self._is_remover
+        host = (float(lw["sim"]), 0.0 if rem else float(lw.get("movement", 0.0)), float(lw["removal"]),
+                float(lw["smoothness"]), 0.0 if rem else float(lw.get("amodal", 0.0)))
+        cache = self.__dict__.setdefault("_wv_cache", {})
+        ent = cache.get(kind)
+        if ent is None:
+            ent = cache[kind] = [None, torch.zeros(5, dtype=torch.float32, device=dev)]
+        if ent[0] != host:
+            ent[1].copy_(torch.tensor(host, dtype=torch.float32))
+            ent[0] = host
+        return ent[1]
+
+    def sync_loss_weights(self, dev):
+        """Upload both weight vectors now (called before replaying a captured optimisation pass)."""
+        for kind in ("self", "cross"):
+            self.loss_weights_device(kind, dev)
 
     def _common_init(self, prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend, controller,
                      empty_scale, use_all, obj_edit_step, mode):

@@ -137,12 +137,11 @@ extern "C" int gd_edit_losses_fwd(const void* eo, const void* ro, const float* t
 }
 
 // ---- losses backward ---------------------------------------------------------------------------------
-struct LossCoef { float c[5]; };
 
 template <typename T>
 __global__ void k_losses_bwd(const T* __restrict__ eo, const T* __restrict__ ro, const float* __restrict__ tgt,
                              const float* __restrict__ m_wo, const float* __restrict__ m_edit, const float* __restrict__ w_am,
-                             const float* __restrict__ m_amodal, const T* __restrict__ gout, LossCoef c, const float* __restrict__ gscale, int blend,
+                             const float* __restrict__ m_amodal, const T* __restrict__ gout, const float* __restrict__ c, const float* __restrict__ gscale, int blend,
                              int H, int S, int D, T* __restrict__ dro) {
     const int N = S * S;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,39 +152,37 @@ __global__ void k_losses_bwd(const T* __restrict__ eo, const T* __restrict__ ro,
     const float r = (float)ro[gid], e = (float)eo[gid];
     const float sg = -sgn(e - r);
     const float me = m_edit[n];
-    float g = c.c[0] * sg * m_wo[n] + c.c[1] * sg * me;
-    if (tgt) g += c.c[2] * (-sgn(tgt[gid] - r)) * w_am[n] * m_amodal[n];
+    float g = c[0] * sg * m_wo[n] + c[1] * sg * me;
+    if (tgt) g += c[2] * (-sgn(tgt[gid] - r)) * w_am[n] * m_amodal[n];
     float gs = 0.f;
     if (y < S - 1) gs -= sgn((float)ro[gid + (size_t)S * D] - r);
     if (y > 0) gs += sgn(r - (float)ro[gid - (size_t)S * D]);
-    g += c.c[3] * gs;
+    g += c[3] * gs;
     gs = 0.f;
     if (x < S - 1) gs -= sgn((float)ro[gid + D] - r);
     if (x > 0) gs += sgn(r - (float)ro[gid - D]);
-    g += c.c[4] * gs;
+    g += c[4] * gs;
     if (gscale) g *= gscale[0];
     if (gout) g += (float)gout[gid] * (blend ? (1.0f - me) : 1.0f);
     dro[gid] = (T)g;
 }
 
 extern "C" int gd_edit_losses_bwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
-                                  const float* w_am, const float* m_amodal, const void* gout, const float* c, const float* gscale_dev,
+                                  const float* w_am, const float* m_amodal, const void* gout, const float* coef_dev, const float* gscale_dev,
                                   int blend, int H, int S, int D, void* dro, int dtype, void* stream) {
-    GD_REQUIRE(eo && ro && m_wo && m_edit && c && dro, GD_EINVAL, "gd_edit_losses_bwd: null pointer");
+    GD_REQUIRE(eo && ro && m_wo && m_edit && coef_dev && dro, GD_EINVAL, "gd_edit_losses_bwd: null pointer");
     GD_REQUIRE(!tgt || (w_am && m_amodal), GD_EINVAL, "gd_edit_losses_bwd: tgt needs w_am and m_amodal");
     GD_REQUIRE(H > 0 && S > 0 && D > 0, GD_EINVAL, "gd_edit_losses_bwd: bad sizes");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_bwd: dtype must be f16/bf16");
-    LossCoef lc;
-    for (int i = 0; i < 5; ++i) lc.c[i] = c[i];
     const long long total = (long long)H * S * S * D;
     const int blocks = (int)((total + 255) / 256);
     hipStream_t st = as_stream(stream);
     if (dtype == GD_F16)
         k_losses_bwd<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)eo, (const f16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal,
-                                                    (const f16_t*)gout, lc, gscale_dev, blend, H, S, D, (f16_t*)dro);
+                                                    (const f16_t*)gout, coef_dev, gscale_dev, blend, H, S, D, (f16_t*)dro);
     else
         k_losses_bwd<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)eo, (const bf16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal,
-                                                     (const bf16_t*)gout, lc, gscale_dev, blend, H, S, D, (bf16_t*)dro);
+                                                     (const bf16_t*)gout, coef_dev, gscale_dev, blend, H, S, D, (bf16_t*)dro);
     GD_CHECK_LAUNCH("gd_edit_losses_bwd");
     return GD_OK;
 }

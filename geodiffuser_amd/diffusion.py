@@ -29,7 +29,7 @@ def _unet_nograd(model, controller, x, t, ctx, tag):
 
 
 def diffusion_step(model, controller, latents, context, t, guidance_scale, low_resource=False, transform_coords=None,
-                   use_cfg=True, return_noise=False, skip_uncond_ref=False):
+                   use_cfg=True, return_noise=False, skip_uncond_ref=False, skip_scheduler=False):
     """diffusion.py:39-59: UNet -> (CFG combine) -> scheduler.step(eta=0) -> controller.step_callback.
     The CFG combine is fused into the DDIM kernel (gd_ddim_step) unless the caller asks for the combined noise."""
     if use_cfg and skip_uncond_ref:
@@ -56,7 +56,10 @@ def diffusion_step(model, controller, latents, context, t, guidance_scale, low_r
                                                guidance_scale=guidance_scale)["prev_sample"]
     else:
         noise_pred_out = model.unet(latents, t, encoder_hidden_states=context)["sample"]
-        latents_out = model.scheduler.step(noise_pred_out.detach(), t, latents.detach(), eta=0.0)["prev_sample"]
+        if skip_scheduler:      # the optimisation pass discards x_{t-1} (editor.py:253); a captured pass cannot read t on the host
+            latents_out = latents.detach()
+        else:
+            latents_out = model.scheduler.step(noise_pred_out.detach(), t, latents.detach(), eta=0.0)["prev_sample"]
     latents_out = controller.step_callback(latents_out, transform_coords)
     warp_utils.SPLATTER.clear_cache()                                   # diffusion.py:54
     if return_noise:

@@ -22,7 +22,9 @@ from .diffusion import diffusion_step, image2latent, latent2image, load_model
 from .generic_torch import binarize_tensor, norm_tensor, reshape_transform_coords, torch_erode
 from .image_processing import masked_histogram_matching
 from .inversion import NullInversion
-from .optimization import _update_latent, adaptive_optimization_step_editing, adaptive_optimization_step_remover
+from .graphs import GraphedOptPass, release_opt_graph
+from .optimization import (_apply_latent_update, _update_latent, adaptive_optimization_step_editing,
+                           adaptive_optimization_step_remover)
 from .warp_utils import warp_grid_edit
 
 UNCOND_TEXT = ""
@@ -135,6 +137,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
         set_attn_processor_for_edit(model, coords_base=(2, 3), coords_edit=(3, 4), use_cfg=True)           # :343,366
         return diffusion_step(model, controller, lat, ctx, tt, guidance_scale, transform_coords=transform_coordinates)
 
+    opt_pass = GraphedOptPass(model, transform_coordinates, guidance_scale)
     for i, t in enumerate(timesteps):
         if uncond_embeddings_ is None:
             context = torch.cat([uncond_embeddings[i].expand(*text_embeddings.shape), text_embeddings])
@@ -149,15 +152,12 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
         if (i < optimize_steps * T) and (i % skip_optim_steps == 0) and (i >= fast_start_steps * T):      # :181
             l_eff = lr * (50 - i) * skip_optim_steps * (50 / (NUM_DDIM_STEPS + 1e-8))                      # :207
             set_attn_processor_for_edit(model, coords_base=(0, 1), coords_edit=(1, 2), use_cfg=False)    # :213
-            latents_in = latents.detach().float().requires_grad_(True)                                     # :218
-            n0 = ops.sumsq(latents_in[-1].detach().contiguous())                                           # orig_norm^2 (:219)
+            n0 = ops.sumsq(latents[-1].detach().float().contiguous())                                      # orig_norm^2 (:219)
             ctx_src = context if context_save is None else context_save
-            context_in = ctx_src.detach().float().requires_grad_(True)                                     # :221-224
-            with torch.enable_grad():
-                diffusion_step(model, controller, latents_in, context_in[2:], t, guidance_scale, transform_coords=transform_coordinates,
-                               use_cfg=False, return_noise=True)                                          # :253
-                latents_new, context_new = _update_latent(latents_in, controller.loss, l_eff, controller.mask_new_warped[:1],
-                                                          context_in)                                      # :273
+            # :218-273 — forward with losses + autograd back to latent / embedding (one hipGraph per edit when enabled)
+            g_lat, g_ctx, latents_in, context_in = opt_pass.grads(controller, latents, ctx_src, t)
+            latents_new, context_new = _apply_latent_update(latents_in, g_lat, context_in, g_ctx, l_eff,
+                                                            controller.mask_new_warped[:1])
             out_loss_log_dict = convert_loss_log_to_numpy(controller.loss_log_dict)                       # :284 (host sync)
             if use_adaptive_optimization:
                 if edit_type == "geometry_editor":
@@ -198,6 +198,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
                 base = latents[:1] if i < T * fast_start_steps else latents[-1:]
                 latents = torch.cat([latents[:-1], base * (1 - i_mask) + i_mask * warped.type_as(latents)], 0)
 
+    release_opt_graph(controller)
     if return_type == "image":
         image = latent2image(model.vae, latents)
     else:

@@ -234,13 +234,16 @@ def edit_losses_fwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int):
     return sums
 
 
-def edit_losses_bwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs: Sequence[float], gscale, blend: bool, S: int):
+def edit_losses_bwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend: bool, S: int):
+    """coefs: device f32 [5] tensor (or a host sequence, uploaded here — not capture-safe)."""
     lib = _lib.load()
     dt = _dt16(eo, "eo")
     H, N, D = eo.shape
     dro = torch.empty_like(ro)
-    c = (ctypes.c_float * 5)(*[float(x) for x in coefs])
-    check(lib.gd_edit_losses_bwd(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), _p(gout), c, _p(gscale), int(blend),
+    if not isinstance(coefs, torch.Tensor):
+        coefs = torch.tensor([float(x) for x in coefs], dtype=torch.float32, device=eo.device)
+    _need(coefs, "coefs", torch.float32)
+    check(lib.gd_edit_losses_bwd(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), _p(gout), _p(coefs), _p(gscale), int(blend),
                                  H, S, D, _p(dro), dt, _stream()), "gd_edit_losses_bwd")
     return dro
 

@@ -52,9 +52,20 @@ def _update_latent(latents: torch.Tensor, loss: torch.Tensor, step_size: float, 
     # In the reference every leaf is graph-reachable through the batched tensors even where its gradient is identically
     # zero (e.g. the text embedding for the remover, whose replace path uses only detached keys/values); the fused layer
     # returns no gradient there, hence allow_unused + explicit zeros.
+    grad_cond, context_grad = _latent_grads(latents, loss, context)
+    return _apply_latent_update(latents, grad_cond, context, context_grad, step_size, mask)
+
+
+def _latent_grads(latents: torch.Tensor, loss: torch.Tensor, context: torch.Tensor):
+    """The autograd half of ``_update_latent`` (optimization.py:190-196): d loss / d latents, d loss / d context."""
     grads = torch.autograd.grad(loss, [latents, context], retain_graph=False, allow_unused=True)
     grad_cond = grads[0] if grads[0] is not None else torch.zeros_like(latents)
     context_grad = grads[1] if grads[1] is not None else torch.zeros_like(context)
+    return grad_cond, context_grad
+
+
+def _apply_latent_update(latents, grad_cond, context, context_grad, step_size: float, mask=None):
+    """The arithmetic half of ``_update_latent`` (optimization.py:197-253)."""
     context_grad = torch.nan_to_num(context_grad, posinf=0.0, neginf=0.0, nan=0.0)
     x1 = latents[-1].detach().float().contiguous()
     g1 = grad_cond[-1].detach().float().contiguous()

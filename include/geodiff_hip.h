@@ -191,12 +191,13 @@ int gd_edit_losses_fwd(const void* eo, const void* ro, const float* tgt, const f
  * d(loss)/d(ro) for the weighted sum of those losses plus the blend path:
  *   g = c[0]*(-sgn(eo-ro)) m_wo + c[1]*(-sgn(eo-ro)) m_edit + c[2]*(-sgn(tgt-ro)) w_am m_amodal
  *     + c[3]*d|D_h| + c[4]*d|D_w| + gout * (blend ? (1-m_edit) : 1)
- * c[5] host coefficients (loss weight / denominator), all multiplied by the optional DEVICE scalar gscale_dev[0]
- * (upstream gradient of the loss); gout [H,N,D] 16-bit (may be NULL);
+ * coef_dev: c[5] f32 in DEVICE memory (loss weight / denominator; on the device so that a captured hipGraph of the
+ * optimisation pass follows the adaptive weight schedule without re-capture), all multiplied by the optional DEVICE
+ * scalar gscale_dev[0] (upstream gradient of the loss); gout [H,N,D] 16-bit (may be NULL);
  * dro [H,N,D] 16-bit.
  */
 int gd_edit_losses_bwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
-                       const float* w_am, const float* m_amodal, const void* gout, const float* c, const float* gscale_dev,
+                       const float* w_am, const float* m_amodal, const void* gout, const float* coef_dev, const float* gscale_dev,
                        int blend, int H, int S, int D, void* dro, int dtype, void* stream);
 
 /* out = a*m + b*(1-m) per token (U/attention_processors.py:504,619); m [N] f32; a,b,out [H,N,D]. */

@@ -83,3 +83,71 @@ def test_cfg_batch3_equals_batch4(pipe):
 def test_remover_runs(pipe):
     images, log, lat = _run(pipe, kind="geometry_remover", seed=2)
     assert torch.isfinite(lat).all() and len(images) == 2
+
+
+def test_graphed_optimisation_pass_equals_eager(pipe):
+    """The optimisation pass (UNet forward with losses + autograd back to latent / embedding) captured as one hipGraph gives
+    the gradients and loss log of the eager pass — for the captured inputs, for new inputs / timestep, and after the
+    adaptive schedule changed a loss weight (the weights are read from device memory, not baked into the graph)."""
+    import cases
+    from geodiffuser_amd import graphs
+    from geodiffuser_amd.attention_processors import (AttentionGeometryEdit, VanillaAttentionProcessor,
+                                                      register_attention_control_diffusers, set_attn_processor_for_edit)
+    from geodiffuser_amd.editor import clear_controller_loss, convert_loss_log_to_numpy
+    from geodiffuser_amd.generic_torch import torch_erode
+    from _util import warped_mask
+    p, tok, sched = pipe
+    mask = cases.ellipse_mask()
+    coords = torch.from_numpy(cases.make_coords("translate", mask))
+    sched.set_timesteps(50)
+    torch.manual_seed(5)
+    lat = [torch.randn(2, 4, 64, 64, device="cuda").half() for _ in range(2)]
+    ctx = [torch.randn(4, 77, 64, device="cuda").half() for _ in range(2)]
+
+    def controller():
+        c = AttentionGeometryEdit(["", ""], 50, {"default_": 0.95}, 0.95, image_mask=mask, obj_edit_step=0.9, device="cuda:0")
+        c.amodal_mask = torch_erode(torch.from_numpy(cases.amodal_input(mask)))
+        c.mask_new_warped = warped_mask("translate")
+        register_attention_control_diffusers(p, c, coords)
+        c._w0 = (c.loss_weight_dict["self"]["sim"], c.loss_weight_dict["cross"]["smoothness"])
+        return c
+
+    def one(c, op, which, t, scale_rm=None):
+        clear_controller_loss(c)
+        if scale_rm is not None:
+            c.loss_weight_dict["self"]["sim"] = c._w0[0] * scale_rm
+            c.loss_weight_dict["cross"]["smoothness"] = c._w0[1] * scale_rm
+        set_attn_processor_for_edit(p, coords_base=(0, 1), coords_edit=(1, 2), use_cfg=False)
+        g_lat, g_ctx, _, _ = op.grads(c, lat[which], ctx[which], t)
+        log = convert_loss_log_to_numpy(c.loss_log_dict)
+        res = (g_lat.float().cpu().clone(), g_ctx.float().cpu().clone(), float(c.loss), log)
+        assert c.cur_att_layer == 0
+        c.cur_step -= 1
+        return res
+
+    plan = [(0, 981, None), (0, 981, None), (1, 901, None), (0, 981, 3.0)]     # eager, capture, replay, replay + new weight
+    prev = graphs.ENABLED
+    try:
+        graphs.ENABLED = True
+        cg = controller()
+        opg = graphs.GraphedOptPass(p, coords, 3.0)
+        got = [one(cg, opg, *a) for a in plan]
+        assert cg.__dict__["_opt_graph"]["graph"] is not None
+        graphs.release_opt_graph(cg)
+        graphs.ENABLED = False
+        ce = controller()
+        ope = graphs.GraphedOptPass(p, coords, 3.0)
+        want = [one(ce, ope, *a) for a in plan]
+        noise = [one(ce, ope, *a) for a in plan]                 # eager run-to-run noise of the same four passes
+    finally:
+        graphs.ENABLED = prev
+        p.unet.set_attn_processor(VanillaAttentionProcessor())
+    for g, w, n in zip(got, want, noise):
+        assert abs(g[2] - w[2]) <= max(5 * abs(n[2] - w[2]), 2e-3 * abs(w[2]))
+        for kind in ("self", "cross"):
+            for key, v in w[3][kind].items():
+                assert abs(g[3][kind][key] - v) <= max(5 * abs(n[3][kind][key] - v), 2e-3 * abs(v) + 1e-6), (kind, key)
+        assert rel_l2(g[0], w[0]) <= max(5 * rel_l2(n[0], w[0]), 2e-2)
+        assert rel_l2(g[1], w[1]) <= max(5 * rel_l2(n[1], w[1]), 2e-2)
+    # the changed weight really changed the loss (so the replay did read it)
+    assert abs(got[3][2] - got[0][2]) > 1e-3 * abs(got[0][2])

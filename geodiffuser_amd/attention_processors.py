@@ -273,7 +273,9 @@ class _EditLayer(torch.autograd.Function):
         lse_van = torch.empty(cb, N, dtype=torch.float32, device=dev) if want_losses else None
         segs = [(q[:cb], k[:cb], v[:cb], out_full[:cb], lse_van)]
         replace_out = torch.empty(f, N, D, dtype=dt, device=dev)
-        lse_e = torch.empty(f, N, dtype=torch.float32, device=dev) if (grad_mode or want_losses) else None
+        # opt-in slow path of the reference (:452-454,562-564): keep the edit row's probability map of layers with N <= 16^2
+        store = ctrl.use_cfg and ctrl.store_attention_maps and (not remover) and N <= 16 ** 2
+        lse_e = torch.empty(f, N, dtype=torch.float32, device=dev) if (grad_mode or want_losses or store) else None
         ident_out = None
         if not remover:
             # q_warp = q_base*(1-m) + m*splat(q_base)                       (:424,544)
@@ -291,6 +293,10 @@ class _EditLayer(torch.autograd.Function):
         ops.attn_fwd(segs, scale)
         if remover:
             edit_out = out_full[b0 * f:b1 * f].clone() if want_losses else out_full[b0 * f:b1 * f]
+        if store:
+            M = K.shape[1]
+            ctrl.attn_store(ops.attn_probs(q_edit, K, lse_e, None, scale)[:, :, :M].float(), is_cross=is_cross,
+                            place_in_unet=ctrl.__dict__.get("_place_in_unet", "up"))
 
         terms = torch.zeros(5, dtype=torch.float32, device=dev)            # sim, movement, removal, smoothness, amodal
         loss = torch.zeros((), dtype=torch.float32, device=dev)
@@ -577,6 +583,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
                 _ = self.cross_replace_alpha[self.cur_step]
             return self._forward_tok(q, k, v, is_cross, transform_coords, float(scale), heads)
         f = q.shape[0] // nb
+        self._place_in_unet = place_in_unet
         if not active:
             return attention(q, k, v, scale)                                   # :646-647
         if is_cross:

@@ -259,6 +259,21 @@ def blend_tokens(a, b, m, out=None):
     return out
 
 
+def hist_match(src, tmpl, m_src, m_tmpl):
+    """src, tmpl [npix, C] uint8; m_src, m_tmpl [npix] uint8 -> (out [npix, C] f64, lut [C,256] f64, counts [2,C,256] i32)."""
+    lib = _lib.load()
+    for t, nm in ((src, "src"), (tmpl, "tmpl"), (m_src, "m_src"), (m_tmpl, "m_tmpl")):
+        _need(t, nm, torch.uint8)
+    npix, C = src.shape
+    if tmpl.shape != src.shape or m_src.numel() != npix or m_tmpl.numel() != npix:
+        raise _lib.GeodiffError("hist_match: shapes disagree")
+    counts = torch.empty(2, C, 256, dtype=torch.int32, device=src.device)
+    lut = torch.empty(C, 256, dtype=torch.float64, device=src.device)
+    out = torch.empty(npix, C, dtype=torch.float64, device=src.device)
+    check(lib.gd_hist_match(_p(src), _p(tmpl), _p(m_src), _p(m_tmpl), npix, C, _p(counts), _p(lut), _p(out), _stream()), "gd_hist_match")
+    return out, lut, counts
+
+
 # ---------------------------------------------------------------------------------------------------
 # R10-R12 scheduler / latent arithmetic
 # ---------------------------------------------------------------------------------------------------

@@ -231,6 +231,16 @@ int gd_norm_rescale(const float* x, const float* num_sumsq, const float* den_sum
 int gd_group_norm_nhwc(const void* x, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
                        int silu, float* stats, void* y, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * N2  post-process: masked per-channel histogram matching (GeoDiffuser/utils/image_processing.py:24-77).
+ * src, tmpl [npix, C] uint8 (interleaved channels, C <= 4); m_src, m_tmpl [npix] uint8 (non-zero = the reference's
+ * `mask > 0.5`); counts [2,C,256] u32 scratch (cleared by the call; on return counts[0] = source histogram inside m_src,
+ * counts[1] = template inside m_tmpl); lut [C,256] f64 = np.interp(src_quantiles, tmpl_quantiles, 0..255);
+ * out [npix, C] f64 = lut[c][src].  Counts are exact; lut/out are bit-identical to numpy's binary64 result.
+ * ---------------------------------------------------------------------------------------------- */
+int gd_hist_match(const uint8_t* src, const uint8_t* tmpl, const uint8_t* m_src, const uint8_t* m_tmpl, int npix, int C,
+                  uint32_t* counts, double* lut, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -301,7 +301,116 @@ def g4_losses(R, packs):
          d_rm_rows=d_rm[:, 300:340], **g)
 
 
+def g14_histogram(R):
+    """masked_histogram_matching on the seeded images / masks of cases.hist_case (float64 out, exact)."""
+    ip = R.image_processing
+    out = {}
+    for name in cases.HIST_CASES:
+        src, tmpl, m, ms = cases.hist_case(name)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):          # the reference prints "iden mask" for mask=None
+            out[name] = ip.masked_histogram_matching(src, tmpl, m, ms)
+    save("G14_histogram", **out)
+
+
+def g15_exp_folder():
+    """Experiment folders written by the reference's ``save_exp`` (committed as data under tests/golden/exp_root/), what its
+    ``read_exp`` returns for them, and the 4x4 transforms ``get_transformed_mask`` composes (``project_image`` intercepted)."""
+    import shutil
+    U = ref_import.import_reference_ui()
+    root = os.path.join(OUT, "exp_root")
+    shutil.rmtree(root, ignore_errors=True)
+    out = {}
+    for cat, idx in cases.EXP_CASES:
+        e = cases.exp_case(cat, idx)
+        U.save_exp(root, e["image"], e["depth"], e["depth_vis"], e["mask"], e["transform"], transformed_image=e.get("transformed"),
+                   background_image=e.get("background"), h=e["h"], w=e["w"], exp_transform_type=cat)
+        d = U.read_exp(os.path.join(root, cat, str(idx)))
+        for k, v in d.items():
+            if isinstance(v, np.ndarray):
+                out[f"{cat}_{idx}__{k}"] = v
+        out[f"{cat}_{idx}__none_keys"] = np.array(sorted(k for k, v in d.items() if v is None))
+    out["is_root"] = np.array(U.check_if_exp_root(root))
+    out["is_root_leaf"] = np.array(U.check_if_exp_root(os.path.join(root, "Mix")))
+    captured = {}
+    U.project_image = lambda *a, **k: captured.setdefault("t", a[4])
+    for i, kw in enumerate(cases.TRANSFORM_CASES):
+        captured.clear()
+        U.get_transformed_mask(None, None, None, None, kw.get("translation_x", 0.0), kw.get("translation_y", 0.0),
+                               kw.get("translation_z", 0.0), kw.get("rotation_x", 0.0), kw.get("rotation_y", 0.0),
+                               kw.get("rotation_z", 0.0), None, 1.3, scale_x=kw.get("scale_x", 1.0), scale_y=kw.get("scale_y", 1.0),
+                               scale_z=kw.get("scale_z", 1.0))
+        out[f"transform_{i}"] = captured["t"].numpy()
+    save("G15_exp_folder", **out)
+
+
+def g17_attention_store(R, packs):
+    """store_attention_maps: what the reference's AttentionGeometryEdit leaves in attention_store after two 3-layer "steps"
+    (self 16^2 down, cross 16^2 mid, self 32^2 up — the last one is above the 16^2 cut and must not be stored)."""
+    case = dict(cases.CONTROLLER_CASES["edit_self_cfg_32"])
+    c = _make_controller(R, case, packs)
+    c.num_att_layers, c.cur_step, c.store_attention_maps = 3, 0, True
+    coords = torch.from_numpy(cases.make_coords(case["coords"], cases.ellipse_mask()))
+    out = {}
+    with torch.no_grad():
+        for step in range(2):
+            for li, (S, cross, place) in enumerate(cases.STORE_LAYERS):
+                N = S * S
+                q, k, v = (torch.from_numpy(a) for a in cases.make_qkv(900 + 10 * step + li, 4, 2, N, 77 if cross else N, 16))
+                c(q, k, v, is_cross=cross, place_in_unet=place, transform_coords=coords, scale=0.25)
+    for key, val in c.attention_store.items():
+        if isinstance(val, list):
+            out["n__" + key] = np.array(len(val))
+            for i, a in enumerate(val):
+                out[f"{key}__{i}"] = a
+        else:
+            out["int__" + key] = np.array(val)
+    avg = c.get_average_attention() if all(isinstance(v, list) for v in c.attention_store.values()) else None
+    out["cur_step"] = np.array(c.cur_step)
+    save("G17_attention_store", **out)
+
+
+def g16_batch_config():
+    """What ``perform_exp`` hands to ``perform_geometric_edit`` for each live edit type (call intercepted) -> JSON."""
+    import json
+    L = ref_import.import_reference_batch_driver()
+    got = {}
+    e = cases.exp_case("Mix", 1)
+    exp_dict = {"input_image_png": e["image"], "input_mask_png": np.repeat((e["mask"] * 255).astype(np.uint8)[..., None], 3, -1),
+                "depth_npy": e["depth"], "transform_npy": e["transform"]}
+    for etype in ("geometry_editor", "geometry_remover"):
+        seen = {}
+
+        def fake(image, depth, image_mask, transform_in, prompt, **kw):
+            seen.update(kw)
+            seen["_mask_sum"] = float(image_mask.sum())
+            seen["_mask_shape"] = list(image_mask.shape)
+            seen["_transform_dtype"] = str(transform_in.dtype)
+            return [image, image], {}
+
+        L.perform_geometric_edit = fake
+        L.perform_exp(exp_dict, edit_type=etype)
+        got[etype] = {k: v for k, v in seen.items() if k not in ("ldm_stable_model", "tokenizer_model", "scheduler_in")}
+    with open(os.path.join(OUT, "G16_batch_config.json"), "w") as fh:
+        json.dump(got, fh, indent=1, sort_keys=True)
+    print("  wrote G16_batch_config.json")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "G15":
+        os.makedirs(OUT, exist_ok=True)
+        print("G15"); g15_exp_folder()
+        print("G16"); g16_batch_config()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "G17":
+        R = ref_import.import_reference()
+        print("G17"); g17_attention_store(R, g_masks_and_warp(R))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "G14":
+        R = ref_import.import_reference()
+        os.makedirs(OUT, exist_ok=True)
+        print("G14"); g14_histogram(R)
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_import.import_reference()
@@ -318,6 +427,9 @@ def main():
     print("G10"); g10_ddim(R)
     print("G11"); g11_geometry(R)
     print("G13"); g13_resample(R)
+    print("G14"); g14_histogram(R)
+    print("G17"); g17_attention_store(R, packs)
+    print("G15"); g15_exp_folder()
 
 
 if __name__ == "__main__":

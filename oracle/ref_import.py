@@ -127,6 +127,11 @@ def install_stubs() -> None:
     xf.ops = _module("xformers.ops")
     sk = _module("skimage")
     sk.exposure = _module("skimage.exposure")
+    try:
+        import matplotlib  # noqa: F401
+    except ImportError:
+        mp = _module("matplotlib")
+        mp.pyplot = _module("matplotlib.pyplot")
 
     # ---- "cuda" -> cpu --------------------------------------------------------------------------
     if not getattr(torch.Tensor, "_gd_to_patched", False):
@@ -164,6 +169,7 @@ def import_reference():
     import GeoDiffuser.utils.loss as loss
     import GeoDiffuser.utils.optimization as optimization
     import GeoDiffuser.utils.generic as generic
+    import GeoDiffuser.utils.image_processing as image_processing
 
     # clone-wrapper (see module docstring)
     cls = warp_utils.RasterizePointsXYsBlending
@@ -178,5 +184,34 @@ def import_reference():
     # the distance singleton defaults to device="cuda" (U/generic_torch.py:130); .to is patched above.
     _REF = types.SimpleNamespace(warp_utils=warp_utils, generic_torch=generic_torch,
                                  attention_sharing=attention_sharing, attention_processors=attention_processors,
-                                 loss=loss, optimization=optimization, generic=generic)
+                                 loss=loss, optimization=optimization, generic=generic,
+                                 image_processing=image_processing)
     return _REF
+
+
+def import_reference_ui():
+    """``GeoDiffuser.utils.ui_utils`` (experiment-folder I/O, transform composition) with its UI / perception / camera imports
+    (gradio, pyrealsense2, the SAM + depth front-end module) replaced by empty stand-ins — none of them is touched by
+    ``save_exp`` / ``read_exp`` / ``read_image`` / ``check_if_exp_root`` or by the matrix composition of ``get_transformed_mask``."""
+    import_reference()
+    for name in ("gradio", "pyrealsense2"):
+        if name not in sys.modules:
+            _module(name)
+    if "GeoDiffuser.utils.depth_predictor" not in sys.modules:
+        _module("GeoDiffuser.utils.depth_predictor")
+    import GeoDiffuser.utils.ui_utils as ui_utils
+    return ui_utils
+
+
+def import_reference_batch_driver():
+    """The reference's ``large_scale_editor.py`` (repo root) with its perception imports (SAM, DepthAnything, DPT/MiDaS) replaced by
+    empty stand-ins; only ``perform_exp`` (the per-edit-type configuration table) is exercised."""
+    import_reference_ui()
+    for name in ("GeoDiffuser.segment_anything", "GeoDiffuser.depth_anything", "GeoDiffuser.depth_anything.util",
+                 "GeoDiffuser.depth_anything.util.transform", "GeoDiffuser.depth_anything.dpt", "GeoDiffuser.dpt",
+                 "GeoDiffuser.dpt.models", "GeoDiffuser.dpt.midas_net", "GeoDiffuser.dpt.transforms"):
+        if name not in sys.modules:
+            _module(name)
+    sys.modules["torchvision.transforms"].Compose = object
+    import large_scale_editor
+    return large_scale_editor

@@ -137,3 +137,76 @@ CONTROLLER_CASES = {
 NUM_STEPS = 50
 SELF_REPLACE = 0.95
 OBJ_EDIT_STEP = 0.9
+
+
+# ---- N2: masked histogram matching ---------------------------------------------------------------------
+HIST_CASES = ("smooth_96", "sparse_levels_64", "disjoint_masks_80", "full_mask_48", "tiny_mask_40", "constant_32")
+
+
+def hist_case(name: str):
+    """-> (source uint8 [H,W,3], template uint8 [H,W,3], mask float64 [H,W] | None, mask_source float64 [H,W] | None)."""
+    size = int(name.rsplit("_", 1)[1])
+    rng = np.random.default_rng(abs(hash_name(name)))
+    yy, xx = np.mgrid[0:size, 0:size]
+    blob = (((xx - size * 0.45) / (size * 0.3)) ** 2 + ((yy - size * 0.55) / (size * 0.25)) ** 2 <= 1.0) * 1.0
+    if name.startswith("smooth"):
+        src = np.clip(rng.normal(120, 40, (size, size, 3)), 0, 255).astype(np.uint8)
+        tmpl = np.clip(rng.normal(90, 25, (size, size, 3)) + xx[..., None] * 0.5, 0, 255).astype(np.uint8)
+        return src, tmpl, 1.0 - blob, 1.0 - blob
+    if name.startswith("sparse_levels"):                    # many empty bins -> plateaus (duplicate quantiles) in both CDFs
+        src = (rng.integers(0, 6, (size, size, 3)) * 50).astype(np.uint8)
+        tmpl = (rng.integers(0, 4, (size, size, 3)) * 80 + 7).astype(np.uint8)
+        return src, tmpl, blob, 1.0 - blob
+    if name.startswith("disjoint_masks"):
+        src = rng.integers(0, 256, (size, size, 3)).astype(np.uint8)
+        tmpl = rng.integers(30, 200, (size, size, 3)).astype(np.uint8)
+        return src, tmpl, blob * 0.75, (1.0 - blob) * 0.51            # soft values either side of 0.5
+    if name.startswith("full_mask"):
+        src = rng.integers(0, 256, (size, size, 3)).astype(np.uint8)
+        tmpl = rng.integers(0, 256, (size, size, 3)).astype(np.uint8)
+        return src, tmpl, None, None                                   # the reference's identity-mask branch
+    if name.startswith("tiny_mask"):
+        src = rng.integers(0, 256, (size, size, 3)).astype(np.uint8)
+        tmpl = rng.integers(0, 256, (size, size, 3)).astype(np.uint8)
+        m = np.zeros((size, size)); m[3, 4] = 1.0; m[10, 2] = 1.0; m[11, 30] = 1.0
+        ms = np.zeros((size, size)); ms[0, 0] = 1.0
+        return src, tmpl, m, ms
+    if name.startswith("constant"):
+        src = np.full((size, size, 3), 77, np.uint8)
+        tmpl = np.full((size, size, 3), 201, np.uint8); tmpl[::2] = 13
+        return src, tmpl, blob, blob
+    raise KeyError(name)
+
+
+def hash_name(name: str) -> int:
+    h = 0
+    for ch in name:
+        h = (h * 131 + ord(ch)) % 1000003
+    return h
+
+
+# ---- N3: experiment folders ------------------------------------------------------------------------------
+EXP_CASES = (("Mix", 1), ("Mix", 2), ("Removal", 1), ("Rotation_2D", 1))
+TRANSFORM_CASES = (dict(translation_x=0.1), dict(translation_x=-0.2, translation_y=0.05, translation_z=0.3, rotation_y=25.0),
+                   dict(rotation_x=10.0, rotation_y=-30.0, rotation_z=45.0), dict(scale_x=0.8, scale_y=1.2, scale_z=0.5, rotation_z=-12.5),
+                   dict(translation_z=-0.1, scale_x=-1.0, rotation_x=90.0), dict())
+
+
+def exp_case(cat: str, idx: int):
+    """Small synthetic experiment (48 x 64 image): arrays in the types the reference's UI hands to ``save_exp``."""
+    rng = np.random.default_rng(hash_name(f"{cat}/{idx}"))
+    h, w = 48, 64
+    image = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    mask = ((((xx - 30) / 14.0) ** 2 + ((yy - 22) / 10.0) ** 2) <= 1.0).astype(np.float32)
+    depth = (0.5 + 0.3 * xx / w + 0.1 * rng.random((h, w))).astype(np.float32)
+    e = dict(image=image, mask=mask if idx == 1 else (mask * 255).astype(np.uint8), depth=depth, depth_vis=depth / depth.max(),
+             transform=np.eye(4, dtype=np.float32) + (rng.random((4, 4)).astype(np.float32) - 0.5) * 0.1, h=480 + idx, w=640)
+    if cat == "Mix" and idx == 2:
+        e["transformed"] = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        e["background"] = rng.random((h, w, 3)).astype(np.float32)          # float RGB in [0, 1]
+    return e
+
+
+# ---- N4: attention-map capture (store_attention_maps) ---------------------------------------------------
+STORE_LAYERS = ((16, False, "down"), (16, True, "mid"), (32, False, "up"))     # (S, is_cross, place_in_unet) of one "step"

@@ -254,6 +254,34 @@ def test_token_major_cfg_pass_equals_head_major(kind, cross, step):
         assert torch.equal(outs[0], outs[1])
 
 
+def test_store_attention_maps_slow_path():
+    """N4: with store_attention_maps the HIP controller keeps the edit row's probability maps of the N <= 16^2 layers exactly where
+    the reference keeps them (oracle pinned by G17), at head dim 64."""
+    mask = cases.ellipse_mask()
+    case = dict(cases.CONTROLLER_CASES["edit_self_cfg_32"])
+    ch = _make_hip_controller(case, mask)
+    co = _make_oracle_controller(case, mask)
+    coords = torch.from_numpy(cases.make_coords(case["coords"], mask))
+    for c in (ch, co):
+        c.num_att_layers, c.cur_step, c.store_attention_maps = 3, 0, True
+    with torch.no_grad():
+        for step in range(2):
+            for li, (S, cross, place) in enumerate(cases.STORE_LAYERS):
+                q, k, v = (torch.from_numpy(a) for a in cases.make_qkv(950 + 10 * step + li, 4, 2, S * S, 77 if cross else S * S, 64))
+                q, k, v = q.half(), k.half(), v.half()
+                ch(q.to(DEV), k.to(DEV), v.to(DEV), is_cross=cross, place_in_unet=place, transform_coords=coords, scale=0.125)
+                co(q.float(), k.float(), v.float(), cross, place, transform_coords=coords, scale=0.125)
+    assert ch.cur_step == co.cur_step == 2
+    assert sorted(ch.attention_store) == sorted(co.attention_store)
+    for key, maps in co.attention_store.items():
+        assert len(ch.attention_store[key]) == len(maps)
+        for a, b in zip(ch.attention_store[key], maps):
+            assert a.shape == b.shape and a.dtype == torch.float32
+            assert rel_err(a.cpu(), b) < TOL_OUT
+            assert float((a.sum(-1) - 1).abs().max()) < 2e-3
+    assert sum(len(v) for v in ch.attention_store.values()) == 4
+
+
 def test_counters_and_inactive_window():
     """AttentionControl bookkeeping on the HIP controller (G7): cur_step gating, the driver's cur_step -= 1."""
     g = load("G7_counters")

@@ -1,0 +1,128 @@
+"""N3 — experiment-folder wire format, transform composition and the batch driver's configuration table / work list,
+against fixtures written by the reference itself (tests/golden/exp_root/ by its save_exp; G15 = what its read_exp returns for
+them and what get_transformed_mask composes; G16 = what its perform_exp passes to perform_geometric_edit)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from _util import GOLDEN as GOLDEN_DIR, load
+
+ROOT = os.path.join(GOLDEN_DIR, "exp_root")
+
+
+@pytest.mark.parametrize("cat,idx", cases.EXP_CASES)
+def test_read_exp_matches_reference(cat, idx):
+    from geodiffuser_amd.ui_utils import read_exp
+    g = load("G15_exp_folder")
+    d = read_exp(os.path.join(ROOT, cat, str(idx)))
+    none_keys = sorted(k for k, v in d.items() if v is None)
+    assert none_keys == list(g[f"{cat}_{idx}__none_keys"])
+    n = 0
+    for k, v in d.items():
+        if isinstance(v, np.ndarray):
+            ref = g[f"{cat}_{idx}__{k}"]
+            assert v.dtype == ref.dtype and v.shape == ref.shape and np.array_equal(v, ref), k
+            n += 1
+    assert n >= 6 and d["path_name"].endswith(os.path.join(cat, str(idx)))
+    assert d["input_image_png"].dtype == np.uint8 and d["input_image_png"].shape == (48, 64, 3)
+
+
+def test_read_exp_defaults_and_missing(tmp_path):
+    from geodiffuser_amd.ui_utils import read_exp
+    d = read_exp(str(tmp_path))
+    assert d["input_image_png"] is None and d["depth_npy"] is None
+    assert np.array_equal(d["image_shape_npy"], np.array([512, 512]))              # ui_utils.py:156-157
+
+
+@pytest.mark.parametrize("cat,idx", cases.EXP_CASES)
+def test_save_exp_round_trip_equals_reference_written_folder(tmp_path, cat, idx):
+    """A folder written by our save_exp reads back exactly like the one the reference wrote for the same arrays
+    (data files exact; depth.png is a min/max-normalised visualisation — also exact here)."""
+    from geodiffuser_amd.ui_utils import read_exp, save_exp
+    g = load("G15_exp_folder")
+    for i in range(1, idx):                                                       # numbering = existing folders + 1
+        os.makedirs(tmp_path / cat / str(i))
+    e = cases.exp_case(cat, idx)
+    folder = save_exp(str(tmp_path), e["image"], e["depth"], e["depth_vis"], e["mask"], e["transform"],
+                      transformed_image=e.get("transformed"), background_image=e.get("background"), h=e["h"], w=e["w"],
+                      exp_transform_type=cat)
+    assert folder.rstrip("/").endswith(os.path.join(cat, str(idx)))
+    d = read_exp(folder)
+    for k, v in d.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(v, g[f"{cat}_{idx}__{k}"]), k
+    assert np.array_equal(d["image_shape_npy"], [e["h"], e["w"]])
+
+
+def test_check_if_exp_root_and_work_list():
+    from geodiffuser_amd.large_scale_editor import list_experiments
+    from geodiffuser_amd.ui_utils import check_if_exp_root
+    from geodiffuser_amd.dist import shard
+    g = load("G15_exp_folder")
+    assert check_if_exp_root(ROOT) == bool(g["is_root"]) and check_if_exp_root(os.path.join(ROOT, "Mix")) == bool(g["is_root_leaf"])
+    work = list_experiments(ROOT)
+    rel = [(os.path.relpath(f, ROOT).rstrip("/"), t) for f, t in work]
+    # Rotation_2D is skipped, Removal maps to the remover (large_scale_editor.py:376-388)
+    assert rel == [("Mix/1", "geometry_editor"), ("Mix/2", "geometry_editor"), ("Removal/1", "geometry_remover")]
+    assert shard(work, 0, 2) == [work[0], work[2]] and shard(work, 1, 2) == [work[1]]
+    leaf = list_experiments(os.path.join(ROOT, "Mix"), "geometry_editor")
+    assert len(leaf) == 2 and all(t == "geometry_editor" for _, t in leaf)
+    with pytest.raises(ValueError):
+        list_experiments(os.path.join(ROOT, "Mix"))
+
+
+def test_compose_transform_matches_reference():
+    from geodiffuser_amd.ui_utils import compose_transform
+    g = load("G15_exp_folder")
+    for i, kw in enumerate(cases.TRANSFORM_CASES):
+        t = compose_transform(**kw)
+        assert t.dtype == torch.float32 and np.array_equal(t.numpy(), g[f"transform_{i}"]), kw
+
+
+@pytest.mark.parametrize("etype", ["geometry_editor", "geometry_remover"])
+def test_perform_exp_passes_the_reference_configuration(monkeypatch, etype):
+    from geodiffuser_amd import editor, large_scale_editor as L
+    with open(os.path.join(GOLDEN_DIR, "G16_batch_config.json")) as fh:
+        want = json.load(fh)[etype]
+    e = cases.exp_case("Mix", 1)
+    exp_dict = {"input_image_png": e["image"], "input_mask_png": np.repeat((e["mask"] * 255).astype(np.uint8)[..., None], 3, -1),
+                "depth_npy": e["depth"], "transform_npy": e["transform"]}
+    seen = {}
+
+    def fake(image, depth, image_mask, transform_in, prompt, **kw):
+        seen.update(kw)
+        seen["_mask_sum"] = float(image_mask.sum()); seen["_mask_shape"] = list(image_mask.shape)
+        seen["_transform_dtype"] = str(transform_in.dtype)
+        return [image, image], {}
+
+    monkeypatch.setattr(editor, "perform_geometric_edit", fake)
+    images, loss, store = L.perform_exp(exp_dict, edit_type=etype)
+    got = {k: v for k, v in seen.items() if k not in ("ldm_stable_model", "tokenizer_model", "scheduler_in")}
+    assert json.loads(json.dumps(got, sort_keys=True)) == want
+    assert store is None and len(images) == 2
+    with pytest.raises(NameError):
+        L.edit_config("geometry_stitch")
+
+
+def test_save_results_writes_the_reference_file_set(tmp_path):
+    from geodiffuser_amd import large_scale_editor as L
+    from geodiffuser_amd.ui_utils import read_exp, read_image, save_exp
+    e = cases.exp_case("Removal", 1)
+    folder = save_exp(str(tmp_path), e["image"], e["depth"], e["depth_vis"], e["mask"], e["transform"], h=96, w=64, exp_transform_type="Removal")
+    exp_dict = read_exp(folder)
+    out = np.clip(e["image"].astype(np.float64) * 0.9 + 3.2, 0, 255)                # float64 like the histogram-matched result
+    loss = {0: {"self": {"sim": 1.0, "removal": -0.5}, "cross": {"sim": 0.25}, "num_layers": 20}, 2: {"self": {}, "cross": {}, "num_layers": 20}}
+    L.save_results(exp_dict, out, loss, "geometry_remover")
+    names = set(os.listdir(folder))
+    assert {"loss.log", "loss.pkl", "result_ls.png", "resized_result_ls.png", "experiment.png", "resized_input_image_png.png",
+            "resized_input_mask_png.png", "resized_transformed_image_png.png"} <= names
+    assert L.load_dictionary(os.path.join(folder, "loss.pkl"))[2]["optimization_step"] == 2
+    assert "optimization_step: 2" in open(os.path.join(folder, "loss.log")).read()
+    assert np.array_equal(read_image(os.path.join(folder, "result_ls.png")), out.astype(np.uint8))
+    # aspect ratio [h, w] = [96, 64] < 1: height stretched by 1/ratio (image_processing.py:100-113)
+    assert read_image(os.path.join(folder, "resized_result_ls.png")).shape == (72, 64, 3)
+    assert read_image(os.path.join(folder, "experiment.png")).shape == (72, 3 * 64 + 2 * 20, 3)

@@ -12,7 +12,7 @@ import torch
 
 import cases
 import ref_cpu as O
-from _util import rel_err, rel_l2
+from _util import load, rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -407,3 +407,40 @@ def test_group_norm_nhwc(ops, dtype, B, C, H):
         if silu:
             ref = F.silu(ref)
         assert rel_err(y.float().cpu(), ref) < tol(dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N2  masked histogram matching (bit-exact: integer counts, binary64 LUT in numpy's operation order)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", cases.HIST_CASES)
+def test_hist_match_bit_exact_vs_golden_and_oracle(ops, name):
+    from geodiffuser_amd.image_processing import masked_histogram_matching
+    src, tmpl, m, ms = cases.hist_case(name)
+    out = masked_histogram_matching(src, tmpl, m, ms)
+    assert out.dtype == np.float64 and out.shape == src.shape
+    assert np.array_equal(out, load("G14_histogram")[name])                  # the reference's own output
+    assert np.array_equal(out, O.masked_histogram_matching(src, tmpl, m, ms))
+
+
+def test_hist_match_full_size_counts_and_lut(ops):
+    """BASELINE size (512 x 512 x 3) with the masks of a real edit: histograms exact, LUT and image bit-identical to the oracle;
+    tensor in -> tensor out stays on the device."""
+    rng = np.random.default_rng(11)
+    mask = cases.ellipse_mask()
+    src = np.clip(rng.normal(128, 60, (512, 512, 3)), 0, 255).astype(np.uint8)
+    tmpl = np.clip(rng.normal(100, 30, (512, 512, 3)), 0, 255).astype(np.uint8)
+    m_t, m_s = 1.0 - mask, ((1.0 - mask) + np.roll(mask, 40, 1) > 0.5) * 1.0
+    want = O.masked_histogram_matching(src, tmpl, m_t, m_s)
+    st, tt = torch.from_numpy(src).to(DEV), torch.from_numpy(tmpl).to(DEV)
+    sel_s = torch.from_numpy((m_s > 0.5).astype(np.uint8)).to(DEV).reshape(-1)
+    sel_t = torch.from_numpy((m_t > 0.5).astype(np.uint8)).to(DEV).reshape(-1)
+    out, lut, counts = ops.hist_match(st.reshape(-1, 3), tt.reshape(-1, 3), sel_s, sel_t)
+    for c in range(3):
+        assert np.array_equal(counts[0, c].cpu().numpy(), np.bincount(src[..., c][m_s > 0.5], minlength=256))
+        assert np.array_equal(counts[1, c].cpu().numpy(), np.bincount(tmpl[..., c][m_t > 0.5], minlength=256))
+    assert np.array_equal(out.reshape(512, 512, 3).cpu().numpy(), want)
+    from geodiffuser_amd.image_processing import masked_histogram_matching
+    dev_out = masked_histogram_matching(st, tt, torch.from_numpy(m_t).to(DEV), torch.from_numpy(m_s).to(DEV))
+    assert isinstance(dev_out, torch.Tensor) and dev_out.is_cuda and np.array_equal(dev_out.cpu().numpy(), want)
+    with pytest.raises(TypeError):
+        masked_histogram_matching(src.astype(np.float32), tmpl, m_t, m_s)

@@ -227,6 +227,49 @@ def test_g13_resample_and_morphology():
     assert abs(float(O.gaussian_kernel_5x5()[2, 2]) - 0.18102) < 1e-4
 
 
+@pytest.mark.parametrize("name", cases.HIST_CASES)
+def test_g14_masked_histogram_matching(name):
+    """Oracle == the reference's own float64 output, bit for bit (plateaus in the CDFs, soft masks, the identity-mask branch,
+    one-pixel masks, constant images), plus the properties the reference's callers rely on."""
+    g = load("G14_histogram")
+    src, tmpl, m, ms = cases.hist_case(name)
+    out = O.masked_histogram_matching(src, tmpl, m, ms)
+    assert out.dtype == np.float64 and np.array_equal(out, g[name])
+    for ch in range(3):                                   # a per-channel monotone look-up table
+        order = np.argsort(src[..., ch].reshape(-1), kind="stable")
+        assert np.all(np.diff(out[..., ch].reshape(-1)[order]) >= 0)
+    if name.startswith("full_mask"):
+        assert np.array_equal(O.masked_histogram_matching(src, src), src.astype(np.float64))     # self-match = identity
+
+
+def test_g17_attention_store():
+    """store_attention_maps: contents of attention_store after two 3-layer steps == the reference's (maps of the 16^2 layers only,
+    list concatenation across steps, no length_ keys because cur_step is already 2 when the second merge happens)."""
+    g = load("G17_attention_store")
+    mask = cases.ellipse_mask()
+    case = cases.CONTROLLER_CASES["edit_self_cfg_32"]
+    c = O.GeometryEditOracle(mask, cases.NUM_STEPS, cases.SELF_REPLACE, cases.OBJ_EDIT_STEP, coords_quant=None)
+    c.amodal_mask = O.torch_erode(torch.from_numpy(cases.amodal_input(mask)))
+    c.mask_new_warped = warped_mask(case["coords"])
+    c.num_att_layers, c.cur_step, c.store_attention_maps = 3, 0, True
+    c.coords_base, c.coords_edit, c.use_cfg = (2, 3), (3, 4), True
+    coords = torch.from_numpy(cases.make_coords(case["coords"], mask))
+    with torch.no_grad():
+        for step in range(2):
+            for li, (S, cross, place) in enumerate(cases.STORE_LAYERS):
+                q, k, v = (torch.from_numpy(a) for a in cases.make_qkv(900 + 10 * step + li, 4, 2, S * S, 77 if cross else S * S, 16))
+                c(q, k, v, cross, place, transform_coords=coords, scale=0.25)
+    assert c.cur_step == int(g["cur_step"])
+    keys = [k[3:] for k in g if k.startswith("n__")]
+    assert sorted(c.attention_store) == sorted(keys)
+    for key in keys:
+        assert len(c.attention_store[key]) == int(g["n__" + key])
+        for i, a in enumerate(c.attention_store[key]):
+            assert rel_err(a, torch.from_numpy(g[f"{key}__{i}"])) < 1e-5
+    avg = c.get_average_attention()
+    assert torch.equal(avg["down_self"][1], c.attention_store["down_self"][1] / 2)
+
+
 def test_rasterizer_boxes_match_bruteforce():
     """The candidate-box rasterizer equals the every-pixel-visits-every-point form (small sizes)."""
     rng = np.random.default_rng(3)

@@ -172,3 +172,22 @@ def test_batch_driver_on_experiment_folder(pipe, tmp_path):
     assert res.shape == (256, 256, 3) and res.dtype == np.uint8
     assert {"loss.log", "loss.pkl", "resized_result_ls.png", "experiment.png"} <= set(os.listdir(folder))
     assert len(L.load_dictionary(os.path.join(folder, "loss.pkl"))) >= 1
+
+
+def test_removal_edit_768(pipe):
+    """BASELINE configs[3] shape: object removal at 768 x 768 (latent 96^2; attention maps at 96^2 / 48^2 / 24^2 / 12^2 tokens)."""
+    images, log, lat = _run(pipe, kind="geometry_remover", seed=3, size=768, steps=4)
+    assert images[1].shape == (768, 768, 3) and lat.shape == (2, 4, 96, 96) and torch.isfinite(lat).all()
+    assert len(log) >= 1 and all(np.isfinite(v) for d in log.values() for v in d["self"].values())
+
+
+def test_mixed_transform_edit_512(pipe):
+    """BASELINE configs[2] shape: a mixed translate + rotate edit at 512 x 512."""
+    from geodiffuser_amd import editor
+    from geodiffuser_amd.synthetic import editor_kwargs, make_edit
+    p, tok, sched = pipe
+    image, depth, mask, T = make_edit(5, size=512, kind="mixed")
+    kw = editor_kwargs("geometry_editor")
+    kw.update(num_ddim_steps=4, ldm_stable_model=p, tokenizer_model=tok, scheduler_in=sched, return_latents=True)
+    images, lat = editor.run_geodiffuser(image, depth, mask, T, **kw)
+    assert images[1].shape == (512, 512, 3) and torch.isfinite(lat.float()).all()

@@ -6,25 +6,33 @@
 // profile of an edit showed ~18 % of the GPU time there.  HBM-bound: reads x twice, writes y once.
 //
 //   k_gn_stats : one workgroup per (batch, pixel slab): coalesced 16-B reads of whole channel rows, per-channel partial sums
-//                in registers, per-group reduction through LDS atomics, one f32 global atomic per (group, moment)
-//   k_gn_apply : y = (x - mean) * rstd * gamma + beta, optional SiLU, 8 channels (16 B) per thread
+//                in registers, per-group reduction through LDS atomics, ONE plain store of the slab's [G,2] partial moments
+//                (no global atomics, no zero-fill launch)
+//   k_gn_apply : every workgroup first folds the <= 64 slab partials of its batch entry into mean / rstd in LDS, then
+//                y = (x - mean) * rstd * gamma + beta, optional SiLU, 8 channels (16 B) per thread
+// Optional add_bc [B,C]: the norm is taken of x + add_bc[b,c] (the ResNet block's time-embedding add folded in).
 #include "common.hpp"
 
 #define GN_MAX_G 64
-#define GN_PIX 32          // pixels per workgroup in the stats pass
+#define GN_MAX_SLABS 64
+
+static inline int gn_pix_per_slab(int HW) {
+    int p = (HW + GN_MAX_SLABS - 1) / GN_MAX_SLABS;
+    return p < 32 ? 32 : p;
+}
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_gn_stats(const T* __restrict__ x, int HW, int C, int G, float* __restrict__ stats) {
+k_gn_stats(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, int HW, int C, int G, int pix, float* __restrict__ partial) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
     __shared__ float s_g[GN_MAX_G * 2];
-    const int b = blockIdx.y, p0 = blockIdx.x * GN_PIX, tid = threadIdx.x;
+    const int b = blockIdx.y, p0 = blockIdx.x * pix, tid = threadIdx.x;
     const int cv = C >> 3, cpg = C / G;
     const T* xb = x + (size_t)b * HW * C;
     if (tid < G * 2) s_g[tid] = 0.f;
     __syncthreads();
-    const int p1 = (p0 + GN_PIX) < HW ? (p0 + GN_PIX) : HW;
+    const int p1 = (p0 + pix) < HW ? (p0 + pix) : HW;
     // Every thread owns one 8-channel column k of the slab and walks pixels with a fixed stride, so its partial sums stay in
     // registers; consecutive threads read consecutive 16-B chunks (coalesced).  cv <= 256: (256 / cv) pixel rows in flight;
     // cv > 256: a thread takes columns tid and tid + 256.
@@ -32,14 +40,20 @@ k_gn_stats(const T* __restrict__ x, int HW, int C, int G, float* __restrict__ st
     for (int k = (cv <= 256 ? tid % cv : tid); k < cv; k += 256) {
         const int r = cv <= 256 ? tid / cv : 0;
         if (r < rows) {
-            float sum[8], sq[8];
+            float sum[8], sq[8], ad[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { sum[i] = 0.f; sq[i] = 0.f; }
+            for (int i = 0; i < 8; ++i) { sum[i] = 0.f; sq[i] = 0.f; ad[i] = 0.f; }
+            if (add_bc) {
+                const V8 av = *(const V8*)(add_bc + (size_t)b * add_ld + k * 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ad[i] = TR::to_f32(av[i]);
+            }
             for (int p = p0 + r; p < p1; p += rows) {
                 const V8 v = *(const V8*)(xb + (size_t)p * C + k * 8);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float f = TR::to_f32(v[i]);
+                    // x + add is rounded to the storage type first, as the unfused `h + temb[:, :, None, None]` does
+                    const float f = add_bc ? TR::to_f32(TR::from_f32(TR::to_f32(v[i]) + ad[i])) : TR::to_f32(v[i]);
                     sum[i] += f;
                     sq[i] = __builtin_fmaf(f, f, sq[i]);
                 }
@@ -57,60 +71,80 @@ k_gn_stats(const T* __restrict__ x, int HW, int C, int G, float* __restrict__ st
         if (cv <= 256) break;
     }
     __syncthreads();
-    if (tid < G * 2) atomicAdd(&stats[(size_t)b * G * 2 + tid], s_g[tid]);
+    if (tid < G * 2) partial[((size_t)b * gridDim.x + blockIdx.x) * G * 2 + tid] = s_g[tid];
 }
 
 template <typename T, bool SILU>
-__global__ void k_gn_apply(const T* __restrict__ x, const float* __restrict__ stats, const T* __restrict__ gamma,
-                           const T* __restrict__ beta, int B, int HW, int C, int G, float eps, T* __restrict__ y) {
+__global__ void __launch_bounds__(256)
+k_gn_apply(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, const float* __restrict__ partial, int nslab,
+           const T* __restrict__ gamma, const T* __restrict__ beta, int HW, int C, int G, float eps, T* __restrict__ y) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
+    __shared__ float s_m[GN_MAX_G * 2];
+    const int b = blockIdx.y, tid = threadIdx.x;
     const int cv = C >> 3, cpg = C / G;
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)B * HW * cv) return;
-    const int k = (int)(gid % cv);
-    const int b = (int)(gid / ((long long)HW * cv));
+    if (tid < G * 2) {
+        const float* pp = partial + (size_t)b * nslab * G * 2 + tid;
+        float acc = 0.f;
+        for (int s = 0; s < nslab; ++s) acc += pp[(size_t)s * G * 2];
+        s_m[tid] = acc;
+    }
+    __syncthreads();
+    const long long idx = (long long)blockIdx.x * 256 + tid;          // vector index inside batch entry b
+    if (idx >= (long long)HW * cv) return;
+    const int k = (int)(idx % cv);
     const float inv_n = 1.0f / ((float)HW * (float)cpg);
     const int c0 = k * 8;
     const int g0 = c0 / cpg, g1 = (c0 + 7) / cpg;
-    const float* st = stats + (size_t)b * G * 2;
-    const float m0 = st[g0 * 2] * inv_n, m1 = st[g1 * 2] * inv_n;
-    const float r0 = rsqrtf(fmaxf(st[g0 * 2 + 1] * inv_n - m0 * m0, 0.f) + eps);
-    const float r1 = rsqrtf(fmaxf(st[g1 * 2 + 1] * inv_n - m1 * m1, 0.f) + eps);
+    const float m0 = s_m[g0 * 2] * inv_n, m1 = s_m[g1 * 2] * inv_n;
+    const float r0 = rsqrtf(fmaxf(s_m[g0 * 2 + 1] * inv_n - m0 * m0, 0.f) + eps);
+    const float r1 = rsqrtf(fmaxf(s_m[g1 * 2 + 1] * inv_n - m1 * m1, 0.f) + eps);
     const int split = (g1 * cpg) - c0;            // elements i >= split belong to g1
-    const V8 v = *(const V8*)(x + gid * 8);
+    const size_t off = ((size_t)b * HW * cv + idx) * 8;
+    const V8 v = *(const V8*)(x + off);
     const V8 ga = *(const V8*)(gamma + c0), be = *(const V8*)(beta + c0);
+    V8 av;
+    if (add_bc) av = *(const V8*)(add_bc + (size_t)b * add_ld + c0);
     V8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const bool hi = (g1 != g0) && (i >= split);
         const float mean = hi ? m1 : m0, rstd = hi ? r1 : r0;
-        float t = (TR::to_f32(v[i]) - mean) * rstd * TR::to_f32(ga[i]) + TR::to_f32(be[i]);
+        const float f = add_bc ? TR::to_f32(TR::from_f32(TR::to_f32(v[i]) + TR::to_f32(av[i]))) : TR::to_f32(v[i]);
+        float t = (f - mean) * rstd * TR::to_f32(ga[i]) + TR::to_f32(be[i]);
         if (SILU) t = t / (1.0f + __expf(-t));
         o[i] = TR::from_f32(t);
     }
-    *(V8*)(y + gid * 8) = o;
+    *(V8*)(y + off) = o;
 }
 
-extern "C" int gd_group_norm_nhwc(const void* x, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
-                                  int silu, float* stats /* [B,G,2] f32 scratch */, void* y, int dtype, void* stream) {
-    GD_REQUIRE(x && gamma && beta && stats && y, GD_EINVAL, "gd_group_norm_nhwc: null pointer");
+extern "C" int64_t gd_group_norm_nhwc_scratch_floats(int B, int HW, int G) {
+    if (B <= 0 || HW <= 0 || G <= 0) return 0;
+    const int pix = gn_pix_per_slab(HW);
+    return (int64_t)B * ((HW + pix - 1) / pix) * G * 2;
+}
+
+extern "C" int gd_group_norm_nhwc(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, int B, int HW, int C, int G,
+                                  float eps, int silu, float* scratch, void* y, int dtype, void* stream) {
+    GD_REQUIRE(x && gamma && beta && scratch && y, GD_EINVAL, "gd_group_norm_nhwc: null pointer");
     GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && C / G >= 8, GD_EINVAL,
                "gd_group_norm_nhwc: unsupported shape B=%d HW=%d C=%d G=%d (need C %% 8 == 0, C/G >= 8, G <= %d)", B, HW, C, G, GN_MAX_G);
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_group_norm_nhwc: dtype must be f16/bf16");
+    GD_REQUIRE(!add_bc || add_ld == 0 || (add_ld >= C && (add_ld & 7) == 0), GD_EINVAL, "gd_group_norm_nhwc: add_ld must be >= C and a multiple of 8");
+    if (add_ld == 0) add_ld = C;
     hipStream_t st = as_stream(stream);
-    gd_zero_async(stats, (size_t)B * G * 2 * sizeof(float), st);
-    dim3 sgrid((HW + GN_PIX - 1) / GN_PIX, B);
-    const long long total = (long long)B * HW * (C >> 3);
-    const int ablocks = (int)((total + 255) / 256);
+    const int pix = gn_pix_per_slab(HW);
+    const int nslab = (HW + pix - 1) / pix;
+    dim3 sgrid(nslab, B);
+    dim3 agrid((unsigned)(((long long)HW * (C >> 3) + 255) / 256), B);
     if (dtype == GD_F16) {
-        k_gn_stats<f16_t><<<sgrid, 256, 0, st>>>((const f16_t*)x, HW, C, G, stats);
-        if (silu) k_gn_apply<f16_t, true><<<ablocks, 256, 0, st>>>((const f16_t*)x, stats, (const f16_t*)gamma, (const f16_t*)beta, B, HW, C, G, eps, (f16_t*)y);
-        else k_gn_apply<f16_t, false><<<ablocks, 256, 0, st>>>((const f16_t*)x, stats, (const f16_t*)gamma, (const f16_t*)beta, B, HW, C, G, eps, (f16_t*)y);
+        k_gn_stats<f16_t><<<sgrid, 256, 0, st>>>((const f16_t*)x, (const f16_t*)add_bc, add_ld, HW, C, G, pix, scratch);
+        if (silu) k_gn_apply<f16_t, true><<<agrid, 256, 0, st>>>((const f16_t*)x, (const f16_t*)add_bc, add_ld, scratch, nslab, (const f16_t*)gamma, (const f16_t*)beta, HW, C, G, eps, (f16_t*)y);
+        else k_gn_apply<f16_t, false><<<agrid, 256, 0, st>>>((const f16_t*)x, (const f16_t*)add_bc, add_ld, scratch, nslab, (const f16_t*)gamma, (const f16_t*)beta, HW, C, G, eps, (f16_t*)y);
     } else {
-        k_gn_stats<bf16_t><<<sgrid, 256, 0, st>>>((const bf16_t*)x, HW, C, G, stats);
-        if (silu) k_gn_apply<bf16_t, true><<<ablocks, 256, 0, st>>>((const bf16_t*)x, stats, (const bf16_t*)gamma, (const bf16_t*)beta, B, HW, C, G, eps, (bf16_t*)y);
-        else k_gn_apply<bf16_t, false><<<ablocks, 256, 0, st>>>((const bf16_t*)x, stats, (const bf16_t*)gamma, (const bf16_t*)beta, B, HW, C, G, eps, (bf16_t*)y);
+        k_gn_stats<bf16_t><<<sgrid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)add_bc, add_ld, HW, C, G, pix, scratch);
+        if (silu) k_gn_apply<bf16_t, true><<<agrid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)add_bc, add_ld, scratch, nslab, (const bf16_t*)gamma, (const bf16_t*)beta, HW, C, G, eps, (bf16_t*)y);
+        else k_gn_apply<bf16_t, false><<<agrid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)add_bc, add_ld, scratch, nslab, (const bf16_t*)gamma, (const bf16_t*)beta, HW, C, G, eps, (bf16_t*)y);
     }
     GD_CHECK_LAUNCH("gd_group_norm_nhwc");
     return GD_OK;

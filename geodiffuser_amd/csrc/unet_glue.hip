@@ -1,0 +1,163 @@
+// UNet plumbing around the hot path (not rows of SURVEY 8a): element-wise fusions for the no-grad passes of the SD-shaped UNet
+// harness.  One UNet pass at batch 1-3 is ~550 kernels of 5-20 us; the GPU is launch-latency-bound there, so what counts is
+// the NUMBER of kernels between the convolutions / GEMMs, not their bandwidth.  All tensors are 16-bit, channels-last / token-major
+// ([rows, C] with C % 8 == 0), 16-byte accesses.
+//
+//   gd_bias_residual : y = x + bias[c] (+ res)         — convolution epilogue (MIOpen adds the bias as a separate kernel and the
+//                                                        residual add is another one)
+//   gd_geglu         : y = x[:, :C] * gelu(x[:, C:])   — GEGLU gate of the transformer feed-forward (exact erf GELU)
+//   gd_add_layer_norm: s = a + b;  y = LayerNorm(s)    — residual add fused with the next LayerNorm (s is also written)
+#include "common.hpp"
+
+template <typename T>
+__global__ void k_bias_residual(const T* __restrict__ x, const T* __restrict__ bias, const T* __restrict__ res, long long nvec, int cv,
+                                T* __restrict__ y) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    const int k = (int)(i % cv);
+    const V8 a = *(const V8*)(x + i * 8), b = *(const V8*)(bias + k * 8);
+    V8 o;
+    if (res) {
+        const V8 r = *(const V8*)(res + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // same rounding points as the unfused ops: conv + bias -> T, then residual add -> T
+            const float t = TR::to_f32(TR::from_f32(TR::to_f32(a[j]) + TR::to_f32(b[j])));
+            o[j] = TR::from_f32(t + TR::to_f32(r[j]));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = TR::from_f32(TR::to_f32(a[j]) + TR::to_f32(b[j]));
+    }
+    *(V8*)(y + i * 8) = o;
+}
+
+extern "C" int gd_bias_residual(const void* x, const void* bias, const void* res, int64_t rows, int C, void* y, int dtype, void* stream) {
+    GD_REQUIRE(x && bias && y, GD_EINVAL, "gd_bias_residual: null pointer");
+    GD_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0, GD_EINVAL, "gd_bias_residual: need C %% 8 == 0 (C=%d)", C);
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_bias_residual: dtype must be f16/bf16");
+    const long long nvec = (long long)rows * (C >> 3);
+    const int blocks = (int)((nvec + 255) / 256);
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16)
+        k_bias_residual<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, (const f16_t*)bias, (const f16_t*)res, nvec, C >> 3, (f16_t*)y);
+    else
+        k_bias_residual<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)bias, (const bf16_t*)res, nvec, C >> 3, (bf16_t*)y);
+    GD_CHECK_LAUNCH("gd_bias_residual");
+    return GD_OK;
+}
+
+template <typename T>
+__global__ void k_geglu(const T* __restrict__ x, long long nvec, int cv, T* __restrict__ y) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    const long long row = i / cv;
+    const int k = (int)(i - row * cv);
+    const T* xr = x + row * (long long)cv * 16;                 // row of 2C elements
+    const V8 h = *(const V8*)(xr + k * 8), g = *(const V8*)(xr + (cv + k) * 8);
+    V8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float gf = TR::to_f32(g[j]);
+        const float ge = TR::to_f32(TR::from_f32(0.5f * gf * (1.0f + erff(gf * 0.70710678118654752440f))));   // F.gelu, rounded like torch
+        o[j] = TR::from_f32(TR::to_f32(h[j]) * ge);
+    }
+    *(V8*)(y + i * 8) = o;
+}
+
+extern "C" int gd_geglu(const void* x, int64_t rows, int C, void* y, int dtype, void* stream) {
+    GD_REQUIRE(x && y, GD_EINVAL, "gd_geglu: null pointer");
+    GD_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0, GD_EINVAL, "gd_geglu: need C %% 8 == 0 (C=%d)", C);
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_geglu: dtype must be f16/bf16");
+    const long long nvec = (long long)rows * (C >> 3);
+    const int blocks = (int)((nvec + 255) / 256);
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16) k_geglu<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, nvec, C >> 3, (f16_t*)y);
+    else k_geglu<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, nvec, C >> 3, (bf16_t*)y);
+    GD_CHECK_LAUNCH("gd_geglu");
+    return GD_OK;
+}
+
+// one wave per row; C <= 8 * 64 * LN_MAXV
+#define LN_MAXV 4
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_add_layer_norm(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ gamma, const T* __restrict__ beta,
+                 long long rows, int C, float eps, T* __restrict__ sum_out, T* __restrict__ y) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int cv = C >> 3;
+    const T* ar = a + row * C;
+    const T* br = b ? b + row * C : nullptr;
+    float v[LN_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        const int k = lane + 64 * t;
+        if (k < cv) {
+            const V8 x = *(const V8*)(ar + k * 8);
+            if (br) {
+                const V8 z = *(const V8*)(br + k * 8);
+                V8 sm;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sm[j] = TR::from_f32(TR::to_f32(x[j]) + TR::to_f32(z[j]));      // the residual stream stays 16-bit, as unfused
+                    v[t][j] = TR::to_f32(sm[j]);
+                }
+                if (sum_out) *(V8*)(sum_out + row * C + k * 8) = sm;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[t][j] = TR::to_f32(x[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[t][j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        const int k = lane + 64 * t;
+        if (k < cv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[t][j] - mean; q = __builtin_fmaf(d, d, q); }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        const int k = lane + 64 * t;
+        if (k < cv) {
+            const V8 ga = *(const V8*)(gamma + k * 8), be = *(const V8*)(beta + k * 8);
+            V8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = TR::from_f32((v[t][j] - mean) * rstd * TR::to_f32(ga[j]) + TR::to_f32(be[j]));
+            *(V8*)(y + row * C + k * 8) = o;
+        }
+    }
+}
+
+extern "C" int gd_add_layer_norm(const void* a, const void* b, const void* gamma, const void* beta, int64_t rows, int C, float eps,
+                                 void* sum_out, void* y, int dtype, void* stream) {
+    GD_REQUIRE(a && gamma && beta && y, GD_EINVAL, "gd_add_layer_norm: null pointer");
+    GD_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0 && C <= 8 * 64 * LN_MAXV, GD_EINVAL,
+               "gd_add_layer_norm: need C %% 8 == 0 and C <= %d (C=%d)", 8 * 64 * LN_MAXV, C);
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_add_layer_norm: dtype must be f16/bf16");
+    const int blocks = (int)((rows + 3) / 4);
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16)
+        k_add_layer_norm<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)a, (const f16_t*)b, (const f16_t*)gamma, (const f16_t*)beta, rows, C, eps,
+                                                        (f16_t*)sum_out, (f16_t*)y);
+    else
+        k_add_layer_norm<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)gamma, (const bf16_t*)beta, rows, C, eps,
+                                                         (bf16_t*)sum_out, (bf16_t*)y);
+    GD_CHECK_LAUNCH("gd_add_layer_norm");
+    return GD_OK;
+}

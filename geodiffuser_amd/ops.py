@@ -319,15 +319,71 @@ def norm_rescale(x, num_sumsq, den_sumsq):
 # ---------------------------------------------------------------------------------------------------
 # UNet plumbing: fused GroupNorm (+SiLU), channels-last, no-grad
 # ---------------------------------------------------------------------------------------------------
-def group_norm_nhwc(x, gamma, beta, groups: int, eps: float, silu: bool):
-    """x [B,C,H,W] in channels_last memory format (16-bit) -> same shape / format."""
+def group_norm_nhwc(x, gamma, beta, groups: int, eps: float, silu: bool, add_bc=None):
+    """x [B,C,H,W] in channels_last memory format (16-bit) -> same shape / format; add_bc [B,C]: norm of x + add_bc[:, :, None, None]."""
     lib = _lib.load()
     dt = _dt16(x, "x")
     if not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last):
         raise _lib.GeodiffError("group_norm_nhwc: expected a channels_last GPU tensor")
     B, C, H, W = x.shape
+    add_ld = 0
+    if add_bc is not None:                 # [B, C], rows may be strided (a column slice of a wider [B, sum C] matrix)
+        if (add_bc.dtype != x.dtype or not add_bc.is_cuda or tuple(add_bc.shape) != (B, C) or add_bc.stride(1) != 1
+                or add_bc.stride(0) % 8 or add_bc.storage_offset() % 8):
+            raise _lib.GeodiffError("group_norm_nhwc: add_bc must be a 16-byte aligned [B, C] matrix of x's dtype with unit column stride")
+        add_ld = add_bc.stride(0) if B > 1 else C
     y = torch.empty_like(x, memory_format=torch.channels_last)
-    stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
-    check(lib.gd_group_norm_nhwc(_p(x), _p(gamma), _p(beta), B, H * W, C, groups, eps, int(silu), _p(stats), _p(y), dt, _stream()),
-          "gd_group_norm_nhwc")
+    scratch = torch.empty(int(lib.gd_group_norm_nhwc_scratch_floats(B, H * W, groups)), dtype=torch.float32, device=x.device)
+    check(lib.gd_group_norm_nhwc(_p(x), _p(add_bc), add_ld, _p(gamma), _p(beta), B, H * W, C, groups, eps, int(silu), _p(scratch), _p(y), dt,
+                                 _stream()), "gd_group_norm_nhwc")
     return y
+
+
+def _rows_c(t, what):
+    _dt16(t, what)
+    if not t.is_cuda:
+        raise _lib.GeodiffError(f"{what}: expected a GPU tensor")
+    if t.dim() == 4:                       # [B,C,H,W] channels_last == [B*H*W, C] rows
+        if not t.is_contiguous(memory_format=torch.channels_last):
+            raise _lib.GeodiffError(f"{what}: expected channels_last memory")
+        return t.shape[0] * t.shape[2] * t.shape[3], t.shape[1]
+    if not t.is_contiguous():
+        raise _lib.GeodiffError(f"{what}: expected a contiguous tensor")
+    return t.numel() // t.shape[-1], t.shape[-1]
+
+
+def bias_residual(x, bias, res=None):
+    """y = x + bias[c] (+ res); x / res either [B,C,H,W] channels_last or [..., C] contiguous."""
+    lib = _lib.load()
+    rows, C = _rows_c(x, "bias_residual x")
+    _need(bias, "bias", x.dtype)
+    if res is not None and (_rows_c(res, "bias_residual res") != (rows, C) or res.dtype != x.dtype):
+        raise _lib.GeodiffError("bias_residual: res must match x")
+    y = torch.empty_like(x, memory_format=torch.channels_last) if x.dim() == 4 else torch.empty_like(x)
+    check(lib.gd_bias_residual(_p(x), _p(bias), _p(res), rows, C, _p(y), _DT[x.dtype], _stream()), "gd_bias_residual")
+    return y
+
+
+def geglu(x):
+    """x [..., 2C] contiguous -> x[..., :C] * gelu(x[..., C:])."""
+    lib = _lib.load()
+    rows, C2 = _rows_c(x, "geglu x")
+    if x.dim() == 4 or C2 % 16:
+        raise _lib.GeodiffError("geglu: expected [..., 2C] with C % 8 == 0")
+    y = torch.empty(*x.shape[:-1], C2 // 2, dtype=x.dtype, device=x.device)
+    check(lib.gd_geglu(_p(x), rows, C2 // 2, _p(y), _DT[x.dtype], _stream()), "gd_geglu")
+    return y
+
+
+def add_layer_norm(a, b, gamma, beta, eps: float):
+    """-> (s, y): s = a + b (a itself when b is None), y = LayerNorm(s)."""
+    lib = _lib.load()
+    rows, C = _rows_c(a, "add_layer_norm a")
+    _need(gamma, "gamma", a.dtype); _need(beta, "beta", a.dtype)
+    if b is not None and (b.shape != a.shape or b.dtype != a.dtype or not b.is_contiguous()):
+        raise _lib.GeodiffError("add_layer_norm: b must match a")
+    y = torch.empty_like(a)
+    s = torch.empty_like(a) if b is not None else a
+    check(lib.gd_add_layer_norm(_p(a), _p(b), _p(gamma), _p(beta), rows, C, eps, _p(s) if b is not None else None, _p(y), _DT[a.dtype],
+                                _stream()), "gd_add_layer_norm")
+    return s, y

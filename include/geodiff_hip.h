@@ -225,11 +225,27 @@ int gd_sumsq(const float* x, int64_t n, float* sumsq, void* stream);
 int gd_norm_rescale(const float* x, const float* num_sumsq, const float* den_sumsq, int64_t n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * UNet plumbing (not a row of the hot path): GroupNorm (+ SiLU) on channels-last 16-bit activations, no-grad passes.
- * x, y [B, HW, C] (NHWC memory), gamma/beta [C] 16-bit, stats [B,G,2] f32 scratch (cleared by the call).
+ * UNet plumbing (not rows of the hot path): element-wise / norm fusions for the no-grad passes of the SD-shaped UNet, which is
+ * launch-latency-bound at batch 1-3.  16-bit, channels-last / token-major rows of C channels, C % 8 == 0.
  * ---------------------------------------------------------------------------------------------- */
-int gd_group_norm_nhwc(const void* x, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
-                       int silu, float* stats, void* y, int dtype, void* stream);
+
+/* GroupNorm (+ SiLU) of x (+ add_bc): x, y [B, HW, C] (NHWC memory), add_bc [B, C] with row stride add_ld elements (0 = C), or NULL
+ * (norm of x + add_bc[b,c]: the ResNet block's time-embedding add), gamma/beta [C];
+ * scratch: gd_group_norm_nhwc_scratch_floats(B, HW, G) f32 (no need to clear). */
+int64_t gd_group_norm_nhwc_scratch_floats(int B, int HW, int G);
+int gd_group_norm_nhwc(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
+                       int silu, float* scratch, void* y, int dtype, void* stream);
+
+/* y = x + bias[c] (+ res): convolution epilogue; x, res, y [rows, C]; bias [C]; res may be NULL. */
+int gd_bias_residual(const void* x, const void* bias, const void* res, int64_t rows, int C, void* y, int dtype, void* stream);
+
+/* y [rows, C] = x[:, :C] * gelu(x[:, C:]) with x [rows, 2C] (GEGLU, exact erf GELU). */
+int gd_geglu(const void* x, int64_t rows, int C, void* y, int dtype, void* stream);
+
+/* s = a + b (16-bit, written to sum_out unless NULL; b may be NULL: s = a);  y = LayerNorm(s) * gamma + beta over the C channels of
+ * each row; C <= 2048. */
+int gd_add_layer_norm(const void* a, const void* b, const void* gamma, const void* beta, int64_t rows, int C, float eps,
+                      void* sum_out, void* y, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * N2  post-process: masked per-channel histogram matching (GeoDiffuser/utils/image_processing.py:24-77).

@@ -191,3 +191,31 @@ def test_mixed_transform_edit_512(pipe):
     kw.update(num_ddim_steps=4, ldm_stable_model=p, tokenizer_model=tok, scheduler_in=sched, return_latents=True)
     images, lat = editor.run_geodiffuser(image, depth, mask, T, **kw)
     assert images[1].shape == (512, 512, 3) and torch.isfinite(lat.float()).all()
+
+
+def test_fused_unet_pass_equals_stock_ops():
+    """The no-grad fast paths of the UNet harness (folded conv biases, time-embedding add inside GroupNorm, one batched time-embedding
+    GEMM, GEGLU, residual + LayerNorm, token-major attention) give the stock-op result up to 16-bit rounding: compared with the
+    run-to-run noise of the stock path itself (split-K atomics)."""
+    from geodiffuser_amd import unet_sd21
+    from geodiffuser_amd import attention_processors as ap
+    torch.manual_seed(0)
+    net = unet_sd21.UNet2DConditionModel(block_out_channels=(256, 512, 512, 512), heads=(4, 8, 8, 8), cross_attention_dim=128)
+    net = net.to("cuda", torch.bfloat16).to(memory_format=torch.channels_last).eval()
+    assert sum(m.fused_ok for m in net.modules() if isinstance(m, unet_sd21.ResnetBlock2D)) == 22
+    x = torch.randn(3, 4, 32, 32, device="cuda", dtype=torch.bfloat16)
+    ctx = torch.randn(3, 77, 128, device="cuda", dtype=torch.bfloat16)
+
+    def run(fused):
+        prev = unet_sd21.FUSED, ap.TOKEN_MAJOR
+        unet_sd21.FUSED, ap.TOKEN_MAJOR = fused, fused
+        try:
+            with torch.no_grad():
+                return net(x, 481, encoder_hidden_states=ctx)["sample"].float().cpu()
+        finally:
+            unet_sd21.FUSED, ap.TOKEN_MAJOR = prev
+
+    stock, stock2, fused = run(False), run(False), run(True)
+    noise = rel_l2(stock2, stock)
+    assert torch.isfinite(fused).all()
+    assert rel_l2(fused, stock) < max(5 * noise, 2e-2)

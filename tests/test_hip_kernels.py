@@ -392,21 +392,58 @@ def test_ddim_and_latent_update(ops):
 
 # ------------------------------------------------------------------------------------------------ UNet plumbing
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("B,C,H", [(3, 320, 64), (2, 1920, 16), (2, 2560, 8), (3, 960, 32), (1, 640, 24), (2, 1280, 8)])
-def test_group_norm_nhwc(ops, dtype, B, C, H):
-    """Fused channels-last GroupNorm(+SiLU) used by the UNet harness on no-grad passes vs torch's GroupNorm in fp32."""
-    import torch.nn.functional as F
+@pytest.mark.parametrize("B,C,H", [(3, 320, 64), (2, 1920, 16), (2, 2560, 8), (3, 960, 32), (1, 640, 24), (2, 1280, 8), (1, 256, 96)])
+@pytest.mark.parametrize("add", [False, True])
+def test_group_norm_nhwc(ops, dtype, B, C, H, add):
+    """UNet plumbing: fused channels-last GroupNorm(+SiLU)(+ folded time-embedding add) == torch (fp32 reference of the same op)."""
     torch.manual_seed(C + H)
-    x = (torch.randn(B, C, H, H) * 2 + 0.5).to(dtype)
-    g = (torch.rand(C) + 0.5).to(dtype); bta = (torch.randn(C) * 0.2).to(dtype)
-    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    x = (torch.randn(B, C, H, H, device=DEV) * 1.5 + 0.3).to(dtype).contiguous(memory_format=torch.channels_last)
+    g = (torch.randn(C, device=DEV) * 0.5 + 1).to(dtype); b = (torch.randn(C, device=DEV) * 0.2).to(dtype)
+    tb = None
+    xin = x.float()
+    if add:                                                   # a strided column slice, as the UNet hands it over
+        wide = (torch.randn(B, C + 64, device=DEV) * 0.7).to(dtype)
+        tb = wide[:, 32:32 + C]
+        xin = (x + tb[:, :, None, None]).float()              # rounded to the storage type like the unfused add
     for silu in (False, True):
-        y = ops.group_norm_nhwc(xd, g.to(DEV), bta.to(DEV), 32, 1e-5, silu)
-        assert y.is_contiguous(memory_format=torch.channels_last)
-        ref = F.group_norm(x.float(), 32, g.float(), bta.float(), 1e-5)
+        y = ops.group_norm_nhwc(x, g, b, 32, 1e-5, silu, add_bc=tb)
+        ref = torch.nn.functional.group_norm(xin, 32, g.float(), b.float(), 1e-5)
         if silu:
-            ref = F.silu(ref)
-        assert rel_err(y.float().cpu(), ref) < tol(dtype)
+            ref = torch.nn.functional.silu(ref)
+        assert y.is_contiguous(memory_format=torch.channels_last)
+        assert rel_err(y.float().cpu(), ref.cpu()) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_unet_glue_kernels(ops, dtype):
+    """UNet plumbing: conv epilogue (bias + residual), GEGLU, residual-add + LayerNorm against the stock torch ops they replace."""
+    torch.manual_seed(3)
+    F = torch.nn.functional
+    for B, C, H in ((3, 320, 64), (1, 1280, 8), (2, 640, 24)):
+        x = torch.randn(B, C, H, H, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        r = torch.randn(B, C, H, H, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        bias = torch.randn(C, device=DEV).to(dtype)
+        y = ops.bias_residual(x, bias, r)
+        assert y.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(y, (x + bias[None, :, None, None]) + r)                      # same rounding points -> identical
+        assert torch.equal(ops.bias_residual(x, bias), x + bias[None, :, None, None])
+    for T, C in ((3 * 4096, 1280), (77, 5120), (2 * 256, 2560)):
+        x = (torch.randn(T // 7, 7, 2 * C, device=DEV) * 1.5).to(dtype) if T % 7 == 0 else (torch.randn(1, T, 2 * C, device=DEV) * 1.5).to(dtype)
+        h, gate = x.chunk(2, dim=-1)
+        ref = h.float() * F.gelu(gate.float())
+        y = ops.geglu(x)
+        assert y.shape == h.shape and rel_err(y.float().cpu(), ref.cpu()) < tol(dtype)
+    for T, C in ((3 * 4096, 320), (2 * 1024, 640), (300, 1280), (5, 2048)):
+        a = torch.randn(1, T, C, device=DEV).to(dtype); b = torch.randn(1, T, C, device=DEV).to(dtype)
+        g = (torch.randn(C, device=DEV) * 0.3 + 1).to(dtype); be = (torch.randn(C, device=DEV) * 0.1).to(dtype)
+        s, y = ops.add_layer_norm(a, b, g, be, 1e-5)
+        assert torch.equal(s, a + b)
+        ref = F.layer_norm((a + b).float(), (C,), g.float(), be.float(), 1e-5)
+        assert rel_err(y.float().cpu(), ref.cpu()) < tol(dtype)
+        s2, y2 = ops.add_layer_norm(a, None, g, be, 1e-5)
+        assert s2 is a and rel_err(y2.float().cpu(), F.layer_norm(a.float(), (C,), g.float(), be.float(), 1e-5).cpu()) < tol(dtype)
+    with pytest.raises(Exception):
+        ops.add_layer_norm(torch.randn(4, 4096, device=DEV).to(dtype), None, torch.ones(4096, device=DEV).to(dtype), torch.ones(4096, device=DEV).to(dtype), 1e-5)
 
 
 # ---------------------------------------------------------------------------------------------------------

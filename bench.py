@@ -38,50 +38,81 @@ PEAK_MFMA_16BIT = 2.5e15     # dense bf16/fp16 MFMA peak of MI355X, /opt/skills/
 
 
 class AttnTimer:
-    """Wraps ops.attn_fwd: HIP events around every launch of the dominant shape (N = M = (size/8)^2) on torch's current
-    stream — the stream the kernel is launched on.  Launches that are being captured into a hipGraph cannot carry timing
-    events; their launch configuration is remembered and ``replay()`` re-issues it after the timed region, un-captured, on the
-    same stream with the same event bracket, so that every dominant-shape launch configuration of the edit is measured."""
+    """Times k_attn_fwd on the dominant launch shape (N = M = (size/8)^2) with HIP events on the stream it is launched on, and
+    counts how often every launch CONFIGURATION of that shape (segments x heads, layout) runs inside the timed region — eager
+    launches directly, launches inside hipGraphs through the graphs' capture / replay (a captured launch cannot carry events).
+    Configurations that only ran inside graphs are re-issued after the timed region, un-captured, on the same stream with the same
+    event bracket.  ``summary()`` weights each configuration's mean launch time by its launch count in the timed region."""
 
     def __init__(self, n_tokens):
         self.n = n_tokens
-        self.records = []
         self.enabled = False
-        self.captured = {}          # launch configuration -> count of captured (untimed) launches
-        self.in_region = 0
+        self.cfgs = {}              # cfg -> dict(count=launches in the timed region, ev=[(e0, e1)], flops=per launch)
+        self._capturing = None      # list of cfgs of the graph being captured
 
-    def _timed(self, segs, scale, heads):
-        q0, k0 = segs[0][0], segs[0][1]
+    def _cfg(self, segs, scale, heads):
+        q0 = segs[0][0]
+        return (tuple((tuple(s[0].shape), tuple(s[1].shape), s[4] is not None) for s in segs), float(scale), heads, q0.dtype)
+
+    def _entry(self, cfg):
+        e = self.cfgs.get(cfg)
+        if e is None:
+            shapes, _, heads, _ = cfg
+            bh = sum(qs[0] for qs, _, _ in shapes) * (heads if heads else 1)
+            e = self.cfgs[cfg] = dict(count=0, ev=[], flops=4.0 * bh * self.n * self.n * 64, heads=bh)
+        return e
+
+    def _timed(self, cfg, segs, scale, heads, key="ev"):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         self._orig(segs, scale, heads)
         e1.record()
-        bh = sum(s[0].shape[0] for s in segs) * (heads if heads else 1)     # token-major rows hold all heads
-        self.records.append((e0, e1, 4.0 * bh * q0.shape[1] * k0.shape[1] * 64))
+        self._entry(cfg).setdefault(key, []).append((e0, e1))
 
     def install(self):
         from geodiffuser_amd import ops
         self._orig = ops.attn_fwd
         timer = self
 
-        def wrapped(segs, scale, heads=0):
+        def wrapped(segs, scale, heads=0, nsplit=None):
             q0, k0 = segs[0][0], segs[0][1]
-            if timer.enabled and q0.shape[1] == timer.n and k0.shape[1] == timer.n:
-                if torch.cuda.is_current_stream_capturing():
-                    cfg = (tuple((tuple(s[0].shape), tuple(s[1].shape), s[4] is not None) for s in segs), float(scale), heads, q0.dtype)
-                    timer.captured[cfg] = timer.captured.get(cfg, 0) + 1
-                    timer._orig(segs, scale, heads)
-                else:
-                    timer._timed(segs, scale, heads)
-                    timer.in_region += 1
-            else:
-                timer._orig(segs, scale, heads)
+            if nsplit is not None or q0.shape[1] != timer.n or k0.shape[1] != timer.n:
+                return timer._orig(segs, scale, heads, nsplit)
+            cfg = timer._cfg(segs, scale, heads)
+            if torch.cuda.is_current_stream_capturing():
+                if timer._capturing is not None:
+                    timer._capturing.append(cfg)
+                timer._entry(cfg)
+                return timer._orig(segs, scale, heads)
+            if timer.enabled:
+                timer._entry(cfg)["count"] += 1
+                return timer._timed(cfg, segs, scale, heads)
+            return timer._orig(segs, scale, heads)
 
         ops.attn_fwd = wrapped
+        G = torch.cuda.CUDAGraph
+        o_begin, o_replay = G.capture_begin, G.replay
 
-    def replay(self, reps=8):
-        """Re-issue every captured launch configuration ``reps`` times with events (outside the timed region)."""
-        for cfg in list(self.captured):
+        def capture_begin(g, *a, **k):
+            timer._capturing = timer._graph_cfgs[id(g)] = []
+            return o_begin(g, *a, **k)
+
+        def replay(g, *a, **k):
+            if timer.enabled:
+                for cfg in timer._graph_cfgs.get(id(g), ()):
+                    timer._entry(cfg)["count"] += 1
+            return o_replay(g, *a, **k)
+
+        self._graph_cfgs = {}
+        G.capture_begin, G.replay = capture_begin, replay
+
+    def replay(self, reps=20):
+        """Re-issue every configuration that ran in the timed region, back to back (outside the timed region).  Event brackets
+        around isolated eager launches also contain the launch latency of an idle queue (+20-40 us); the back-to-back samples agree
+        with rocprofv3's kernel durations and are the ones reported, the in-region eager samples are kept as ``eager_avg_us``."""
+        for cfg, e in self.cfgs.items():
+            if e["count"] == 0:
+                continue
             shapes, scale, heads, dt = cfg
             segs = []
             for qs, ks, want_lse in shapes:
@@ -89,27 +120,44 @@ class AttnTimer:
                 lse = torch.empty(qs[0] * (heads if heads else 1), qs[1], device="cuda") if want_lse else None
                 segs.append((q, k, v, torch.empty_like(q), lse))
             self._orig(segs, scale, heads)                 # warm
+            # one event bracket around `reps` back-to-back launches: the queue stays full, so host dispatch time is not measured
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
             for _ in range(reps):
-                self._timed(segs, scale, heads)
+                self._orig(segs, scale, heads)
+            e1.record()
+            e["rep"] = (e0, e1, reps)
         torch.cuda.synchronize()
 
     def summary(self):
-        if not self.records:
+        rows = []
+        for cfg, e in self.cfgs.items():
+            if e["count"] and (e.get("rep") or e["ev"]):
+                if e.get("rep"):
+                    us = 1e3 * e["rep"][0].elapsed_time(e["rep"][1]) / e["rep"][2]
+                else:
+                    us = 1e3 * sum(a.elapsed_time(b) for a, b in e["ev"]) / len(e["ev"])
+                row = dict(heads=e["heads"], token_major=bool(cfg[2]), launches=e["count"], avg_us=us, tflops=e["flops"] / us * 1e-6)
+                if e["ev"]:
+                    row["eager_avg_us"] = 1e3 * sum(a.elapsed_time(b) for a, b in e["ev"]) / len(e["ev"])
+                rows.append(row)
+        if not rows:
             return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
+        n = sum(r["launches"] for r in rows)
+        t_us = sum(r["launches"] * r["avg_us"] for r in rows)
+        fl = sum(r["launches"] * r["tflops"] * r["avg_us"] * 1e6 for r in rows)
         # HBM traffic of the most frequent launch shape, from the committed PMC run of the same kernel (profiles/)
         traffic = None
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", "r01_attn_traffic.json")))["bytes_per_launch"]
-            per = 4.0 * self.n * self.n * 64
-            heads = [int(round(f / per)) for _, _, f in self.records]
-            common = max(set(heads), key=heads.count)
+            common = max(rows, key=lambda r: r["launches"])["heads"]
             traffic = tab.get(str(common))
+            if traffic is None:                       # measured at 10 / 15 / 20 heads; linear in the head count (Q, K, V, O once each)
+                traffic = int(tab["10"] + (tab["20"] - tab["10"]) * (common - 10) / 10.0)
         except Exception:  # noqa: BLE001
             pass
-        return dict(launches=len(self.records), launches_in_region=self.in_region, avg_us=1e3 * ms / len(self.records),
-                    flops_per_launch=fl / len(self.records), achieved=fl / (ms * 1e-3), traffic=traffic)
+        rows.sort(key=lambda r: -r["launches"])
+        return dict(launches=n, avg_us=t_us / n, flops_per_launch=fl / n, achieved=fl / (t_us * 1e-6), traffic=traffic, configs=rows)
 
 
 def cpu_baseline(budget_s=45.0):
@@ -280,8 +328,8 @@ def main():
         if roof:
             line["roofline"] = {"kernel": "k_attn_fwd (64^2 self-attention launches)", "bound": "mfma", "achieved": roof["achieved"] / 1e12,
                                 "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s", "frac": roof["achieved"] / PEAK_MFMA_16BIT,
-                                "traffic": roof["traffic"], "launches": roof["launches"],
-                                "launches_in_timed_region": roof["launches_in_region"], "avg_launch_us": roof["avg_us"],
+                                "traffic": roof["traffic"], "launches": roof["launches"], "avg_launch_us": roof["avg_us"],
+                                "configs": roof["configs"],
                                 "flops_per_launch": roof["flops_per_launch"]}
         if not args.no_cpu_baseline and world == 1:
             try:

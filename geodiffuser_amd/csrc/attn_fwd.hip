@@ -18,6 +18,11 @@ struct FwdArgs {
     int nwg;
     float c;                        // scale * log2(e)
     float scale;
+    // split-KV (launches that would leave most CUs idle): split sp handles key tiles [sp*tps, (sp+1)*tps) and leaves an
+    // un-normalised partial (O, m, l) in the workspace; k_attn_combine merges them
+    int nsplit, tps, tot_bh;
+    float* ws_o;                    // [nsplit, tot_bh, N, 64] f32
+    float* ws_ml;                   // [nsplit, tot_bh, N, 2]  f32 (reference max, row sum)
 };
 
 // Per-lane LDS byte offsets of the fragment reads, computed once (the swizzle term does not depend on the k-step /
@@ -114,7 +119,9 @@ k_attn_fwd(const FwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2][2][ATT_TILE_BYTES];   // [buf][K|V]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int wg = xcd_remap(blockIdx.x, a.nwg);
+    const int wg0 = xcd_remap(blockIdx.x, a.nwg);
+    const int sp = a.nsplit > 1 ? wg0 % a.nsplit : 0;
+    const int wg = a.nsplit > 1 ? wg0 / a.nsplit : wg0;
     const int gbh = wg / a.tiles, tile = wg - gbh * a.tiles;
     int sidx = 0;
 #pragma unroll
@@ -151,21 +158,23 @@ k_attn_fwd(const FwdArgs a) {
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int T_full = M / ATT_BN;                     // tiles without a key tail
-    const int T_tiles = (M + ATT_BN - 1) / ATT_BN;
+    const int T_all = (M + ATT_BN - 1) / ATT_BN;
+    const int t0 = sp * a.tps;                          // this split's key tiles [t0, T_tiles)
+    const int T_tiles = (t0 + a.tps) < T_all ? (t0 + a.tps) : T_all;
+    const int T_full = (M / ATT_BN) < T_tiles ? (M / ATT_BN) : T_tiles;     // tiles without a key tail
     u32x4 kr[2], vr[2];
-    tile_load<T>(kp, 0, M, tid, kr, rs);
-    tile_load<T>(vp, 0, M, tid, vr, rs);
+    tile_load<T>(kp, t0 * ATT_BN, M, tid, kr, rs);
+    tile_load<T>(vp, t0 * ATT_BN, M, tid, vr, rs);
     tile_store(lds[0][0], tid, kr);
     tile_store(lds[0][1], tid, vr);
     __syncthreads();
-    // this thread's chunk of the NEXT tile (rows tid/8 and tid/8 + 32 of tile 1); advanced by one tile per iteration
-    const T* kq = kp + (size_t)(ATT_BN + (tid >> 3)) * rs + (tid & 7) * 8;
-    const T* vq = vp + (size_t)(ATT_BN + (tid >> 3)) * rs + (tid & 7) * 8;
+    // this thread's chunk of the NEXT tile (rows tid/8 and tid/8 + 32 of tile t0 + 1); advanced by one tile per iteration
+    const T* kq = kp + (size_t)((t0 + 1) * ATT_BN + (tid >> 3)) * rs + (tid & 7) * 8;
+    const T* vq = vp + (size_t)((t0 + 1) * ATT_BN + (tid >> 3)) * rs + (tid & 7) * 8;
 
 #pragma unroll 1
-    for (int t = 0; t < T_full; ++t) {
-        const int cur = t & 1;
+    for (int t = t0; t < T_full; ++t) {
+        const int cur = (t - t0) & 1;
         const bool more = (t + 1) < T_tiles;
         if (t + 1 < T_full) {                      // next tile is full: no clamping
             kr[0] = *(const u32x4*)kq; kr[1] = *(const u32x4*)(kq + (size_t)32 * rs);
@@ -182,10 +191,27 @@ k_attn_fwd(const FwdArgs a) {
         }
         __syncthreads();
     }
-    if (T_full < T_tiles)        // key tail (M % 64 != 0): one masked tile
-        fwd_tile<T, true>(lds[T_full & 1][0], lds[T_full & 1][1], fo, qf, o, m_run, l_run, a.c, T_full * ATT_BN, M, h);
+    if (T_full < T_tiles)        // key tail (M % 64 != 0): one masked tile, always the last tile of the last split
+        fwd_tile<T, true>(lds[(T_full - t0) & 1][0], lds[(T_full - t0) & 1][1], fo, qf, o, m_run, l_run, a.c, T_full * ATT_BN, M, h);
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (a.nsplit > 1) {                                  // partial result of this split, merged by k_attn_combine
+        if (qrow < N) {
+            const size_t r = ((size_t)sp * a.tot_bh + gbh) * N + qrow;
+            float* wo = a.ws_o + r * ATT_D;
+#pragma unroll
+            for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = o[dblk][4 * g + j];
+                    *(f32x4*)(wo + dblk * 32 + 8 * g + 4 * h) = w;
+                }
+            if (h == 0) { a.ws_ml[r * 2] = m_run; a.ws_ml[r * 2 + 1] = l_tot; }
+        }
+        return;
+    }
     const float inv = 1.0f / l_tot;
     if (qrow < N) {
         T* __restrict__ op = (T*)sg.out + qoff + (size_t)qrow * rs;
@@ -202,7 +228,79 @@ k_attn_fwd(const FwdArgs a) {
     }
 }
 
+// merge the split-KV partials: one thread per (row, 4 channels)
+template <typename T>
+__global__ void k_attn_combine(const FwdArgs a) {
+    using TR = elem_traits<T>;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)a.tot_bh * a.N * (ATT_D / 4);
+    if (gid >= total) return;
+    const int dq = (int)(gid % (ATT_D / 4));
+    const long long rr = gid / (ATT_D / 4);
+    const int row = (int)(rr % a.N), gbh = (int)(rr / a.N);
+    float mref = -INFINITY;
+    for (int s = 0; s < a.nsplit; ++s) mref = fmaxf(mref, a.ws_ml[(((size_t)s * a.tot_bh + gbh) * a.N + row) * 2]);
+    float L = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < a.nsplit; ++s) {
+        const size_t r = ((size_t)s * a.tot_bh + gbh) * a.N + row;
+        const float w = __builtin_amdgcn_exp2f((a.ws_ml[r * 2] - mref) * a.c);
+        L = __builtin_fmaf(w, a.ws_ml[r * 2 + 1], L);
+        const f32x4 o = *(const f32x4*)(a.ws_o + r * ATT_D + dq * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(w, o[j], acc[j]);
+    }
+    int sidx = 0;
+#pragma unroll
+    for (int i = 0; i < GD_ATTN_MAX_SEGS - 1; ++i)
+        if (i < a.nseg - 1 && gbh >= a.bh_end[i]) sidx = i + 1;
+    const int bh = gbh - (sidx ? a.bh_end[sidx - 1] : 0);
+    const gd_attn_seg_t sg = a.seg[sidx];
+    size_t off;
+    if (sg.heads > 0) {
+        const int b = bh / sg.heads, hh = bh - b * sg.heads;
+        off = ((size_t)b * a.N + row) * sg.heads * ATT_D + (size_t)hh * ATT_D;
+    } else {
+        off = ((size_t)bh * a.N + row) * ATT_D;
+    }
+    const float inv = 1.0f / L;
+    typename TR::vec4 w4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = TR::from_f32(acc[j] * inv);
+    *(typename TR::vec4*)((T*)sg.out + off + dq * 4) = w4;
+    if (sg.lse && dq == 0) sg.lse[(size_t)bh * a.N + row] = mref * a.scale + __logf(L);
+}
+
+// Split-KV plan: how many key splits make a launch of tot_bh heads fill the chip (1 = none), and the workspace they need.
+extern "C" int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_bytes) {
+    if (workspace_bytes) *workspace_bytes = 0;
+    if (tot_bh <= 0 || N <= 0 || M <= 0) return 1;
+    const int tiles = (N + ATT_BM - 1) / ATT_BM, t_all = (M + ATT_BN - 1) / ATT_BN;
+    const long long nwg = (long long)tiles * tot_bh;
+    // measured on MI355X (tools/bench_splitkv.py): 5 heads at 64^2 80 -> 50 us with 4 splits, 10 heads 99 -> 72 us with 3, 15 heads
+    // 100 -> 97 us with 2, nothing from 20 heads (640 workgroups) up; 32^2 launches lose more to the merge kernel than they gain
+    int ns = (int)(1000 / nwg);
+    if (ns > 4) ns = 4;
+    if (ns > t_all / 16) ns = t_all / 16;             // at least 16 key tiles (1024 keys) per split
+    if (ns < 2) return 1;
+    if (workspace_bytes) *workspace_bytes = (size_t)ns * tot_bh * N * (ATT_D + 2) * sizeof(float);
+    return ns;
+}
+
+static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
+                           size_t workspace_bytes, int dtype, void* stream);
+
 extern "C" int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int dtype, void* stream) {
+    return attn_fwd_launch(segs, nseg, N, M, D, scale, 1, nullptr, 0, dtype, stream);
+}
+
+extern "C" int gd_attn_fwd_splitkv(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
+                                   size_t workspace_bytes, int dtype, void* stream) {
+    return attn_fwd_launch(segs, nseg, N, M, D, scale, nsplit, workspace, workspace_bytes, dtype, stream);
+}
+
+static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
+                           size_t workspace_bytes, int dtype, void* stream) {
     GD_REQUIRE(segs && nseg >= 1 && nseg <= GD_ATTN_MAX_SEGS, GD_EINVAL, "gd_attn_fwd: nseg=%d (1..%d)", nseg, GD_ATTN_MAX_SEGS);
     GD_REQUIRE(D == ATT_D, GD_EUNSUPPORTED, "gd_attn_fwd: head dim %d unsupported (only 64)", D);
     GD_REQUIRE(N > 0 && M > 0, GD_EINVAL, "gd_attn_fwd: bad sizes N=%d M=%d", N, M);
@@ -219,11 +317,29 @@ extern "C" int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, in
     }
     a.nseg = nseg; a.N = N; a.M = M;
     a.tiles = (N + ATT_BM - 1) / ATT_BM;
-    a.nwg = a.tiles * tot;
     a.scale = scale;
     a.c = scale * 1.4426950408889634f;
-    if (dtype == GD_F16) k_attn_fwd<f16_t><<<a.nwg, 256, 0, as_stream(stream)>>>(a);
-    else k_attn_fwd<bf16_t><<<a.nwg, 256, 0, as_stream(stream)>>>(a);
+    const int t_all = (M + ATT_BN - 1) / ATT_BN;
+    GD_REQUIRE(nsplit >= 1 && nsplit <= 8 && nsplit <= t_all, GD_EINVAL, "gd_attn_fwd: nsplit=%d (1..min(8, key tiles=%d))", nsplit, t_all);
+    a.nsplit = nsplit; a.tot_bh = tot;
+    a.tps = (t_all + nsplit - 1) / nsplit;
+    GD_REQUIRE((long long)a.tps * (nsplit - 1) < t_all, GD_EINVAL, "gd_attn_fwd: nsplit=%d leaves an empty split for %d key tiles", nsplit, t_all);
+    if (nsplit > 1) {
+        const size_t need = (size_t)nsplit * tot * N * (ATT_D + 2) * sizeof(float);
+        GD_REQUIRE(workspace && workspace_bytes >= need, GD_EINVAL, "gd_attn_fwd_splitkv: workspace %zu B < %zu B", workspace_bytes, need);
+        a.ws_o = (float*)workspace;
+        a.ws_ml = a.ws_o + (size_t)nsplit * tot * N * ATT_D;
+    }
+    a.nwg = a.tiles * tot * nsplit;
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16) k_attn_fwd<f16_t><<<a.nwg, 256, 0, st>>>(a);
+    else k_attn_fwd<bf16_t><<<a.nwg, 256, 0, st>>>(a);
+    if (nsplit > 1) {
+        const long long total = (long long)tot * N * (ATT_D / 4);
+        const int blocks = (int)((total + 255) / 256);
+        if (dtype == GD_F16) k_attn_combine<f16_t><<<blocks, 256, 0, st>>>(a);
+        else k_attn_combine<bf16_t><<<blocks, 256, 0, st>>>(a);
+    }
     GD_CHECK_LAUNCH("gd_attn_fwd");
     return GD_OK;
 }

@@ -5,6 +5,7 @@ tensor or a missing library raises.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -104,7 +105,21 @@ def mesh_coverage(verts, faces, S: int):
 # ---------------------------------------------------------------------------------------------------
 # R5-R7 attention
 # ---------------------------------------------------------------------------------------------------
-def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0) -> None:
+SPLIT_KV = os.environ.get("GD_ATTN_SPLIT_KV", "1") == "1"
+_PLAN_CACHE = {}
+
+
+def _attn_plan(lib, tot_bh: int, N: int, M: int):
+    key = (tot_bh, N, M)
+    p = _PLAN_CACHE.get(key)
+    if p is None:
+        nb = ctypes.c_size_t(0)
+        ns = int(lib.gd_attn_fwd_plan(tot_bh, N, M, ctypes.byref(nb)))
+        p = _PLAN_CACHE[key] = (ns, int(nb.value))
+    return p
+
+
+def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Optional[int] = None) -> None:
     """segs: list of (q, k, v, out, lse | None); one launch.
     heads == 0: q/out [bh,N,D], k/v [bh,M,D] (head-major).  heads > 0: token-major q/out [B,N,heads*D], k/v [B,M,heads*D]
     exactly as to_q/to_k/to_v produce them (no head_to_batch_dim copies); lse [B*heads, N]."""
@@ -115,6 +130,7 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0) -> None:
     D = 64 if heads else q0.shape[2]
     N, M = q0.shape[1], k0.shape[1]
     dt = _dt16(q0, "q")
+    tot_bh = 0
     for i, (q, k, v, o, lse) in enumerate(segs):
         for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "out")):
             _need(t, nm, q0.dtype)
@@ -128,8 +144,17 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0) -> None:
         if lse is not None:
             _need(lse, "lse", torch.float32)
         bh = q.shape[0] * (heads if heads else 1)
+        tot_bh += bh
         arr[i] = GdAttnSeg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 0 if lse is None else lse.data_ptr(), bh, heads)
-    check(lib.gd_attn_fwd(arr, n, N, M, D, scale, dt, _stream()), "gd_attn_fwd")
+    if nsplit is None:
+        nsplit, ws_bytes = _attn_plan(lib, tot_bh, N, M) if SPLIT_KV else (1, 0)
+    else:
+        ws_bytes = nsplit * tot_bh * N * (D + 2) * 4 if nsplit > 1 else 0
+    if nsplit > 1:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q0.device)
+        check(lib.gd_attn_fwd_splitkv(arr, n, N, M, D, scale, nsplit, _p(ws), ws_bytes, dt, _stream()), "gd_attn_fwd_splitkv")
+    else:
+        check(lib.gd_attn_fwd(arr, n, N, M, D, scale, dt, _stream()), "gd_attn_fwd")
 
 
 def attn_bwd(q, k, v, out, lse, dout, scale: float, need_dk: bool):

@@ -108,6 +108,15 @@ typedef struct {
  * (vanilla rows, edit_out with warped queries, replace_out) that share N, M, D.  D must be 64. */
 int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int dtype, void* stream);
 
+/* Split-KV variant for launches that would leave most of the 256 CUs idle (e.g. the batch-1 inversion pass: 5 heads x 32 query
+ * tiles = 160 workgroups): the keys are cut into nsplit ranges handled by separate workgroups, whose un-normalised partial results
+ * (O, reference max, row sum; f32) go through `workspace` and are merged by a second small kernel.  Same result as gd_attn_fwd up to
+ * f32 summation order.  gd_attn_fwd_plan returns the nsplit worth using for tot_bh = sum of segment bh (1 = do not split) and the
+ * workspace size it needs. */
+int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_bytes);
+int gd_attn_fwd_splitkv(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
+                        size_t workspace_bytes, int dtype, void* stream);
+
 /*
  * Backward of out = softmax(scale q k^T) v w.r.t. q (always) and k (dk_f32 != NULL).
  *   dout [BH,N,D] 16-bit; lse from the forward; dq [BH,N,D] 16-bit (overwritten);

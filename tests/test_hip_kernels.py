@@ -162,7 +162,8 @@ def test_attention_forward_full_size_and_segments(ops):
     l1 = torch.empty(3 * f, N, device=DEV); l3 = torch.empty(f, N, device=DEV)
     ops.attn_fwd([(q1, k1, v1, o1, l1), (q2, k2, v1[:f], o2, None), (q3, k2, v1[:f], o3, l3)], 0.125)
     s1 = torch.empty_like(q1); s2 = torch.empty_like(q2); s3 = torch.empty_like(q3)
-    ops.attn_fwd([(q1, k1, v1, s1, None)], 0.125); ops.attn_fwd([(q2, k2, v1[:f], s2, None)], 0.125); ops.attn_fwd([(q3, k2, v1[:f], s3, None)], 0.125)
+    # (nsplit=1: a 5-head launch on its own would be split over the keys, which changes the f32 summation order)
+    ops.attn_fwd([(q1, k1, v1, s1, None)], 0.125, nsplit=1); ops.attn_fwd([(q2, k2, v1[:f], s2, None)], 0.125, nsplit=1); ops.attn_fwd([(q3, k2, v1[:f], s3, None)], 0.125, nsplit=1)
     assert torch.equal(o1, s1) and torch.equal(o2, s2) and torch.equal(o3, s3)
     rows = torch.arange(7, N, 97)
     ro, rl, _ = _ref_attn(q1[:, rows].cpu(), k1.cpu(), v1.cpu(), 0.125)
@@ -170,6 +171,48 @@ def test_attention_forward_full_size_and_segments(ops):
     assert float((l1[:, rows].cpu().double() - rl).abs().max()) < 1e-4
     # softmax rows are convex combinations: every output lies inside the value range
     assert float(o2.float().abs().max()) <= float(v1[:f].float().abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("BH,N,M,nsplit", [(5, 4096, 4096, 4), (2, 1024, 1024, 2), (3, 512, 1100, 3), (1, 256, 4096 + 37, 8), (2, 100, 640, 2)])
+def test_attention_forward_split_kv(ops, dtype, BH, N, M, nsplit):
+    """Split-KV launches (keys cut into nsplit ranges, partials merged by k_attn_combine) equal the single-pass kernel up to f32
+    summation order, incl. a ragged key tail in the last split and two segments; the planner only splits under-filled launches."""
+    torch.manual_seed(BH * N + M)
+    mk = lambda n: (torch.randn(BH, n, 64, device=DEV) * 1.4).to(dtype)
+    q, k, v, q2 = mk(N), mk(M), mk(M), mk(N)
+    o1 = torch.empty_like(q); o1b = torch.empty_like(q); l1 = torch.empty(BH, N, device=DEV); l1b = torch.empty(BH, N, device=DEV)
+    ops.attn_fwd([(q, k, v, o1, l1), (q2, k, v, o1b, l1b)], 0.125, nsplit=1)
+    o2 = torch.empty_like(q); o2b = torch.empty_like(q); l2 = torch.empty(BH, N, device=DEV); l2b = torch.empty(BH, N, device=DEV)
+    ops.attn_fwd([(q, k, v, o2, l2), (q2, k, v, o2b, l2b)], 0.125, nsplit=nsplit)
+    for a, b in ((o2, o1), (o2b, o1b)):
+        assert rel_err(a.float().cpu(), b.float().cpu()) < (2e-3 if dtype == torch.float16 else 8e-3)
+    assert float((l2 - l1).abs().max()) < 1e-4 and float((l2b - l1b).abs().max()) < 1e-4
+    ro, rl, _ = _ref_attn(q[:1, :64].cpu(), k[:1].cpu(), v[:1].cpu(), 0.125)
+    assert rel_err(o2[:1, :64].float().cpu(), ro) < tol(dtype)
+    # token-major + split
+    H = BH
+    qt = q.permute(1, 0, 2).reshape(1, N, H * 64).contiguous(); kt = k.permute(1, 0, 2).reshape(1, M, H * 64).contiguous()
+    vt = v.permute(1, 0, 2).reshape(1, M, H * 64).contiguous()
+    ot = torch.empty_like(qt)
+    ops.attn_fwd([(qt, kt, vt, ot, None)], 0.125, heads=H, nsplit=nsplit)
+    assert torch.equal(ot.reshape(N, H, 64).permute(1, 0, 2), o2)
+    with pytest.raises(Exception):
+        ops.attn_fwd([(q, k[:, :64], v[:, :64], o2, None)], 0.125, nsplit=2)        # more splits than key tiles
+
+
+def test_attention_split_kv_plan():
+    import ctypes
+    from geodiffuser_amd import _lib
+    lib = _lib.load()
+    nb = ctypes.c_size_t(0)
+    assert lib.gd_attn_fwd_plan(5, 4096, 4096, ctypes.byref(nb)) == 4 and nb.value == 4 * 5 * 4096 * 66 * 4    # inversion pass, 64^2
+    assert lib.gd_attn_fwd_plan(10, 4096, 4096, ctypes.byref(nb)) == 3                                            # inversion pass (batch 2)
+    assert lib.gd_attn_fwd_plan(15, 4096, 4096, ctypes.byref(nb)) == 2                                            # optimisation pass
+    assert lib.gd_attn_fwd_plan(20, 4096, 4096, ctypes.byref(nb)) == 1                                            # CFG pass fills the chip
+    assert lib.gd_attn_fwd_plan(25, 4096, 4096, ctypes.byref(nb)) == 1 and nb.value == 0                          # CFG pass fills the chip
+    assert lib.gd_attn_fwd_plan(20, 4096, 77, ctypes.byref(nb)) == 1                                              # cross attention: one key tile
+    assert lib.gd_attn_fwd_plan(10, 1024, 1024, ctypes.byref(nb)) == 1                                            # 32^2: the merge costs more than it saves
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

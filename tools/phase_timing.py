@@ -1,5 +1,6 @@
 """Wall-clock breakdown of one edit by phase (development aid; adds synchronisations)."""
 import os, sys, time, torch, collections
+torch.backends.cudnn.benchmark = os.environ.get('GD_MIOPEN_FIND', '1') == '1'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from geodiffuser_amd import editor, inversion, diffusion, optimization, vis_utils
 from geodiffuser_amd.diffusion import load_model
@@ -18,13 +19,15 @@ def wrap(mod, name, key=None):
 wrap(inversion.NullInversion, "ddim_loop")
 wrap(inversion.NullInversion, "image2latent")
 wrap(editor, "diffusion_step", key=lambda a, k: "diffusion_step_opt_fwd" if k.get("use_cfg", True) is False else "diffusion_step_cfg")
-wrap(editor, "_update_latent")
+from geodiffuser_amd import graphs
+wrap(graphs.GraphedOptPass, "grads")
+wrap(editor, "_apply_latent_update")
 wrap(editor, "latent2image")
 wrap(editor.vis_utils, "get_transform_coordinates")
 wrap(editor, "masked_histogram_matching")
 wrap(editor, "convert_loss_log_to_numpy")
 kw = editor_kwargs(); kw.update(ldm_stable_model=pipe, tokenizer_model=tok, scheduler_in=sched)
-for it in range(2):
+for it in range(3):
     acc.clear(); cnt.clear()
     image, depth, mask, T = make_edit(it, kind="rotate")
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -17,6 +17,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libgeodiff_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+# per-file extras.  attn_fwd: -O3's SLP vectoriser packs the softmax's neighbouring f32 adds / multiplies into v_pk_*_f32, which cost
+# more issue time beside MFMAs than the single instructions they replace (MI355X_MICROARCH.md, per-instruction constants)
+EXTRA_FLAGS = {"attn_fwd.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -44,8 +47,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s[:-4] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+        if force or _stale(obj, [src, os.path.abspath(__file__)] + headers):
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -55,9 +55,13 @@ __device__ __forceinline__ typename elem_traits<T>::vec8 rd_tr(const char* lds, 
     return u.x;
 }
 
-// log2-domain slack before the running maximum is raised: while a row's maximum grows by less than this, the
-// accumulators are NOT rescaled (probabilities then reach at most 2^RESCALE_SLACK, harmless in f32 / 16-bit)
-#define RESCALE_SLACK 6.0f
+// largest partial row sum (16 probabilities of one lane) tolerated before the reference maximum is raised: every probability
+// then stays <= 2^14, inside fp16 range (bf16 / f32 have far more)
+#define P_SUM_LIMIT 16384.0f
+
+// (this file is built with -fno-slp-vectorize, see build.py: packed f32 VALU beside MFMAs is an anti-lever.  An inline-asm v_add_f32
+// is NOT an alternative: the compiler's hazard recogniser does not look inside asm, and a VALU read of a v_exp_f32 result needs a wait
+// state — an asm add read stale registers.)
 
 // one 64-key tile, processed as two 32-key half steps (S^T = K Q^T, online softmax, O^T += V^T P^T).  Half steps keep
 // only 16 score + 8 probability registers live, which fits 4 waves per SIMD (<= 128 VGPRs): on this kernel latency
@@ -79,30 +83,52 @@ __device__ __forceinline__ void fwd_tile(const char* lk, const char* lv, const F
             for (int i = 0; i < 16; ++i)
                 if (kv0 + blk * 32 + acc_key(i, h) >= M) s_acc[i] = -INFINITY;
         }
-        float mx = s_acc[0];
+        // Probabilities against the CURRENT reference maximum, no per-step row maximum: p = exp2(c*s - c*m_run).  A row maximum is
+        // only needed to keep p inside the 16-bit range, so it is recomputed (slow path, wave-uniform, executed at most once per
+        // half step) only when a lane's partial row sum leaves [0, 2^14] — which also covers the first tile (m_run = -inf gives
+        // p = inf) and NaN.  Everything downstream (l, O, lse = m_run*scale + ln l, the split-KV merge) is exact for ANY reference
+        // value; it need not be the true maximum.  This removes a 10-deep dependent max chain, an LDS round trip and a branch
+        // from every half step (+9-12 % on the 64^2 launches).
+        float mc = m_run * c;
+        V8 pf0, pf1;
+        float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s_acc[i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // raise the running maximum only when some row of the wave outgrew it by more than the slack (wave-uniform branch)
-        if (__builtin_amdgcn_ballot_w64((mx - m_run) * c > RESCALE_SLACK) != 0) {
+        for (int i = 0; i < 8; i += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], c, -mc));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i + 1], c, -mc));
+            pf0[i] = TR::from_f32(p0); pf0[i + 1] = TR::from_f32(p1);
+            ps0 += p0; ps1 += p1;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[8 + i], c, -mc));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[8 + i + 1], c, -mc));
+            pf1[i] = TR::from_f32(p0); pf1[i + 1] = TR::from_f32(p1);
+            ps0 += p0; ps1 += p1;
+        }
+        float ps = ps0 + ps1;
+        if (__builtin_amdgcn_ballot_w64(!(ps <= P_SUM_LIMIT)) != 0) {
+            float mx = s_acc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s_acc[i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);       // 0 on the first tile
             l_run *= alpha;
             m_run = m_new;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-        }
-        const float mc = m_run * c;
-        float ps0 = 0.f, ps1 = 0.f;
+            mc = m_run * c;
+            ps = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], c, -mc));
-            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i + 1], c, -mc));
-            s_acc[i] = p0; s_acc[i + 1] = p1;
-            ps0 += p0; ps1 += p1;
+            for (int i = 0; i < 8; ++i) {
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], c, -mc));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[8 + i], c, -mc));
+                pf0[i] = TR::from_f32(p0); pf1[i] = TR::from_f32(p1);
+                ps += p0 + p1;
+            }
         }
-        l_run += ps0 + ps1;
-        const V8 pf0 = acc_to_frag<T>(s_acc, 0), pf1 = acc_to_frag<T>(s_acc, 1);
+        l_run += ps;
 #pragma unroll
         for (int dblk = 0; dblk < 2; ++dblk) {
             o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 2 * blk), pf0, o[dblk]);
@@ -277,9 +303,9 @@ extern "C" int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_byte
     if (tot_bh <= 0 || N <= 0 || M <= 0) return 1;
     const int tiles = (N + ATT_BM - 1) / ATT_BM, t_all = (M + ATT_BN - 1) / ATT_BN;
     const long long nwg = (long long)tiles * tot_bh;
-    // measured on MI355X (tools/bench_splitkv.py): 5 heads at 64^2 80 -> 50 us with 4 splits, 10 heads 99 -> 72 us with 3, 15 heads
-    // 100 -> 97 us with 2, nothing from 20 heads (640 workgroups) up; 32^2 launches lose more to the merge kernel than they gain
-    int ns = (int)(1000 / nwg);
+    // measured on MI355X (tools/bench_splitkv.py): 5 heads at 64^2 68 -> 47 us with 4 splits, 10 heads 86 -> 73 us with 2, nothing from
+    // 15 heads (480 workgroups) up; 32^2 launches lose more to the merge kernel than they gain
+    int ns = (int)(768 / nwg);                        // 3 resident workgroups per CU (140 VGPRs)
     if (ns > 4) ns = 4;
     if (ns > t_all / 16) ns = t_all / 16;             // at least 16 key tiles (1024 keys) per split
     if (ns < 2) return 1;

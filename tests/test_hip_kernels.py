@@ -151,6 +151,39 @@ def test_attention_forward(ops, dtype, BH, N, M):
     assert float((lse.cpu().double() - rl).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("pattern", ["ascending", "descending", "late_outlier", "early_outlier", "flat_large"])
+def test_attention_forward_adversarial_score_ranges(ops, dtype, pattern):
+    """The kernel keeps a per-row REFERENCE value instead of the running maximum and raises it only when probabilities would
+    leave the 16-bit range: drive it with score profiles that force many raises (scores climbing by ~25 nats per key tile),
+    none at all (falling), and single outliers at either end; also through the split-KV merge."""
+    torch.manual_seed(7)
+    BH, N, M = 2, 160, 1024 + 40
+    u = torch.nn.functional.normalize(torch.randn(64), dim=0)
+    q = (u[None, None] * 8.0 + torch.randn(BH, N, 64) * 0.05)
+    ramp = torch.linspace(-1.0, 1.0, M)
+    if pattern == "ascending":
+        amp = ramp * 50.0
+    elif pattern == "descending":
+        amp = -ramp * 50.0
+    elif pattern == "late_outlier":
+        amp = torch.zeros(M); amp[-3] = 60.0
+    elif pattern == "early_outlier":
+        amp = torch.zeros(M); amp[1] = 60.0
+    else:
+        amp = torch.full((M,), 70.0)
+    k = u[None, None] * amp[None, :, None] + torch.randn(BH, M, 64) * 0.05          # s*scale ~ amp (scale 0.125, |q.u| = 8)
+    v = torch.randn(BH, M, 64)
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    ro, rl, _ = _ref_attn(q, k, v, 0.125)
+    for ns in (1, 2):
+        out = torch.empty(BH, N, 64, dtype=dtype, device=DEV); lse = torch.empty(BH, N, device=DEV)
+        ops.attn_fwd([(q.to(DEV), k.to(DEV), v.to(DEV), out, lse)], 0.125, nsplit=ns)
+        assert torch.isfinite(out.float()).all()
+        assert rel_err(out.float().cpu(), ro) < tol(dtype)
+        assert float((lse.cpu().double() - rl).abs().max()) < 2e-4 * max(1.0, float(rl.abs().max()))
+
+
 def test_attention_forward_full_size_and_segments(ops):
     """BASELINE full size (64^2 tokens, 5 heads) checked against the reference on a row sample, plus a size-independent
     property: three segments in one launch equal three separate launches bit for bit."""
@@ -207,8 +240,8 @@ def test_attention_split_kv_plan():
     lib = _lib.load()
     nb = ctypes.c_size_t(0)
     assert lib.gd_attn_fwd_plan(5, 4096, 4096, ctypes.byref(nb)) == 4 and nb.value == 4 * 5 * 4096 * 66 * 4    # inversion pass, 64^2
-    assert lib.gd_attn_fwd_plan(10, 4096, 4096, ctypes.byref(nb)) == 3                                            # inversion pass (batch 2)
-    assert lib.gd_attn_fwd_plan(15, 4096, 4096, ctypes.byref(nb)) == 2                                            # optimisation pass
+    assert lib.gd_attn_fwd_plan(10, 4096, 4096, ctypes.byref(nb)) == 2                                            # inversion pass (batch 2)
+    assert lib.gd_attn_fwd_plan(15, 4096, 4096, ctypes.byref(nb)) == 1                                            # optimisation pass
     assert lib.gd_attn_fwd_plan(20, 4096, 4096, ctypes.byref(nb)) == 1                                            # CFG pass fills the chip
     assert lib.gd_attn_fwd_plan(25, 4096, 4096, ctypes.byref(nb)) == 1 and nb.value == 0                          # CFG pass fills the chip
     assert lib.gd_attn_fwd_plan(20, 4096, 77, ctypes.byref(nb)) == 1                                              # cross attention: one key tile

@@ -63,6 +63,8 @@ SIGNATURES = {
     "gd_group_norm_nhwc_scratch_floats": (c_int64, [c_int, c_int, c_int]),
     "gd_group_norm_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
                                    c_int, c_void_p]),
+    "gd_group_norm_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gd_bias_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "gd_geglu": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "gd_add_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),

@@ -149,3 +149,165 @@ extern "C" int gd_group_norm_nhwc(const void* x, const void* add_bc, int add_ld,
     GD_CHECK_LAUNCH("gd_group_norm_nhwc");
     return GD_OK;
 }
+
+
+// ---- backward (optimisation passes; weights are frozen, so only dx) -------------------------------------------------------
+//   f = x (+ add);  xh = (f - mean) * rstd;  z = xh * gamma + beta;  y = SILU ? z * sigmoid(z) : z
+//   dz = dy * (SILU ? sigmoid(z) * (1 + z * (1 - sigmoid(z))) : 1);  g = dz * gamma
+//   dx = rstd * (g - S1 / n - xh * S2 / n),   S1 = sum_group g,  S2 = sum_group g * xh,   n = HW * C / G
+// Same two-kernel shape as the forward: slab partials of (S1, S2), then the apply kernel folds them.  mean / rstd come from the
+// forward's slab partials (kept by the caller), so x is read twice and dy twice, nothing else.
+template <typename T>
+__device__ __forceinline__ void gn_fold_fwd_stats(const float* __restrict__ fwd_partial, int nslab, int G, int b, float inv_n, float eps,
+                                                  float* s_mr /* [G][2] mean, rstd */) {
+    const int tid = threadIdx.x;
+    if (tid < G) {
+        float a = 0.f, q = 0.f;
+        const float* pp = fwd_partial + (size_t)b * nslab * G * 2 + tid * 2;
+        for (int s = 0; s < nslab; ++s) { a += pp[(size_t)s * G * 2]; q += pp[(size_t)s * G * 2 + 1]; }
+        const float m = a * inv_n;
+        s_mr[tid * 2] = m;
+        s_mr[tid * 2 + 1] = rsqrtf(fmaxf(q * inv_n - m * m, 0.f) + eps);
+    }
+    __syncthreads();
+}
+
+template <typename T, bool SILU>
+__device__ __forceinline__ float gn_g(float xv, float addv, bool has_add, float mean, float rstd, float ga, float be, float dyv, float& xh) {
+    using TR = elem_traits<T>;
+    const float f = has_add ? TR::to_f32(TR::from_f32(xv + addv)) : xv;
+    xh = (f - mean) * rstd;
+    float dz = dyv;
+    if (SILU) {
+        const float z = xh * ga + be;
+        const float sg = 1.0f / (1.0f + __expf(-z));
+        dz *= sg * (1.0f + z * (1.0f - sg));
+    }
+    return dz * ga;
+}
+
+template <typename T, bool SILU>
+__global__ void __launch_bounds__(256)
+k_gn_bwd_stats(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, const T* __restrict__ gamma, const T* __restrict__ beta,
+               const T* __restrict__ dy, const float* __restrict__ fwd_partial, int nslab, int HW, int C, int G, int pix, float eps,
+               float* __restrict__ partial) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    __shared__ float s_mr[GN_MAX_G * 2];
+    __shared__ float s_g[GN_MAX_G * 2];
+    const int b = blockIdx.y, p0 = blockIdx.x * pix, tid = threadIdx.x;
+    const int cv = C >> 3, cpg = C / G;
+    const float inv_n = 1.0f / ((float)HW * (float)cpg);
+    if (tid < G * 2) s_g[tid] = 0.f;
+    gn_fold_fwd_stats<T>(fwd_partial, nslab, G, b, inv_n, eps, s_mr);
+    const size_t boff = (size_t)b * HW * C;
+    const int p1 = (p0 + pix) < HW ? (p0 + pix) : HW;
+    const int rows = cv <= 256 ? 256 / cv : 1;
+    for (int k = (cv <= 256 ? tid % cv : tid); k < cv; k += 256) {
+        const int r = cv <= 256 ? tid / cv : 0;
+        if (r < rows) {
+            const int c0 = k * 8, g0 = c0 / cpg, g1 = (c0 + 7) / cpg, split = g1 * cpg - c0;
+            const V8 gav = *(const V8*)(gamma + c0), bev = *(const V8*)(beta + c0);
+            float ad[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ad[i] = 0.f;
+            if (add_bc) {
+                const V8 av = *(const V8*)(add_bc + (size_t)b * add_ld + c0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ad[i] = TR::to_f32(av[i]);
+            }
+            float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
+            for (int p = p0 + r; p < p1; p += rows) {
+                const V8 xv = *(const V8*)(x + boff + (size_t)p * C + c0);
+                const V8 dv = *(const V8*)(dy + boff + (size_t)p * C + c0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool hi = (g1 != g0) && (i >= split);
+                    float xh;
+                    const float g = gn_g<T, SILU>(TR::to_f32(xv[i]), ad[i], add_bc != nullptr, s_mr[(hi ? g1 : g0) * 2], s_mr[(hi ? g1 : g0) * 2 + 1],
+                                                  TR::to_f32(gav[i]), TR::to_f32(bev[i]), TR::to_f32(dv[i]), xh);
+                    if (hi) { a1 += g; q1 = __builtin_fmaf(g, xh, q1); } else { a0 += g; q0 = __builtin_fmaf(g, xh, q0); }
+                }
+            }
+            atomicAdd(&s_g[g0 * 2], a0); atomicAdd(&s_g[g0 * 2 + 1], q0);
+            if (g1 != g0) { atomicAdd(&s_g[g1 * 2], a1); atomicAdd(&s_g[g1 * 2 + 1], q1); }
+        }
+        if (cv <= 256) break;
+    }
+    __syncthreads();
+    if (tid < G * 2) partial[((size_t)b * gridDim.x + blockIdx.x) * G * 2 + tid] = s_g[tid];
+}
+
+template <typename T, bool SILU>
+__global__ void __launch_bounds__(256)
+k_gn_bwd_apply(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, const T* __restrict__ gamma, const T* __restrict__ beta,
+               const T* __restrict__ dy, const float* __restrict__ fwd_partial, const float* __restrict__ partial, int nslab, int HW, int C,
+               int G, float eps, T* __restrict__ dx) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    __shared__ float s_mr[GN_MAX_G * 2];
+    __shared__ float s_s[GN_MAX_G * 2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cv = C >> 3, cpg = C / G;
+    const float inv_n = 1.0f / ((float)HW * (float)cpg);
+    if (tid < G * 2) {
+        const float* pp = partial + (size_t)b * nslab * G * 2 + tid;
+        float acc = 0.f;
+        for (int s = 0; s < nslab; ++s) acc += pp[(size_t)s * G * 2];
+        s_s[tid] = acc * inv_n;                                    // S1 / n, S2 / n
+    }
+    gn_fold_fwd_stats<T>(fwd_partial, nslab, G, b, inv_n, eps, s_mr);
+    const long long idx = (long long)blockIdx.x * 256 + tid;
+    if (idx >= (long long)HW * cv) return;
+    const int k = (int)(idx % cv);
+    const int c0 = k * 8, g0 = c0 / cpg, g1 = (c0 + 7) / cpg, split = g1 * cpg - c0;
+    const size_t off = ((size_t)b * HW * cv + idx) * 8;
+    const V8 xv = *(const V8*)(x + off), dv = *(const V8*)(dy + off);
+    const V8 gav = *(const V8*)(gamma + c0), bev = *(const V8*)(beta + c0);
+    V8 av;
+    if (add_bc) av = *(const V8*)(add_bc + (size_t)b * add_ld + c0);
+    V8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gi = ((g1 != g0) && (i >= split)) ? g1 : g0;
+        float xh;
+        const float g = gn_g<T, SILU>(TR::to_f32(xv[i]), add_bc ? TR::to_f32(av[i]) : 0.f, add_bc != nullptr, s_mr[gi * 2], s_mr[gi * 2 + 1],
+                                      TR::to_f32(gav[i]), TR::to_f32(bev[i]), TR::to_f32(dv[i]), xh);
+        o[i] = TR::from_f32(s_mr[gi * 2 + 1] * (g - s_s[gi * 2] - xh * s_s[gi * 2 + 1]));
+    }
+    *(V8*)(dx + off) = o;
+}
+
+template <typename T, bool SILU>
+static void gn_bwd_launch(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, const void* dy,
+                          const float* fwd_scratch, float* scratch, int B, int HW, int C, int G, float eps, void* dx, hipStream_t st) {
+    const int pix = gn_pix_per_slab(HW);
+    const int nslab = (HW + pix - 1) / pix;
+    dim3 sgrid(nslab, B);
+    dim3 agrid((unsigned)(((long long)HW * (C >> 3) + 255) / 256), B);
+    k_gn_bwd_stats<T, SILU><<<sgrid, 256, 0, st>>>((const T*)x, (const T*)add_bc, add_ld, (const T*)gamma, (const T*)beta, (const T*)dy,
+                                                  fwd_scratch, nslab, HW, C, G, pix, eps, scratch);
+    k_gn_bwd_apply<T, SILU><<<agrid, 256, 0, st>>>((const T*)x, (const T*)add_bc, add_ld, (const T*)gamma, (const T*)beta, (const T*)dy,
+                                                  fwd_scratch, scratch, nslab, HW, C, G, eps, (T*)dx);
+}
+
+extern "C" int gd_group_norm_nhwc_bwd(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, const void* dy,
+                                      int B, int HW, int C, int G, float eps, int silu, const float* fwd_scratch, float* scratch, void* dx,
+                                      int dtype, void* stream) {
+    GD_REQUIRE(x && gamma && beta && dy && fwd_scratch && scratch && dx, GD_EINVAL, "gd_group_norm_nhwc_bwd: null pointer");
+    GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && C / G >= 8, GD_EINVAL,
+               "gd_group_norm_nhwc_bwd: unsupported shape B=%d HW=%d C=%d G=%d", B, HW, C, G);
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_group_norm_nhwc_bwd: dtype must be f16/bf16");
+    GD_REQUIRE(!add_bc || add_ld == 0 || (add_ld >= C && (add_ld & 7) == 0), GD_EINVAL, "gd_group_norm_nhwc_bwd: bad add_ld");
+    if (add_ld == 0) add_ld = C;
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16) {
+        if (silu) gn_bwd_launch<f16_t, true>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, st);
+        else gn_bwd_launch<f16_t, false>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, st);
+    } else {
+        if (silu) gn_bwd_launch<bf16_t, true>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, st);
+        else gn_bwd_launch<bf16_t, false>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, st);
+    }
+    GD_CHECK_LAUNCH("gd_group_norm_nhwc_bwd");
+    return GD_OK;
+}

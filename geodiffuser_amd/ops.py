@@ -344,24 +344,43 @@ def norm_rescale(x, num_sumsq, den_sumsq):
 # ---------------------------------------------------------------------------------------------------
 # UNet plumbing: fused GroupNorm (+SiLU), channels-last, no-grad
 # ---------------------------------------------------------------------------------------------------
-def group_norm_nhwc(x, gamma, beta, groups: int, eps: float, silu: bool, add_bc=None):
+def _add_ld(add_bc, x, B, C):
+    if add_bc is None:
+        return 0
+    # [B, C], rows may be strided (a column slice of a wider [B, sum C] matrix)
+    if (add_bc.dtype != x.dtype or not add_bc.is_cuda or tuple(add_bc.shape) != (B, C) or add_bc.stride(1) != 1
+            or add_bc.stride(0) % 8 or add_bc.storage_offset() % 8):
+        raise _lib.GeodiffError("group_norm_nhwc: add_bc must be a 16-byte aligned [B, C] matrix of x's dtype with unit column stride")
+    return add_bc.stride(0) if B > 1 else C
+
+
+def group_norm_nhwc_bwd(x, add_bc, gamma, beta, dy, groups: int, eps: float, silu: bool, fwd_scratch):
+    """dx of group_norm_nhwc for frozen gamma / beta; fwd_scratch = the scratch the forward returned."""
+    lib = _lib.load()
+    dt = _dt16(x, "x")
+    B, C, H, W = x.shape
+    if not (x.is_contiguous(memory_format=torch.channels_last) and dy.is_contiguous(memory_format=torch.channels_last)) or dy.dtype != x.dtype:
+        raise _lib.GeodiffError("group_norm_nhwc_bwd: expected channels_last x and dy of one dtype")
+    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    scratch = torch.empty_like(fwd_scratch)
+    check(lib.gd_group_norm_nhwc_bwd(_p(x), _p(add_bc), _add_ld(add_bc, x, B, C), _p(gamma), _p(beta), _p(dy), B, H * W, C, groups, eps,
+                                     int(silu), _p(fwd_scratch), _p(scratch), _p(dx), dt, _stream()), "gd_group_norm_nhwc_bwd")
+    return dx
+
+
+def group_norm_nhwc(x, gamma, beta, groups: int, eps: float, silu: bool, add_bc=None, return_scratch: bool = False):
     """x [B,C,H,W] in channels_last memory format (16-bit) -> same shape / format; add_bc [B,C]: norm of x + add_bc[:, :, None, None]."""
     lib = _lib.load()
     dt = _dt16(x, "x")
     if not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last):
         raise _lib.GeodiffError("group_norm_nhwc: expected a channels_last GPU tensor")
     B, C, H, W = x.shape
-    add_ld = 0
-    if add_bc is not None:                 # [B, C], rows may be strided (a column slice of a wider [B, sum C] matrix)
-        if (add_bc.dtype != x.dtype or not add_bc.is_cuda or tuple(add_bc.shape) != (B, C) or add_bc.stride(1) != 1
-                or add_bc.stride(0) % 8 or add_bc.storage_offset() % 8):
-            raise _lib.GeodiffError("group_norm_nhwc: add_bc must be a 16-byte aligned [B, C] matrix of x's dtype with unit column stride")
-        add_ld = add_bc.stride(0) if B > 1 else C
+    add_ld = _add_ld(add_bc, x, B, C)
     y = torch.empty_like(x, memory_format=torch.channels_last)
     scratch = torch.empty(int(lib.gd_group_norm_nhwc_scratch_floats(B, H * W, groups)), dtype=torch.float32, device=x.device)
     check(lib.gd_group_norm_nhwc(_p(x), _p(add_bc), add_ld, _p(gamma), _p(beta), B, H * W, C, groups, eps, int(silu), _p(scratch), _p(y), dt,
                                  _stream()), "gd_group_norm_nhwc")
-    return y
+    return (y, scratch) if return_scratch else y
 
 
 def _rows_c(t, what):

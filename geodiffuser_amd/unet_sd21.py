@@ -27,8 +27,52 @@ import torch.nn.functional as F
 FUSED = os.environ.get("GD_UNET_FUSED", "1") == "1"
 
 
-def _fast(x: torch.Tensor) -> bool:
-    return FUSED and (not torch.is_grad_enabled()) and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)
+def _fast(x: torch.Tensor, grad_ok: bool = False) -> bool:
+    """no-grad passes; with ``grad_ok`` also passes that differentiate w.r.t. activations only (the caller checks that the
+    parameters involved are frozen and routes through an autograd Function with a HIP backward)."""
+    return FUSED and (grad_ok or not torch.is_grad_enabled()) and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)
+
+
+class _GroupNormFn(torch.autograd.Function):
+    """Fused channels-last GroupNorm (+SiLU, + per-(batch, channel) add) with a HIP backward w.r.t. x (frozen gamma / beta)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, silu, add_bc):
+        from . import ops
+        y, scratch = ops.group_norm_nhwc(x, weight, bias, groups, eps, silu, add_bc=add_bc, return_scratch=True)
+        ctx.save_for_backward(x, weight, bias, scratch)
+        ctx.add_bc = add_bc
+        ctx.cfg = (groups, eps, silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, weight, bias, scratch = ctx.saved_tensors
+        groups, eps, silu = ctx.cfg
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        return ops.group_norm_nhwc_bwd(x, ctx.add_bc, weight, bias, dy, groups, eps, silu, scratch), None, None, None, None, None, None
+
+
+class _BiasResidualFn(torch.autograd.Function):
+    """y = x + bias[c] + res with a frozen bias: both gradients are the incoming gradient (no kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, res):
+        from . import ops
+        return ops.bias_residual(x, bias, res)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, g
+
+
+def group_norm_fused(x, weight, bias, groups, eps, silu, add_bc=None):
+    """Fused GroupNorm on a channels-last 16-bit GPU tensor; differentiable w.r.t. x when the parameters are frozen."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _GroupNormFn.apply(x, weight, bias, groups, eps, silu, None if add_bc is None else add_bc.detach())
+    from . import ops
+    return ops.group_norm_nhwc(x, weight, bias, groups, eps, silu, add_bc=add_bc)
 
 
 class UNetOutput(dict):
@@ -48,12 +92,14 @@ class GroupNormAct(nn.GroupNorm):
     """nn.GroupNorm with an optional fused SiLU.  On no-grad passes over channels-last 16-bit GPU activations it runs the fused
     HIP kernel (gd_group_norm_nhwc: no NCHW round trip, 2 launches); otherwise stock PyTorch (autograd-capable)."""
 
+    def fusable(self, x) -> bool:
+        frozen = not (self.weight.requires_grad or self.bias.requires_grad)
+        return (_fast(x, grad_ok=frozen) and x.dim() == 4 and self.num_channels // self.num_groups >= 8 and self.num_channels % 8 == 0
+                and x.is_contiguous(memory_format=torch.channels_last) and self.weight.dtype == x.dtype)
+
     def forward(self, x, silu: bool = False):
-        if (not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16)
-                and self.num_channels // self.num_groups >= 8 and x.is_contiguous(memory_format=torch.channels_last)
-                and self.weight.dtype == x.dtype):
-            from . import ops
-            return ops.group_norm_nhwc(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+        if self.fusable(x):
+            return group_norm_fused(x, self.weight, self.bias, self.num_groups, self.eps, silu)
         y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
         return F.silu(y) if silu else y
 
@@ -185,10 +231,12 @@ class ResnetBlock2D(nn.Module):
         the time-embedding add folded into GroupNorm 2."""
         from . import ops
         h = F.conv2d(self.norm1(x, silu=True), self.conv1.weight, None, padding=1)
-        h = ops.group_norm_nhwc(h, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, True, add_bc=tb)
+        h = group_norm_fused(h, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, True, add_bc=tb)
         h = F.conv2d(h, self.conv2.weight, None, padding=1)
         if self.conv_shortcut is not None:
             x = F.conv2d(x, self.conv_shortcut.weight, None)
+        if torch.is_grad_enabled() and (h.requires_grad or x.requires_grad):
+            return _BiasResidualFn.apply(h, self._out_bias(), x)
         return ops.bias_residual(h, self._out_bias(), x)
 
     def _out_bias(self):
@@ -203,7 +251,7 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, temb):
         tb, self._tb = self._tb, None
-        if tb is not None and _fast(x) and x.is_contiguous(memory_format=torch.channels_last):
+        if tb is not None and x.is_contiguous(memory_format=torch.channels_last) and self.norm1.fusable(x) and self.norm2.fusable(x):
             return self._fused(x, tb)
         h = self.conv1(self.norm1(x, silu=True))
         h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
@@ -351,6 +399,9 @@ class UNet2DConditionModel(nn.Module):
         for name, m in self._attn_modules():
             m.set_processor(processor[name] if isinstance(processor, dict) else processor)
 
+    def _frozen(self) -> bool:
+        return not torch.is_grad_enabled() or not any(p.requires_grad for p in self.parameters())
+
     def _project_all_temb(self, temb):
         """One GEMM for the time-embedding projections of all ResNet blocks (22 GEMMs + 22 SiLUs otherwise), with each block's
         conv1 bias folded into the projection bias; every fusable block gets its [B, cout] column slice for this forward."""
@@ -390,7 +441,7 @@ class UNet2DConditionModel(nn.Module):
         temb = self.time_embedding(timestep_embedding(t, self.t_dim).to(dt))
         if self.conv_in.weight.is_contiguous(memory_format=torch.channels_last) and not self.conv_in.weight.is_contiguous():
             x = x.contiguous(memory_format=torch.channels_last)
-        if _fast(x) and x.is_contiguous(memory_format=torch.channels_last):
+        if _fast(x, grad_ok=self._frozen()) and x.is_contiguous(memory_format=torch.channels_last):
             self._project_all_temb(temb)
         x = self.conv_in(x)
         skips = [x]

@@ -245,6 +245,12 @@ int64_t gd_group_norm_nhwc_scratch_floats(int B, int HW, int G);
 int gd_group_norm_nhwc(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
                        int silu, float* scratch, void* y, int dtype, void* stream);
 
+/* dx of the above for frozen gamma / beta (the optimisation pass differentiates w.r.t. activations only): x, add_bc, gamma, beta as in
+ * the forward, dy and dx [B, HW, C]; fwd_scratch = the forward call's scratch (its slab moments give mean / rstd); scratch: same size. */
+int gd_group_norm_nhwc_bwd(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, const void* dy,
+                           int B, int HW, int C, int G, float eps, int silu, const float* fwd_scratch, float* scratch, void* dx,
+                           int dtype, void* stream);
+
 /* y = x + bias[c] (+ res): convolution epilogue; x, res, y [rows, C]; bias [C]; res may be NULL. */
 int gd_bias_residual(const void* x, const void* bias, const void* res, int64_t rows, int C, void* y, int dtype, void* stream);
 

@@ -219,3 +219,45 @@ def test_fused_unet_pass_equals_stock_ops():
     noise = rel_l2(stock2, stock)
     assert torch.isfinite(fused).all()
     assert rel_l2(fused, stock) < max(5 * noise, 2e-2)
+
+
+def test_fused_unet_backward_equals_stock_ops():
+    """Optimisation-pass regime (frozen weights, gradient w.r.t. the latent and the text embedding): the fused ResNet-block path
+    (HIP GroupNorm forward/backward, folded biases) gives the stock-op gradients up to 16-bit rounding / split-K noise."""
+    from geodiffuser_amd import unet_sd21
+    torch.manual_seed(1)
+    net = unet_sd21.UNet2DConditionModel(block_out_channels=(256, 512, 512, 512), heads=(4, 8, 8, 8), cross_attention_dim=128)
+    net = net.to("cuda", torch.bfloat16).to(memory_format=torch.channels_last).eval()
+    for p_ in net.parameters():
+        p_.requires_grad = False
+
+    class TorchAttention:        # differentiable w.r.t. q, k and v at any size (the HIP vanilla path has no self-attention dK: the edit never needs it)
+        def __call__(self, attn, hidden_states, encoder_hidden_states=None, **kw):
+            ctx_ = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+            b, n, _ = hidden_states.shape
+            sp = lambda t: t.reshape(b, t.shape[1], attn.heads, -1).transpose(1, 2)
+            o = torch.nn.functional.scaled_dot_product_attention(sp(attn.to_q(hidden_states)), sp(attn.to_k(ctx_)), sp(attn.to_v(ctx_)))
+            return attn.to_out[0](o.transpose(1, 2).reshape(b, n, -1))
+
+    net.set_attn_processor(TorchAttention())
+    x0 = torch.randn(2, 4, 32, 32, device="cuda")
+    c0 = torch.randn(2, 77, 128, device="cuda")
+    w = torch.randn(2, 4, 32, 32, device="cuda")
+
+    def run(fused):
+        prev = unet_sd21.FUSED
+        unet_sd21.FUSED = fused
+        try:
+            x = x0.clone().requires_grad_(True); c = c0.clone().requires_grad_(True)
+            with torch.enable_grad():
+                out = net(x, 481, encoder_hidden_states=c)["sample"]
+                gx, gc = torch.autograd.grad((out.float() * w).sum(), [x, c])
+            return out.float().detach().cpu(), gx.cpu(), gc.cpu()
+        finally:
+            unet_sd21.FUSED = prev
+
+    a, a2, f = run(False), run(False), run(True)
+    for i in range(3):
+        noise = rel_l2(a2[i], a[i])
+        assert torch.isfinite(f[i]).all()
+        assert rel_l2(f[i], a[i]) < max(5 * noise, 3e-2), i

@@ -11,6 +11,9 @@ from .attention_processors import VanillaAttentionProcessor
 from .scheduler import DDIMInverseScheduler, DDIMScheduler
 
 
+SINGLE_ROW_WHEN_PROMPT_IS_UNCOND = True
+
+
 class NullInversion:
     def prev_step(self, model_output, timestep: int, sample):
         """inversion.py:47-55 (closed form, executed by gd_ddim_step)."""
@@ -65,10 +68,17 @@ class NullInversion:
         if latent_2 is not None:
             uncond_e, cond_e = context_in.chunk(2)
             context_in = torch.cat([uncond_e, uncond_e, cond_e, cond_e], 0)
+        # Parity-preserving saving: when the prompt equals the unconditional text (the batch driver always passes "",
+        # large_scale_editor.py:196) the two CFG rows of the inversion pass are the same sample, eps_u == eps_c and the guided
+        # noise is eps_u for any guidance scale: run that sample once.  (One host sync per edit for the comparison.)
+        single = (SINGLE_ROW_WHEN_PROMPT_IS_UNCOND and latent_2 is None and context_in.shape[0] == 2
+                  and bool(torch.equal(context_in[0], context_in[1])))
+        if single:
+            context_in = context_in[1:2]
         for i, t in enumerate(inv.timesteps):
             if self.progress_bar is not None:
                 self.progress_bar(i / self.num_ddim_steps, desc="Performing DDIM Inversion")
-            latent_model_input = torch.cat([latents] * 2)
+            latent_model_input = latents if single else torch.cat([latents] * 2)
             if graphs.ENABLED and not torch.is_grad_enabled():
                 runner = self.model.__dict__.get("_graphed")
                 if runner is None:
@@ -76,9 +86,13 @@ class NullInversion:
                 noise_pred, _ = runner(("inversion",), latent_model_input, t, context_in)
             else:
                 noise_pred = self.model.unet(latent_model_input, t, encoder_hidden_states=context_in, return_dict=False)[0]
-            noise_pred_uncond, noise_pred_cond = noise_pred.chunk(2)
-            latents = inv.step(noise_pred_uncond, t, latents, eps_cond=noise_pred_cond, guidance_scale=self.guidance_scale,
-                               return_dict=False)[0]
+            if single:
+                noise_pred_uncond = noise_pred_cond = noise_pred
+                latents = inv.step(noise_pred, t, latents, return_dict=False)[0]
+            else:
+                noise_pred_uncond, noise_pred_cond = noise_pred.chunk(2)
+                latents = inv.step(noise_pred_uncond, t, latents, eps_cond=noise_pred_cond, guidance_scale=self.guidance_scale,
+                                   return_dict=False)[0]
             all_latent.append(latents.detach())
             all_noise.append(noise_pred_cond.detach())
         return all_latent, all_noise

@@ -261,3 +261,28 @@ def test_fused_unet_backward_equals_stock_ops():
         noise = rel_l2(a2[i], a[i])
         assert torch.isfinite(f[i]).all()
         assert rel_l2(f[i], a[i]) < max(5 * noise, 3e-2), i
+
+
+def test_inversion_single_row_equals_cfg_batch(pipe):
+    """With prompt == the unconditional text the inversion's two CFG rows are one sample: running it once gives the trajectory
+    of the reference's batch-2 pass (up to the kernels' run-to-run noise)."""
+    from geodiffuser_amd import inversion
+    p, tok, sched = pipe
+    torch.manual_seed(9)
+    lat0 = torch.randn(1, 4, 32, 32, device="cuda").half()
+
+    def run(single):
+        prev = inversion.SINGLE_ROW_WHEN_PROMPT_IS_UNCOND
+        inversion.SINGLE_ROW_WHEN_PROMPT_IS_UNCOND = single
+        try:
+            inv = inversion.NullInversion(p, num_ddim_steps=6, guidance_scale=3.0)
+            inv.init_prompt("")
+            lats, noise = inv.ddim_loop(lat0.clone())
+            return torch.stack([l.float().cpu() for l in lats]), torch.stack([n.float().cpu() for n in noise[1:]])
+        finally:
+            inversion.SINGLE_ROW_WHEN_PROMPT_IS_UNCOND = prev
+
+    a, a2, b = run(False), run(False), run(True)
+    assert a[0].shape == b[0].shape == (7, 1, 4, 32, 32)
+    for i in range(2):
+        assert rel_err(b[i], a[i]) < max(5 * rel_err(a2[i], a[i]), 5e-3)

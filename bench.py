@@ -283,11 +283,12 @@ def main():
 
     timer = AttnTimer((args.size // 8) ** 2)
     timer.install()
-    kw = editor_kwargs()
-    kw.update(num_ddim_steps=args.ddim_steps, ldm_stable_model=pipe, tokenizer_model=tok, scheduler_in=sched)
-
     def one_edit(j):
         image, depth, mask, T = make_edit(j * world + rank, size=args.size, kind=args.kind)
+        # fresh keyword arguments per edit: like the reference, the controller aliases the caller's loss_weights_dict and the adaptive
+        # schedule edits it in place (attention_processors.py:667-668) — a shared dict would leak one edit's weights into the next
+        kw = editor_kwargs()
+        kw.update(num_ddim_steps=args.ddim_steps, ldm_stable_model=pipe, tokenizer_model=tok, scheduler_in=sched)
         return editor.run_geodiffuser(image, depth, mask, T, **kw)
 
     for j in range(args.warmup):

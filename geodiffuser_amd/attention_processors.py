@@ -232,6 +232,7 @@ def _persist(enabled: bool, key: tuple, t: torch.Tensor) -> torch.Tensor:
 
 
 _CONST: Dict[tuple, torch.Tensor] = {}
+_WEIGHT_VECTORS: Dict[tuple, list] = {}
 
 
 def _perm5(dev) -> torch.Tensor:
@@ -310,7 +311,7 @@ class _EditLayer(torch.autograd.Function):
             if R > 0:
                 Pb = ops.attn_probs(q_base, k_base, lse_van[b0 * f:b1 * f], None, scale)     # base_att (:307-317)
                 Pe = ops.attn_probs(q_edit, K, lse_e, c["rows"], scale)                      # replace_att[:, inpaint rows]
-                aux, rm = ops.removal_fwd(Pe, Pb, c["m_inp"], c["m_wo"], c["rows"], S)
+                aux, rm = ops.removal_fwd(Pe, Pb, c["m_inp"], c["m_wo"], c["rows"], S, n_valid=c.get("n_rows"))
                 ctrl._last_removal_aux = aux          # diagnostics: arg-max indices / values of this layer
             use_amodal = (not remover) and N > 32 ** 2                                       # :479-480,596-597
             if use_amodal:
@@ -319,16 +320,6 @@ class _EditLayer(torch.autograd.Function):
             sums = ops.edit_losses_fwd(edit_out, replace_out, tgt, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), S)
             # Everything that depends on the (adaptive) loss weights stays on the device: a captured hipGraph of the
             # optimisation pass then follows the schedule without re-capture, and no host->device copy sits in the layer.
-            if "inv5" not in c:
-                cnt = float(f * S * (S - 1) * D)
-                inv = [1.0 / (f * D * c["s_wo"] + 1e-8), 1.0 / (f * D * c["s_edit"] + 1e-8),
-                       1.0 / (f * D * c.get("s_am", 0.0) + 1e-8), 1.0 / cnt, 1.0 / cnt, 1.0 / (c["s_inp"] * f + 1e-8)]
-                t = torch.tensor(inv, dtype=torch.float32, device=dev)
-                c["inv5"], c["inv_rm"] = t[:5].contiguous(), t[5:6].contiguous()
-                tb = t[:5].clone()
-                if not use_amodal:
-                    tb[2] = 0.0
-                c["inv5_bwd"] = tb
             wv = ctrl.loss_weights_device(kind, dev)                 # [sim, movement, removal, smoothness, amodal]
             t5 = sums * c["inv5"]
             l_rm = rm[0] * c["inv_rm"][0]
@@ -412,10 +403,11 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         rem = self._is_remover
         host = (float(lw["sim"]), 0.0 if rem else float(lw.get("movement", 0.0)), float(lw["removal"]),
                 float(lw["smoothness"]), 0.0 if rem else float(lw.get("amodal", 0.0)))
-        cache = self.__dict__.setdefault("_wv_cache", {})
-        ent = cache.get(kind)
+        # one buffer per (kind, controller type, device) for the whole process: captured optimisation passes of earlier edits read it
+        key = (kind, rem, str(dev))
+        ent = _WEIGHT_VECTORS.get(key)
         if ent is None:
-            ent = cache[kind] = [None, torch.zeros(5, dtype=torch.float32, device=dev)]
+            ent = _WEIGHT_VECTORS[key] = [None, torch.zeros(5, dtype=torch.float32, device=dev)]
         if ent[0] != host:
             ent[1].copy_(torch.tensor(host, dtype=torch.float32))
             ent[0] = host
@@ -499,26 +491,64 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             c = self.masks_cache_dict.setdefault(S, {})
             c["mask_1_empty"], c["mask_wo_edit"] = m_empty, m_wo
         pt = getattr(self, "persistent_tables", False)
-        c["m_inp"] = _persist(pt, ("m_inp", S, self._is_remover), _flat(m_empty))
-        c["m_wo"] = _flat(m_wo)
-        c["zeros"] = torch.zeros(N, dtype=torch.float32, device=dev)
-        c["rows"] = torch.nonzero(c["m_inp"] > 0.5).reshape(-1).to(torch.int32).contiguous()
+        rem = self._is_remover
+        c["m_inp"] = _persist(pt, ("m_inp", S, rem), _flat(m_empty))
+        c["m_wo"] = _persist(pt, ("m_wo", S, rem), _flat(m_wo))
+        c["zeros"] = _persist(pt, ("zeros", S), torch.zeros(N, dtype=torch.float32, device=dev))
+        rows = torch.nonzero(c["m_inp"] > 0.5).reshape(-1).to(torch.int32).contiguous()
         sums = [c["m_wo"].sum(), c["m_inp"].sum()]
-        if not self._is_remover:
+        if not rem:
+            c["m_amodal"] = _persist(pt, ("m_amodal", S), c["m_amodal"])
             sums.append(c["m_edit"].sum())
             if N > 32 ** 2:
-                c["nn_idx"], c["nn_w"], c["w_dist"] = ops.nn_table(c["m_edit"], S)
+                nn_idx, nn_w, w_dist = ops.nn_table(c["m_edit"], S)
+                c["nn_idx"], c["nn_w"], c["w_dist"] = (_persist(pt, ("nn_idx", S), nn_idx), _persist(pt, ("nn_w", S), nn_w),
+                                                       _persist(pt, ("w_dist", S), w_dist))
                 sums.append((c["w_dist"] * c["m_amodal"]).sum())
         host = torch.stack(sums).tolist()                                      # one sync per resolution per edit
         c["s_wo"], c["s_inp"] = host[0], host[1]
         c["s_edit"] = host[2] if len(host) > 2 else 0.0
         c["s_am"] = host[3] if len(host) > 3 else 0.0
+        # inpaint-row list.  With persistent tables (hipGraph reuse across edits) its length is rounded up to a bucket so that the
+        # launch dimensions of the loss kernels repeat from edit to edit; the padding slots carry weight 0 (gd_removal_loss_reduce)
+        R = rows.numel()
+        c["n_rows"] = None
+        if pt and N >= 32 ** 2:
+            bucket = max(64, N // 16)
+            R_pad = max(bucket, -(-R // bucket) * bucket)
+            pad = rows[:1].expand(R_pad - R) if R else torch.zeros(R_pad, dtype=torch.int32, device=dev)
+            rows = _persist(pt, ("rows", S, rem, R_pad), torch.cat([rows, pad]).contiguous())
+            c["n_rows"] = _persist(pt, ("n_rows", S, rem), torch.tensor([R], dtype=torch.int32, device=dev))
+        c["rows"] = rows
+        # reciprocals of the loss denominators (U/attention_processors.py:231-305) on the device: sim, movement, amodal, smooth_h,
+        # smooth_w, removal
+        D = 64
+        use_amodal = (not rem) and N > 32 ** 2
+        cnt = float(f * S * (S - 1) * D)
+        inv = torch.tensor([1.0 / (f * D * c["s_wo"] + 1e-8), 1.0 / (f * D * c["s_edit"] + 1e-8), 1.0 / (f * D * c["s_am"] + 1e-8),
+                            1.0 / cnt, 1.0 / cnt, 1.0 / (c["s_inp"] * f + 1e-8)], dtype=torch.float32, device=dev)
+        c["inv5"], c["inv_rm"] = _persist(pt, ("inv5", S, rem), inv[:5].contiguous()), _persist(pt, ("inv_rm", S, rem), inv[5:6].contiguous())
+        tb = inv[:5].clone()
+        if not use_amodal:
+            tb[2] = 0.0
+        c["inv5_bwd"] = _persist(pt, ("inv5_bwd", S, rem), tb)
         c["S"], c["f"] = S, f
         if N >= 32 ** 2:                                                       # :413-415,575-576 / :778-780
             self.mask_wo_edit = m_wo.detach()
             self.mask_1_empty = m_empty.detach()
             self.mask_inpaint = m_empty[0, 0].detach().clone()
         return c
+
+    def table_signature(self):
+        """What a captured optimisation pass bakes in besides graph_key(): the (padded) inpaint-row count per resolution."""
+        return tuple(sorted((S, c["rows"].numel() if S * S >= 32 ** 2 else 0, c["f"])        # losses exist only at N >= 32^2
+                            for S, c in self.masks_cache_dict.items() if "f" in c))
+
+    def prebuild_tables(self, layers, q_like: torch.Tensor, transform_coords):
+        """Build the per-resolution tables for the (S, heads) pairs of a previous pass now (one host sync each) instead of lazily
+        inside the first hooked call, so that a captured pass can be replayed as the very first pass of an edit."""
+        for S, f in layers:
+            self._tables(S, f, q_like, transform_coords)
 
     def graph_key(self):
         """Everything a no-grad UNet pass of this controller branches on (the launch sequence is static for a given key)."""

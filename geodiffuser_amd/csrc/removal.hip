@@ -152,30 +152,40 @@ __device__ __forceinline__ float pix_dist(int a, int b, int S) {
     return sqrtf(dx * dx + dy * dy + 1e-12f);
 }
 
-__global__ void k_removal_reduce(const unsigned long long* __restrict__ best, const int32_t* __restrict__ rows, int H, int R, int S,
+__global__ void k_removal_reduce(const unsigned long long* __restrict__ best, const int32_t* __restrict__ rows,
+                                 const int32_t* __restrict__ n_valid, int H, int R, int S,
                                  float* __restrict__ p_in, int32_t* __restrict__ j_in, float* __restrict__ p_wo,
                                  int32_t* __restrict__ j_wo, float* __restrict__ wgt, float* __restrict__ loss_acc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float term = 0.f;
     if (i < H * R) {
         const unsigned long long bi = best[(size_t)i * 2], bw = best[(size_t)i * 2 + 1];
-        const float pi = __uint_as_float((unsigned)(bi >> 32)), pw = __uint_as_float((unsigned)(bw >> 32));
-        const int ji = (int)(0xFFFFFFFFu - (unsigned)(bi & 0xFFFFFFFFu)), jw = (int)(0xFFFFFFFFu - (unsigned)(bw & 0xFFFFFFFFu));
+        // best == 0: no correlation value of this row compared greater than the initial -1, i.e. every one of them was NaN (diverged
+        // latents).  torch.max would return NaN there; do the same for the value and keep the INDEX valid — the backward addresses
+        // rows of Pb with it (an index of -1 here was an out-of-bounds read).
+        const float qnan = __uint_as_float(0x7FC00000u);
+        const float pi = bi ? __uint_as_float((unsigned)(bi >> 32)) : qnan, pw = bw ? __uint_as_float((unsigned)(bw >> 32)) : qnan;
+        int ji = bi ? (int)(0xFFFFFFFFu - (unsigned)(bi & 0xFFFFFFFFu)) : 0, jw = bw ? (int)(0xFFFFFFFFu - (unsigned)(bw & 0xFFFFFFFFu)) : 0;
+        ji = ji < 0 ? 0 : (ji >= S * S ? S * S - 1 : ji);
+        jw = jw < 0 ? 0 : (jw >= S * S ? S * S - 1 : jw);
         const int r = i % R;
-        const float w = __expf(-pix_dist(rows[r], jw, S));
+        // slots r >= n_valid are padding (row list rounded up so that launch dimensions repeat across edits): weight 0 removes
+        // them from the loss and, through wgt, from every term of the backward
+        const bool live = !n_valid || r < n_valid[0];
+        const float w = live ? __expf(-pix_dist(rows[r], jw, S)) : 0.f;
         p_in[i] = pi; j_in[i] = ji; p_wo[i] = pw; j_wo[i] = jw; wgt[i] = w;
-        term = w * (-__logf(pw + 1e-4f) + __logf(pi + 1e-4f));
+        term = live ? w * (-__logf(pw + 1e-4f) + __logf(pi + 1e-4f)) : 0.f;
     }
     term = wave_sum(term);
     if ((threadIdx.x & 63) == 0) atomicAdd(loss_acc, term);
 }
 
-extern "C" int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, int H, int R, int S,
+extern "C" int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, const int32_t* n_valid_dev, int H, int R, int S,
                                       float* p_in, int32_t* j_in, float* p_wo, int32_t* j_wo, float* wgt,
                                       float* loss_acc, void* stream) {
     GD_REQUIRE(best && rows && p_in && j_in && p_wo && j_wo && wgt && loss_acc, GD_EINVAL, "gd_removal_loss_reduce: null pointer");
     GD_REQUIRE(H > 0 && R > 0 && S > 0, GD_EINVAL, "gd_removal_loss_reduce: bad sizes");
-    k_removal_reduce<<<(H * R + 255) / 256, 256, 0, as_stream(stream)>>>(best, rows, H, R, S, p_in, j_in, p_wo, j_wo, wgt, loss_acc);
+    k_removal_reduce<<<(H * R + 255) / 256, 256, 0, as_stream(stream)>>>(best, rows, n_valid_dev, H, R, S, p_in, j_in, p_wo, j_wo, wgt, loss_acc);
     GD_CHECK_LAUNCH("gd_removal_loss_reduce");
     return GD_OK;
 }

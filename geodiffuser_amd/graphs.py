@@ -13,11 +13,13 @@ controller, which need one host sync), captured the second time, replayed afterw
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Callable, Dict, Hashable, Optional, Tuple
 
 import torch
 
 ENABLED = os.environ.get("GD_GRAPHS", "1") == "1"
+OPT_PASS_ENABLED = os.environ.get("GD_OPT_GRAPH", "1") == "1"
 
 
 class _Entry:
@@ -71,16 +73,31 @@ class GraphedUNet:
         return e.out, True
 
 
+# Captured optimisation passes, shared by all edits of the process.  key -> dict(graph, lat, ctx, t, g_lat, g_ctx, loss, log)
+_OPT_GRAPHS: Dict[Hashable, dict] = {}
+_OPT_GRAPH_LIMIT = 6            # each holds the activations of a batch-2 forward + backward in its private pool
+_SEEN_LAYERS: Dict[tuple, tuple] = {}   # (id(unet), latent shape) -> (weakref, [(S, heads)] of the hooked layers), learnt from the first eager pass
+
+
+def reset_opt_graphs():
+    for e in _OPT_GRAPHS.values():
+        e["graph"].reset()
+    _OPT_GRAPHS.clear()
+
+
 class GraphedOptPass:
     """The optimisation pass — UNet forward with the geometry controller's losses, then autograd back to the latent and the
-    text embedding — as one hipGraph per edit.
+    text embedding — as one hipGraph, reused across edits.
 
-    ``grads(...) -> (d loss / d latents, d loss / d context)`` with ``controller.loss`` / ``controller.loss_log_dict`` left
-    as the eager pass leaves them.  The first pass of an edit runs eagerly (it builds the controller's per-resolution tables,
-    which needs one host sync per resolution), the second is captured, later ones replay.  What changes from pass to pass
-    is read from device memory: latents, embedding, timestep and the adaptive loss weights
-    (``controller.loss_weights_device``); the launch sequence itself is fixed while ``controller.graph_key()`` is.
-    The graph lives on the controller, i.e. for one edit."""
+    ``grads(...) -> (d loss / d latents, d loss / d context, latents leaf, context leaf)`` with ``controller.loss`` /
+    ``controller.loss_log_dict`` left as the eager pass leaves them.  What changes from pass to pass and from edit to edit is read
+    from device memory: latents, embedding, timestep, the adaptive loss weights (``controller.loss_weights_device``) and the
+    controller's per-resolution tables, which live in persistent buffers that every new edit overwrites in place
+    (``attention_processors._persist``; the inpaint-row list is padded to a bucketed length).  The launch sequence itself is fixed
+    for a given ``controller.graph_key()`` + ``controller.table_signature()``; graphs are kept per such key.
+
+    The first optimisation pass a UNet ever sees runs eagerly (MIOpen / rocBLAS warm-up, and it tells which (resolution, heads) pairs
+    the hooked layers have); from then on a new edit builds its tables up front (one host sync per resolution) and replays."""
 
     def __init__(self, model, transform_coords, guidance_scale):
         self.model = model
@@ -95,26 +112,40 @@ class GraphedOptPass:
                            use_cfg=False, return_noise=True, skip_scheduler=skip_scheduler)
             return _latent_grads(lat, controller.loss, ctx)
 
+    def _key(self, controller, lat, ctx):
+        return (id(self.model.unet), controller.graph_key(), controller.table_signature(), tuple(lat.shape), tuple(ctx.shape),
+                self.model.unet.dtype)
+
     def grads(self, controller, latents: torch.Tensor, context: torch.Tensor, t):
         lat = latents.detach().float().requires_grad_(True)                    # editor.py:218
         ctx = context.detach().float().requires_grad_(True)                    # editor.py:221-224
-        st = controller.__dict__.setdefault("_opt_graph", {"seen": 0, "key": None, "graph": None})
-        key = (controller.graph_key(), tuple(lat.shape), tuple(ctx.shape))
-        if not ENABLED or not lat.is_cuda or not hasattr(controller, "graph_key"):
+        usable = (ENABLED and OPT_PASS_ENABLED and lat.is_cuda and hasattr(controller, "graph_key") and getattr(controller, "persistent_tables", False))
+        if not usable:
             return self._eager(controller, lat, ctx, t) + (lat, ctx)
-        if st["key"] != key:                                                   # regime change (blend / replace window): start over
-            release_opt_graph(controller)
-            st = controller.__dict__["_opt_graph"] = {"seen": 0, "key": key, "graph": None}
-        st["seen"] += 1
-        if st["seen"] == 1:
-            return self._eager(controller, lat, ctx, t) + (lat, ctx)
+        uid = (id(self.model.unet), tuple(lat.shape))                          # the hooked layers' resolutions follow the latent size
+        seen = _SEEN_LAYERS.get(uid)
+        if seen is not None and seen[0]() is not self.model.unet:              # a dead model's id was recycled
+            seen = None
+            for k in [k for k in _OPT_GRAPHS if k[0] == uid[0]]:
+                _OPT_GRAPHS.pop(k)["graph"].reset()
+        if seen is None:                                                       # very first pass on this UNet: eager, learn the layers
+            out = self._eager(controller, lat, ctx, t)
+            _SEEN_LAYERS[uid] = (weakref.ref(self.model.unet),
+                                 sorted((S, c["f"]) for S, c in controller.masks_cache_dict.items() if "f" in c))
+            return out + (lat, ctx)
+        layers = seen[1]
+        if not all(S in controller.masks_cache_dict and "f" in controller.masks_cache_dict[S] for S, _ in layers):
+            q_like = torch.empty(1, device=lat.device, dtype=self.model.unet.dtype)
+            controller.prebuild_tables(layers, q_like, self.transform_coords)
         dev = lat.device
         controller.sync_loss_weights(dev)
-        if st["graph"] is None:
-            st["lat"] = lat.detach().clone().requires_grad_(True)
-            st["ctx"] = ctx.detach().clone().requires_grad_(True)
-            st["t"] = torch.tensor([int(t)], device=dev, dtype=torch.long)
-            layer, step = controller.cur_att_layer, controller.cur_step
+        key = self._key(controller, lat, ctx)
+        st = _OPT_GRAPHS.get(key)
+        if st is None:
+            while len(_OPT_GRAPHS) >= _OPT_GRAPH_LIMIT:                        # oldest first
+                _OPT_GRAPHS.pop(next(iter(_OPT_GRAPHS)))["graph"].reset()
+            st = {"lat": lat.detach().clone().requires_grad_(True), "ctx": ctx.detach().clone().requires_grad_(True),
+                  "t": torch.tensor([int(t)], device=dev, dtype=torch.long)}
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -122,6 +153,7 @@ class GraphedOptPass:
             st["loss"] = controller.loss
             st["log"] = {k: (dict(v) if isinstance(v, dict) else v) for k, v in controller.loss_log_dict.items()}
             st["graph"] = g
+            _OPT_GRAPHS[key] = st
             g.replay()                                                         # the capture itself executed nothing
             return st["g_lat"], st["g_ctx"], st["lat"], st["ctx"]              # Python side effects ran during capture
         with torch.no_grad():
@@ -136,7 +168,5 @@ class GraphedOptPass:
 
 
 def release_opt_graph(controller):
-    """Free the captured optimisation pass (and its private memory pool) of a controller."""
-    st = controller.__dict__.pop("_opt_graph", None)
-    if st and st.get("graph") is not None:
-        st["graph"].reset()
+    """Kept for callers of the per-edit design: captured optimisation passes now outlive the controller (``reset_opt_graphs``)."""
+    controller.__dict__.pop("_opt_graph", None)

@@ -193,7 +193,7 @@ def attn_probs(q, k, lse, rows: Optional[torch.Tensor], scale: float):
 # ---------------------------------------------------------------------------------------------------
 # R8 losses
 # ---------------------------------------------------------------------------------------------------
-def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int):
+def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int, n_valid=None):
     """-> dict(p_in, j_in, p_wo, j_wo, wgt [H,R]) and loss_sum [1] f32 (un-normalised)."""
     lib = _lib.load()
     dt = _dt16(Pe, "Pe")
@@ -207,7 +207,7 @@ def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int):
     p_in = torch.empty(H, R, dtype=torch.float32, device=dev); p_wo = torch.empty_like(p_in); wgt = torch.empty_like(p_in)
     j_in = torch.empty(H, R, dtype=torch.int32, device=dev); j_wo = torch.empty_like(j_in)
     loss = torch.zeros(1, dtype=torch.float32, device=dev)
-    check(lib.gd_removal_loss_reduce(_p(best), _p(rows), H, R, S, _p(p_in), _p(j_in), _p(p_wo), _p(j_wo), _p(wgt), _p(loss), _stream()),
+    check(lib.gd_removal_loss_reduce(_p(best), _p(rows), _p(n_valid), H, R, S, _p(p_in), _p(j_in), _p(p_wo), _p(j_wo), _p(wgt), _p(loss), _stream()),
           "gd_removal_loss_reduce")
     return dict(p_in=p_in, j_in=j_in, p_wo=p_wo, j_wo=j_wo, wgt=wgt), loss
 

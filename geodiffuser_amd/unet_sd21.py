@@ -25,6 +25,7 @@ import torch.nn.functional as F
 # Element-wise fusions on the no-grad passes (gd_bias_residual / gd_geglu / gd_add_layer_norm / GroupNorm with the time-embedding
 # add folded in, one batched time-embedding projection per pass): ~550 -> ~300 kernels per UNet pass.  GD_UNET_FUSED=0 = stock ops.
 FUSED = os.environ.get("GD_UNET_FUSED", "1") == "1"
+_DBG = {k: os.environ.get(k, "1") == "1" for k in ("GD_FUSE_RES", "GD_FUSE_TF", "GD_FUSE_GEGLU", "GD_FUSE_GN")}
 
 
 def _fast(x: torch.Tensor, grad_ok: bool = False) -> bool:
@@ -94,7 +95,7 @@ class GroupNormAct(nn.GroupNorm):
 
     def fusable(self, x) -> bool:
         frozen = not (self.weight.requires_grad or self.bias.requires_grad)
-        return (_fast(x, grad_ok=frozen) and x.dim() == 4 and self.num_channels // self.num_groups >= 8 and self.num_channels % 8 == 0
+        return (_DBG["GD_FUSE_GN"] and _fast(x, grad_ok=frozen) and x.dim() == 4 and self.num_channels // self.num_groups >= 8 and self.num_channels % 8 == 0
                 and x.is_contiguous(memory_format=torch.channels_last) and self.weight.dtype == x.dtype)
 
     def forward(self, x, silu: bool = False):
@@ -149,7 +150,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        if _fast(x) and self.proj.out_features % 16 == 0:
+        if _DBG["GD_FUSE_GEGLU"] and _fast(x) and self.proj.out_features % 16 == 0:
             from . import ops
             return ops.geglu(self.proj(x))
         x, gate = self.proj(x).chunk(2, dim=-1)
@@ -178,7 +179,7 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, ctx):
-        if _fast(x) and x.is_contiguous() and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048:
+        if _DBG["GD_FUSE_TF"] and _fast(x) and x.is_contiguous() and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048:
             from . import ops
             a = self.attn1(self.norm1(x))
             x, h = ops.add_layer_norm(a.contiguous(), x, self.norm2.weight, self.norm2.bias, self.norm2.eps)   # x = a + x; h = LN(x)
@@ -251,7 +252,7 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, temb):
         tb, self._tb = self._tb, None
-        if tb is not None and x.is_contiguous(memory_format=torch.channels_last) and self.norm1.fusable(x) and self.norm2.fusable(x):
+        if _DBG["GD_FUSE_RES"] and tb is not None and x.is_contiguous(memory_format=torch.channels_last) and self.norm1.fusable(x) and self.norm2.fusable(x):
             return self._fused(x, tb)
         h = self.conv1(self.norm1(x, silu=True))
         h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]

@@ -153,8 +153,11 @@ int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, cons
 
 /* Unpacks best -> p_in,p_wo [H,R] f32, j_in,j_wo [H,R] i32, writes wgt[h,r] = exp(-dist(rows[r], j_wo)) and
  * loss_acc[0] += sum_{h,r} wgt * (-log(p_wo+1e-4) + log(p_in+1e-4))      (U/attention_processors.py:262-268).
- * dist = CoordinateDistances (U/generic_torch.py:126-140) evaluated analytically on the S x S grid. */
-int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, int H, int R, int S,
+ * dist = CoordinateDistances (U/generic_torch.py:126-140) evaluated analytically on the S x S grid.
+ * n_valid_dev (DEVICE int32[1], may be NULL = R): only rows[0 .. n_valid) are inpaint rows, the rest of the list is padding (any
+ * valid row index) that gets weight 0 — so that R, and with it every launch dimension of the layer, can be rounded up to a
+ * value that repeats from edit to edit (hipGraph reuse). */
+int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, const int32_t* n_valid_dev, int H, int R, int S,
                            float* p_in, int32_t* j_in, float* p_wo, int32_t* j_wo, float* wgt,
                            float* loss_acc, void* stream);
 

@@ -129,11 +129,18 @@ def test_graphed_optimisation_pass_equals_eager(pipe):
     prev = graphs.ENABLED
     try:
         graphs.ENABLED = True
+        graphs.reset_opt_graphs(); graphs._SEEN_LAYERS.clear()
         cg = controller()
+        cg.persistent_tables = True                      # tables in the process-wide buffers the captured pass reads
         opg = graphs.GraphedOptPass(p, coords, 3.0)
         got = [one(cg, opg, *a) for a in plan]
-        assert cg.__dict__["_opt_graph"]["graph"] is not None
-        graphs.release_opt_graph(cg)
+        assert len(graphs._OPT_GRAPHS) == 1
+        # a NEW controller (next edit) replays the same graph from its very first pass: no eager pass, no capture
+        cg2 = controller()
+        cg2.persistent_tables = True
+        again = one(cg2, graphs.GraphedOptPass(p, coords, 3.0), *plan[0])
+        assert len(graphs._OPT_GRAPHS) == 1 and abs(again[2] - got[0][2]) <= 5e-3 * abs(got[0][2])
+        graphs.reset_opt_graphs()
         graphs.ENABLED = False
         ce = controller()
         ope = graphs.GraphedOptPass(p, coords, 3.0)
@@ -286,3 +293,20 @@ def test_inversion_single_row_equals_cfg_batch(pipe):
     assert a[0].shape == b[0].shape == (7, 1, 4, 32, 32)
     for i in range(2):
         assert rel_err(b[i], a[i]) < max(5 * rel_err(a2[i], a[i]), 5e-3)
+
+
+def test_edits_are_independent_of_history(pipe):
+    """Captured passes and the controller's per-resolution tables are shared by successive edits (persistent device buffers): an
+    edit must come out the same whether it is the first of the process or follows another one."""
+    from geodiffuser_amd import graphs
+    graphs.reset_opt_graphs()
+    _, log_a, lat_a = _run(pipe, seed=1, steps=10)                  # first: eager warm-ups + captures
+    _run(pipe, seed=0, steps=10)
+    _, log_b, lat_b = _run(pipe, seed=1, steps=10)                  # again, now entirely on replays of graphs captured by other edits
+    _, log_c, lat_c = _run(pipe, seed=1, steps=10)                  # run-to-run noise of the same situation
+    first = min(log_a)
+    for kind in ("self", "cross"):
+        for key, v in log_a[first][kind].items():                     # first optimisation pass: depends on the inversion only
+            assert abs(log_b[first][kind][key] - v) <= 2e-2 * abs(v) + 1e-5, (kind, key)
+    noise = rel_l2(lat_c, lat_b)
+    assert rel_l2(lat_b, lat_a) < max(5 * noise, 5e-2)

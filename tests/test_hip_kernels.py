@@ -429,6 +429,42 @@ def test_removal_loss_forward_backward(ops, M):
 
 
 # ------------------------------------------------------------------------------------------------ scheduler arithmetic
+def test_removal_loss_nan_rows_keep_indices_valid(ops):
+    """Diverged latents give NaN probability rows; torch.max would return NaN, and so does the loss here — but the arg-max INDEX
+    must stay a valid row of the base map, because the backward addresses memory with it (it used to come out as -1)."""
+    torch.manual_seed(0)
+    H, N, S = 2, 1024, 32
+    R = 70
+    Pb = torch.softmax(torch.randn(H, N, N, device=DEV), -1).half()
+    Pe = torch.softmax(torch.randn(H, R, N, device=DEV), -1).half()
+    Pe[0, 3] = float("nan"); Pe[1, 10:20] = float("nan")
+    m_inp = torch.zeros(N, device=DEV); m_inp[300:300 + R] = 1
+    m_wo = 1 - m_inp
+    rows = torch.arange(300, 300 + R, device=DEV, dtype=torch.int32)
+    aux, loss = ops.removal_fwd(Pe, Pb, m_inp, m_wo, rows, S)
+    for key in ("j_in", "j_wo"):
+        assert int(aux[key].min()) >= 0 and int(aux[key].max()) < N
+    assert torch.isnan(aux["p_in"][0, 3]) and torch.isnan(aux["p_wo"][1, 15]) and torch.isnan(loss).all()
+    assert torch.isfinite(aux["p_in"][0, 4]) and torch.isfinite(aux["p_in"][1, 25])
+    q = torch.randn(H, N, 64, device=DEV).half(); k = torch.randn(H, N, 64, device=DEV).half()
+    dq = torch.zeros(H, N, 64, device=DEV)
+    ops.removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, 1.0, None, 0.125, dq, None)       # must not fault
+    torch.cuda.synchronize()
+    # padded row lists (hipGraph reuse across edits): slots past n_valid carry weight 0 and leave loss / gradients unchanged
+    ok = torch.softmax(torch.randn(H, R, N, device=DEV), -1).half()
+    aux1, loss1 = ops.removal_fwd(ok, Pb, m_inp, m_wo, rows, S)
+    pad = 128 - R
+    rows_p = torch.cat([rows, rows[:1].expand(pad)]).contiguous()
+    ok_p = torch.cat([ok, ok[:, :1].expand(H, pad, N)], 1).contiguous()
+    aux2, loss2 = ops.removal_fwd(ok_p, Pb, m_inp, m_wo, rows_p, S, n_valid=torch.tensor([R], dtype=torch.int32, device=DEV))
+    assert torch.allclose(loss1, loss2, rtol=1e-6) and float(aux2["wgt"][:, R:].abs().max()) == 0.0
+    assert torch.equal(aux1["j_in"], aux2["j_in"][:, :R]) and torch.equal(aux1["wgt"], aux2["wgt"][:, :R])
+    d1 = torch.zeros(H, N, 64, device=DEV); d2 = torch.zeros(H, N, 64, device=DEV)
+    ops.removal_bwd(ok, Pb, q, k, rows, aux1, m_inp, m_wo, 1.0, None, 0.125, d1, None)
+    ops.removal_bwd(ok_p, Pb, q, k, rows_p, aux2, m_inp, m_wo, 1.0, None, 0.125, d2, None)
+    assert rel_err(d2.cpu(), d1.cpu()) < 1e-5
+
+
 def test_ddim_and_latent_update(ops):
     ac = O.alphas_cumprod()
     rng = np.random.default_rng(10)

@@ -127,8 +127,9 @@ extern "C" int64_t gd_group_norm_nhwc_scratch_floats(int B, int HW, int G) {
 extern "C" int gd_group_norm_nhwc(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, int B, int HW, int C, int G,
                                   float eps, int silu, float* scratch, void* y, int dtype, void* stream) {
     GD_REQUIRE(x && gamma && beta && scratch && y, GD_EINVAL, "gd_group_norm_nhwc: null pointer");
-    GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && C / G >= 8, GD_EINVAL,
-               "gd_group_norm_nhwc: unsupported shape B=%d HW=%d C=%d G=%d (need C %% 8 == 0, C/G >= 8, G <= %d)", B, HW, C, G, GN_MAX_G);
+    // an 8-channel vector may touch at most two groups: C/G >= 8, or exactly 4 (the VAE's 128-channel norms)
+    GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && (C / G >= 8 || C / G == 4), GD_EINVAL,
+               "gd_group_norm_nhwc: unsupported shape B=%d HW=%d C=%d G=%d (need C %% 8 == 0, C/G >= 8 or == 4, G <= %d)", B, HW, C, G, GN_MAX_G);
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_group_norm_nhwc: dtype must be f16/bf16");
     GD_REQUIRE(!add_bc || add_ld == 0 || (add_ld >= C && (add_ld & 7) == 0), GD_EINVAL, "gd_group_norm_nhwc: add_ld must be >= C and a multiple of 8");
     if (add_ld == 0) add_ld = C;
@@ -295,7 +296,7 @@ extern "C" int gd_group_norm_nhwc_bwd(const void* x, const void* add_bc, int add
                                       int B, int HW, int C, int G, float eps, int silu, const float* fwd_scratch, float* scratch, void* dx,
                                       int dtype, void* stream) {
     GD_REQUIRE(x && gamma && beta && dy && fwd_scratch && scratch && dx, GD_EINVAL, "gd_group_norm_nhwc_bwd: null pointer");
-    GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && C / G >= 8, GD_EINVAL,
+    GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && (C / G >= 8 || C / G == 4), GD_EINVAL,
                "gd_group_norm_nhwc_bwd: unsupported shape B=%d HW=%d C=%d G=%d", B, HW, C, G);
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_group_norm_nhwc_bwd: dtype must be f16/bf16");
     GD_REQUIRE(!add_bc || add_ld == 0 || (add_ld >= C && (add_ld & 7) == 0), GD_EINVAL, "gd_group_norm_nhwc_bwd: bad add_ld");

@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .scheduler import DDIMScheduler
-from .unet_sd21 import UNet2DConditionModel, tiny_unet
+from .unet_sd21 import GroupNormAct, UNet2DConditionModel, tiny_unet
 
 
 # ------------------------------------------------------------------------------------------------ tokenizer
@@ -76,14 +76,23 @@ class TextEncoder(nn.Module):
 class _VRes(nn.Module):
     def __init__(self, cin, cout):
         super().__init__()
-        self.n1, self.c1 = nn.GroupNorm(32, cin, eps=1e-6), nn.Conv2d(cin, cout, 3, padding=1)
-        self.n2, self.c2 = nn.GroupNorm(32, cout, eps=1e-6), nn.Conv2d(cout, cout, 3, padding=1)
+        self.n1, self.c1 = GroupNormAct(32, cin, eps=1e-6), nn.Conv2d(cin, cout, 3, padding=1)
+        self.n2, self.c2 = GroupNormAct(32, cout, eps=1e-6), nn.Conv2d(cout, cout, 3, padding=1)
         self.sc = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x):
-        h = self.c1(F.silu(self.n1(x)))
-        h = self.c2(F.silu(self.n2(h)))
+        h = self.c1(self.n1(x, silu=True))              # fused channels-last GroupNorm + SiLU (HIP) on 16-bit GPU tensors
+        h = self.c2(self.n2(h, silu=True))
         return (self.sc(x) if self.sc is not None else x) + h
+
+
+class _NormSiLU(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.norm = GroupNormAct(32, ch, eps=1e-6)
+
+    def forward(self, x):
+        return self.norm(x, silu=True)
 
 
 class _VAttn(nn.Module):
@@ -91,7 +100,7 @@ class _VAttn(nn.Module):
 
     def __init__(self, ch):
         super().__init__()
-        self.norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.norm = GroupNormAct(32, ch, eps=1e-6)
         self.q, self.k, self.v, self.o = (nn.Linear(ch, ch) for _ in range(4))
 
     def forward(self, x):
@@ -114,7 +123,7 @@ class AutoencoderKL(nn.Module):
             cin = c
         enc += [_VRes(cin, cin), _VAttn(cin), _VRes(cin, cin)]
         self.encoder = nn.Sequential(*enc)
-        self.enc_out = nn.Sequential(nn.GroupNorm(32, cin, eps=1e-6), nn.SiLU(), nn.Conv2d(cin, 2 * latent, 3, padding=1))
+        self.enc_out = nn.Sequential(_NormSiLU(cin), nn.Conv2d(cin, 2 * latent, 3, padding=1))
         self.quant_conv = nn.Conv2d(2 * latent, 2 * latent, 1)
         self.post_quant_conv = nn.Conv2d(latent, latent, 1)
         dec = [nn.Conv2d(latent, cin, 3, padding=1), _VRes(cin, cin), _VAttn(cin), _VRes(cin, cin)]
@@ -124,7 +133,7 @@ class AutoencoderKL(nn.Module):
                 dec += [nn.Upsample(scale_factor=2.0, mode="nearest"), nn.Conv2d(c, c, 3, padding=1)]
             cin = c
         self.decoder = nn.Sequential(*dec)
-        self.dec_out = nn.Sequential(nn.GroupNorm(32, cin, eps=1e-6), nn.SiLU(), nn.Conv2d(cin, 3, 3, padding=1))
+        self.dec_out = nn.Sequential(_NormSiLU(cin), nn.Conv2d(cin, 3, 3, padding=1))
 
     @property
     def dtype(self):

@@ -95,7 +95,8 @@ class GroupNormAct(nn.GroupNorm):
 
     def fusable(self, x) -> bool:
         frozen = not (self.weight.requires_grad or self.bias.requires_grad)
-        return (_DBG["GD_FUSE_GN"] and _fast(x, grad_ok=frozen) and x.dim() == 4 and self.num_channels // self.num_groups >= 8 and self.num_channels % 8 == 0
+        cpg = self.num_channels // self.num_groups
+        return (_DBG["GD_FUSE_GN"] and _fast(x, grad_ok=frozen) and x.dim() == 4 and (cpg >= 8 or cpg == 4) and self.num_channels % 8 == 0
                 and x.is_contiguous(memory_format=torch.channels_last) and self.weight.dtype == x.dtype)
 
     def forward(self, x, silu: bool = False):

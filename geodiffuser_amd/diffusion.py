@@ -82,8 +82,10 @@ def image2latent(image, model, mask=None, device="cuda:0"):
     """diffusion.py:71-97 (mask=None branch; the masked variants are only used by the stitch editors, which do not exist)."""
     if type(image) is torch.Tensor and image.dim() == 4:
         return image
-    image = torch.from_numpy(np.asarray(image)).float() / 127.5 - 1
-    image = image.permute(2, 0, 1).unsqueeze(0).to(device)
+    # upload the uint8 image and do the arithmetic on the device (same float32 operations; a 786k-element CPU op wakes torch's whole
+    # intra-op thread pool on a many-core host, which cost up to 200 ms per edit)
+    image = torch.from_numpy(np.ascontiguousarray(image)).to(device).float() / 127.5 - 1
+    image = image.permute(2, 0, 1).unsqueeze(0)
     latents = model.vae.encode(image)["latent_dist"].mean
     return latents * 0.18215
 

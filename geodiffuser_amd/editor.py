@@ -313,7 +313,7 @@ def _perform_geometric_edit(image, depth, image_mask, transform_in, prompt, ldm_
 
     edited_image = images[-1]
     if edit_type == "geometry_editor":                                                                     # :660-682
-        img_t = (torch.from_numpy(image[None]).permute(0, 3, 1, 2) / 255.0).float()
+        img_t = (torch.from_numpy(np.ascontiguousarray(image[None])).to(DEVICE).permute(0, 3, 1, 2) / 255.0).float()   # on the device
         image_warped = warp_grid_edit(img_t.to(DEVICE), transform_coordinates.float())
         p_image = (image_warped[0].permute(1, 2, 0).float().cpu().numpy() * 255.0).astype("uint8")
         mask_edit = controller.mask_new_warped[0, 0].detach().float().cpu().numpy()

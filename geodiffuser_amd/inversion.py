@@ -37,8 +37,8 @@ class NullInversion:
     def image2latent(self, image):
         if type(image) is torch.Tensor and image.dim() == 4:
             return image
-        image = torch.from_numpy(np.asarray(image)).float() / 127.5 - 1
-        image = image.permute(2, 0, 1).unsqueeze(0).to(self.device)
+        image = torch.from_numpy(np.ascontiguousarray(image)).to(self.device).float() / 127.5 - 1      # arithmetic on the device
+        image = image.permute(2, 0, 1).unsqueeze(0)
         latents = self.model.vae.encode(image)["latent_dist"].mean
         return latents * self.model.vae.config.scaling_factor
 

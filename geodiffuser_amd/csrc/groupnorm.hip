@@ -16,9 +16,27 @@
 #define GN_MAX_G 64
 #define GN_MAX_SLABS 64
 
+// Sum the slab partials of batch entry b into s_out[G*2] (LDS): all 256 threads take part — (256 / (2G)) threads per value, each
+// adding every (256 / 2G)-th slab with independent loads (a single thread per value walked <= 64 dependent-looking loads: 6 us).
+__device__ __forceinline__ void gn_fold_partials(const float* __restrict__ partial, int nslab, int G, int b, float* s_out) {
+    const int tid = threadIdx.x, nv = G * 2, parts = 256 / nv;          // G <= 64 -> parts >= 2
+    if (tid < nv) s_out[tid] = 0.f;
+    __syncthreads();
+    if (tid < nv * parts) {
+        const int v = tid % nv, p = tid / nv;
+        const float* pp = partial + (size_t)b * nslab * nv + v;
+        float a0 = 0.f, a1 = 0.f;
+        int s = p;
+        for (; s + parts < nslab; s += 2 * parts) { a0 += pp[(size_t)s * nv]; a1 += pp[(size_t)(s + parts) * nv]; }
+        if (s < nslab) a0 += pp[(size_t)s * nv];
+        atomicAdd(&s_out[v], a0 + a1);
+    }
+    __syncthreads();
+}
+
 static inline int gn_pix_per_slab(int HW) {
     int p = (HW + GN_MAX_SLABS - 1) / GN_MAX_SLABS;
-    return p < 32 ? 32 : p;
+    return p < 4 ? 4 : p;             // small maps: many thin slabs rather than two workgroups walking 32 pixels each
 }
 
 template <typename T>
@@ -48,14 +66,23 @@ k_gn_stats(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, in
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ad[i] = TR::to_f32(av[i]);
             }
-            for (int p = p0 + r; p < p1; p += rows) {
-                const V8 v = *(const V8*)(xb + (size_t)p * C + k * 8);
+            for (int p = p0 + r; p < p1; p += 4 * rows) {            // four pixel rows in flight per thread
+                V8 v[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    // x + add is rounded to the storage type first, as the unfused `h + temb[:, :, None, None]` does
-                    const float f = add_bc ? TR::to_f32(TR::from_f32(TR::to_f32(v[i]) + ad[i])) : TR::to_f32(v[i]);
-                    sum[i] += f;
-                    sq[i] = __builtin_fmaf(f, f, sq[i]);
+                for (int u = 0; u < 4; ++u) {
+                    const int pp = p + u * rows;
+                    v[u] = *(const V8*)(xb + (size_t)(pp < p1 ? pp : p) * C + k * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (p + u * rows >= p1) break;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        // x + add is rounded to the storage type first, as the unfused `h + temb[:, :, None, None]` does
+                        const float f = add_bc ? TR::to_f32(TR::from_f32(TR::to_f32(v[u][i]) + ad[i])) : TR::to_f32(v[u][i]);
+                        sum[i] += f;
+                        sq[i] = __builtin_fmaf(f, f, sq[i]);
+                    }
                 }
             }
             // an 8-channel column touches at most two groups (C / G >= 8)
@@ -83,13 +110,7 @@ k_gn_apply(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, co
     __shared__ float s_m[GN_MAX_G * 2];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cv = C >> 3, cpg = C / G;
-    if (tid < G * 2) {
-        const float* pp = partial + (size_t)b * nslab * G * 2 + tid;
-        float acc = 0.f;
-        for (int s = 0; s < nslab; ++s) acc += pp[(size_t)s * G * 2];
-        s_m[tid] = acc;
-    }
-    __syncthreads();
+    gn_fold_partials(partial, nslab, G, b, s_m);
     const long long idx = (long long)blockIdx.x * 256 + tid;          // vector index inside batch entry b
     if (idx >= (long long)HW * cv) return;
     const int k = (int)(idx % cv);
@@ -162,14 +183,14 @@ template <typename T>
 __device__ __forceinline__ void gn_fold_fwd_stats(const float* __restrict__ fwd_partial, int nslab, int G, int b, float inv_n, float eps,
                                                   float* s_mr /* [G][2] mean, rstd */) {
     const int tid = threadIdx.x;
+    gn_fold_partials(fwd_partial, nslab, G, b, s_mr);                  // (sum, sum of squares) per group
+    float m = 0.f, r = 0.f;
     if (tid < G) {
-        float a = 0.f, q = 0.f;
-        const float* pp = fwd_partial + (size_t)b * nslab * G * 2 + tid * 2;
-        for (int s = 0; s < nslab; ++s) { a += pp[(size_t)s * G * 2]; q += pp[(size_t)s * G * 2 + 1]; }
-        const float m = a * inv_n;
-        s_mr[tid * 2] = m;
-        s_mr[tid * 2 + 1] = rsqrtf(fmaxf(q * inv_n - m * m, 0.f) + eps);
+        m = s_mr[tid * 2] * inv_n;
+        r = rsqrtf(fmaxf(s_mr[tid * 2 + 1] * inv_n - m * m, 0.f) + eps);
     }
+    __syncthreads();
+    if (tid < G) { s_mr[tid * 2] = m; s_mr[tid * 2 + 1] = r; }
     __syncthreads();
 }
 
@@ -251,12 +272,8 @@ k_gn_bwd_apply(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cv = C >> 3, cpg = C / G;
     const float inv_n = 1.0f / ((float)HW * (float)cpg);
-    if (tid < G * 2) {
-        const float* pp = partial + (size_t)b * nslab * G * 2 + tid;
-        float acc = 0.f;
-        for (int s = 0; s < nslab; ++s) acc += pp[(size_t)s * G * 2];
-        s_s[tid] = acc * inv_n;                                    // S1 / n, S2 / n
-    }
+    gn_fold_partials(partial, nslab, G, b, s_s);
+    if (tid < G * 2) s_s[tid] *= inv_n;                            // S1 / n, S2 / n  (made visible by the barriers of the next fold)
     gn_fold_fwd_stats<T>(fwd_partial, nslab, G, b, inv_n, eps, s_mr);
     const long long idx = (long long)blockIdx.x * 256 + tid;
     if (idx >= (long long)HW * cv) return;

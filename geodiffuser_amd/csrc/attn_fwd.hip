@@ -66,74 +66,92 @@ __device__ __forceinline__ typename elem_traits<T>::vec8 rd_tr(const char* lds, 
 // one 64-key tile, processed as two 32-key half steps (S^T = K Q^T, online softmax, O^T += V^T P^T).  Half steps keep
 // only 16 score + 8 probability registers live, which fits 4 waves per SIMD (<= 128 VGPRs): on this kernel latency
 // hiding by occupancy is worth more than the few extra max/rescale checks.
+// softmax of one 32-key half step: probabilities of s_acc against the row's reference value -> two 16-bit B fragments, l_run updated
+template <typename T>
+__device__ __forceinline__ void softmax_half(const f32x16& s_acc, f32x16 (&o)[2], float& m_run, float& l_run, float c,
+                                             typename elem_traits<T>::vec8& pf0, typename elem_traits<T>::vec8& pf1) {
+    using TR = elem_traits<T>;
+    // Probabilities against the CURRENT reference maximum, no per-step row maximum: p = exp2(c*s - c*m_run).  A row maximum is
+    // only needed to keep p inside the 16-bit range, so it is recomputed (slow path, wave-uniform, executed at most once per
+    // half step) only when a lane's partial row sum leaves [0, 2^14] — which also covers the first tile (m_run = -inf gives
+    // p = inf) and NaN.  Everything downstream (l, O, lse = m_run*scale + ln l, the split-KV merge) is exact for ANY reference
+    // value; it need not be the true maximum.  This removes a 10-deep dependent max chain, an LDS round trip and a branch
+    // from every half step (+9-12 % on the 64^2 launches).
+    float mc = m_run * c;
+    float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], c, -mc));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i + 1], c, -mc));
+        pf0[i] = TR::from_f32(p0); pf0[i + 1] = TR::from_f32(p1);
+        ps0 += p0; ps1 += p1;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[8 + i], c, -mc));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[8 + i + 1], c, -mc));
+        pf1[i] = TR::from_f32(p0); pf1[i + 1] = TR::from_f32(p1);
+        ps0 += p0; ps1 += p1;
+    }
+    float ps = ps0 + ps1;
+    if (__builtin_amdgcn_ballot_w64(!(ps <= P_SUM_LIMIT)) != 0) {
+        float mx = s_acc[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s_acc[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);       // 0 on the first tile
+        l_run *= alpha;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        mc = m_run * c;
+        ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], c, -mc));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[8 + i], c, -mc));
+            pf0[i] = TR::from_f32(p0); pf1[i] = TR::from_f32(p1);
+            ps += p0 + p1;
+        }
+    }
+    l_run += ps;
+}
+
+// one 64-key tile as two 32-key half steps (S^T = K Q^T, online softmax, O^T += V^T P^T), software-pipelined inside the tile: both
+// score GEMMs are issued up front and the first half's P.V before the second half's softmax, so that within ONE wave the matrix
+// pipe has independent work (QK^T of half 1, PV of half 0) while the vector pipe runs the exponentials of the other half.
 template <typename T, bool MASKED>
 __device__ __forceinline__ void fwd_tile(const char* lk, const char* lv, const FragOffs& fo, const typename elem_traits<T>::vec8 (&qf)[4],
                                          f32x16 (&o)[2], float& m_run, float& l_run, float c, int kv0, int M, int h) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
+    f32x16 s0, s1;
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        f32x16 s_acc;
+    for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s_acc[i] = 0.f;
+    for (int s = 0; s < 4; ++s) s0 = TR::mfma32(rd_row<T>(lk, fo, 0, s), qf[s], s0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(rd_row<T>(lk, fo, blk, s), qf[s], s_acc);
-        if (MASKED) {
+    for (int s = 0; s < 4; ++s) s1 = TR::mfma32(rd_row<T>(lk, fo, 1, s), qf[s], s1);
+    if (MASKED) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (kv0 + blk * 32 + acc_key(i, h) >= M) s_acc[i] = -INFINITY;
+        for (int i = 0; i < 16; ++i) {
+            if (kv0 + acc_key(i, h) >= M) s0[i] = -INFINITY;
+            if (kv0 + 32 + acc_key(i, h) >= M) s1[i] = -INFINITY;
         }
-        // Probabilities against the CURRENT reference maximum, no per-step row maximum: p = exp2(c*s - c*m_run).  A row maximum is
-        // only needed to keep p inside the 16-bit range, so it is recomputed (slow path, wave-uniform, executed at most once per
-        // half step) only when a lane's partial row sum leaves [0, 2^14] — which also covers the first tile (m_run = -inf gives
-        // p = inf) and NaN.  Everything downstream (l, O, lse = m_run*scale + ln l, the split-KV merge) is exact for ANY reference
-        // value; it need not be the true maximum.  This removes a 10-deep dependent max chain, an LDS round trip and a branch
-        // from every half step (+9-12 % on the 64^2 launches).
-        float mc = m_run * c;
-        V8 pf0, pf1;
-        float ps0 = 0.f, ps1 = 0.f;
+    }
+    V8 pa0, pa1, pb0, pb1;
+    softmax_half<T>(s0, o, m_run, l_run, c, pa0, pa1);
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], c, -mc));
-            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i + 1], c, -mc));
-            pf0[i] = TR::from_f32(p0); pf0[i + 1] = TR::from_f32(p1);
-            ps0 += p0; ps1 += p1;
-        }
+    for (int dblk = 0; dblk < 2; ++dblk) {
+        o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 0), pa0, o[dblk]);
+        o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 1), pa1, o[dblk]);
+    }
+    softmax_half<T>(s1, o, m_run, l_run, c, pb0, pb1);
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[8 + i], c, -mc));
-            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[8 + i + 1], c, -mc));
-            pf1[i] = TR::from_f32(p0); pf1[i + 1] = TR::from_f32(p1);
-            ps0 += p0; ps1 += p1;
-        }
-        float ps = ps0 + ps1;
-        if (__builtin_amdgcn_ballot_w64(!(ps <= P_SUM_LIMIT)) != 0) {
-            float mx = s_acc[0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s_acc[i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);       // 0 on the first tile
-            l_run *= alpha;
-            m_run = m_new;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-            mc = m_run * c;
-            ps = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], c, -mc));
-                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[8 + i], c, -mc));
-                pf0[i] = TR::from_f32(p0); pf1[i] = TR::from_f32(p1);
-                ps += p0 + p1;
-            }
-        }
-        l_run += ps;
-#pragma unroll
-        for (int dblk = 0; dblk < 2; ++dblk) {
-            o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 2 * blk), pf0, o[dblk]);
-            o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 2 * blk + 1), pf1, o[dblk]);
-        }
+    for (int dblk = 0; dblk < 2; ++dblk) {
+        o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 2), pb0, o[dblk]);
+        o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 3), pb1, o[dblk]);
     }
 }
 

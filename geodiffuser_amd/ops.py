@@ -284,6 +284,30 @@ def blend_tokens(a, b, m, out=None):
     return out
 
 
+def softsplat_fwd(tenIn, tenFlow):
+    """in [N,C,H,W] f32, flow [N,2,H,W] f32 -> summation splat [N,C,H,W] f32."""
+    lib = _lib.load()
+    _need(tenIn, "tenIn", torch.float32); _need(tenFlow, "tenFlow", torch.float32)
+    N, C, H, W = tenIn.shape
+    if tuple(tenFlow.shape) != (N, 2, H, W):
+        raise _lib.GeodiffError("softsplat: flow must be [N, 2, H, W]")
+    out = torch.empty_like(tenIn)
+    check(lib.gd_softsplat_fwd(_p(tenIn), _p(tenFlow), N, C, H, W, _p(out), _stream()), "gd_softsplat_fwd")
+    return out
+
+
+def softsplat_bwd(tenIn, tenFlow, outgrad, need_in: bool, need_flow: bool):
+    lib = _lib.load()
+    _need(outgrad, "outgrad", torch.float32)
+    N, C, H, W = tenIn.shape
+    gi = torch.empty_like(tenIn) if need_in else None
+    gf = torch.empty_like(tenFlow) if need_flow else None
+    if gi is None and gf is None:
+        return None, None
+    check(lib.gd_softsplat_bwd(_p(tenIn), _p(tenFlow), _p(outgrad), N, C, H, W, _p(gi), _p(gf), _stream()), "gd_softsplat_bwd")
+    return gi, gf
+
+
 def hist_match(src, tmpl, m_src, m_tmpl):
     """src, tmpl [npix, C] uint8; m_src, m_tmpl [npix] uint8 -> (out [npix, C] f64, lut [C,256] f64, counts [2,C,256] i32)."""
     lib = _lib.load()

@@ -275,6 +275,15 @@ int gd_add_layer_norm(const void* a, const void* b, const void* gamma, const voi
 int gd_hist_match(const uint8_t* src, const uint8_t* tmpl, const uint8_t* m_src, const uint8_t* m_tmpl, int npix, int C,
                   uint32_t* counts, double* lut, double* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * N4  bilinear forward splatting, summation form (GeoDiffuser/utils/softsplat.py:284-510; dead on the reference's live path).
+ * in [N,C,H,W], flow [N,2,H,W] (x, y displacement in pixels), out / outgrad / ingrad [N,C,H,W], flowgrad [N,2,H,W]; all f32 NCHW.
+ * out is cleared by the call; source pixels with a non-finite target contribute nothing (gradients 0); ingrad or flowgrad may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int gd_softsplat_fwd(const float* in, const float* flow, int N, int C, int H, int W, float* out, void* stream);
+int gd_softsplat_bwd(const float* in, const float* flow, const float* outgrad, int N, int C, int H, int W, float* ingrad,
+                     float* flowgrad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -623,3 +623,37 @@ def test_hist_match_full_size_counts_and_lut(ops):
     assert isinstance(dev_out, torch.Tensor) and dev_out.is_cuda and np.array_equal(dev_out.cpu().numpy(), want)
     with pytest.raises(TypeError):
         masked_histogram_matching(src.astype(np.float32), tmpl, m_t, m_s)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N4  bilinear forward splatting (softsplat): HIP vs the torch restatement, forward and both gradients
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["sum", "avg", "linear", "soft", "soft-zeroeps", "linear-clipeps"])
+def test_softsplat_forward_backward(ops, mode):
+    from geodiffuser_amd.softsplat import softsplat
+    torch.manual_seed(len(mode))
+    N, C, H, W = 2, 5, 37, 52
+    x = torch.randn(N, C, H, W)
+    flow = torch.randn(N, 2, H, W) * 6.0                      # many targets leave the image
+    flow[0, 0, 3, 4] = float("inf"); flow[1, 1, 10, 11] = float("nan")       # dropped source pixels
+    flow[0, :, 5, 5] = 0.0                                      # an exactly integer target
+    metric = None if mode in ("sum", "avg") else torch.randn(N, 1, H, W) * 0.5 + (1.5 if mode.startswith("linear") else 0.0)
+    if mode.startswith("linear"):
+        metric = metric.abs() + 0.1
+    xo, fo = x.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    ref = O.softsplat(xo, fo, metric, mode)
+    g = torch.randn_like(ref)
+    gx_ref, gf_ref = torch.autograd.grad(ref, [xo, fo], g)
+    xd, fd = x.to(DEV).requires_grad_(True), flow.to(DEV).requires_grad_(True)
+    out = softsplat(xd, fd, None if metric is None else metric.to(DEV), mode)
+    gx, gf = torch.autograd.grad(out, [xd, fd], g.to(DEV))
+    assert out.shape == ref.shape and rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(gx.cpu(), gx_ref) < 1e-5
+    gf_ref = torch.nan_to_num(gf_ref)                           # autograd gives NaN at the non-finite flow entries, the kernels 0
+    assert float(gf[0, :, 3, 4].abs().max()) == 0.0 and float(gf[1, :, 10, 11].abs().max()) == 0.0
+    assert rel_err(gf.cpu(), gf_ref) < 1e-4
+    # mass conservation of the summation form: what lands inside equals the weights that fell inside
+    if mode == "sum":
+        ones = torch.ones(1, 1, H, W, device=DEV)
+        inside = softsplat(ones, torch.zeros(1, 2, H, W, device=DEV), None, "sum")
+        assert torch.allclose(inside, ones)

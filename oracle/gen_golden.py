@@ -370,6 +370,67 @@ def g17_attention_store(R, packs):
     save("G17_attention_store", **out)
 
 
+def g18_loop(R):
+    """The reference's own per-step driver (``text2image_ldm_stable``, U/editor.py:65-423: optimisation pass -> _update_latent ->
+    adaptive schedule -> CFG pass -> reference-latent replacement -> latent warp) with its own processors / controller, driving the
+    narrow SD-topology UNet of geodiffuser_amd (seeded random weights, fp32, CPU) through a CPU DDIM scheduler built from the
+    reference's closed form.  Records the final latents and the loss log of every optimisation step."""
+    import GeoDiffuser.utils.editor as RE
+    from types import SimpleNamespace
+    from geodiffuser_amd.pipeline import build_random_sd21
+    import ref_cpu as O
+    c = cases.LOOP
+    inp = cases.loop_inputs()
+    pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=True)
+
+    class CpuDDIM:
+        def __init__(self):
+            self.alphas_cumprod = O.alphas_cumprod()
+
+        def set_timesteps(self, n):
+            self.num_inference_steps = n
+            self.timesteps = torch.from_numpy(O.ddim_timesteps(n))
+
+        def step(self, eps, t, x, eta=0.0):
+            return {"prev_sample": O.prev_step(eps, int(t), x, self.alphas_cumprod, self.num_inference_steps)}
+
+    model = SimpleNamespace(unet=pipe.unet, vae=pipe.vae, tokenizer=pipe.tokenizer, text_encoder=pipe.text_encoder, scheduler=CpuDDIM(),
+                            device=torch.device("cpu"))
+    ap = R.attention_processors
+    ap.USE_PEFT_BACKEND = True                 # plain nn.Linear projections: no LoRA scale argument (diffusers' PEFT branch)
+    orig_rtc = ap.reshape_transform_coords
+    RE.IMAGE_SIZE, RE.NUM_DDIM_STEPS, RE.GUIDANCE_SCALE, RE.SKIP_OPTIM_STEPS, RE.PROGRESS_BAR = c["size"], c["steps"], c["guidance"], c["skip_optim"], None
+    mask = torch.from_numpy(inp["mask"])
+    coords = torch.from_numpy(inp["coords"])
+    lw = {"self": {"sim": 55, "movement": 30.5, "removal": 2.6, "smoothness": 30.0, "amodal": 80.5},
+          "cross": {"sim": 45, "movement": 30.34, "removal": 2.6, "smoothness": 15.0, "amodal": 3.5}}
+    ctrl = ap.AttentionGeometryEdit(["", ""], c["steps"], {"default_": c["cross_replace"]}, c["self_replace"], image_mask=inp["mask"],
+                                    obj_edit_step=c["obj_edit_step"], device="cpu")
+    ctrl.amodal_mask = R.generic_torch.torch_erode(torch.from_numpy(cases.amodal_input(inp["mask"], dx=32, dy=-12)))
+    ctrl.default_loss_weights = lw
+    ctrl.initialize_default_loss_weights()
+    ddim = [torch.from_numpy(a) for a in inp["ddim_latents"]]
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        lat, _, log = RE.text2image_ldm_stable(model, ["", ""], ctrl, latent=torch.from_numpy(inp["x_T"]), num_inference_steps=c["steps"],
+                                               guidance_scale=c["guidance"], uncond_embeddings=None, transform_coordinates=coords,
+                                               mask_obj=mask, optimize_steps=c["optimize_steps"], latent_replace=c["latent_replace"], lr=c["lr"],
+                                               optimize_embeddings=True, optimize_latents=True, ddim_latents=ddim, ddim_noise=None,
+                                               edit_type="geometry_editor", fast_start_steps=0.0, num_first_optim_steps=1,
+                                               use_adaptive_optimization=True, return_type="latents")
+    ap.reshape_transform_coords = orig_rtc
+    out = {"latents": lat.detach(), "steps": np.array(sorted(log))}
+    for i, d in log.items():
+        for kind in ("self", "cross"):
+            for k, v in d[kind].items():
+                out[f"log_{i}_{kind}_{k}"] = np.array(float(v))
+        out[f"log_{i}_num_layers"] = np.array(d["num_layers"])
+    w = torch.cat([p.detach().reshape(-1)[:64] for p in pipe.unet.parameters()])
+    out["weight_probe"] = w                                         # to recognise the same seeded weights on the test machine
+    out["final_weights_self_removal"] = np.array(float(ctrl.loss_weight_dict["self"]["removal"]))
+    save("G18_loop", **out)
+
+
 def g16_batch_config():
     """What ``perform_exp`` hands to ``perform_geometric_edit`` for each live edit type (call intercepted) -> JSON."""
     import json
@@ -401,6 +462,11 @@ def main():
         os.makedirs(OUT, exist_ok=True)
         print("G15"); g15_exp_folder()
         print("G16"); g16_batch_config()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "G18":
+        R = ref_import.import_reference()
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        print("G18"); g18_loop(R)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "G17":
         R = ref_import.import_reference()

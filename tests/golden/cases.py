@@ -210,3 +210,19 @@ def exp_case(cat: str, idx: int):
 
 # ---- N4: attention-map capture (store_attention_maps) ---------------------------------------------------
 STORE_LAYERS = ((16, False, "down"), (16, True, "mid"), (32, False, "up"))     # (S, is_cross, place_in_unet) of one "step"
+
+
+# ---- loop-level fixture (G18): the reference's text2image_ldm_stable driving a narrow UNet of the SD topology ------------------
+LOOP = dict(size=256, steps=6, guidance=3.0, skip_optim=2, optimize_steps=0.65, latent_replace=0.4, lr=0.03, obj_edit_step=0.9,
+            self_replace=0.95, cross_replace=0.95, seed=77)
+
+
+def loop_inputs():
+    """-> dict(mask [256,256] f32, coords [1,256,256,3] f32, x_T [1,4,32,32], ddim_latents list of steps+1 [1,4,32,32])."""
+    c = LOOP
+    size = c["size"]
+    mask = ellipse_mask(cx=118.0, cy=131.0, ax=35.0, ay=29.0, size=size)
+    coords = coords_translate(dx_px=32.0, dy_px=-12.0, z=0.5, size=size)
+    rng = np.random.default_rng(c["seed"])
+    traj = [rng.standard_normal((1, 4, size // 8, size // 8)).astype(np.float32) for _ in range(c["steps"] + 1)]
+    return dict(mask=mask.astype(np.float32), coords=coords.astype(np.float32), x_T=traj[-1], ddim_latents=traj)       # coords [1,256,256,3]

@@ -14,7 +14,8 @@ def main():
     rows = []
     with open(trace) as fh:
         for r in csv.DictReader(fh):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+                         int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0) // max(1, int(r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or 256))))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if "spin_kernel" in r[2]]
     if len(marks) >= 2:
@@ -27,7 +28,11 @@ def main():
     agg = collections.defaultdict(lambda: [0, 0.0, 1e30, 0.0])
     busy, cur_end = 0.0, t_first
     gaps = collections.Counter()
-    for s, e, n in rows:
+    by_grid = collections.defaultdict(lambda: [0, 0.0])
+    for s, e, n, wgs in rows:
+        if "k_attn_fwd" in n:
+            g = by_grid[wgs]
+            g[0] += 1; g[1] += (e - s) * 1e-3
         a = agg[n]
         d = (e - s) * 1e-3
         a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
@@ -59,6 +64,13 @@ def main():
         for n, a in own:
             fh.write(f"| `{n[:72]}` | {a[0]} | {a[1] * 1e-3:.1f} | {a[1] / a[0]:.1f} | {a[2]:.1f} | {a[3]:.1f} |\n")
         fh.write(f"\nown kernels total {sum(a[1] for _, a in own) * 1e-3:.1f} ms of {tot:.1f} ms\n")
+        if by_grid:
+            fh.write("\n## k_attn_fwd by launch size (workgroups = 128-query tiles x heads x key splits)\n\n"
+                     "The 64^2 self-attention launches that bench.py's `roofline` is computed from are the ones with >= 320 workgroups "
+                     "(32 query tiles x 10-20 heads, x key splits); the rest are 32^2 / 16^2 / 8^2 layers and 77-key cross attention.\n\n"
+                     "| workgroups | launches | total ms | avg us |\n|---|---|---|---|\n")
+            for wgs, (cnt, us) in sorted(by_grid.items(), key=lambda kv: -kv[1][1])[:16]:
+                fh.write(f"| {wgs} | {cnt} | {us * 1e-3:.1f} | {us / cnt:.1f} |\n")
 
 
 if __name__ == "__main__":

@@ -370,7 +370,7 @@ def g17_attention_store(R, packs):
     save("G17_attention_store", **out)
 
 
-def g18_loop(R):
+def g18_loop(R, kind="geometry_editor"):
     """The reference's own per-step driver (``text2image_ldm_stable``, U/editor.py:65-423: optimisation pass -> _update_latent ->
     adaptive schedule -> CFG pass -> reference-latent replacement -> latent warp) with its own processors / controller, driving the
     narrow SD-topology UNet of geodiffuser_amd (seeded random weights, fp32, CPU) through a CPU DDIM scheduler built from the
@@ -402,11 +402,16 @@ def g18_loop(R):
     RE.IMAGE_SIZE, RE.NUM_DDIM_STEPS, RE.GUIDANCE_SCALE, RE.SKIP_OPTIM_STEPS, RE.PROGRESS_BAR = c["size"], c["steps"], c["guidance"], c["skip_optim"], None
     mask = torch.from_numpy(inp["mask"])
     coords = torch.from_numpy(inp["coords"])
-    lw = {"self": {"sim": 55, "movement": 30.5, "removal": 2.6, "smoothness": 30.0, "amodal": 80.5},
-          "cross": {"sim": 45, "movement": 30.34, "removal": 2.6, "smoothness": 15.0, "amodal": 3.5}}
-    ctrl = ap.AttentionGeometryEdit(["", ""], c["steps"], {"default_": c["cross_replace"]}, c["self_replace"], image_mask=inp["mask"],
-                                    obj_edit_step=c["obj_edit_step"], device="cpu")
-    ctrl.amodal_mask = R.generic_torch.torch_erode(torch.from_numpy(cases.amodal_input(inp["mask"], dx=32, dy=-12)))
+    if kind == "geometry_editor":
+        lw = {"self": {"sim": 55, "movement": 30.5, "removal": 2.6, "smoothness": 30.0, "amodal": 80.5},
+              "cross": {"sim": 45, "movement": 30.34, "removal": 2.6, "smoothness": 15.0, "amodal": 3.5}}
+        ctrl = ap.AttentionGeometryEdit(["", ""], c["steps"], {"default_": c["cross_replace"]}, c["self_replace"], image_mask=inp["mask"],
+                                        obj_edit_step=c["obj_edit_step"], device="cpu")
+        ctrl.amodal_mask = R.generic_torch.torch_erode(torch.from_numpy(cases.amodal_input(inp["mask"], dx=32, dy=-12)))
+    else:
+        lw = {"self": {"sim": 55, "removal": 4.6, "smoothness": 30.0}, "cross": {"sim": 45, "removal": 4.6, "smoothness": 15.0}}
+        ctrl = ap.AttentionGeometryRemover(["", ""], c["steps"], {"default_": 0.9}, 0.9, image_mask=inp["mask"], obj_edit_step=1.0,
+                                           device="cpu")
     ctrl.default_loss_weights = lw
     ctrl.initialize_default_loss_weights()
     ddim = [torch.from_numpy(a) for a in inp["ddim_latents"]]
@@ -416,19 +421,19 @@ def g18_loop(R):
                                                guidance_scale=c["guidance"], uncond_embeddings=None, transform_coordinates=coords,
                                                mask_obj=mask, optimize_steps=c["optimize_steps"], latent_replace=c["latent_replace"], lr=c["lr"],
                                                optimize_embeddings=True, optimize_latents=True, ddim_latents=ddim, ddim_noise=None,
-                                               edit_type="geometry_editor", fast_start_steps=0.0, num_first_optim_steps=1,
+                                               edit_type=kind, fast_start_steps=0.0, num_first_optim_steps=1,
                                                use_adaptive_optimization=True, return_type="latents")
     ap.reshape_transform_coords = orig_rtc
     out = {"latents": lat.detach(), "steps": np.array(sorted(log))}
     for i, d in log.items():
-        for kind in ("self", "cross"):
-            for k, v in d[kind].items():
-                out[f"log_{i}_{kind}_{k}"] = np.array(float(v))
+        for att in ("self", "cross"):
+            for k, v in d[att].items():
+                out[f"log_{i}_{att}_{k}"] = np.array(float(v))
         out[f"log_{i}_num_layers"] = np.array(d["num_layers"])
     w = torch.cat([p.detach().reshape(-1)[:64] for p in pipe.unet.parameters()])
     out["weight_probe"] = w                                         # to recognise the same seeded weights on the test machine
     out["final_weights_self_removal"] = np.array(float(ctrl.loss_weight_dict["self"]["removal"]))
-    save("G18_loop", **out)
+    save("G18_loop" if kind == "geometry_editor" else "G19_loop_remover", **out)
 
 
 def g16_batch_config():
@@ -467,6 +472,7 @@ def main():
         R = ref_import.import_reference()
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         print("G18"); g18_loop(R)
+        print("G19"); g18_loop(R, "geometry_remover")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "G17":
         R = ref_import.import_reference()

@@ -312,7 +312,8 @@ def test_edits_are_independent_of_history(pipe):
     assert rel_l2(lat_b, lat_a) < max(5 * noise, 5e-2)
 
 
-def test_loop_matches_reference_driver_g18(pipe):
+@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover"])
+def test_loop_matches_reference_driver_g18(pipe, kind):
     """Loop-level parity: fixture G18 is the REFERENCE's own text2image_ldm_stable (its processors, controller, _update_latent,
     adaptive schedule, latent replacement / warp) run on CPU in fp32 over the same narrow SD-topology UNet (same seeded weights) and the
     same seeded trajectory.  Here the same call runs through the HIP path in fp16.  Differences are rounding only (16-bit storage, the
@@ -320,9 +321,9 @@ def test_loop_matches_reference_driver_g18(pipe):
     (step order, cur_step bookkeeping, which latent is replaced / warped when, the weight schedule) would show up at order 1."""
     import cases
     from geodiffuser_amd import editor
-    from geodiffuser_amd.attention_processors import AttentionGeometryEdit, VanillaAttentionProcessor
+    from geodiffuser_amd.attention_processors import AttentionGeometryEdit, AttentionGeometryRemover, VanillaAttentionProcessor
     from geodiffuser_amd.generic_torch import torch_erode
-    g = load("G18_loop")
+    g = load("G18_loop" if kind == "geometry_editor" else "G19_loop_remover")
     p, tok, sched = pipe
     probe = torch.cat([q.detach().float().reshape(-1)[:64] for q in p.unet.parameters()]).cpu()
     if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=2e-3):
@@ -330,11 +331,16 @@ def test_loop_matches_reference_driver_g18(pipe):
     c = cases.LOOP
     inp = cases.loop_inputs()
     coords = torch.from_numpy(inp["coords"])
-    lw = {"self": {"sim": 55, "movement": 30.5, "removal": 2.6, "smoothness": 30.0, "amodal": 80.5},
-          "cross": {"sim": 45, "movement": 30.34, "removal": 2.6, "smoothness": 15.0, "amodal": 3.5}}
-    ctrl = AttentionGeometryEdit(["", ""], c["steps"], {"default_": c["cross_replace"]}, c["self_replace"], image_mask=inp["mask"],
-                                 obj_edit_step=c["obj_edit_step"], device="cuda:0")
-    ctrl.amodal_mask = torch_erode(torch.from_numpy(cases.amodal_input(inp["mask"], dx=32, dy=-12)))
+    if kind == "geometry_editor":
+        lw = {"self": {"sim": 55, "movement": 30.5, "removal": 2.6, "smoothness": 30.0, "amodal": 80.5},
+              "cross": {"sim": 45, "movement": 30.34, "removal": 2.6, "smoothness": 15.0, "amodal": 3.5}}
+        ctrl = AttentionGeometryEdit(["", ""], c["steps"], {"default_": c["cross_replace"]}, c["self_replace"], image_mask=inp["mask"],
+                                     obj_edit_step=c["obj_edit_step"], device="cuda:0")
+        ctrl.amodal_mask = torch_erode(torch.from_numpy(cases.amodal_input(inp["mask"], dx=32, dy=-12)))
+    else:
+        lw = {"self": {"sim": 55, "removal": 4.6, "smoothness": 30.0}, "cross": {"sim": 45, "removal": 4.6, "smoothness": 15.0}}
+        ctrl = AttentionGeometryRemover(["", ""], c["steps"], {"default_": 0.9}, 0.9, image_mask=inp["mask"], obj_edit_step=1.0,
+                                        device="cuda:0")
     ctrl.default_loss_weights = lw
     ctrl.initialize_default_loss_weights()
     prev = (editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS, editor.SKIP_UNCOND_REF)
@@ -352,7 +358,7 @@ def test_loop_matches_reference_driver_g18(pipe):
                 p, ["", ""], ctrl, latent=torch.from_numpy(inp["x_T"]).to("cuda").half(), num_inference_steps=c["steps"],
                 guidance_scale=c["guidance"], uncond_embeddings=None, transform_coordinates=coords, mask_obj=torch.from_numpy(inp["mask"]),
                 optimize_steps=c["optimize_steps"], latent_replace=c["latent_replace"], lr=c["lr"], optimize_embeddings=True,
-                optimize_latents=True, ddim_latents=ddim, ddim_noise=None, edit_type="geometry_editor", fast_start_steps=0.0,
+                optimize_latents=True, ddim_latents=ddim, ddim_noise=None, edit_type=kind, fast_start_steps=0.0,
                 num_first_optim_steps=1, use_adaptive_optimization=True, return_type="latents", image_size=c["size"])
             runs.append((lat.float().cpu(), log, float(ctrl.loss_weight_dict["self"]["removal"])))
     finally:
@@ -366,7 +372,9 @@ def test_loop_matches_reference_driver_g18(pipe):
             for k, v in log[first][kind].items():                                       # first pass: inputs identical -> 16-bit rounding only
                 ref = float(g[f"log_{first}_{kind}_{k}"])
                 print(f"[G18] first pass {kind}/{k}: {float(v):.5f} vs {ref:.5f}")
-                assert abs(float(v) - ref) <= 2e-2 * abs(ref) + 1e-4, (kind, k, float(v), ref)
+                # (absolute floor: an L1 mean of two 16-bit-rounded attention outputs that are EQUAL in exact arithmetic — the remover's
+                #  background term, which is 0.0 in the fp32 reference — sits at the rounding noise, ~1.5e-4)
+                assert abs(float(v) - ref) <= 2e-2 * abs(ref) + 5e-4, (kind, k, float(v), ref)
             assert log[first]["num_layers"] == int(g[f"log_{first}_num_layers"])
         last = int(g["steps"][-1])
         for kind in ("self", "cross"):

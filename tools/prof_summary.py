@@ -29,10 +29,14 @@ def main():
     busy, cur_end = 0.0, t_first
     gaps = collections.Counter()
     by_grid = collections.defaultdict(lambda: [0, 0.0])
+    big = [0, 0.0]                      # 64^2 self-attention launches: >= 320 workgroups AND >= 35 us (77-key cross attention at 64^2 has
+    #                                     the same workgroup count but runs ~8 us, 32^2 self-attention with 40 heads ~29 us)
     for s, e, n, wgs in rows:
         if "k_attn_fwd" in n:
             g = by_grid[wgs]
             g[0] += 1; g[1] += (e - s) * 1e-3
+            if wgs >= 320 and (e - s) >= 35000:
+                big[0] += 1; big[1] += (e - s) * 1e-3
         a = agg[n]
         d = (e - s) * 1e-3
         a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
@@ -66,8 +70,11 @@ def main():
         fh.write(f"\nown kernels total {sum(a[1] for _, a in own) * 1e-3:.1f} ms of {tot:.1f} ms\n")
         if by_grid:
             fh.write("\n## k_attn_fwd by launch size (workgroups = 128-query tiles x heads x key splits)\n\n"
-                     "The 64^2 self-attention launches that bench.py's `roofline` is computed from are the ones with >= 320 workgroups "
-                     "(32 query tiles x 10-20 heads, x key splits); the rest are 32^2 / 16^2 / 8^2 layers and 77-key cross attention.\n\n"
+                     "bench.py's `roofline` is computed from the 64^2 SELF-attention launches (N = M = 4096): 32 query tiles x 5-20 heads x 1-4 key "
+                     "splits = 320-640 workgroups.  64^2 CROSS attention (77 keys) has the same workgroup counts but runs ~8 us, so the classes "
+                     "below mix the two (and the 320 class also holds the 40-head 32^2 launches, ~29 us); the launches of those classes that take >= 35 us are the 64^2 self-attention ones:\n\n"
+                     f"* **64^2 self-attention launches: {big[0]}, total {big[1] * 1e-3:.1f} ms, average {big[1] / max(1, big[0]):.1f} us** "
+                     "(bench.py's `avg_launch_us` additionally contains the ~6 us split-KV merge kernel of the inversion-pass launches)\n\n"
                      "| workgroups | launches | total ms | avg us |\n|---|---|---|---|\n")
             for wgs, (cnt, us) in sorted(by_grid.items(), key=lambda kv: -kv[1][1])[:16]:
                 fh.write(f"| {wgs} | {cnt} | {us * 1e-3:.1f} | {us / cnt:.1f} |\n")

@@ -370,7 +370,7 @@ def g17_attention_store(R, packs):
     save("G17_attention_store", **out)
 
 
-def g18_loop(R, kind="geometry_editor"):
+def g18_loop(R, kind="geometry_editor", cfg=None, name=None):
     """The reference's own per-step driver (``text2image_ldm_stable``, U/editor.py:65-423: optimisation pass -> _update_latent ->
     adaptive schedule -> CFG pass -> reference-latent replacement -> latent warp) with its own processors / controller, driving the
     narrow SD-topology UNet of geodiffuser_amd (seeded random weights, fp32, CPU) through a CPU DDIM scheduler built from the
@@ -379,8 +379,8 @@ def g18_loop(R, kind="geometry_editor"):
     from types import SimpleNamespace
     from geodiffuser_amd.pipeline import build_random_sd21
     import ref_cpu as O
-    c = cases.LOOP
-    inp = cases.loop_inputs()
+    c = cfg or cases.LOOP
+    inp = cases.loop_inputs(c)
     pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=True)
 
     class CpuDDIM:
@@ -433,7 +433,7 @@ def g18_loop(R, kind="geometry_editor"):
     w = torch.cat([p.detach().reshape(-1)[:64] for p in pipe.unet.parameters()])
     out["weight_probe"] = w                                         # to recognise the same seeded weights on the test machine
     out["final_weights_self_removal"] = np.array(float(ctrl.loss_weight_dict["self"]["removal"]))
-    save("G18_loop" if kind == "geometry_editor" else "G19_loop_remover", **out)
+    save(name or ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover"), **out)
 
 
 def g16_batch_config():
@@ -473,6 +473,7 @@ def main():
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         print("G18"); g18_loop(R)
         print("G19"); g18_loop(R, "geometry_remover")
+        print("G20"); g18_loop(R, "geometry_editor", cases.LOOP_CFG0, "G20_loop_cfg0")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "G17":
         R = ref_import.import_reference()

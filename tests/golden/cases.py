@@ -217,9 +217,13 @@ LOOP = dict(size=256, steps=6, guidance=3.0, skip_optim=2, optimize_steps=0.65, 
             self_replace=0.95, cross_replace=0.95, seed=77)
 
 
-def loop_inputs():
+# BASELINE configs[0]: single 256 x 256 image, 2-D translation edit, 20-step DDIM (the reference's own CPU-runnable case)
+LOOP_CFG0 = dict(LOOP, steps=20, seed=78)
+
+
+def loop_inputs(c=None):
     """-> dict(mask [256,256] f32, coords [1,256,256,3] f32, x_T [1,4,32,32], ddim_latents list of steps+1 [1,4,32,32])."""
-    c = LOOP
+    c = c or LOOP
     size = c["size"]
     mask = ellipse_mask(cx=118.0, cy=131.0, ax=35.0, ay=29.0, size=size)
     coords = coords_translate(dx_px=32.0, dy_px=-12.0, z=0.5, size=size)

@@ -312,7 +312,7 @@ def test_edits_are_independent_of_history(pipe):
     assert rel_l2(lat_b, lat_a) < max(5 * noise, 5e-2)
 
 
-@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover"])
+@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0"])
 def test_loop_matches_reference_driver_g18(pipe, kind):
     """Loop-level parity: fixture G18 is the REFERENCE's own text2image_ldm_stable (its processors, controller, _update_latent,
     adaptive schedule, latent replacement / warp) run on CPU in fp32 over the same narrow SD-topology UNet (same seeded weights) and the
@@ -323,13 +323,16 @@ def test_loop_matches_reference_driver_g18(pipe, kind):
     from geodiffuser_amd import editor
     from geodiffuser_amd.attention_processors import AttentionGeometryEdit, AttentionGeometryRemover, VanillaAttentionProcessor
     from geodiffuser_amd.generic_torch import torch_erode
-    g = load("G18_loop" if kind == "geometry_editor" else "G19_loop_remover")
+    cfg0 = kind == "cfg0"                # BASELINE configs[0]: 256 x 256, 2-D translation, 20-step DDIM (7 optimisation passes)
+    if cfg0:
+        kind = "geometry_editor"
+    g = load("G20_loop_cfg0" if cfg0 else ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover"))
     p, tok, sched = pipe
     probe = torch.cat([q.detach().float().reshape(-1)[:64] for q in p.unet.parameters()]).cpu()
     if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=2e-3):
         pytest.skip("seeded weights differ from the fixture's (different torch build): the fixture does not apply")
-    c = cases.LOOP
-    inp = cases.loop_inputs()
+    c = cases.LOOP_CFG0 if cfg0 else cases.LOOP
+    inp = cases.loop_inputs(c)
     coords = torch.from_numpy(inp["coords"])
     if kind == "geometry_editor":
         lw = {"self": {"sim": 55, "movement": 30.5, "removal": 2.6, "smoothness": 30.0, "amodal": 80.5},
@@ -380,9 +383,9 @@ def test_loop_matches_reference_driver_g18(pipe, kind):
         for kind in ("self", "cross"):
             for k, v in log[last][kind].items():
                 ref = float(g[f"log_{last}_{kind}_{k}"])
-                assert abs(float(v) - ref) <= 0.15 * abs(ref) + 1e-3, (kind, k, float(v), ref)
+                assert abs(float(v) - ref) <= (0.3 if cfg0 else 0.15) * abs(ref) + 1e-3, (kind, k, float(v), ref)
         assert w_rm == pytest.approx(float(g["final_weights_self_removal"]), rel=1e-6)   # the adaptive schedule took the same branches
         assert lat.shape == ref_lat.shape
         assert torch.equal(lat[0], ref_lat[0].half().float())                           # reference row = the trajectory's last replacement
         print(f"[G18] edit-latent rel_l2 vs the reference driver: {rel_l2(lat[1], ref_lat[1]):.4f}")
-        assert rel_l2(lat[1], ref_lat[1]) < 0.06                                         # measured 0.022 (fp16 HIP path vs fp32 CPU reference)
+        assert rel_l2(lat[1], ref_lat[1]) < (0.04 if cfg0 else 0.06)     # measured 0.007 (cfg0, 20 steps) / 0.022 / 0.018; fp16 HIP path vs fp32 CPU reference

@@ -106,7 +106,7 @@ class AttnTimer:
         self._graph_cfgs = {}
         G.capture_begin, G.replay = capture_begin, replay
 
-    def replay(self, reps=20):
+    def replay(self, reps=100):
         """Re-issue every configuration that ran in the timed region, back to back (outside the timed region).  Event brackets
         around isolated eager launches also contain the launch latency of an idle queue (+20-40 us); the back-to-back samples agree
         with rocprofv3's kernel durations and are the ones reported, the in-region eager samples are kept as ``eager_avg_us``."""
@@ -119,7 +119,8 @@ class AttnTimer:
                 q = torch.randn(qs, device="cuda").to(dt); k = torch.randn(ks, device="cuda").to(dt); v = torch.randn(ks, device="cuda").to(dt)
                 lse = torch.empty(qs[0] * (heads if heads else 1), qs[1], device="cuda") if want_lse else None
                 segs.append((q, k, v, torch.empty_like(q), lse))
-            self._orig(segs, scale, heads)                 # warm
+            for _ in range(30):                            # warm: clocks ramp down while the host builds the tensors above
+                self._orig(segs, scale, heads)
             # one event bracket around `reps` back-to-back launches: the queue stays full, so host dispatch time is not measured
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -8,8 +8,8 @@
 //   k_attn_bwd_dq : same swapped geometry as the forward.  S^T = K Q^T and dP^T = V dO^T have the query on the
 //                   lane, so P, dS = P o (dP - delta) stay lane-local and dS (16-bit) is directly the B operand
 //                   of dQ^T += K^T dS^T (K^T by hardware-transposed LDS read).  No atomics, no [N,N] traffic.
-//   k_attn_bwd_dk : cross-attention only (M <= 128 keys): one thread pair per key, queries broadcast from LDS,
-//                   fp32 atomics into dk_f32.  0.6 GFLOP per 64^2 layer — VALU is plenty.
+//   k_attn_bwd_dk : cross-attention only (M <= 128 keys): key on the MFMA lane, query tiles streamed through LDS, per-chunk
+//                   partial dK summed by a second kernel (see below).
 // MFMA-bound (dq): algorithmic FLOPs = 6 * BH * N * M * D.
 #include "attn_common.hpp"
 
@@ -119,18 +119,24 @@ k_attn_bwd_dq(const BwdArgs a) {
     }
 }
 
-// ---- dK for cross-attention (few keys) -------------------------------------------------------------
-#define DK_QCHUNK 64
-#define DK_CHUNKS 1      // query chunks per workgroup
+// ---- dK for cross-attention (M <= 128 keys) on the matrix cores ------------------------------------------
+// The forward's geometry with the roles swapped: the KEY sits on the MFMA lane (4 waves x 32 keys = every key of a 77-key text
+// context in one workgroup, K / V fragments in registers for the whole kernel) and 64-query tiles of Q and dO stream through LDS.
+//   S[q, key]  = Q_tile K^T,   dP[q, key] = dO_tile V^T           (A = row fragments of the LDS tile, B = K / V registers)
+//   dS = P o (dP - delta[q]),  P = exp2(c S - lse[q] log2 e)      (per-ROW constants: broadcast reads from a small LDS table)
+//   dK^T[d, key] += Q_tile^T dS                                   (A = hardware-transposed read of the SAME Q tile, B = dS as it
+//                                                                  leaves the accumulators — the forward's P.V trick)
+// One workgroup per (head, DK_QCHUNK queries); the per-chunk partials are summed by k_attn_bwd_dk_reduce (no atomics).
+#define DK_QCHUNK 128
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_attn_bwd_dk(const BwdArgs a) {
     using TR = elem_traits<T>;
-    __shared__ float sq[DK_QCHUNK][ATT_D + 1];
-    __shared__ float sg[DK_QCHUNK][ATT_D + 1];
-    __shared__ float slse[DK_QCHUNK], sdelta[DK_QCHUNK];
-    const int tid = threadIdx.x;
-    const int bh = blockIdx.y;
+    using V8 = typename TR::vec8;
+    __shared__ __attribute__((aligned(16))) char lds[2][ATT_TILE_BYTES];      // [Q | dO] tile images
+    __shared__ float s_lse2[ATT_BN], s_delta[ATT_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int bh = blockIdx.y, chunk = blockIdx.x;
     const int N = a.N, M = a.M;
     const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * ATT_D;
     const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * ATT_D;
@@ -138,62 +144,79 @@ k_attn_bwd_dk(const BwdArgs a) {
     const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * ATT_D;
     const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * ATT_D;
 
-    const int key = tid >> 1, half = tid & 1;       // 128 keys x 2 feature halves
-    const bool valid = key < M;
-    float kreg[32], vreg[32], acc[32];
+    const int key = wave * 32 + (lane & 31);
+    const int kld = key < M ? key : M - 1;
+    V8 kf[4], vf[4];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        kreg[j] = valid ? TR::to_f32(kp[(size_t)key * ATT_D + half * 32 + j]) : 0.f;
-        vreg[j] = valid ? TR::to_f32(vp[(size_t)key * ATT_D + half * 32 + j]) : 0.f;
-        acc[j] = 0.f;
+    for (int s = 0; s < 4; ++s) {
+        kf[s] = *(const V8*)(kp + (size_t)kld * ATT_D + 16 * s + 8 * h);
+        vf[s] = *(const V8*)(vp + (size_t)kld * ATT_D + 16 * s + 8 * h);
     }
-    for (int ch = 0; ch < DK_CHUNKS; ++ch) {
-        const int q0 = (blockIdx.x * DK_CHUNKS + ch) * DK_QCHUNK;
-        if (q0 >= N) break;
-        __syncthreads();
-        // stage 64 queries: thread (qq = tid/4, part = tid%4) handles 16 features
-        {
-            const int qq = tid >> 2, part = tid & 3;
-            const int qi = q0 + qq;
+    f32x16 dk[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; }
+
+    const int q_begin = chunk * DK_QCHUNK;
+    const int q_end = (q_begin + DK_QCHUNK) < N ? (q_begin + DK_QCHUNK) : N;
+    for (int q0 = q_begin; q0 < q_end; q0 += ATT_BN) {
+        u32x4 qr[2], gr[2], orr[2];
+        tile_load<T>(qp, q0, N, tid, qr);
+        tile_load<T>(gp, q0, N, tid, gr);
+        tile_load<T>(op, q0, N, tid, orr);
+        __syncthreads();                                  // the previous tile's reads are done
+        tile_store(lds[0], tid, qr);
+        tile_store(lds[1], tid, gr);
+        // delta[row] = sum_d dO o O: this thread holds chunk (tid & 7) of rows (tid >> 3) and (tid >> 3) + 32
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const V8 g8 = __builtin_bit_cast(V8, gr[i]), o8 = __builtin_bit_cast(V8, orr[i]);
             float d = 0.f;
-            for (int j = 0; j < 16; ++j) {
-                const int dd = part * 16 + j;
-                float qv = 0.f, gv = 0.f, ov = 0.f;
-                if (qi < N) {
-                    qv = TR::to_f32(qp[(size_t)qi * ATT_D + dd]);
-                    gv = TR::to_f32(gp[(size_t)qi * ATT_D + dd]);
-                    ov = TR::to_f32(op[(size_t)qi * ATT_D + dd]);
-                }
-                sq[qq][dd] = qv; sg[qq][dd] = gv;
-                d = __builtin_fmaf(gv, ov, d);
-            }
-            d += __shfl_xor(d, 1, 64);
-            d += __shfl_xor(d, 2, 64);
-            if (part == 0) {
-                sdelta[qq] = d;
-                slse[qq] = qi < N ? a.lse[(size_t)bh * N + qi] : INFINITY;     // exp(-inf) = 0 for padding queries
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d = __builtin_fmaf(TR::to_f32(g8[j]), TR::to_f32(o8[j]), d);
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            if ((tid & 7) == 0) {
+                const int row = (tid >> 3) + 32 * i, qi = q0 + row;
+                s_delta[row] = d;
+                s_lse2[row] = qi < N ? a.lse[(size_t)bh * N + qi] * a.l2e : INFINITY;     // exp2(-inf) = 0 for padding queries
             }
         }
         __syncthreads();
-        for (int qq = 0; qq < DK_QCHUNK; ++qq) {
-            float s_ = 0.f, dp = 0.f;
+        V8 dsf[4];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                s_ = __builtin_fmaf(sq[qq][half * 32 + j], kreg[j], s_);
-                dp = __builtin_fmaf(sg[qq][half * 32 + j], vreg[j], dp);
+        for (int blk = 0; blk < 2; ++blk) {
+            f32x16 s_acc, p_acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s_acc[i] = 0.f; p_acc[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(read_row_frag<T>(lds[0], blk, s, lane), kf[s], s_acc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) p_acc = TR::mfma32(read_row_frag<T>(lds[1], blk, s, lane), vf[s], p_acc);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = blk * 32 + acc_key(i, h);                 // query row of accumulator register i
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], a.c, -s_lse2[row]));
+                if (key >= M) p = 0.f;
+                s_acc[i] = p * (p_acc[i] - s_delta[row]);
             }
-            s_ += __shfl_xor(s_, 1, 64);
-            dp += __shfl_xor(dp, 1, 64);
-            const float p = __expf(s_ * a.scale - slse[qq]);
-            const float ds = p * (dp - sdelta[qq]) * a.scale;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) acc[j] = __builtin_fmaf(ds, sq[qq][half * 32 + j], acc[j]);
+            dsf[2 * blk] = acc_to_frag<T>(s_acc, 0);
+            dsf[2 * blk + 1] = acc_to_frag<T>(s_acc, 1);
         }
-    }
-    if (valid) {          // partial dK of this query chunk (plain stores; summed by k_attn_bwd_dk_reduce)
-        float* dst = a.dk_part + (((size_t)bh * gridDim.x + blockIdx.x) * M + key) * ATT_D + half * 32;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) dst[j] = acc[j];
+        for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dk[dblk] = TR::mfma32(read_tr_frag<T>(lds[0], dblk, ks, lane), dsf[ks], dk[dblk]);
+    }
+    if (key < M) {            // partial dK of this query chunk (plain stores; summed by k_attn_bwd_dk_reduce)
+        float* dst = a.dk_part + (((size_t)bh * gridDim.x + chunk) * M + key) * ATT_D;
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = dk[dblk][4 * g + j] * a.scale;
+                *(f32x4*)(dst + dblk * 32 + 8 * g + 4 * h) = w;
+            }
     }
 }
 
@@ -209,7 +232,7 @@ __global__ void k_attn_bwd_dk_reduce(const float* __restrict__ part, int nchunks
 
 extern "C" size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk) {
     if (!need_dk) return 0;
-    const size_t chunks = (size_t)(N + DK_QCHUNK * DK_CHUNKS - 1) / (DK_QCHUNK * DK_CHUNKS);
+    const size_t chunks = (size_t)(N + DK_QCHUNK - 1) / DK_QCHUNK;
     return (size_t)BH * chunks * M * D * sizeof(float);
 }
 
@@ -235,7 +258,7 @@ extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const vo
     if (dtype == GD_F16) k_attn_bwd_dq<f16_t><<<a.nwg, 256, 0, st>>>(a);
     else k_attn_bwd_dq<bf16_t><<<a.nwg, 256, 0, st>>>(a);
     if (dk_f32) {
-        dim3 grid((N + DK_QCHUNK * DK_CHUNKS - 1) / (DK_QCHUNK * DK_CHUNKS), BH);
+        dim3 grid((N + DK_QCHUNK - 1) / DK_QCHUNK, BH);
         if (dtype == GD_F16) k_attn_bwd_dk<f16_t><<<grid, 256, 0, st>>>(a);
         else k_attn_bwd_dk<bf16_t><<<grid, 256, 0, st>>>(a);
         dim3 rgrid((M * ATT_D + 255) / 256, BH);

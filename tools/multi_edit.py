@@ -16,5 +16,5 @@ for it in [int(a) for a in sys.argv[1:]]:
     if os.environ.get('DBG_GC') == '1':
         import gc; gc.collect(); torch.cuda.empty_cache()
     print('   removal(self) per opt step:', [round(float(v['self']['removal']), 3) for v in log.values()], flush=True)
-    print(it, f"{time.perf_counter()-t0:.3f}s", "opt graphs:", len(graphs._OPT_GRAPHS), [k[2] for k in graphs._OPT_GRAPHS], flush=True)
+    print(it, f"{time.perf_counter()-t0:.3f}s", f"reserved {torch.cuda.memory_reserved()/2**30:.1f} GiB", "opt graphs:", len(graphs._OPT_GRAPHS), [k[2] for k in graphs._OPT_GRAPHS], flush=True)
 print("done", flush=True)

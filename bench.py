@@ -158,6 +158,13 @@ class AttnTimer:
         except Exception:  # noqa: BLE001
             pass
         rows.sort(key=lambda r: -r["launches"])
+        # launch-count-weighted mean over the configurations, like `achieved`
+        try:
+            tw = [(r["launches"], tab.get(str(r["heads"]))) for r in rows]
+            if all(t is not None for _, t in tw):
+                traffic = int(sum(c * t for c, t in tw) / sum(c for c, _ in tw))
+        except Exception:  # noqa: BLE001
+            pass
         return dict(launches=n, avg_us=t_us / n, flops_per_launch=fl / n, achieved=fl / (t_us * 1e-6), traffic=traffic, configs=rows)
 
 

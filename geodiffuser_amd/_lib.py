@@ -18,7 +18,8 @@ GD_ATTN_MAX_SEGS = 4
 
 class GdAttnSeg(Structure):
     _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("lse", c_void_p),
-                ("bh", c_int32), ("heads", c_int32)]
+                ("bh", c_int32), ("heads", c_int32),
+                ("warp_idx", c_void_p), ("warp_w", c_void_p), ("warp_m", c_void_p), ("warp_K", c_int32), ("q_scaled", c_int32)]
 
 
 class GeodiffError(RuntimeError):
@@ -39,6 +40,7 @@ SIGNATURES = {
     "gd_mesh_coverage": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gd_attn_fwd": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "gd_attn_fwd_plan": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
+    "gd_attn_fwd_set_config": (c_int, [c_int, c_int]),
     "gd_attn_fwd_splitkv": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "gd_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "gd_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -55,8 +57,10 @@ SIGNATURES = {
     "gd_nn_table": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_amodal_target": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_int, c_void_p]),
+    "gd_edit_losses_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gd_edit_losses_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+                                   c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "gd_removal_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "gd_edit_losses_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gd_blend_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
@@ -97,8 +101,8 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
             raise GeodiffError(f"libgeodiff_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.gd_version() != 1:
-        raise GeodiffError(f"ABI version mismatch: library {lib.gd_version()} != binding 1")
+    if lib.gd_version() != 2:
+        raise GeodiffError(f"ABI version mismatch: library {lib.gd_version()} != binding 2")
     _lib = lib
     return lib
 

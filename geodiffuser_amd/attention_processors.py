@@ -89,7 +89,17 @@ def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_
     if getattr(attn, "group_norm", None) is not None:
         hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
     lin_args = args if getattr(attn, "linear_takes_scale", False) else ()
-    query = attn.to_q(hidden_states, *lin_args)
+    q_scaled = False
+    if token_major and SCALED_Q and not lin_args and type(attn.to_q) is torch.nn.Linear and attn.to_q.bias is None:
+        # q' = 16-bit(scale*log2(e) * (x W^T)): the softmax scale and the base change applied as the GEMM's alpha in its fp32
+        # epilogue, BEFORE the one rounding to 16 bits (no extra rounding, unlike scaling a rounded q).  The attention kernels
+        # then compute p = exp2(q'.k - mu) with one vector instruction per probability (gd_attn_seg_t::q_scaled).
+        w = attn.to_q.weight
+        x2 = hidden_states.reshape(-1, hidden_states.shape[-1])
+        query = torch.addmm(w[:, 0], x2, w.t(), beta=0.0, alpha=float(attn.scale) * LOG2E).view(*hidden_states.shape[:-1], w.shape[0])
+        q_scaled = True
+    else:
+        query = attn.to_q(hidden_states, *lin_args)
     is_cross = True
     if encoder_hidden_states is None:
         encoder_hidden_states = hidden_states
@@ -101,14 +111,17 @@ def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_
     if token_major:
         # to_q/to_k/to_v output [B, N, heads*D] is consumed in place by the attention kernel's token-major mode: the
         # reference's head_to_batch_dim / batch_to_head_dim permutes (4 copies per layer) disappear
-        return query.contiguous(), key.contiguous(), value.contiguous(), is_cross, shape4, lin_args
+        return query.contiguous(), key.contiguous(), value.contiguous(), is_cross, shape4, lin_args, q_scaled
     query = attn.head_to_batch_dim(query).contiguous()
     key = attn.head_to_batch_dim(key).contiguous()
     value = attn.head_to_batch_dim(value).contiguous()
-    return query, key, value, is_cross, shape4, lin_args
+    return query, key, value, is_cross, shape4, lin_args, False
 
 
 TOKEN_MAJOR = os.environ.get("GD_TOKEN_MAJOR", "1") == "1"
+SCALED_Q = os.environ.get("GD_SCALED_Q", "1") == "1"      # token-major passes: scale*log2(e) folded into the query projection
+LOG2E = 1.4426950408889634
+FUSED_WARP = os.environ.get("GD_FUSED_WARP", "1") == "1"   # build the warped queries inside the attention launch
 
 
 def _tok_ok(attn, hidden_states) -> bool:
@@ -138,8 +151,8 @@ class VanillaAttentionProcessor:
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale: float = 1.0):
         residual = hidden_states
         tok = _tok_ok(attn, hidden_states)
-        q, k, v, _, shape4, lin_args = _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, tok)
-        out = attention_tok(q, k, v, attn.scale, attn.heads) if tok else attention(q, k, v, attn.scale)
+        q, k, v, _, shape4, lin_args, qs = _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, tok)
+        out = attention_tok(q, k, v, attn.scale, attn.heads, q_scaled=qs) if tok else attention(q, k, v, attn.scale)
         return _finish(attn, out, residual, shape4, lin_args, tok)
 
 
@@ -162,17 +175,19 @@ class EditProcessor:
         # losses (use_cfg False) and stored maps stay on the head-major path
         tok = _tok_ok(attn, hidden_states) and (not self.perform_edit or (
             getattr(ctrl, "supports_token_major", False) and ctrl.use_cfg and not getattr(ctrl, "store_attention_maps", False)))
-        q, k, v, is_cross, shape4, lin_args = _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, tok)
+        q, k, v, is_cross, shape4, lin_args, qs = _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, tok)
         if self.perform_edit:
             if tok:
                 ctrl.heads_tok = attn.heads
+                ctrl.q_scaled_tok = qs
             try:
                 out = ctrl(q, k, v, is_cross=is_cross, place_in_unet=self.place_in_unet,
                            transform_coords=self.transform_coords, scale=attn.scale, mask=None)
             finally:
                 ctrl.heads_tok = 0
+                ctrl.q_scaled_tok = False
         else:
-            out = attention_tok(q, k, v, attn.scale, attn.heads) if tok else attention(q, k, v, attn.scale)
+            out = attention_tok(q, k, v, attn.scale, attn.heads, q_scaled=qs) if tok else attention(q, k, v, attn.scale)
         return _finish(attn, out, residual, shape4, lin_args, tok)
 
 
@@ -280,10 +295,14 @@ class _EditLayer(torch.autograd.Function):
         lse_e = torch.empty(f, N, dtype=torch.float32, device=dev) if (grad_mode or want_losses or store) else None
         ident_out = None
         if not remover:
-            # q_warp = q_base*(1-m) + m*splat(q_base)                       (:424,544)
-            q_warp = ops.splat_composite(q_base, c["idx"], c["w"], c["m_edit"], GD_TOKEN_MAJOR)
+            # q_warp = q_base*(1-m) + m*splat(q_base) (:424,544), built in the attention kernel's prologue from the splat tables
+            # (the fused attention-warp launch; bit-identical to the separate gd_splat_composite launch, GD_FUSED_WARP=0)
             edit_out = torch.empty(f, N, D, dtype=dt, device=dev)
-            segs.append((q_warp, k_base, v_base, edit_out, None))           # :427-428,548-549
+            if FUSED_WARP:
+                segs.append((q_base, k_base, v_base, edit_out, None, (c["idx"], c["w"], c["m_edit"])))       # :427-428,548-549
+            else:
+                q_warp = ops.splat_composite(q_base, c["idx"], c["w"], c["m_edit"], GD_TOKEN_MAJOR)
+                segs.append((q_warp, k_base, v_base, edit_out, None))
             K = k_edit if is_cross else k_base                              # :432 / :555
         else:
             edit_out = None                                                 # :786,879 vanilla reference output (below)
@@ -540,9 +559,15 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         return c
 
     def table_signature(self):
-        """What a captured optimisation pass bakes in besides graph_key(): the (padded) inpaint-row count per resolution."""
-        return tuple(sorted((S, c["rows"].numel() if S * S >= 32 ** 2 else 0, c["f"])        # losses exist only at N >= 32^2
+        """What a captured pass bakes in besides graph_key(): per resolution the (padded) inpaint-row count, the head count and the
+        slot count K of the splat tables — i.e. every launch dimension / buffer shape that comes from the per-resolution tables
+        (``_persist`` keys its buffers on shape: a different K lives in different buffers, so it must be a different graph)."""
+        return tuple(sorted((S, c["rows"].numel() if S * S >= 32 ** 2 else 0, c["f"],            # losses exist only at N >= 32^2
+                             int(c["idx"].shape[-1]) if "idx" in c else 0)
                             for S, c in self.masks_cache_dict.items() if "f" in c))
+
+    def tables_built(self, layers) -> bool:
+        return all(S in self.masks_cache_dict and "f" in self.masks_cache_dict[S] for S, _ in layers)
 
     def prebuild_tables(self, layers, q_like: torch.Tensor, transform_coords):
         """Build the per-resolution tables for the (S, heads) pairs of a previous pass now (one host sync each) instead of lazily
@@ -565,6 +590,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
 
     supports_token_major = True
     heads_tok = 0
+    q_scaled_tok = False
 
     def _forward_tok(self, q, k, v, is_cross: bool, transform_coords, scale: float, heads: int):
         """No-grad CFG pass on token-major q/k/v [B, N, heads*64]; the caller (EditProcessor) routes passes that accumulate
@@ -585,10 +611,13 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         if not remover:
             K = k_edit if is_cross else k_base
             if blend:
-                q_warp = ops.splat_composite(q_base, c["idx"], c["w"], c["m_edit"], GD_TOKEN_MAJOR)   # all heads in one row
                 edit_out = torch.empty_like(q_edit)
                 replace_out = torch.empty_like(q_edit)
-                segs.append((q_warp, k_base, v_base, edit_out, None))
+                if FUSED_WARP:                                  # warped queries built in the attention kernel's prologue
+                    segs.append((q_base, k_base, v_base, edit_out, None, (c["idx"], c["w"], c["m_edit"])))
+                else:
+                    q_warp = ops.splat_composite(q_base, c["idx"], c["w"], c["m_edit"], GD_TOKEN_MAJOR)   # all heads in one row
+                    segs.append((q_warp, k_base, v_base, edit_out, None))
         else:
             K = k_base
             if not blend:
@@ -596,7 +625,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
                 replace_out = torch.empty_like(q_edit)
                 segs.append((q_edit, k_edit, v_edit, ident_out, None))
         segs.append((q_edit, K, v_base, replace_out, None))
-        ops.attn_fwd(segs, scale, heads=heads)
+        ops.attn_fwd(segs, scale, heads=heads, q_scaled=self.q_scaled_tok)
         if edit_out is not None:
             ops.blend_tokens(edit_out, replace_out, c["m_edit"], out=out_full[cb:])
         elif ident_out is not None:
@@ -609,7 +638,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         heads = self.heads_tok
         if heads:
             if not active:
-                return attention_tok(q, k, v, scale, heads)
+                return attention_tok(q, k, v, scale, heads, q_scaled=self.q_scaled_tok)
             if is_cross:
                 _ = self.cross_replace_alpha[self.cur_step]
             return self._forward_tok(q, k, v, is_cross, transform_coords, float(scale), heads)

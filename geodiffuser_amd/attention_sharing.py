@@ -53,10 +53,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -
     return out
 
 
-def attention_tok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, heads: int) -> torch.Tensor:
-    """No-grad attention on the projections' own layout: q [B,N,heads*64], k/v [B,M,heads*64] -> [B,N,heads*64]."""
+def attention_tok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, heads: int, q_scaled: bool = False) -> torch.Tensor:
+    """No-grad attention on the projections' own layout: q [B,N,heads*64], k/v [B,M,heads*64] -> [B,N,heads*64].
+    q_scaled: q already carries scale*log2(e) (attention_processors._project_qkv)."""
     out = torch.empty_like(q)
-    ops.attn_fwd([(q, k, v, out, None)], scale, heads=heads)
+    ops.attn_fwd([(q, k, v, out, None)], scale, heads=heads, q_scaled=q_scaled)
     return out
 
 

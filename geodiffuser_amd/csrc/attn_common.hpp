@@ -20,6 +20,7 @@
 //   One image therefore serves both kinds of read (K in the backward is read both ways).
 #pragma once
 #include "common.hpp"
+#include "splat_common.hpp"
 
 #define ATT_D 64
 #define ATT_BM 128   // query rows per workgroup
@@ -98,3 +99,71 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + loc;
 }
+
+// ---- forward kernels: launch arguments and fragment helpers shared by attn_fwd.hip and attn_fwd_mp.hip ----
+struct FwdArgs {
+    gd_attn_seg_t seg[GD_ATTN_MAX_SEGS];
+    int bh_end[GD_ATTN_MAX_SEGS];   // exclusive prefix of bh
+    int nseg;
+    int N, M;
+    int tiles;                      // query tiles per (bh)
+    int nwg;
+    float c;                        // scale * log2(e)
+    float scale;
+    int q_prescaled;                // the queries already carry c (gd_attn_seg_t::q_scaled): scores arrive in the log2 domain
+    // split-KV (launches that would leave most CUs idle): split sp handles key tiles [sp*tps, (sp+1)*tps) and leaves an
+    // un-normalised partial (O, m, l) in the workspace; k_attn_combine merges them
+    int nsplit, tps, tot_bh;
+    float* ws_o;                    // [nsplit, tot_bh, N, 64] f32
+    float* ws_ml;                   // [nsplit, tot_bh, N, 2]  f32 (reference max, row sum)
+};
+
+// Per-lane LDS byte offsets of the fragment reads, computed once (the swizzle term does not depend on the k-step /
+// key block, which therefore become immediates): krd[s] for the row fragments, vrd[dblk][hh] for the transposed ones.
+struct FragOffs { int krd[4]; int vrd[2][2]; };
+
+__device__ __forceinline__ FragOffs make_frag_offs(int lane) {
+    FragOffs f;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f.krd[s] = img_off(r, 2 * s + h);
+    const int g1 = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+#pragma unroll
+    for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            f.vrd[dblk][hh] = img_off(8 * hh + 4 * h + q, dblk * 4 + g1 * 2 + (p >> 1)) + (p & 1) * 8;
+    return f;
+}
+
+template <typename T>
+__device__ __forceinline__ typename elem_traits<T>::vec8 rd_row(const char* lds, const FragOffs& f, int blk, int s) {
+    return *(const typename elem_traits<T>::vec8*)(lds + f.krd[s] + blk * 4096);
+}
+template <typename T>
+__device__ __forceinline__ typename elem_traits<T>::vec8 rd_tr(const char* lds, const FragOffs& f, int dblk, int ks) {
+    union { s16x4 v[2]; typename elem_traits<T>::vec8 x; } u;
+    u.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + f.vrd[dblk][0] + ks * 2048));
+    u.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + f.vrd[dblk][1] + ks * 2048));
+    return u.x;
+}
+
+// This lane's query row as the four B fragments of S^T = K Q^T (8 channels at d = 16 s + 8 h).  With warp tables on the segment the row
+// is the warped, blended query of U/attention_processors.py:424,544 built here from the <= K splat slots of q_base (same code as
+// k_composite_tok: bit-identical to reading a q_warp tensor that gd_splat_composite wrote).
+template <typename T>
+__device__ __forceinline__ void load_q_frags(const gd_attn_seg_t& sg, const T* __restrict__ qp, int rs, int qld, int h,
+                                             typename elem_traits<T>::vec8 (&qf)[4]) {
+    using V8 = typename elem_traits<T>::vec8;
+    if (sg.warp_idx) {
+        const int coff[4] = {8 * h, 16 + 8 * h, 32 + 8 * h, 48 + 8 * h};
+        composite_chunks<T, 4>(qp, (size_t)rs, coff, sg.warp_idx, sg.warp_w, sg.warp_m, qld, sg.warp_K, qf);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const V8*)(qp + (size_t)qld * rs + 16 * s + 8 * h);
+    }
+}
+
+
+// software-pipelined forward (attn_fwd_mp.hip): QB query blocks x KS key ranges per workgroup; a.seg / bh_end / N / M / c / scale filled in
+int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st);

@@ -7,53 +7,8 @@
 // edit_out with the warped queries, replace_out) so that small resolutions still fill 256 CUs.
 //
 // MFMA-bound: algorithmic FLOPs = 4 * BH * N * M * D per launch (QK^T and PV).
+#include <stdlib.h>
 #include "attn_common.hpp"
-
-struct FwdArgs {
-    gd_attn_seg_t seg[GD_ATTN_MAX_SEGS];
-    int bh_end[GD_ATTN_MAX_SEGS];   // exclusive prefix of bh
-    int nseg;
-    int N, M;
-    int tiles;                      // query tiles per (bh)
-    int nwg;
-    float c;                        // scale * log2(e)
-    float scale;
-    // split-KV (launches that would leave most CUs idle): split sp handles key tiles [sp*tps, (sp+1)*tps) and leaves an
-    // un-normalised partial (O, m, l) in the workspace; k_attn_combine merges them
-    int nsplit, tps, tot_bh;
-    float* ws_o;                    // [nsplit, tot_bh, N, 64] f32
-    float* ws_ml;                   // [nsplit, tot_bh, N, 2]  f32 (reference max, row sum)
-};
-
-// Per-lane LDS byte offsets of the fragment reads, computed once (the swizzle term does not depend on the k-step /
-// key block, which therefore become immediates): krd[s] for the row fragments, vrd[dblk][hh] for the transposed ones.
-struct FragOffs { int krd[4]; int vrd[2][2]; };
-
-__device__ __forceinline__ FragOffs make_frag_offs(int lane) {
-    FragOffs f;
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) f.krd[s] = img_off(r, 2 * s + h);
-    const int g1 = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
-#pragma unroll
-    for (int dblk = 0; dblk < 2; ++dblk)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-            f.vrd[dblk][hh] = img_off(8 * hh + 4 * h + q, dblk * 4 + g1 * 2 + (p >> 1)) + (p & 1) * 8;
-    return f;
-}
-
-template <typename T>
-__device__ __forceinline__ typename elem_traits<T>::vec8 rd_row(const char* lds, const FragOffs& f, int blk, int s) {
-    return *(const typename elem_traits<T>::vec8*)(lds + f.krd[s] + blk * 4096);
-}
-template <typename T>
-__device__ __forceinline__ typename elem_traits<T>::vec8 rd_tr(const char* lds, const FragOffs& f, int dblk, int ks) {
-    union { s16x4 v[2]; typename elem_traits<T>::vec8 x; } u;
-    u.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + f.vrd[dblk][0] + ks * 2048));
-    u.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + f.vrd[dblk][1] + ks * 2048));
-    return u.x;
-}
 
 // largest partial row sum (16 probabilities of one lane) tolerated before the reference maximum is raised: every probability
 // then stays <= 2^14, inside fp16 range (bf16 / f32 have far more)
@@ -193,8 +148,7 @@ k_attn_fwd(const FwdArgs a) {
     const int qrow = tile * ATT_BM + wave * 32 + (lane & 31);
     const int qld = qrow < N ? qrow : N - 1;
     V8 qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const V8*)(qp + (size_t)qld * rs + 16 * s + 8 * h);
+    load_q_frags<T>(sg, qp, rs, qld, h, qf);
     const FragOffs fo = make_frag_offs(lane);
 
     f32x16 o[2];
@@ -315,10 +269,17 @@ __global__ void k_attn_combine(const FwdArgs a) {
     if (sg.lse && dq == 0) sg.lse[(size_t)bh * a.N + row] = mref * a.scale + __logf(L);
 }
 
+static void mp_config(int tot_bh, int N, int M, int* qb, int* ks);
+
 // Split-KV plan: how many key splits make a launch of tot_bh heads fill the chip (1 = none), and the workspace they need.
 extern "C" int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_bytes) {
     if (workspace_bytes) *workspace_bytes = 0;
     if (tot_bh <= 0 || N <= 0 || M <= 0) return 1;
+    {
+        int qb = 0, ks = 0;
+        mp_config(tot_bh, N, M, &qb, &ks);
+        if (qb > 0) return 1;          // the pipelined kernel splits keys inside the workgroup (no workspace)
+    }
     const int tiles = (N + ATT_BM - 1) / ATT_BM, t_all = (M + ATT_BN - 1) / ATT_BN;
     const long long nwg = (long long)tiles * tot_bh;
     // measured on MI355X (tools/bench_splitkv.py): 5 heads at 64^2 68 -> 47 us with 4 splits, 10 heads 86 -> 73 us with 2, nothing from
@@ -333,6 +294,45 @@ extern "C" int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_byte
 
 static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
                            size_t workspace_bytes, int dtype, void* stream);
+
+// Which pipelined configuration serves a launch of tot_bh heads: QB query blocks (32 rows each) x KS key ranges per workgroup; qb = 0:
+// use k_attn_fwd (key tails, short key lists).  GD_ATTN_CFG="QBxKS" forces one (development / benchmarking), "0" disables the kernel.
+static int env_qb = -2, env_ks = 0;
+
+extern "C" int gd_attn_fwd_set_config(int qb, int ks) {
+    if (qb > 0) {
+        const int cfg = qb * 10 + ks;
+        GD_REQUIRE(cfg == 41 || cfg == 22 || cfg == 42 || cfg == 24, GD_EINVAL, "gd_attn_fwd_set_config: no kernel for QB=%d KS=%d", qb, ks);
+    }
+    env_qb = qb < 0 ? -1 : qb;
+    env_ks = qb > 0 ? ks : 0;
+    return GD_OK;
+}
+
+static void mp_config(int tot_bh, int N, int M, int* qb, int* ks) {
+    if (env_qb == -2) {
+        const char* e = getenv("GD_ATTN_CFG");
+        int q = -1, k = 0;
+        if (e && e[0] == '0' && e[1] == 0) q = 0;
+        else if (e && sscanf(e, "%dx%d", &q, &k) != 2) q = -1;
+        env_ks = k;
+        env_qb = q;
+    }
+    *qb = 0; *ks = 0;
+    const int T = M / ATT_BN;
+    if (M % ATT_BN != 0 || env_qb == 0) return;
+    if (env_qb > 0) {
+        if (T % (2 * env_ks) == 0) { *qb = env_qb; *ks = env_ks; }
+        return;
+    }
+    if (T % 2 != 0) return;
+    // wave-sized query blocks against the chip's 1024 SIMDs x 2 resident waves.  Measured on MI355X (tools/bench_mp.py, bf16, 64^2):
+    // 5 heads (640 blocks) 43 -> 34 us with two key ranges per workgroup, 10 heads (1280 blocks) 59 us unsplit vs 69 split, 32^2 with
+    // 30 heads (960 blocks) 14.5 -> 13.3 us split; from 1280 blocks up the unsplit 128-query workgroup wins.
+    const long long blocks = (long long)((N + 31) / 32) * tot_bh;
+    if (blocks < 1280 && T % 4 == 0) { *qb = 4; *ks = 2; return; }
+    *qb = 4; *ks = 1;
+}
 
 extern "C" int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int dtype, void* stream) {
     return attn_fwd_launch(segs, nseg, N, M, D, scale, 1, nullptr, 0, dtype, stream);
@@ -355,6 +355,7 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
     for (int i = 0; i < nseg; ++i) {
         GD_REQUIRE(segs[i].q && segs[i].k && segs[i].v && segs[i].out && segs[i].bh > 0, GD_EINVAL,
                    "gd_attn_fwd: segment %d has a null pointer or bh<=0", i);
+        GD_REQUIRE((segs[i].q_scaled != 0) == (segs[0].q_scaled != 0), GD_EINVAL, "gd_attn_fwd: segments disagree on q_scaled");
         a.seg[i] = segs[i];
         tot += segs[i].bh;
         a.bh_end[i] = tot;
@@ -363,6 +364,11 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
     a.tiles = (N + ATT_BM - 1) / ATT_BM;
     a.scale = scale;
     a.c = scale * 1.4426950408889634f;
+    a.q_prescaled = segs[0].q_scaled != 0;
+    if (a.q_prescaled) {             // scores arrive as exponents of 2: nothing left to multiply; lse = m ln 2 + ln l
+        a.c = 1.0f;
+        a.scale = 0.6931471805599453f;
+    }
     const int t_all = (M + ATT_BN - 1) / ATT_BN;
     GD_REQUIRE(nsplit >= 1 && nsplit <= 8 && nsplit <= t_all, GD_EINVAL, "gd_attn_fwd: nsplit=%d (1..min(8, key tiles=%d))", nsplit, t_all);
     a.nsplit = nsplit; a.tot_bh = tot;
@@ -374,8 +380,13 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
         a.ws_o = (float*)workspace;
         a.ws_ml = a.ws_o + (size_t)nsplit * tot * N * ATT_D;
     }
-    a.nwg = a.tiles * tot * nsplit;
     hipStream_t st = as_stream(stream);
+    if (nsplit == 1) {
+        int qb = 0, ks = 0;
+        mp_config(tot, N, M, &qb, &ks);
+        if (qb > 0) return gd_attn_fwd_mp_launch(a, qb, ks, dtype, st);       // software-pipelined kernels (attn_fwd_mp.hip)
+    }
+    a.nwg = a.tiles * tot * nsplit;
     if (dtype == GD_F16) k_attn_fwd<f16_t><<<a.nwg, 256, 0, st>>>(a);
     else k_attn_fwd<bf16_t><<<a.nwg, 256, 0, st>>>(a);
     if (nsplit > 1) {

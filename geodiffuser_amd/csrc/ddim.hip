@@ -56,21 +56,30 @@ extern "C" int gd_masked_latent_update(const float* x, const float* g, const flo
     return GD_OK;
 }
 
-__global__ void k_sumsq(const float* __restrict__ x, long long n, float* __restrict__ acc) {
+// Deterministic: ONE workgroup, fixed summation order (thread-strided partials -> wave tree -> the 16 wave sums in index order), no
+// atomics.  The latents this is called on are 16-37 K elements, so a single workgroup costs nothing against the launch itself.
+__global__ void __launch_bounds__(1024)
+k_sumsq(const float* __restrict__ x, long long n, float* __restrict__ acc) {
+    __shared__ float part[16];
     float s = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = threadIdx.x; i < n; i += 1024) {
         const float v = x[i];
         s = __builtin_fmaf(v, v, s);
     }
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w];
+        acc[0] += t;
+    }
 }
 
 extern "C" int gd_sumsq(const float* x, int64_t n, float* sumsq, void* stream) {
     GD_REQUIRE(x && sumsq && n > 0, GD_EINVAL, "gd_sumsq: bad argument");
-    int blocks = (int)((n + 1023) / 1024);
-    if (blocks > 256) blocks = 256;
-    k_sumsq<<<blocks, 256, 0, as_stream(stream)>>>(x, n, sumsq);
+    k_sumsq<<<1, 1024, 0, as_stream(stream)>>>(x, n, sumsq);
     GD_CHECK_LAUNCH("gd_sumsq");
     return GD_OK;
 }

@@ -90,7 +90,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_losses_fwd(const T* __restrict__ eo, const T* __restrict__ ro, const float* __restrict__ tgt, const float* __restrict__ m_wo,
              const float* __restrict__ m_edit, const float* __restrict__ w_am, const float* __restrict__ m_amodal,
-             int H, int S, int D, float* __restrict__ sums) {
+             int H, int S, int D, float* __restrict__ sums /* [gridDim.x, 5] partials */) {
     const int N = S * S;
     const long long total = (long long)H * N * D;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
@@ -113,25 +113,47 @@ k_losses_fwd(const T* __restrict__ eo, const T* __restrict__ ro, const float* __
     __syncthreads();
     if (threadIdx.x < 5) {
         const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-        atomicAdd(&sums[threadIdx.x], v);
+        sums[(size_t)blockIdx.x * 5 + threadIdx.x] = v;          // per-workgroup partial (summed in fixed order by k_losses_fold)
     }
 }
 
-extern "C" int gd_edit_losses_fwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
-                                  const float* w_am, const float* m_amodal, int H, int S, int D, float* sums, int dtype, void* stream) {
-    GD_REQUIRE(eo && ro && m_wo && m_edit && sums, GD_EINVAL, "gd_edit_losses_fwd: null pointer");
-    GD_REQUIRE(!tgt || (w_am && m_amodal), GD_EINVAL, "gd_edit_losses_fwd: tgt needs w_am and m_amodal");
-    GD_REQUIRE(H > 0 && S > 0 && D > 0, GD_EINVAL, "gd_edit_losses_fwd: bad sizes");
-    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_fwd: dtype must be f16/bf16");
+// sums[k] += sum_b partial[b][k], b in a fixed order: wave k folds column k (lane-strided, then the wave tree).  Together with the
+// grid-stride loop above (fixed element -> workgroup assignment) the five loss sums are bit-reproducible from run to run.
+__global__ void __launch_bounds__(320)
+k_losses_fold(const float* __restrict__ partial, int nblocks, float* __restrict__ sums) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * 5 + k];
+    s = wave_sum(s);
+    if (lane == 0) sums[k] += s;
+}
+
+static int losses_fwd_blocks(int H, int S, int D) {
     const long long total = (long long)H * S * S * D;
     int blocks = (int)((total + 256 * 8 - 1) / (256 * 8));
     if (blocks < 1) blocks = 1;
     if (blocks > 1024) blocks = 1024;
+    return blocks;
+}
+
+extern "C" size_t gd_edit_losses_fwd_workspace_bytes(int H, int S, int D) {
+    return (size_t)losses_fwd_blocks(H, S, D) * 5 * sizeof(float);
+}
+
+extern "C" int gd_edit_losses_fwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
+                                  const float* w_am, const float* m_amodal, int H, int S, int D, float* sums, float* workspace,
+                                  int dtype, void* stream) {
+    GD_REQUIRE(eo && ro && m_wo && m_edit && sums && workspace, GD_EINVAL, "gd_edit_losses_fwd: null pointer");
+    GD_REQUIRE(!tgt || (w_am && m_amodal), GD_EINVAL, "gd_edit_losses_fwd: tgt needs w_am and m_amodal");
+    GD_REQUIRE(H > 0 && S > 0 && D > 0, GD_EINVAL, "gd_edit_losses_fwd: bad sizes");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_fwd: dtype must be f16/bf16");
+    const int blocks = losses_fwd_blocks(H, S, D);
     hipStream_t st = as_stream(stream);
     if (dtype == GD_F16)
-        k_losses_fwd<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)eo, (const f16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal, H, S, D, sums);
+        k_losses_fwd<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)eo, (const f16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal, H, S, D, workspace);
     else
-        k_losses_fwd<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)eo, (const bf16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal, H, S, D, sums);
+        k_losses_fwd<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)eo, (const bf16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal, H, S, D, workspace);
+    k_losses_fold<<<1, 320, 0, st>>>(workspace, blocks, sums);
     GD_CHECK_LAUNCH("gd_edit_losses_fwd");
     return GD_OK;
 }

@@ -156,9 +156,11 @@ __global__ void k_removal_reduce(const unsigned long long* __restrict__ best, co
                                  const int32_t* __restrict__ n_valid, int H, int R, int S,
                                  float* __restrict__ p_in, int32_t* __restrict__ j_in, float* __restrict__ p_wo,
                                  int32_t* __restrict__ j_wo, float* __restrict__ wgt, float* __restrict__ loss_acc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // ONE workgroup walks all H*R rows (a few thousand) in a fixed thread-strided order and folds the loss terms through the wave tree
+    // and the four wave sums in index order: bit-reproducible, no floating-point atomics
+    __shared__ float part[4];
     float term = 0.f;
-    if (i < H * R) {
+    for (int i = threadIdx.x; i < H * R; i += blockDim.x) {
         const unsigned long long bi = best[(size_t)i * 2], bw = best[(size_t)i * 2 + 1];
         // best == 0: no correlation value of this row compared greater than the initial -1, i.e. every one of them was NaN (diverged
         // latents).  torch.max would return NaN there; do the same for the value and keep the INDEX valid — the backward addresses
@@ -174,10 +176,12 @@ __global__ void k_removal_reduce(const unsigned long long* __restrict__ best, co
         const bool live = !n_valid || r < n_valid[0];
         const float w = live ? __expf(-pix_dist(rows[r], jw, S)) : 0.f;
         p_in[i] = pi; j_in[i] = ji; p_wo[i] = pw; j_wo[i] = jw; wgt[i] = w;
-        term = live ? w * (-__logf(pw + 1e-4f) + __logf(pi + 1e-4f)) : 0.f;
+        term += live ? w * (-__logf(pw + 1e-4f) + __logf(pi + 1e-4f)) : 0.f;
     }
     term = wave_sum(term);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss_acc, term);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_acc[0] += (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 extern "C" int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, const int32_t* n_valid_dev, int H, int R, int S,
@@ -185,7 +189,7 @@ extern "C" int gd_removal_loss_reduce(const unsigned long long* best, const int3
                                       float* loss_acc, void* stream) {
     GD_REQUIRE(best && rows && p_in && j_in && p_wo && j_wo && wgt && loss_acc, GD_EINVAL, "gd_removal_loss_reduce: null pointer");
     GD_REQUIRE(H > 0 && R > 0 && S > 0, GD_EINVAL, "gd_removal_loss_reduce: bad sizes");
-    k_removal_reduce<<<(H * R + 255) / 256, 256, 0, as_stream(stream)>>>(best, rows, n_valid_dev, H, R, S, p_in, j_in, p_wo, j_wo, wgt, loss_acc);
+    k_removal_reduce<<<1, 256, 0, as_stream(stream)>>>(best, rows, n_valid_dev, H, R, S, p_in, j_in, p_wo, j_wo, wgt, loss_acc);
     GD_CHECK_LAUNCH("gd_removal_loss_reduce");
     return GD_OK;
 }
@@ -196,7 +200,7 @@ struct RmBwdArgs {
     const void* Pe; const void* Pb; const void* q; const void* k; const int32_t* rows;
     const float* p_in; const int32_t* j_in; const float* p_wo; const int32_t* j_wo; const float* wgt;
     const float* m_inp; const float* m_wo; float coef; const float* gscale;
-    int H, R, N, M, Mpad; float scale; float* dq; float* dk; float* ds_ws; const float* rowdot;
+    int H, R, N, M, Mpad; float scale; float* dq; float* dk; float* ds_ws; const float* rowdot; float* dq_part;
 };
 
 // rowdot[h, r] = sum_m A[h,r,m] * dA[h,r,m]   (one wave per inpaint row; feeds the softmax backward below)
@@ -223,7 +227,7 @@ k_removal_rowdot(const RmBwdArgs a, float* __restrict__ rowdot) {
 }
 
 #define RM_RB 8      // inpaint rows per wave: each K row fetched from L2 serves 8 rows
-#define RM_MCH 512   // keys per wave: the key range is split over waves (more parallelism; dq combined with f32 atomics)
+#define RM_MCH 512   // keys per wave: the key range is split over waves (more parallelism; per-chunk dq partials folded in order)
 
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -287,9 +291,24 @@ k_removal_bwd(const RmBwdArgs a) {
                     acc[i] = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ds[i]), mb + u)), kv[u], acc[i]);
         }
     }
+    // per-(key chunk) partial of dq; the chunks of a row are summed in index order by k_removal_dq_fold (no f32 atomics: bit-reproducible)
 #pragma unroll
     for (int i = 0; i < RM_RB; ++i)
-        if ((r0 + i) < a.R) atomicAdd(&a.dq[((size_t)hd * a.N + qrow[i]) * ATT_D + lane], acc[i]);
+        if ((r0 + i) < a.R) a.dq_part[(((size_t)mc * a.H + hd) * a.R + r0 + i) * ATT_D + lane] = acc[i];
+}
+
+// dq[h, rows[r], :] += sum_c dq_part[c, h, r, :]  (c ascending).  Padding slots of the row list (weight 0, contribution exactly 0) are
+// skipped, so every live row has exactly one writer.
+__global__ void k_removal_dq_fold(const float* __restrict__ dq_part, const int32_t* __restrict__ rows, const float* __restrict__ wgt,
+                                  int msplit, int H, int R, int N, float* __restrict__ dq) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= H * R * ATT_D) return;
+    const int d = gid % ATT_D, hr = gid / ATT_D;
+    if (wgt[hr] == 0.f) return;
+    const int hd = hr / R, r = hr - hd * R;
+    float s = 0.f;
+    for (int c = 0; c < msplit; ++c) s += dq_part[((size_t)c * H * R + hr) * ATT_D + d];
+    dq[((size_t)hd * N + rows[r]) * ATT_D + d] += s;
 }
 
 // dk[h, m, d] += sum_r dS[h, r, m] * q[h, rows[r], d]   (cross-attention: few keys; one thread per (m, d) of a head)
@@ -315,6 +334,11 @@ __global__ void k_removal_dk(const float* __restrict__ ds_ws, const T* __restric
     dk[((size_t)hd * M + m) * ATT_D + d] += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
+extern "C" size_t gd_removal_bwd_workspace_bytes(int H, int R, int M, int Mpad, int need_dk) {
+    const size_t msplit = (size_t)(M + RM_MCH - 1) / RM_MCH;
+    return ((size_t)H * R * (1 + msplit * ATT_D + (need_dk ? (size_t)Mpad : 0))) * sizeof(float);
+}
+
 extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
                               const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
                               const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
@@ -328,9 +352,13 @@ extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, con
     RmBwdArgs a;
     a.Pe = Pe; a.Pb = Pb; a.q = q; a.k = k; a.rows = rows; a.p_in = p_in; a.j_in = j_in; a.p_wo = p_wo; a.j_wo = j_wo;
     a.wgt = wgt; a.m_inp = m_inp; a.m_wo = m_wo; a.coef = coef; a.gscale = gscale_dev; a.H = H; a.R = R; a.N = N; a.M = M; a.Mpad = Mpad;
-    GD_REQUIRE(ds_ws, GD_EINVAL, "gd_removal_bwd: workspace required: H*R floats (+ H*R*Mpad floats when dk_f32 != NULL)");
+    GD_REQUIRE(ds_ws, GD_EINVAL, "gd_removal_bwd: workspace of gd_removal_bwd_workspace_bytes() required");
+    // workspace: rowdot [H*R] | dq partials [msplit, H, R, 64] | dS [H, R, Mpad] (only with dk_f32)
+    const int msplit = (M + RM_MCH - 1) / RM_MCH;
     float* rowdot = ds_ws;
-    a.scale = scale; a.dq = dq_f32; a.dk = dk_f32; a.ds_ws = dk_f32 ? ds_ws + (size_t)H * R : nullptr; a.rowdot = rowdot;
+    a.dq_part = ds_ws + (size_t)H * R;
+    a.scale = scale; a.dq = dq_f32; a.dk = dk_f32; a.rowdot = rowdot;
+    a.ds_ws = dk_f32 ? a.dq_part + (size_t)msplit * H * R * ATT_D : nullptr;
     const int waves = H * ((R + RM_RB - 1) / RM_RB) * ((M + RM_MCH - 1) / RM_MCH);
     const int blocks = (waves + 3) / 4;
     hipStream_t st = as_stream(stream);
@@ -338,6 +366,7 @@ extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, con
     else k_removal_rowdot<bf16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rowdot);
     if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, st>>>(a);
     else k_removal_bwd<bf16_t><<<blocks, 256, 0, st>>>(a);
+    k_removal_dq_fold<<<(H * R * ATT_D + 255) / 256, 256, 0, st>>>(a.dq_part, rows, wgt, msplit, H, R, N, dq_f32);
     if (dk_f32) {
         dim3 grid((M * ATT_D + 255) / 256, H);
         if (dtype == GD_F16) k_removal_dk<f16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const f16_t*)q, rows, R, N, M, Mpad, dk_f32);

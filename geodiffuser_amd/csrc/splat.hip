@@ -5,6 +5,7 @@
 // HBM-bound: per call it reads src once, idx/w once (shared by all heads) and writes out once:
 // algorithmic bytes = 2*B*P*C*sizeof(T) + npix*K*8  (5.7 MB at 64^2, f=5, D=64).
 #include "common.hpp"
+#include "splat_common.hpp"
 
 __global__ void k_splat_weights(const int32_t* __restrict__ idx, const float* __restrict__ dist2, int npix, int K,
                                 float inv_rpow, float tau, float* __restrict__ w) {
@@ -52,50 +53,10 @@ __global__ void k_composite_tok(const T* __restrict__ src, const int32_t* __rest
     const int pix = (int)(t2 % npix);
     const int b = (int)(t2 / npix);
     const T* sb = src + (size_t)b * P * C;
-    float acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
-    // the K gathers of a pixel are independent: fetch the index/weight slots 8 at a time, issue the 8 row loads together
-    // (a dependent idx -> row chain per slot made this kernel latency-bound), then accumulate in slot order
-    for (int k0 = 0; k0 < K; k0 += 8) {
-        int pk[8];
-        float wk[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int kk = k0 + j;
-            const int p = kk < K ? idx[(size_t)pix * K + kk] : -1;
-            pk[j] = p;
-            wk[j] = (kk < K && p >= 0) ? w[(size_t)pix * K + kk] : 0.0f;
-        }
-        V8 f[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = *(const V8*)(sb + (size_t)(pk[j] < 0 ? 0 : pk[j]) * C + ch * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (pk[j] >= 0) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(wk[j], TR::to_f32(f[j][i]), acc[i]);
-            }
-    }
-    V8 o;
-    if (m) {
-        // blend in the query dtype, op by op, as torch does on fp16 tensors:
-        //   q*(1-m) + m*half(splat)          (U/attention_processors.py:424,544)
-        const float mm = m[pix];
-        const V8 q = *(const V8*)(sb + (size_t)pix * C + ch * 8);     // npix == P on this path
-        const float one_m = TR::to_f32(TR::from_f32(1.0f - mm));
-        const float m_t = TR::to_f32(TR::from_f32(mm));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float s16 = (float)(f16_t)acc[i];                  // `.to(torch.half)` U/warp_utils.py:176
-            const float t1 = TR::to_f32(TR::from_f32(TR::to_f32(q[i]) * one_m));
-            const float t2b = TR::to_f32(TR::from_f32(m_t * s16));
-            o[i] = TR::from_f32(t1 + t2b);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = TR::from_f32((float)(f16_t)acc[i]);
-    }
+    const int coff[1] = {ch * 8};
+    V8 o1[1];
+    composite_chunks<T, 1>(sb, (size_t)C, coff, idx, w, m, pix, K, o1);      // splat_common.hpp (shared with the attention prologue)
+    const V8 o = o1[0];
     *(V8*)(out + ((size_t)b * npix + pix) * C + ch * 8) = o;
 }
 

@@ -13,19 +13,45 @@ from .pipeline import build_random_sd21
 from .scheduler import DDIMScheduler
 
 
-def _unet_nograd(model, controller, x, t, ctx, tag):
-    """UNet call of a no-grad pass, through a captured hipGraph when the controller's launch sequence is static."""
+def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None):
+    """UNet call of a no-grad pass, through a captured hipGraph when the controller's launch sequence is static.
+
+    A replay runs no Python, and the captured kernels read the controller's per-resolution tables (masks, splat idx / w, inpaint
+    rows) by ADDRESS from persistent buffers that outlive an edit.  So before any replay the CURRENT controller must have written
+    its tables into those buffers: the (resolution, heads) pairs of the hooked layers are learnt from the first eager pass on this
+    model / latent size, and a controller that has not built them yet (a new edit whose first UNet pass is a CFG pass:
+    optimize_steps == 0, or fast_start_steps > 0) builds them up front.  The table shapes are part of the graph key."""
     key_fn = getattr(controller, "graph_key", None)
     if not graphs.ENABLED or torch.is_grad_enabled() or key_fn is None or getattr(controller, "store_attention_maps", False) \
             or not getattr(controller, "persistent_tables", False):
         return model.unet(x, t, encoder_hidden_states=ctx)["sample"]
+    seen = model.__dict__.setdefault("_cfg_layers", {})
+    lk = tuple(x.shape[2:])
+    layers = seen.get(lk)
+    if layers is None:                                    # first hooked no-grad pass at this latent size: eager, learn the layers
+        out = model.unet(x, t, encoder_hidden_states=ctx)["sample"]
+        seen[lk] = sorted((S, c["f"]) for S, c in controller.masks_cache_dict.items() if "f" in c)
+        return out
+    if not controller.tables_built(layers):
+        q_like = torch.empty(1, device=x.device, dtype=model.unet.dtype)
+        controller.prebuild_tables(layers, q_like, transform_coords)
     runner = model.__dict__.get("_graphed")
     if runner is None:
         runner = model.__dict__["_graphed"] = graphs.GraphedUNet(model.unet)
-    out, replayed = runner((tag,) + key_fn(), x, t, ctx)
+    out, replayed = runner((tag,) + key_fn() + (controller.table_signature(),), x, t, ctx)
     if replayed:
         controller.after_graph_replay()
     return out
+
+
+def _sched_step(scheduler, eps_uncond, t, sample, eps_cond, guidance_scale):
+    """scheduler.step with the classifier-free-guidance combine.  The repo's own schedulers fuse the combine into the DDIM kernel
+    (``eps_cond`` / ``guidance_scale`` keywords of gd_ddim_step); any other scheduler object (e.g. a diffusers ``DDIMScheduler`` a
+    caller passes as ``scheduler_in``) gets the reference's explicit combine (diffusion.py:47-49) and its plain ``step`` signature."""
+    if isinstance(scheduler, DDIMScheduler):
+        return scheduler.step(eps_uncond, t, sample, eta=0.0, eps_cond=eps_cond, guidance_scale=guidance_scale)["prev_sample"]
+    eps = eps_uncond + guidance_scale * (eps_cond - eps_uncond)
+    return scheduler.step(eps, t, sample, eta=0.0)["prev_sample"]
 
 
 def diffusion_step(model, controller, latents, context, t, guidance_scale, low_resource=False, transform_coords=None,
@@ -38,22 +64,20 @@ def diffusion_step(model, controller, latents, context, t, guidance_scale, low_r
         # is not (vanilla attention, per-sample norms => no influence on other rows).  Batch [uncond_edit, cond_ref, cond_edit].
         latents_input = torch.cat([latents[1:2], latents[0:1], latents[1:2]])
         ctx3 = torch.cat([context[1:2], context[2:3], context[3:4]])
-        noise_pred = _unet_nograd(model, controller, latents_input, t, ctx3, "cfg3")
-        edit_out = model.scheduler.step(noise_pred[0:1], t, latents[1:2], eta=0.0, eps_cond=noise_pred[2:3],
-                                        guidance_scale=guidance_scale)["prev_sample"]
+        noise_pred = _unet_nograd(model, controller, latents_input, t, ctx3, "cfg3", transform_coords)
+        edit_out = _sched_step(model.scheduler, noise_pred[0:1], t, latents[1:2], noise_pred[2:3], guidance_scale)
         latents_out = torch.cat([latents[0:1].to(edit_out.dtype), edit_out])
         noise_pred_out = None
     elif use_cfg:
         latents_input = torch.cat([latents] * 2)
-        noise_pred = _unet_nograd(model, controller, latents_input, t, context, "cfg4")
+        noise_pred = _unet_nograd(model, controller, latents_input, t, context, "cfg4", transform_coords)
         noise_pred_uncond, noise_prediction_text = noise_pred.chunk(2)
         if return_noise:
             noise_pred_out = noise_pred_uncond + guidance_scale * (noise_prediction_text - noise_pred_uncond)
             latents_out = model.scheduler.step(noise_pred_out, t, latents, eta=0.0)["prev_sample"]
         else:
             noise_pred_out = None
-            latents_out = model.scheduler.step(noise_pred_uncond, t, latents, eta=0.0, eps_cond=noise_prediction_text,
-                                               guidance_scale=guidance_scale)["prev_sample"]
+            latents_out = _sched_step(model.scheduler, noise_pred_uncond, t, latents, noise_prediction_text, guidance_scale)
     else:
         noise_pred_out = model.unet(latents, t, encoder_hidden_states=context)["sample"]
         if skip_scheduler:      # the optimisation pass discards x_{t-1} (editor.py:253); a captured pass cannot read t on the host
@@ -101,10 +125,13 @@ def load_model(diffusion_model="stabilityai/stable-diffusion-2-1-base", unet_pat
     except Exception:  # noqa: BLE001
         have_diffusers = False
     if have_diffusers and not random_init:  # pragma: no cover - not reachable in the build image
-        from diffusers import DDIMScheduler as _DS, StableDiffusionPipeline as _SDP
+        from diffusers import StableDiffusionPipeline as _SDP
         from .attention_processors import VanillaAttentionProcessor
         pipe = _SDP.from_pretrained(unet_path or diffusion_model, torch_dtype=dtype).to(device)
-        pipe.scheduler = _DS(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)
+        # the repo's own scheduler (same betas / alphas / 'leading' timestep table as the diffusers object the reference builds at
+        # diffusion.py:110): its step runs the fused CFG + DDIM kernel and accepts the keywords diffusion_step passes
+        pipe.scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                                       set_alpha_to_one=False)
         pipe.unet.set_attn_processor(VanillaAttentionProcessor())
         pipe.unet.eval()
         return pipe, pipe.tokenizer, pipe.scheduler

@@ -138,6 +138,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
         return diffusion_step(model, controller, lat, ctx, tt, guidance_scale, transform_coords=transform_coordinates)
 
     opt_pass = GraphedOptPass(model, transform_coordinates, guidance_scale)
+    first_optim_complete = False
     for i, t in enumerate(timesteps):
         if uncond_embeddings_ is None:
             context = torch.cat([uncond_embeddings[i].expand(*text_embeddings.shape), text_embeddings])
@@ -153,22 +154,39 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
             l_eff = lr * (50 - i) * skip_optim_steps * (50 / (NUM_DDIM_STEPS + 1e-8))                      # :207
             set_attn_processor_for_edit(model, coords_base=(0, 1), coords_edit=(1, 2), use_cfg=False)    # :213
             n0 = ops.sumsq(latents[-1].detach().float().contiguous())                                      # orig_norm^2 (:219)
-            ctx_src = context if context_save is None else context_save
-            # :218-273 — forward with losses + autograd back to latent / embedding (one hipGraph per edit when enabled)
-            g_lat, g_ctx, latents_in, context_in = opt_pass.grads(controller, latents, ctx_src, t)
-            latents_new, context_new = _apply_latent_update(latents_in, g_lat, context_in, g_ctx, l_eff,
-                                                            controller.mask_new_warped[:1])
-            out_loss_log_dict = convert_loss_log_to_numpy(controller.loss_log_dict)                       # :284 (host sync)
-            if use_adaptive_optimization:
-                if edit_type == "geometry_editor":
-                    adaptive_optimization_step_editing(controller, i, skip_optim_steps, out_loss_log_dict, num_ddim_steps=NUM_DDIM_STEPS,
-                                                       removal_loss_value_in=removal_loss_value_in)
-                elif edit_type == "geometry_remover":
-                    adaptive_optimization_step_remover(controller, i, skip_optim_steps, out_loss_log_dict, num_ddim_steps=NUM_DDIM_STEPS,
-                                                       removal_loss_value_in=removal_loss_value_in)
-            global_loss_log_dict[i] = out_loss_log_dict
-            clear_controller_loss(controller)
-            controller.cur_step -= 1                                                                       # :307
+            ctx_cur = context if context_save is None else context_save
+            lat_cur = latents
+            # :183-187 — the first optimised step after a fast start runs num_first_optim_steps iterations and keeps the inputs of
+            # the lowest-loss one (:236-239); every other step runs one iteration and keeps its updated latents (:252-254)
+            if (not first_optim_complete) and fast_start_steps > 0.0:
+                num_optim_steps = max(int(num_first_optim_steps), 1)
+                first_optim_complete = True
+            else:
+                num_optim_steps = 1
+            best_loss, latents_new, context_new = 1e8, None, None
+            for _opt_iter in range(num_optim_steps):
+                # :218-273 — forward with losses + autograd back to latent / embedding (one hipGraph, reused across edits)
+                g_lat, g_ctx, latents_in, context_in = opt_pass.grads(controller, lat_cur, ctx_cur, t)
+                if num_optim_steps > 1:
+                    loss_val = float(controller.loss)                                                      # :236 (host sync)
+                    if loss_val < best_loss:
+                        best_loss = loss_val
+                        latents_new, context_new = latents_in.detach().clone(), context_in.detach().clone()
+                lat_upd, ctx_upd = _apply_latent_update(latents_in, g_lat, context_in, g_ctx, l_eff, controller.mask_new_warped[:1])
+                if num_optim_steps == 1:
+                    latents_new, context_new = lat_upd, ctx_upd
+                lat_cur, ctx_cur = lat_upd.detach(), ctx_upd.detach()
+                out_loss_log_dict = convert_loss_log_to_numpy(controller.loss_log_dict)                   # :284 (host sync)
+                if use_adaptive_optimization:
+                    if edit_type == "geometry_editor":
+                        adaptive_optimization_step_editing(controller, i, skip_optim_steps, out_loss_log_dict, num_ddim_steps=NUM_DDIM_STEPS,
+                                                           removal_loss_value_in=removal_loss_value_in)
+                    elif edit_type == "geometry_remover":
+                        adaptive_optimization_step_remover(controller, i, skip_optim_steps, out_loss_log_dict, num_ddim_steps=NUM_DDIM_STEPS,
+                                                           removal_loss_value_in=removal_loss_value_in)
+                global_loss_log_dict[i] = out_loss_log_dict
+                clear_controller_loss(controller)
+                controller.cur_step -= 1                                                                   # :307
             if optimize_latents:                                                                           # :312-316
                 latents = latents_new.detach()
                 last = latents[-1].float().contiguous()

@@ -1,6 +1,6 @@
 """DDIM inversion.  Mirror of GeoDiffuser/utils/inversion.py (``NullInversion``: ``invert`` :261-277, ``ddim_loop``
-:131-196, ``prev_step`` / ``next_step`` :47-65, ``init_prompt`` :113-128).  Null-text optimisation (:213-259) is switched
-off in every reference driver (``perform_inversion=False``) and is not implemented."""
+:131-196, ``prev_step`` / ``next_step`` :47-65, ``init_prompt`` :113-128, ``null_optimization`` :213-259 — off in every reference
+driver (``perform_inversion=False``), on in ``perform_geometric_edit``'s default signature)."""
 from __future__ import annotations
 
 import numpy as np
@@ -94,7 +94,7 @@ class NullInversion:
                 latents = inv.step(noise_pred_uncond, t, latents, eps_cond=noise_pred_cond, guidance_scale=self.guidance_scale,
                                    return_dict=False)[0]
             all_latent.append(latents.detach())
-            all_noise.append(noise_pred_cond.detach())
+            all_noise.append(noise_pred_cond.detach().clone())      # a graphed pass returns its static output buffer: keep a copy per step
         return all_latent, all_noise
 
     @property
@@ -109,15 +109,82 @@ class NullInversion:
         ddim_latents, ddim_noise = self.ddim_loop(latent, latent_2)
         return image_rec, ddim_latents, ddim_noise
 
+    def _prev_step_autograd(self, model_output, timestep: int, sample):
+        """inversion.py:47-55 in torch ops: the null-text loss differentiates through the step (gd_ddim_step has no backward)."""
+        sch = self.scheduler
+        t = int(timestep)
+        tp = t - sch.config.num_train_timesteps // sch.num_inference_steps
+        a_t = float(sch.alphas_cumprod[t])
+        a_p = float(sch.alphas_cumprod[tp]) if tp >= 0 else float(sch.final_alpha_cumprod)
+        x0 = (sample - (1 - a_t) ** 0.5 * model_output) / a_t ** 0.5
+        return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * model_output
+
+    def get_noise_pred_single(self, latents, t, context):
+        """inversion.py:67-70."""
+        return self.model.unet(latents, t, encoder_hidden_states=context)["sample"]
+
+    def get_noise_pred(self, latents, t, is_forward=True, context=None):
+        """inversion.py:72-85."""
+        latents_input = torch.cat([latents] * 2)
+        if context is None:
+            context = self.context
+        guidance_scale = 1 if is_forward else self.guidance_scale
+        noise_pred = self.model.unet(latents_input, t, encoder_hidden_states=context)["sample"]
+        noise_pred_uncond, noise_prediction_text = noise_pred.chunk(2)
+        if is_forward:
+            return self.next_step(noise_pred_uncond + guidance_scale * (noise_prediction_text - noise_pred_uncond), t, latents)
+        return self.scheduler.step(noise_pred_uncond, t, latents, eta=0.0, eps_cond=noise_prediction_text,
+                                   guidance_scale=guidance_scale)["prev_sample"]
+
+    def null_optimization(self, latents, num_inner_steps, epsilon, t_coords=None):
+        """inversion.py:213-259 — null-text inversion: per DDIM step, up to ``num_inner_steps`` Adam steps (lr 1e-2 (1 - i/100)) on the
+        unconditional embedding so that the guided step from x_t reproduces the inversion trajectory's x_{t-1}; early stop at
+        ``epsilon + 2e-5 i``.  The UNet passes run with the vanilla processor; their attention goes through gd_attn_fwd and the full
+        backward (dQ, dK, dV: gd_attn_bwd / gd_attn_bwd_dkv).  Off in every reference driver ("not required for GeoDiffuser",
+        inversion.py:269), on by default in ``perform_geometric_edit``'s signature (editor.py:437)."""
+        self.model.unet.set_attn_processor(VanillaAttentionProcessor())
+        uncond_embeddings, cond_embeddings = self.context.chunk(2)
+        uncond_embeddings_list = []
+        latent_cur = latents[-1]
+        with torch.enable_grad():
+            for p in self.model.unet.parameters():
+                p.requires_grad = False
+            for i in range(self.num_ddim_steps):
+                uncond_embeddings = uncond_embeddings.clone().detach().float()
+                uncond_embeddings.requires_grad = True
+                optimizer = torch.optim.Adam([uncond_embeddings], lr=1e-2 * (1.0 - i / 100.0))
+                latent_prev = latents[len(latents) - i - 2].detach().float()
+                t = self.model.scheduler.timesteps[i]
+                with torch.no_grad():
+                    noise_pred_cond = self.get_noise_pred_single(latent_cur, t, cond_embeddings).float()
+                for j in range(num_inner_steps):
+                    if self.progress_bar is not None:
+                        self.progress_bar((i * num_inner_steps + j) / (self.num_ddim_steps * num_inner_steps), desc="Null-text optimization")
+                    noise_pred_uncond = self.get_noise_pred_single(latent_cur, t, uncond_embeddings).float()
+                    noise_pred = noise_pred_uncond + self.guidance_scale * (noise_pred_cond - noise_pred_uncond)
+                    latents_prev_rec = self._prev_step_autograd(noise_pred, t, latent_cur.float())
+                    loss = torch.nn.functional.mse_loss(latents_prev_rec, latent_prev)
+                    optimizer.zero_grad()
+                    loss.backward()
+                    optimizer.step()
+                    if loss.item() < epsilon + i * 2e-5:
+                        break
+                uncond_embeddings_list.append(uncond_embeddings[:1].detach())
+                with torch.no_grad():
+                    context = torch.cat([uncond_embeddings.detach().to(cond_embeddings.dtype), cond_embeddings])
+                    latent_cur = self.get_noise_pred(latent_cur, t, False, context)
+        return uncond_embeddings_list
+
     def invert(self, image_gt, prompt: str, offsets=(0, 0, 0, 0), num_inner_steps=10, early_stop_epsilon=1e-5, verbose=False,
                t_coords=None, perform_inversion=True, image_2=None):
         """inversion.py:261-277."""
         self.init_prompt(prompt)
         image_rec, ddim_latents, ddim_noise = self.ddim_inversion(image_gt, image_2)
         if perform_inversion:
-            raise NotImplementedError("null-text optimisation is off in every reference driver (large_scale_editor.py:208, "
-                                      "ui_utils.py:596,626); call with perform_inversion=False")
-        return (image_gt, image_rec), ddim_latents[-1], None, ddim_latents, ddim_noise
+            uncond_embeddings = self.null_optimization(ddim_latents, num_inner_steps, early_stop_epsilon, t_coords=t_coords)
+        else:
+            uncond_embeddings = None
+        return (image_gt, image_rec), ddim_latents[-1], uncond_embeddings, ddim_latents, ddim_noise
 
     def __init__(self, model, num_ddim_steps=50, uncond_text="", device="cuda:0", progress_bar=None, guidance_scale=3.0):
         self.guidance_scale = guidance_scale

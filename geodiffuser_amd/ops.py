@@ -119,10 +119,15 @@ def _attn_plan(lib, tot_bh: int, N: int, M: int):
     return p
 
 
-def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Optional[int] = None) -> None:
-    """segs: list of (q, k, v, out, lse | None); one launch.
+def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Optional[int] = None, q_scaled: bool = False) -> None:
+    """segs: list of (q, k, v, out, lse | None[, warp]); one launch.
     heads == 0: q/out [bh,N,D], k/v [bh,M,D] (head-major).  heads > 0: token-major q/out [B,N,heads*D], k/v [B,M,heads*D]
-    exactly as to_q/to_k/to_v produce them (no head_to_batch_dim copies); lse [B*heads, N]."""
+    exactly as to_q/to_k/to_v produce them (no head_to_batch_dim copies); lse [B*heads, N].
+    warp = (idx [N,K] i32, w [N,K] f32, m [N] f32 | None): the segment attends with the warped, blended queries
+    q*(1-m) + m*half(sum_k w*q[idx]) built inside the kernel (U/attention_processors.py:424-428,544-549) — the fused
+    attention-warp launch; bit-identical to passing splat_composite(q, idx, w, m) as q.
+    q_scaled: every q already carries scale*log2(e) (applied by the projection GEMM before its rounding, see attention_processors
+    ``_project_qkv``); ``scale`` is then ignored."""
     lib = _lib.load()
     n = len(segs)
     arr = (GdAttnSeg * n)()
@@ -131,7 +136,9 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
     N, M = q0.shape[1], k0.shape[1]
     dt = _dt16(q0, "q")
     tot_bh = 0
-    for i, (q, k, v, o, lse) in enumerate(segs):
+    for i, seg in enumerate(segs):
+        q, k, v, o, lse = seg[:5]
+        warp = seg[5] if len(seg) > 5 else None
         for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "out")):
             _need(t, nm, q0.dtype)
         if heads:
@@ -145,7 +152,19 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
             _need(lse, "lse", torch.float32)
         bh = q.shape[0] * (heads if heads else 1)
         tot_bh += bh
-        arr[i] = GdAttnSeg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 0 if lse is None else lse.data_ptr(), bh, heads)
+        widx = ww = wm = 0
+        wK = 0
+        if warp is not None:
+            t_idx, t_w, t_m = warp
+            _need(t_idx, "warp idx", torch.int32); _need(t_w, "warp w", torch.float32)
+            wK = t_idx.shape[-1]
+            if t_idx.numel() != N * wK or t_w.numel() != N * wK or (t_m is not None and t_m.numel() != N):
+                raise _lib.GeodiffError("attn_fwd: warp tables must have N rows")
+            if t_m is not None:
+                _need(t_m, "warp m", torch.float32)
+            widx, ww, wm = t_idx.data_ptr(), t_w.data_ptr(), 0 if t_m is None else t_m.data_ptr()
+        arr[i] = GdAttnSeg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 0 if lse is None else lse.data_ptr(), bh, heads,
+                           widx, ww, wm, wK, int(bool(q_scaled)))
     if nsplit is None:
         nsplit, ws_bytes = _attn_plan(lib, tot_bh, N, M) if SPLIT_KV else (1, 0)
     else:
@@ -219,7 +238,8 @@ def removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, scale
     N, D = q.shape[1], q.shape[2]
     M = k.shape[1]
     _need(dq_f32, "dq_f32", torch.float32)
-    ds_ws = torch.empty(H * R * (1 + (Mpad if dk_f32 is not None else 0)), dtype=torch.float32, device=Pe.device)
+    ds_ws = torch.empty(lib.gd_removal_bwd_workspace_bytes(H, R, M, Mpad, int(dk_f32 is not None)) // 4, dtype=torch.float32,
+                        device=Pe.device)
     check(lib.gd_removal_bwd(_p(Pe), _p(Pb), _p(q), _p(k), _p(rows), _p(aux["p_in"]), _p(aux["j_in"]), _p(aux["p_wo"]),
                              _p(aux["j_wo"]), _p(aux["wgt"]), _p(m_inp), _p(m_wo), coef, _p(gscale), H, R, N, M, Mpad, D, scale,
                              _p(dq_f32), _p(dk_f32), _p(ds_ws), dt, _stream()), "gd_removal_bwd")
@@ -254,8 +274,9 @@ def edit_losses_fwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int):
     _need(eo, "eo"); _need(ro, "ro", eo.dtype)
     H, N, D = eo.shape
     sums = torch.zeros(5, dtype=torch.float32, device=eo.device)
-    check(lib.gd_edit_losses_fwd(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), H, S, D, _p(sums), dt, _stream()),
-          "gd_edit_losses_fwd")
+    ws = torch.empty(lib.gd_edit_losses_fwd_workspace_bytes(H, S, D) // 4, dtype=torch.float32, device=eo.device)
+    check(lib.gd_edit_losses_fwd(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), H, S, D, _p(sums), _p(ws), dt,
+                                 _stream()), "gd_edit_losses_fwd")
     return sums
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 1
+#define GD_ABI_VERSION 2
 
 enum { GD_F16 = 0, GD_BF16 = 1, GD_F32 = 2 };
 enum { GD_TOKEN_MAJOR = 0 /* [B, P, C] */, GD_CHANNEL_MAJOR = 1 /* [B, C, P] */ };
@@ -100,6 +100,21 @@ typedef struct {
     int32_t bh;      /* batch*heads entries in this segment */
     int32_t heads;   /* 0: head-major (the reference's head_to_batch_dim layout); > 0: token-major as produced by to_q/to_k/to_v,
                         which saves the four head_to_batch_dim / batch_to_head_dim copies per attention layer */
+    /* Fused geometric warp of the queries (the north star's "fused attention-warp kernel"), U/attention_processors.py:424-428,
+     * 544-549: when warp_idx != NULL the segment attends with
+     *     q_warp[n] = q[n] * (1 - m[n]) + m[n] * half(sum_k warp_w[n,k] * q[warp_idx[n,k]])
+     * built in the kernel's prologue from the per-resolution splat tables (gd_rasterize_points / gd_splat_weights) instead of
+     * reading a q_warp tensor written by gd_splat_composite: bit-identical to that two-launch path (same code, splat_common.hpp),
+     * one launch and one HBM round trip of the queries less.  warp_m == NULL: no blend.  Needs N == number of table rows. */
+    const int32_t* warp_idx;   /* [N, warp_K] i32 (packed point index, -1 = empty slot) or NULL */
+    const float* warp_w;       /* [N, warp_K] f32 composite weights */
+    const float* warp_m;       /* [N] f32 soft edit mask or NULL */
+    int32_t warp_K;
+    /* Nonzero: q already holds scale*log2(e)*q — the query projection applied that factor in its fp32 GEMM epilogue, BEFORE the one
+     * rounding to 16 bits.  The kernels then take the scores as exponents of 2 directly (p = exp2(q.k - mu): one vector instruction
+     * per probability instead of two on the vector-issue-bound D = 64 path) and `scale` is ignored.  All segments of a launch must
+     * agree.  lse stays the natural-log sum-exp of the scaled scores. */
+    int32_t q_scaled;
 } gd_attn_seg_t;
 
 #define GD_ATTN_MAX_SEGS 4
@@ -114,6 +129,11 @@ int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float 
  * f32 summation order.  gd_attn_fwd_plan returns the nsplit worth using for tot_bh = sum of segment bh (1 = do not split) and the
  * workspace size it needs. */
 int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_bytes);
+
+/* Tuning hook (benchmarks / tests): which software-pipelined kernel gd_attn_fwd uses on launches with full key tiles
+ * (M % 128 == 0): a workgroup of QB query blocks (32 rows each) x KS key ranges merged through LDS; (4,1), (2,2), (4,2), (2,4)
+ * exist.  qb < 0: automatic (default; also GD_ATTN_CFG="QBxKS" in the environment), qb == 0: always the plain kernel. */
+int gd_attn_fwd_set_config(int qb, int ks);
 int gd_attn_fwd_splitkv(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
                         size_t workspace_bytes, int dtype, void* stream);
 
@@ -165,9 +185,10 @@ int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, 
  * Backward of the removal loss through replace_att rows into q (and k for cross):
  *   dA[h,r,m] = coef * wgt[h,r] * ( -Pb[h,j_wo,m] * m_wo[j_wo]/(p_wo+1e-4) + Pb[h,j_in,m] * m_inp[j_in]/(p_in+1e-4) )
  *   dS = A o (dA - rowsum(A o dA));  dq[h,rows[r]] += scale * dS K;  dk_f32[h] += scale * dS^T q   (dk_f32 may be NULL)
- * dq_f32 [H,N,D] f32 accumulated (caller zeroes).  ds_ws: scratch, H*R floats (+ H*R*Mpad floats when dk_f32 != NULL).  gscale_dev: optional DEVICE scalar multiplied into coef (the
+ * dq_f32 [H,N,D] f32 accumulated (caller zeroes).  ds_ws: scratch of gd_removal_bwd_workspace_bytes() bytes (row dots, per-key-chunk dq partials that are folded in a fixed order — no f32 atomics, bit-reproducible — and dS when dk_f32 != NULL).  gscale_dev: optional DEVICE scalar multiplied into coef (the
  * upstream gradient of the loss, so that no host sync is needed to read it).
  */
+size_t gd_removal_bwd_workspace_bytes(int H, int R, int M, int Mpad, int need_dk);
 int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
                    const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
                    const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
@@ -195,9 +216,13 @@ int gd_amodal_target(const void* eo, const int32_t* nn_idx, const float* nn_w, c
  * The four feature losses in one pass (U/attention_processors.py:231-246,283-305; U/loss.py:29-41).
  * sums[0] += sum |eo-ro| m_wo      sums[1] += sum |eo-ro| m_edit      sums[2] += sum |tgt-ro| w_am m_amodal
  * sums[3] += sum |ro[y+1]-ro[y]|   sums[4] += sum |ro[x+1]-ro[x]|      (tgt/w_am/m_amodal may be NULL)
+ * Bit-reproducible: per-workgroup partials go through `workspace` (gd_edit_losses_fwd_workspace_bytes) and are folded in a
+ * fixed order — no floating-point atomics.
  */
+size_t gd_edit_losses_fwd_workspace_bytes(int H, int S, int D);
 int gd_edit_losses_fwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
-                       const float* w_am, const float* m_amodal, int H, int S, int D, float* sums, int dtype, void* stream);
+                       const float* w_am, const float* m_amodal, int H, int S, int D, float* sums, float* workspace,
+                       int dtype, void* stream);
 
 /*
  * d(loss)/d(ro) for the weighted sum of those losses plus the blend path:

@@ -35,6 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_MFMA_16BIT = 2.5e15     # dense bf16/fp16 MFMA peak of MI355X, /opt/skills/guides/MI355X_MICROARCH.md
+TRAFFIC_TABLE = "r01_attn_traffic.json"   # PMC-measured HBM bytes per launch of the attention kernel, by head count (profiles/)
 
 
 class AttnTimer:
@@ -50,22 +51,25 @@ class AttnTimer:
         self.cfgs = {}              # cfg -> dict(count=launches in the timed region, ev=[(e0, e1)], flops=per launch)
         self._capturing = None      # list of cfgs of the graph being captured
 
-    def _cfg(self, segs, scale, heads):
+    def _cfg(self, segs, scale, heads, q_scaled=False):
         q0 = segs[0][0]
-        return (tuple((tuple(s[0].shape), tuple(s[1].shape), s[4] is not None) for s in segs), float(scale), heads, q0.dtype)
+        # per segment: q shape, k shape, lse wanted, slot count K of a fused query warp (0 = plain queries)
+        return (tuple((tuple(s[0].shape), tuple(s[1].shape), s[4] is not None,
+                       int(s[5][0].shape[-1]) if len(s) > 5 and s[5] is not None else 0) for s in segs),
+                float(scale), heads, q0.dtype, bool(q_scaled))
 
     def _entry(self, cfg):
         e = self.cfgs.get(cfg)
         if e is None:
-            shapes, _, heads, _ = cfg
-            bh = sum(qs[0] for qs, _, _ in shapes) * (heads if heads else 1)
+            shapes, _, heads, _, _ = cfg
+            bh = sum(sh[0][0] for sh in shapes) * (heads if heads else 1)
             e = self.cfgs[cfg] = dict(count=0, ev=[], flops=4.0 * bh * self.n * self.n * 64, heads=bh)
         return e
 
-    def _timed(self, cfg, segs, scale, heads, key="ev"):
+    def _timed(self, cfg, segs, scale, heads, q_scaled, key="ev"):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        self._orig(segs, scale, heads)
+        self._orig(segs, scale, heads, q_scaled=q_scaled)
         e1.record()
         self._entry(cfg).setdefault(key, []).append((e0, e1))
 
@@ -74,20 +78,20 @@ class AttnTimer:
         self._orig = ops.attn_fwd
         timer = self
 
-        def wrapped(segs, scale, heads=0, nsplit=None):
+        def wrapped(segs, scale, heads=0, nsplit=None, q_scaled=False):
             q0, k0 = segs[0][0], segs[0][1]
             if nsplit is not None or q0.shape[1] != timer.n or k0.shape[1] != timer.n:
-                return timer._orig(segs, scale, heads, nsplit)
-            cfg = timer._cfg(segs, scale, heads)
+                return timer._orig(segs, scale, heads, nsplit, q_scaled=q_scaled)
+            cfg = timer._cfg(segs, scale, heads, q_scaled)
             if torch.cuda.is_current_stream_capturing():
                 if timer._capturing is not None:
                     timer._capturing.append(cfg)
                 timer._entry(cfg)
-                return timer._orig(segs, scale, heads)
+                return timer._orig(segs, scale, heads, q_scaled=q_scaled)
             if timer.enabled:
                 timer._entry(cfg)["count"] += 1
-                return timer._timed(cfg, segs, scale, heads)
-            return timer._orig(segs, scale, heads)
+                return timer._timed(cfg, segs, scale, heads, q_scaled)
+            return timer._orig(segs, scale, heads, q_scaled=q_scaled)
 
         ops.attn_fwd = wrapped
         G = torch.cuda.CUDAGraph
@@ -113,19 +117,34 @@ class AttnTimer:
         for cfg, e in self.cfgs.items():
             if e["count"] == 0:
                 continue
-            shapes, scale, heads, dt = cfg
+            shapes, scale, heads, dt, q_scaled = cfg
             segs = []
-            for qs, ks, want_lse in shapes:
-                q = torch.randn(qs, device="cuda").to(dt); k = torch.randn(ks, device="cuda").to(dt); v = torch.randn(ks, device="cuda").to(dt)
+            for qs, ks, want_lse, warp_k in shapes:
+                # unit-variance q / k (scaled scores ~ N(0, 1) nats, as at a freshly initialised layer); queries that arrive
+                # pre-scaled carry scale*log2(e) like the projection's output
+                q = torch.randn(qs, device="cuda")
+                if q_scaled:
+                    q = q * (scale * 1.4426950408889634)
+                q = q.to(dt); k = torch.randn(ks, device="cuda").to(dt); v = torch.randn(ks, device="cuda").to(dt)
                 lse = torch.empty(qs[0] * (heads if heads else 1), qs[1], device="cuda") if want_lse else None
-                segs.append((q, k, v, torch.empty_like(q), lse))
+                seg = (q, k, v, torch.empty_like(q), lse)
+                if warp_k:                                 # fused query warp: a translation-like table (each pixel gathers near-by rows)
+                    n = qs[1]
+                    idx = ((torch.arange(n, device="cuda")[:, None] + torch.randint(-70, 70, (n, warp_k), device="cuda")) % n).to(torch.int32)
+                    idx[:, 4:] = -1
+                    w = torch.rand(n, warp_k, device="cuda") * 0.25
+                    side = int(round(n ** 0.5))
+                    yy, xx = torch.meshgrid(torch.arange(side, device="cuda"), torch.arange(side, device="cuda"), indexing="ij")
+                    m = ((((xx - 0.56 * side) / (0.17 * side)) ** 2 + ((yy - 0.47 * side) / (0.14 * side)) ** 2) <= 1.0).float().reshape(-1)   # compact object mask (~8 % of the map)
+                    seg = seg + ((idx.contiguous(), w.contiguous(), m.contiguous()),)
+                segs.append(seg)
             for _ in range(30):                            # warm: clocks ramp down while the host builds the tensors above
-                self._orig(segs, scale, heads)
+                self._orig(segs, scale, heads, q_scaled=q_scaled)
             # one event bracket around `reps` back-to-back launches: the queue stays full, so host dispatch time is not measured
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                self._orig(segs, scale, heads)
+                self._orig(segs, scale, heads, q_scaled=q_scaled)
             e1.record()
             e["rep"] = (e0, e1, reps)
         torch.cuda.synchronize()
@@ -138,7 +157,8 @@ class AttnTimer:
                     us = 1e3 * e["rep"][0].elapsed_time(e["rep"][1]) / e["rep"][2]
                 else:
                     us = 1e3 * sum(a.elapsed_time(b) for a, b in e["ev"]) / len(e["ev"])
-                row = dict(heads=e["heads"], token_major=bool(cfg[2]), launches=e["count"], avg_us=us, tflops=e["flops"] / us * 1e-6)
+                row = dict(heads=e["heads"], token_major=bool(cfg[2]), q_scaled=bool(cfg[4]),
+                           fused_warp=any(sh[3] for sh in cfg[0]), launches=e["count"], avg_us=us, tflops=e["flops"] / us * 1e-6)
                 if e["ev"]:
                     row["eager_avg_us"] = 1e3 * sum(a.elapsed_time(b) for a, b in e["ev"]) / len(e["ev"])
                 rows.append(row)
@@ -150,7 +170,7 @@ class AttnTimer:
         # HBM traffic of the most frequent launch shape, from the committed PMC run of the same kernel (profiles/)
         traffic = None
         try:
-            tab = json.load(open(os.path.join(ROOT, "profiles", "r01_attn_traffic.json")))["bytes_per_launch"]
+            tab = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_TABLE)))["bytes_per_launch"]
             common = max(rows, key=lambda r: r["launches"])["heads"]
             traffic = tab.get(str(common))
             if traffic is None:                       # measured at 10 / 15 / 20 heads; linear in the head count (Q, K, V, O once each)

@@ -101,6 +101,7 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 }
 
 // ---- forward kernels: launch arguments and fragment helpers shared by attn_fwd.hip and attn_fwd_mp.hip ----
+#define GD_ATTN_MAX_ORDER 160
 struct FwdArgs {
     gd_attn_seg_t seg[GD_ATTN_MAX_SEGS];
     int bh_end[GD_ATTN_MAX_SEGS];   // exclusive prefix of bh
@@ -111,6 +112,10 @@ struct FwdArgs {
     float c;                        // scale * log2(e)
     float scale;
     int q_prescaled;                // the queries already carry c (gd_attn_seg_t::q_scaled): scores arrive in the log2 domain
+    // pipelined kernels: launch order of the heads.  order[g] = (segment << 12) | head-in-segment for the g-th head of the grid; heads
+    // of different segments are interleaved (n_order == 0: segment after segment, via bh_end)
+    int n_order;
+    unsigned short order[GD_ATTN_MAX_ORDER];
     // split-KV (launches that would leave most CUs idle): split sp handles key tiles [sp*tps, (sp+1)*tps) and leaves an
     // un-normalised partial (O, m, l) in the workspace; k_attn_combine merges them
     int nsplit, tps, tot_bh;

@@ -204,11 +204,17 @@ k_attn_fwd_mp(const FwdArgs a) {
     const int ks = wave / QB, qb = wave - ks * QB, gtid = tid - ks * GT;
     const int wg = xcd_remap(blockIdx.x, a.nwg);
     const int gbh = wg / a.tiles, tile = wg - gbh * a.tiles;
-    int sidx = 0;
+    int sidx = 0, bh;
+    if (a.n_order > 0) {                                   // interleaved head order (see gd_attn_fwd_mp_launch)
+        const int code = a.order[gbh];
+        sidx = code >> 12;
+        bh = code & 4095;
+    } else {
 #pragma unroll
-    for (int i = 0; i < GD_ATTN_MAX_SEGS - 1; ++i)
-        if (i < a.nseg - 1 && gbh >= a.bh_end[i]) sidx = i + 1;
-    const int bh = gbh - (sidx ? a.bh_end[sidx - 1] : 0);
+        for (int i = 0; i < GD_ATTN_MAX_SEGS - 1; ++i)
+            if (i < a.nseg - 1 && gbh >= a.bh_end[i]) sidx = i + 1;
+        bh = gbh - (sidx ? a.bh_end[sidx - 1] : 0);
+    }
     const gd_attn_seg_t sg = a.seg[sidx];
     const int N = a.N, M = a.M;
     // row stride / base offsets: head-major [bh, N, 64] or token-major [B, N, heads*64]
@@ -410,6 +416,32 @@ int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st) 
     int tot = 0;
     for (int i = 0; i < a.nseg; ++i) tot = a.bh_end[i];
     a.nwg = a.tiles * tot;
+    // Head order of the grid.  The 1-D grid is cut into 8 contiguous chunks, one per XCD (xcd_remap), and an XCD runs its chunk in
+    // ascending order.  Segment after segment, the heads whose workgroups build warped queries in their prologue (~8 us of dependent
+    // gathers) all land on two XCDs, which then finish last (measured: +17 us on a 106 us launch).  Interleaving the segments by
+    // relative position spreads them over the XCDs, puts a warped head before the plain heads of its neighbourhood, and places the
+    // edit_out / replace_out heads that share k_base / v_base on the same XCD's L2.
+    a.n_order = 0;
+    if (a.nseg > 1 && tot <= GD_ATTN_MAX_ORDER) {
+        float key[GD_ATTN_MAX_ORDER];
+        int n = 0, start = 0;
+        for (int sgi = 0; sgi < a.nseg; ++sgi) {
+            const int cnt = a.bh_end[sgi] - start;
+            for (int i = 0; i < cnt; ++i) {
+                key[n] = ((float)i + (a.seg[sgi].warp_idx ? 0.25f : 0.5f)) / (float)cnt + 1e-4f * (float)sgi;
+                a.order[n++] = (unsigned short)((sgi << 12) | i);
+            }
+            start = a.bh_end[sgi];
+        }
+        for (int i = 1; i < n; ++i) {                                        // insertion sort by key (n <= 160)
+            const float kx = key[i];
+            const unsigned short ox = a.order[i];
+            int j = i - 1;
+            for (; j >= 0 && key[j] > kx; --j) { key[j + 1] = key[j]; a.order[j + 1] = a.order[j]; }
+            key[j + 1] = kx; a.order[j + 1] = ox;
+        }
+        a.n_order = n;
+    }
     const int Tg = (a.M / ATT_BN) / ks;
     GD_REQUIRE(a.M % ATT_BN == 0 && (a.M / ATT_BN) % ks == 0 && Tg >= 2 && Tg % 2 == 0, GD_EINVAL,
                "gd_attn_fwd: the pipelined kernel needs an even number of full key tiles per key range (M=%d, KS=%d)", a.M, ks);

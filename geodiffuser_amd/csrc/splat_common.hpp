@@ -17,42 +17,79 @@ __device__ __forceinline__ void composite_chunks(const T* __restrict__ sb, size_
                                                  typename elem_traits<T>::vec8 (&out)[NCH]) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
+    // Everything that does not depend on another load is issued up front, in one round trip: the mask value, this pixel's own row
+    // (needed for the blend) and the first 16 index / weight slots (K = 15 on this path).
+    const float mm = m ? m[pix] : 1.0f;
+    V8 qown[NCH];
+    if (m) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) qown[c] = *(const V8*)(sb + (size_t)pix * rs + coff[c]);      // npix == P on this path
+    }
+    int pk[16];
+    float wk[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int kc = j < K ? j : K - 1;                                    // branch-free: all table loads issue together
+        const int p = idx[(size_t)pix * K + kc];
+        const float wv = w[(size_t)pix * K + kc];                            // unconditional: no index -> weight dependency
+        pk[j] = j < K ? p : -1;
+        wk[j] = pk[j] >= 0 ? wv : 0.0f;                                      // weight 0 for empty slots: fma(0, x, acc) == acc
+    }
+    // Pixels outside the warped mask (m == 0: ~90 % of an attention map) keep their own row: q*1 + 0*splat == q, so the K gathers are
+    // skipped for them (exec-masked; most waves skip entirely).  [With m == 0 the blend can differ from this only in the sign of a
+    // zero (-0 + +0) or when the splat is non-finite; both kernels that use this function take the same shortcut.]
+    if (m && mm == 0.0f) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) out[c] = qown[c];
+        return;
+    }
     float acc[NCH][8];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[c][i] = 0.0f;
-    // the K gathers of a pixel are independent: fetch the index / weight slots 8 at a time, issue the row loads together
-    // (a dependent idx -> row chain per slot is latency-bound), then accumulate in slot order
-    for (int k0 = 0; k0 < K; k0 += 8) {
-        int pk[8];
-        float wk[8];
+    // The K gathers of a pixel are independent and latency-bound: the row loads of two 8-channel chunks for all 16 slots are issued
+    // together (32 loads in flight; empty slots fetch row 0 with weight 0 — a predicated load per slot would serialise the round
+    // trips), then accumulated in slot order — the summation order per element never changes.
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        if (k0 > 0) {                                                        // K > 16: further table batches
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int kk = k0 + j;
-            const int kc = kk < K ? kk : K - 1;                              // branch-free: all 16 table loads issue together
-            const int p = idx[(size_t)pix * K + kc];
-            pk[j] = kk < K ? p : -1;
-            wk[j] = pk[j] >= 0 ? w[(size_t)pix * K + kc] : 0.0f;             // weight 0 for empty slots: fma(0, x, acc) == acc
+            for (int j = 0; j < 16; ++j) {
+                const int kk = k0 + j;
+                const int kc = kk < K ? kk : K - 1;
+                const int p = idx[(size_t)pix * K + kc];
+                const float wv = w[(size_t)pix * K + kc];
+                pk[j] = kk < K ? p : -1;
+                wk[j] = pk[j] >= 0 ? wv : 0.0f;
+            }
         }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            V8 f[8];
+        for (int c0 = 0; c0 < NCH; c0 += 2) {
+            V8 f[2][16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = *(const V8*)(sb + (size_t)(pk[j] < 0 ? 0 : pk[j]) * rs + coff[c]);
+            for (int cc = 0; cc < 2; ++cc)
+                if (c0 + cc < NCH) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < 16; ++j)
+                        f[cc][j] = *(const V8*)(sb + (size_t)(pk[j] < 0 ? 0 : pk[j]) * rs + coff[c0 + cc]);
+                }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[c][i] = __builtin_fmaf(wk[j], TR::to_f32(f[j][i]), acc[c][i]);
+            for (int cc = 0; cc < 2; ++cc)
+                if (c0 + cc < NCH) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            acc[c0 + cc][i] = __builtin_fmaf(wk[j], TR::to_f32(f[cc][j][i]), acc[c0 + cc][i]);
+                }
         }
     }
     if (m) {
-        const float mm = m[pix];
         const float one_m = TR::to_f32(TR::from_f32(1.0f - mm));
         const float m_t = TR::to_f32(TR::from_f32(mm));
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const V8 q = *(const V8*)(sb + (size_t)pix * rs + coff[c]);      // npix == P on this path
+            const V8 q = qown[c];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float s16 = (float)(f16_t)acc[c][i];                   // `.to(torch.half)` U/warp_utils.py:176

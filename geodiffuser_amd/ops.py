@@ -97,8 +97,9 @@ def mesh_coverage(verts, faces, S: int):
     if faces.numel():
         _need(faces, "faces", torch.int32)
     out = torch.empty(S, S, dtype=torch.float32, device=verts.device)
-    check(lib.gd_mesh_coverage(_p(verts), _p(faces) if faces.numel() else None, verts.shape[0], faces.shape[0], S, _p(out), _stream()),
-          "gd_mesh_coverage")
+    if verts.numel() == 0 or faces.numel() == 0:               # empty mesh: nothing is covered (no launch needed, no null pointers)
+        return out.zero_()
+    check(lib.gd_mesh_coverage(_p(verts), _p(faces), verts.shape[0], faces.shape[0], S, _p(out), _stream()), "gd_mesh_coverage")
     return out
 
 

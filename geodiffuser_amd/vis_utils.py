@@ -38,6 +38,24 @@ def camera_matrix(focal_x, focal_y, c_x, c_y):
     return np.array([[focal_x, 0, c_x], [0, focal_y, c_y], [0, 0, 1]])
 
 
+def get_mesh(t_coords_hw3: torch.Tensor, mask_hw: torch.Tensor):
+    """warp_utils.py:304-399 (get_coordinate_array, get_indexing_grid, create_triangles, get_mesh) on the device: vertices = (-x, -y, Z)
+    of the masked pixels in row-major order (float32 [V,3]); faces int32 [F,3] = for every 2x2 pixel quad the triangles
+    (tl, tr, bl) and (bl, tr, br) — first all upper, then all lower triangles, each kept iff ITS OWN three corners are in the mask
+    (:354-361: the test is per triangle, not per quad)."""
+    m = mask_hw >= 0.5
+    mapping = (torch.cumsum(m.reshape(-1).to(torch.int32), 0, dtype=torch.int32) - 1).reshape(m.shape)
+    mapping = torch.where(m, mapping, torch.full_like(mapping, -1))
+    tl, trr, bl, br = mapping[:-1, :-1], mapping[:-1, 1:], mapping[1:, :-1], mapping[1:, 1:]
+    up = torch.stack([tl, trr, bl], 0).reshape(3, -1)
+    lo = torch.stack([bl, trr, br], 0).reshape(3, -1)
+    faces = torch.cat([up, lo], -1)
+    faces = faces[:, faces.min(0).values > -1].t().contiguous()
+    verts = t_coords_hw3[m].float().clone()
+    verts[:, :2] = -verts[:, :2]                                                      # warp_utils.py:373-375
+    return verts.contiguous(), faces
+
+
 @torch.no_grad()
 def get_transform_coordinates(image, depth, obj_mask=None, transform_in=torch.eye(4), use_softsplat=True, focal_length=550,
                               return_mesh=False, device="cuda", as_torch=False):
@@ -78,14 +96,8 @@ def get_transform_coordinates(image, depth, obj_mask=None, transform_in=torch.ey
 
     amodal = None
     if return_mesh:                                                                    # get_mesh + splatter_mesh
-        m = mask_t[0, 0] >= 0.5
-        quad = m[:-1, :-1] & m[:-1, 1:] & m[1:, :-1] & m[1:, 1:]
-        ids = torch.arange(H * W, device=dev, dtype=torch.int32).reshape(H, W)
-        tl, trr, bl, br = ids[:-1, :-1][quad], ids[:-1, 1:][quad], ids[1:, :-1][quad], ids[1:, 1:][quad]
-        faces = torch.cat([torch.stack([tl, trr, bl], 1), torch.stack([bl, trr, br], 1)], 0).contiguous()
-        verts = t_coords[0].reshape(-1, 3).clone()
-        verts[:, :2] = -verts[:, :2]                                                  # warp_utils.py:373-375
-        amodal = ops.mesh_coverage(verts.contiguous(), faces, H)[None, None]
+        verts, faces = get_mesh(t_coords[0], mask_t[0, 0])
+        amodal = ops.mesh_coverage(verts, faces, H)[None, None]
     # preview image (warp_utils.py:470); depth_projected of the reference is garbage and unused
     img = torch.from_numpy(image)[None].permute(0, 3, 1, 2).float().to(dev)
     idx, w = warp_utils.SPLATTER.tables(t_coords[0].reshape(-1, 3))

@@ -259,6 +259,41 @@ def g11_geometry(R):
     save("G11_geometry", **out)
 
 
+def g12_mesh(R):
+    """get_mesh / create_triangles / get_coordinate_array / get_indexing_grid (U/warp_utils.py:304-399) — the reference's own
+    code (pure torch) on masks that tell the per-TRIANGLE corner test from a per-quad one (holes, one-pixel notches, thin bars, a
+    diagonal staircase), with the projected coordinates of G11's transforms: vertices and face lists as the reference hands them to
+    pytorch3d's ``Meshes`` (captured by a recording stand-in)."""
+    import GeoDiffuser.utils.vis_utils as vis
+    wu = R.warp_utils
+    captured = {}
+
+    class Rec:
+        def __init__(self, verts=None, faces=None, textures=None):
+            captured["verts"], captured["faces"] = verts[0].detach().clone(), faces[0].detach().clone()
+
+    old_meshes, old_tex = wu.Meshes, wu.TexturesVertex
+    wu.Meshes, wu.TexturesVertex = Rec, (lambda **k: None)
+    out = {}
+    try:
+        size = 64
+        for name, mask in cases.mesh_masks(size).items():
+            v, u = np.mgrid[0:size, 0:size].astype(np.float32)
+            depth = np.where(mask > 0.5, 0.5 + 0.2 * (u / size - 0.5), 0.9).astype(np.float32)
+            T = (vis.translateMatrix(0.05, 0.0, 0.05) @ vis.rotateAxis(-15.0, 1).float() @ vis.rotateAxis(10.0, 2).float()).float()
+            image = np.zeros((size, size, 3), dtype=np.float32)
+            t_coords, _ = vis.get_transform_coordinates(image, depth.copy(), mask, transform_in=T, focal_length=550 * size / 512.0,
+                                                        return_mesh=False)
+            tc = torch.from_numpy(t_coords)[None].permute(0, 3, 1, 2)                 # b, 3, h, w as at U/warp_utils.py:456
+            wu.get_mesh(tc, torch.from_numpy(mask)[None, None].float())
+            out[name + "_verts"] = captured["verts"].numpy()
+            out[name + "_faces"] = captured["faces"].numpy().astype(np.int32)
+            out[name + "_t_coords"] = t_coords
+    finally:
+        wu.Meshes, wu.TexturesVertex = old_meshes, old_tex
+    save("G12_mesh", **out)
+
+
 def g13_resample(R):
     gt = R.generic_torch
     mask = cases.ellipse_mask()
@@ -479,6 +514,10 @@ def main():
         R = ref_import.import_reference()
         print("G17"); g17_attention_store(R, g_masks_and_warp(R))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "G12":
+        R = ref_import.import_reference()
+        print("G12"); g12_mesh(R)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "G14":
         R = ref_import.import_reference()
         os.makedirs(OUT, exist_ok=True)
@@ -499,6 +538,7 @@ def main():
     print("G9"); g9_adaptive(R)
     print("G10"); g10_ddim(R)
     print("G11"); g11_geometry(R)
+    print("G12"); g12_mesh(R)
     print("G13"); g13_resample(R)
     print("G14"); g14_histogram(R)
     print("G17"); g17_attention_store(R, packs)

@@ -230,3 +230,23 @@ def loop_inputs(c=None):
     rng = np.random.default_rng(c["seed"])
     traj = [rng.standard_normal((1, 4, size // 8, size // 8)).astype(np.float32) for _ in range(c["steps"] + 1)]
     return dict(mask=mask.astype(np.float32), coords=coords.astype(np.float32), x_T=traj[-1], ddim_latents=traj)       # coords [1,256,256,3]
+
+
+def mesh_masks(size=64) -> dict:
+    """Object masks for the mesh fixtures (G12) and the mesh-coverage parity tests: shapes on which a per-triangle corner test
+    (the reference, U/warp_utils.py:331-362) and a per-quad test give different face lists."""
+    out = {"ellipse": ellipse_mask(cx=30, cy=33, ax=11, ay=9, size=size)}
+    m = np.zeros((size, size), dtype=np.float32)
+    m[20:40, 18:44] = 1.0
+    m[27:30, 25:28] = 0.0            # hole
+    m[20, 30] = 0.0                  # one-pixel notch on the top edge
+    m[39, 18] = 0.0                  # missing corner
+    out["holes"] = m
+    m = np.zeros((size, size), dtype=np.float32)
+    for i in range(24):              # diagonal staircase, two pixels thick
+        m[16 + i, 14 + i:16 + i + 1] = 1.0
+        m[17 + i, 14 + i:16 + i + 1] = 1.0
+    m[45:47, 10:50] = 1.0            # thin horizontal bar
+    m[10:50, 52] = 1.0               # one-pixel-wide column: no faces
+    out["thin"] = m
+    return out

@@ -193,10 +193,17 @@ def test_attention_forward_full_size_and_segments(ops):
     q1, q2, q3, k1, k2, v1 = mk(3 * f, N), mk(f, N), mk(f, N), mk(3 * f, N), mk(f, N), mk(3 * f, N)
     o1 = torch.empty_like(q1); o2 = torch.empty_like(q2); o3 = torch.empty_like(q3)
     l1 = torch.empty(3 * f, N, device=DEV); l3 = torch.empty(f, N, device=DEV)
-    ops.attn_fwd([(q1, k1, v1, o1, l1), (q2, k2, v1[:f], o2, None), (q3, k2, v1[:f], o3, l3)], 0.125)
-    s1 = torch.empty_like(q1); s2 = torch.empty_like(q2); s3 = torch.empty_like(q3)
-    # (nsplit=1: a 5-head launch on its own would be split over the keys, which changes the f32 summation order)
-    ops.attn_fwd([(q1, k1, v1, s1, None)], 0.125, nsplit=1); ops.attn_fwd([(q2, k2, v1[:f], s2, None)], 0.125, nsplit=1); ops.attn_fwd([(q3, k2, v1[:f], s3, None)], 0.125, nsplit=1)
+    from geodiffuser_amd import _lib
+    lib = _lib.load()
+    # one workgroup shape for the four launches: on its own a 5-head launch would split the keys inside the workgroup (a different
+    # f32 summation order than the 25-head launch's)
+    lib.gd_attn_fwd_set_config(4, 1)
+    try:
+        ops.attn_fwd([(q1, k1, v1, o1, l1), (q2, k2, v1[:f], o2, None), (q3, k2, v1[:f], o3, l3)], 0.125)
+        s1 = torch.empty_like(q1); s2 = torch.empty_like(q2); s3 = torch.empty_like(q3)
+        ops.attn_fwd([(q1, k1, v1, s1, None)], 0.125, nsplit=1); ops.attn_fwd([(q2, k2, v1[:f], s2, None)], 0.125, nsplit=1); ops.attn_fwd([(q3, k2, v1[:f], s3, None)], 0.125, nsplit=1)
+    finally:
+        lib.gd_attn_fwd_set_config(-1, 0)
     assert torch.equal(o1, s1) and torch.equal(o2, s2) and torch.equal(o3, s3)
     rows = torch.arange(7, N, 97)
     ro, rl, _ = _ref_attn(q1[:, rows].cpu(), k1.cpu(), v1.cpu(), 0.125)
@@ -204,6 +211,77 @@ def test_attention_forward_full_size_and_segments(ops):
     assert float((l1[:, rows].cpu().double() - rl).abs().max()) < 1e-4
     # softmax rows are convex combinations: every output lies inside the value range
     assert float(o2.float().abs().max()) <= float(v1[:f].float().abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("BH,N,M", [(3, 4096, 4096), (2, 1000, 1024), (4, 256, 256), (2, 4096, 512), (2, 300, 128)])
+def test_attention_forward_pipelined_configs(ops, dtype, BH, N, M):
+    """The software-pipelined kernels (attn_fwd_mp.hip): every (query blocks x key ranges) workgroup shape, one and two key tiles per
+    barrier, exact and pre-scaled queries, against the fp32 formulation on the full tensors — including rows that FORCE the rescue
+    path (scores climbing by ~100 nats across the keys, one outlier key 6x the others) and a ragged query count."""
+    from geodiffuser_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(BH * 7 + M)
+    q = (torch.randn(BH, N, 64, device=DEV) * 1.5).to(dtype); k = (torch.randn(BH, M, 64, device=DEV) * 1.5).to(dtype)
+    v = torch.randn(BH, M, 64, device=DEV).to(dtype)
+    k[0, :, 0] += torch.linspace(-40, 40, M, device=DEV).to(dtype); q[0, :, 0] = 8.0
+    k[1, M // 2, :] *= 6.0
+    ro, rl, _ = _ref_attn(q.cpu(), k.cpu(), v.cpu(), 0.125)
+    C2 = 0.125 * 1.4426950408889634
+    qs = (q.float() * C2).to(dtype)                                       # what the processors' alpha-GEMM hands over
+    rso, rsl, _ = _ref_attn(qs.cpu(), k.cpu(), v.cpu(), 0.6931471805599453)
+    ran = 0
+    try:
+        for (qb, ks) in ((4, 1), (2, 2), (4, 2), (2, 4)):
+            if (M // 64) % (2 * ks) != 0:
+                continue
+            lib.gd_attn_fwd_set_config(qb, ks)
+            out = torch.zeros_like(q); lse = torch.zeros(BH, N, device=DEV)
+            ops.attn_fwd([(q, k, v, out, lse)], 0.125, nsplit=1)
+            out2 = torch.zeros_like(q); lse2 = torch.zeros(BH, N, device=DEV)
+            ops.attn_fwd([(qs, k, v, out2, lse2)], 0.125, nsplit=1, q_scaled=True)
+            torch.cuda.synchronize()
+            assert rel_err(out.float().cpu(), ro) < tol(dtype), (qb, ks)
+            assert float((lse.cpu().double() - rl).abs().max()) < 2e-4, (qb, ks)
+            assert rel_err(out2.float().cpu(), rso) < tol(dtype), (qb, ks, "q_scaled")
+            assert float((lse2.cpu().double() - rsl).abs().max()) < 2e-4, (qb, ks, "q_scaled")
+            ran += 1
+    finally:
+        lib.gd_attn_fwd_set_config(-1, 0)
+    assert ran >= 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("f,N,M,heads", [(3, 1024, 1024, 0), (2, 1024, 77, 0), (1, 1024, 1024, 5), (1, 256, 256, 4), (2, 4096, 4096, 0)])
+def test_fused_query_warp_is_bit_identical_to_two_launches(ops, dtype, f, N, M, heads):
+    """X1 — the fused attention-warp launch: a segment with warp tables (gd_attn_seg_t::warp_idx/w/m) builds
+    q*(1-m) + m*half(sum_k w q[idx]) in the attention kernel's prologue; the result equals, bit for bit, attending with the q_warp
+    tensor that gd_splat_composite writes (U/attention_processors.py:424-428,544-549), in every kernel that serves the launch
+    (plain kernel for 77 keys, pipelined kernels otherwise), head-major and token-major."""
+    from geodiffuser_amd import _lib
+    from geodiffuser_amd._lib import GD_TOKEN_MAJOR
+    lib = _lib.load()
+    torch.manual_seed(N + M + heads)
+    K = 15
+    C = 64 * (heads if heads else 1)
+    q = torch.randn(f, N, C, device=DEV).to(dtype); k = torch.randn(f, M, C, device=DEV).to(dtype); v = torch.randn(f, M, C, device=DEV).to(dtype)
+    idx = torch.randint(-1, N, (N, K), device=DEV, dtype=torch.int32)
+    w = torch.rand(N, K, device=DEV) * 0.3
+    m = torch.tensor([0.0, 0.25, 0.5, 1.0], device=DEV)[torch.randint(0, 4, (N,), device=DEV)].contiguous()
+    qw = ops.splat_composite(q, idx, w, m, GD_TOKEN_MAJOR)
+    try:
+        for (qb, ks) in ((-1, 0), (0, 0), (4, 1), (4, 2), (2, 4)):
+            if qb > 0 and (M % 64 or (M // 64) % (2 * ks) != 0):
+                continue
+            lib.gd_attn_fwd_set_config(qb, ks)
+            o1 = torch.zeros_like(q); o2 = torch.zeros_like(q)
+            ops.attn_fwd([(qw, k, v, o1, None)], 0.125, heads=heads, nsplit=1)
+            ops.attn_fwd([(q, k, v, o2, None, (idx, w, m))], 0.125, heads=heads, nsplit=1)
+            torch.cuda.synchronize()
+            assert torch.equal(o1, o2), (qb, ks)
+            assert bool(torch.isfinite(o2.float()).all())
+    finally:
+        lib.gd_attn_fwd_set_config(-1, 0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -235,17 +313,23 @@ def test_attention_forward_split_kv(ops, dtype, BH, N, M, nsplit):
 
 
 def test_attention_split_kv_plan():
+    """gd_attn_fwd_plan: launches served by the software-pipelined kernels (full key tiles) split their keys INSIDE the workgroup and
+    need no HBM workspace (plan = 1); the HBM split remains for under-filled launches with a key tail."""
     import ctypes
     from geodiffuser_amd import _lib
     lib = _lib.load()
     nb = ctypes.c_size_t(0)
-    assert lib.gd_attn_fwd_plan(5, 4096, 4096, ctypes.byref(nb)) == 4 and nb.value == 4 * 5 * 4096 * 66 * 4    # inversion pass, 64^2
-    assert lib.gd_attn_fwd_plan(10, 4096, 4096, ctypes.byref(nb)) == 2                                            # inversion pass (batch 2)
-    assert lib.gd_attn_fwd_plan(15, 4096, 4096, ctypes.byref(nb)) == 1                                            # optimisation pass
-    assert lib.gd_attn_fwd_plan(20, 4096, 4096, ctypes.byref(nb)) == 1                                            # CFG pass fills the chip
-    assert lib.gd_attn_fwd_plan(25, 4096, 4096, ctypes.byref(nb)) == 1 and nb.value == 0                          # CFG pass fills the chip
+    for bh in (5, 10, 15, 20, 25):                                                                                # 64^2 self-attention launches
+        assert lib.gd_attn_fwd_plan(bh, 4096, 4096, ctypes.byref(nb)) == 1 and nb.value == 0
     assert lib.gd_attn_fwd_plan(20, 4096, 77, ctypes.byref(nb)) == 1                                              # cross attention: one key tile
-    assert lib.gd_attn_fwd_plan(10, 1024, 1024, ctypes.byref(nb)) == 1                                            # 32^2: the merge costs more than it saves
+    assert lib.gd_attn_fwd_plan(5, 4096, 4096 + 37, ctypes.byref(nb)) == 4 and nb.value == 4 * 5 * 4096 * 66 * 4  # key tail: plain kernel + HBM split
+    try:
+        lib.gd_attn_fwd_set_config(0, 0)                                                                          # pipelined kernels off
+        assert lib.gd_attn_fwd_plan(5, 4096, 4096, ctypes.byref(nb)) == 4 and nb.value == 4 * 5 * 4096 * 66 * 4
+        assert lib.gd_attn_fwd_plan(10, 4096, 4096, ctypes.byref(nb)) == 2
+        assert lib.gd_attn_fwd_plan(15, 4096, 4096, ctypes.byref(nb)) == 1
+    finally:
+        lib.gd_attn_fwd_set_config(-1, 0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -657,3 +741,85 @@ def test_softsplat_forward_backward(ops, mode):
         ones = torch.ones(1, 1, H, W, device=DEV)
         inside = softsplat(ones, torch.zeros(1, 2, H, W, device=DEV), None, "sum")
         assert torch.allclose(inside, ones)
+
+
+# ------------------------------------------------------------------------------------------------ R14 / N1 geometry pre-pass
+def _g11_inputs(size=64):
+    mask = cases.ellipse_mask(cx=30, cy=33, ax=11, ay=9, size=size)
+    v, u = np.mgrid[0:size, 0:size].astype(np.float32)
+    depth = np.where(mask > 0.5, 0.5 + 0.2 * (u / size - 0.5), 0.9).astype(np.float32)
+    return mask, depth
+
+
+def test_get_transform_coordinates_matches_reference_g11():
+    """vis_utils.get_transform_coordinates (device path) vs the REFERENCE's own output (G11): warp grid t_coords for a translation,
+    a rotation about y, a mixed transform and the constant-depth case, <= 1e-5 relative."""
+    from geodiffuser_amd import vis_utils
+    g = load("G11_geometry")
+    size = 64
+    mask, depth = _g11_inputs(size)
+    image = np.zeros((size, size, 3), dtype=np.float32)
+    for name in ("translate", "rotate", "mixed"):
+        out = vis_utils.get_transform_coordinates(image, depth.copy(), mask, transform_in=torch.from_numpy(g[name + "_T"]).float(),
+                                                  focal_length=550 * size / 512.0, return_mesh=True, device=DEV, as_torch=True)
+        t = out[0].float().cpu().numpy()
+        assert t.shape == (size, size, 3)
+        assert rel_err(t, g[name]) < 1e-5, name
+        assert tuple(out[2].shape) == (1, 1, size, size)
+    const = np.ones((size, size), dtype=np.float32) * 0.5
+    T = torch.eye(4); T[0, 3] = 0.1
+    t = vis_utils.get_transform_coordinates(image, const, mask, transform_in=T, focal_length=550 * size / 512.0, device=DEV, as_torch=True)[0]
+    assert rel_err(t.float().cpu().numpy(), g["const_depth"]) < 1e-5
+    # numpy return convention of the reference
+    tn, pn = vis_utils.get_transform_coordinates(image, const, mask, transform_in=T, focal_length=550 * size / 512.0, device=DEV)
+    assert isinstance(tn, np.ndarray) and tn.dtype == np.float32 and pn.shape == (size, size, 3)
+
+
+def test_get_mesh_matches_reference_g12():
+    """vis_utils.get_mesh (device) vs the reference's own get_mesh / create_triangles output (G12): faces and vertices exact."""
+    from geodiffuser_amd import vis_utils
+    g = load("G12_mesh")
+    for name, mask in cases.mesh_masks(64).items():
+        v, f = vis_utils.get_mesh(torch.from_numpy(g[name + "_t_coords"]).to(DEV), torch.from_numpy(mask).to(DEV))
+        assert f.dtype == torch.int32 and np.array_equal(f.cpu().numpy(), g[name + "_faces"]), name
+        assert np.array_equal(v.cpu().numpy(), g[name + "_verts"]), name
+
+
+@pytest.mark.parametrize("S", [64, 96, 512])
+def test_mesh_coverage_bit_exact_vs_oracle(ops, S):
+    """gd_mesh_coverage vs oracle/c/mesh_ref.c (pytorch3d's naive mesh rasterizer restated, PARITY UNPINNED): identical masks for
+    translated / rotated / scaled object meshes, a mesh half off screen, fully off screen, behind the camera, degenerate, empty."""
+    from geodiffuser_amd import vis_utils
+    mask = cases.ellipse_mask(cx=0.47 * S, cy=0.52 * S, ax=0.17 * S, ay=0.14 * S, size=S)
+    v, u = np.mgrid[0:S, 0:S].astype(np.float32)
+    depth = np.where(mask > 0.5, 0.5 + 0.2 * (u / S - 0.5), 0.9).astype(np.float32)
+    image = np.zeros((S, S, 3), dtype=np.float32)
+    R_y = vis_utils.rotateAxis(25.0, 1).float()
+    R_z = vis_utils.rotateAxis(-40.0, 2).float()
+    Sc = torch.diag(torch.tensor([1.3, 1.3, 1.3, 1.0]))
+    cases_T = {"translate": vis_utils.translateMatrix(0.1, -0.05, 0.02), "rotate_y": R_y, "rotate_z": R_z, "scale": Sc,
+               "mixed": vis_utils.translateMatrix(0.05, 0.0, 0.05) @ R_y @ Sc, "half_off": vis_utils.translateMatrix(0.45, 0.0, 0.0),
+               "off_screen": vis_utils.translateMatrix(3.0, 0.0, 0.0)}
+    total = 0
+    for name, T in cases_T.items():
+        t, _, amodal = vis_utils.get_transform_coordinates(image, depth.copy(), mask, transform_in=T.float(), focal_length=550 * S / 512.0,
+                                                           return_mesh=True, device=DEV, as_torch=True)
+        vo, fo = O.get_mesh(t.float().cpu().numpy(), mask)
+        ref = O.splatter_mesh(vo, fo, S)
+        got = amodal.cpu().numpy()
+        assert np.array_equal(got, ref), (name, int(np.abs(got - ref).sum()))
+        if name == "off_screen":
+            assert ref.sum() == 0
+        if name in ("translate", "rotate_y", "scale"):
+            assert ref.sum() > 0.5 * mask.sum()
+        total += ref.sum()
+    assert total > 0
+    # direct kernel calls: behind the camera, degenerate faces, empty mesh
+    vo, fo = O.get_mesh(t.float().cpu().numpy(), mask)
+    vneg = vo.copy(); vneg[:, 2] = -1.0
+    vdeg = vo.copy(); vdeg[:, 1] = 0.25
+    for vv in (vneg, vdeg):
+        got = ops.mesh_coverage(torch.from_numpy(vv).to(DEV), torch.from_numpy(fo.astype(np.int32)).to(DEV), S).cpu().numpy()
+        assert np.array_equal(got[None, None], O.splatter_mesh(vv, fo, S)) and got.sum() == 0
+    got = ops.mesh_coverage(torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, dtype=torch.int32, device=DEV), S)
+    assert float(got.sum()) == 0.0

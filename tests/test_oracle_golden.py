@@ -281,3 +281,41 @@ def test_rasterizer_boxes_match_bruteforce():
         b = O.rasterize_points(pts, S, rpx / S * 2.0, K, bruteforce=True)
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+def test_g12_mesh_faces_and_vertices_match_the_reference():
+    """get_mesh / create_triangles restated (oracle) vs the reference's own output (G12): face lists exact (per-TRIANGLE corner
+    test, upper triangles first), vertices exact."""
+    g = load("G12_mesh")
+    for name, mask in cases.mesh_masks(64).items():
+        v, f = O.get_mesh(g[name + "_t_coords"], mask)
+        assert np.array_equal(f, g[name + "_faces"]), name
+        assert np.array_equal(v, g[name + "_verts"]), name
+    # the ellipse outline and the notches keep triangles whose 2x2 quad has its fourth corner outside the mask
+    for name in ("ellipse", "holes"):
+        m = cases.mesh_masks(64)[name] >= 0.5
+        quads = (m[:-1, :-1] & m[:-1, 1:] & m[1:, :-1] & m[1:, 1:]).sum()
+        assert g[name + "_faces"].shape[0] > 2 * quads, name
+
+
+def test_mesh_coverage_oracle_bbox_walk_equals_bruteforce():
+    """oracle/c/mesh_ref.c: the bounding-box walk accepts exactly the pixels of the all-pairs loop (rules M1-M5), including faces
+    partly or wholly off screen, degenerate faces and an empty mesh."""
+    g = load("G12_mesh")
+    for name, mask in cases.mesh_masks(64).items():
+        v, f = O.get_mesh(g[name + "_t_coords"], mask)
+        for shift in (0.0, 0.9, 2.5):                       # on screen, half off screen, fully off screen
+            vv = v.copy(); vv[:, 0] += shift
+            a = O.splatter_mesh(vv, f, 64)
+            assert np.array_equal(a, O.splatter_mesh(vv, f, 64, bruteforce=True)), (name, shift)
+            if shift == 2.5:
+                assert a.sum() == 0
+            if shift == 0.0:
+                assert a.sum() > 0
+    # behind the camera (negative depth) -> nothing; degenerate (zero-area) faces -> nothing; empty mesh -> zeros
+    v, f = O.get_mesh(g["ellipse_t_coords"], cases.mesh_masks(64)["ellipse"])
+    vneg = v.copy(); vneg[:, 2] = -1.0
+    assert O.splatter_mesh(vneg, f, 64).sum() == 0
+    vdeg = v.copy(); vdeg[:, 1] = 0.25
+    assert O.splatter_mesh(vdeg, f, 64).sum() == 0
+    assert O.splatter_mesh(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), 64).sum() == 0

@@ -580,7 +580,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         active = self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1]
         blend = self.cur_step < int(self.num_steps * self.obj_edit_step)
         return (type(self).__name__, active, blend, getattr(self, "n_batch", None), self.coords_base, self.coords_edit,
-                self.use_cfg, self.store_attention_maps)
+                self.use_cfg, self.store_attention_maps, bool(self.rows_identical))
 
     def after_graph_replay(self):
         """A replayed pass ran no Python: advance the counters as its num_att_layers hooked calls would have."""
@@ -591,6 +591,21 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
     supports_token_major = True
     heads_tok = 0
     q_scaled_tok = False
+    # Set by the driver for an optimisation pass whose reference and edit samples are the SAME sample in every layer (the first pass of
+    # a removal edit: both rows start from x_T with the same text, and the remover's output for the edit row equals the vanilla
+    # output, so the rows never diverge).  In exact arithmetic their q / k / v are then equal, the attention outputs
+    # compared by the L1 losses are equal, and d|x|/dx = sign(0) = 0 (the reference's CPU run gives exactly that).  On the device the
+    # two rows of a batch drift apart by the convolution library's run-to-run rounding (~1e-5 per layer, MIOpen split-K kernels), the
+    # L1 terms see +-noise and their sign() gradient becomes full-magnitude noise (measured: the remover's first latent update 34 %
+    # off the reference, 2 % with ideal 16-bit storage).  _tie_rows restores the symmetry where it matters.
+    rows_identical = False
+
+    def _tie_rows(self, t, f):
+        """The edit rows take the VALUES of the base rows and keep their own autograd history: base.detach() + (edit - edit.detach())."""
+        (b0, b1), (e0, e1) = self.coords_base, self.coords_edit
+        te = t[e0 * f:e1 * f]
+        tied = t[b0 * f:b1 * f].detach() + (te - te.detach())
+        return torch.cat([t[:e0 * f], tied, t[e1 * f:]], 0)
 
     def _forward_tok(self, q, k, v, is_cross: bool, transform_coords, scale: float, heads: int):
         """No-grad CFG pass on token-major q/k/v [B, N, heads*64]; the caller (EditProcessor) routes passes that accumulate
@@ -650,6 +665,8 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             _ = self.cross_replace_alpha[self.cur_step]                        # :654 (indexing only; value unused)
         S = int(math.isqrt(q.shape[1]))
         c = self._tables(S, f, q, transform_coords)
+        if self.rows_identical and torch.is_grad_enabled():
+            q, k, v = (self._tie_rows(t, f) for t in (q, k, v))
         out, loss, terms = _EditLayer.apply(q.contiguous(), k.contiguous(), v.contiguous(), self, is_cross, float(scale), c)
         if (q.shape[1] >= 32 ** 2) and (not self.use_cfg):
             kind = "cross" if is_cross else "self"

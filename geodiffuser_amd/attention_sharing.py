@@ -17,12 +17,11 @@ LOW_RESOURCE = False
 
 
 class _VanillaAttention(torch.autograd.Function):
-    """out = softmax(scale q k^T) v through gd_attn_fwd / gd_attn_bwd.
+    """out = softmax(scale q k^T) v through gd_attn_fwd; backward through gd_attn_bwd (dQ) and gd_attn_bwd_dkv (dK, dV).
 
-    Backward returns dQ (and dK for few-key cross-attention).  dV and self-attention dK are not produced:
-    on the GeoDiffuser path every tensor that would receive them is detached (v_base.detach(), k_base.detach(),
-    attention_sharing.py:242; attention_processors.py:433,555-557), so asking for them raises instead of
-    silently returning zeros."""
+    On the GeoDiffuser edit path only dQ is ever asked for (every k / v that would receive gradient is detached in the reference:
+    attention_sharing.py:242, attention_processors.py:433,555-557); null-text optimisation (inversion.py:213-259) differentiates the
+    UNet w.r.t. its text context and needs all three."""
 
     @staticmethod
     def forward(ctx, q, k, v, scale):
@@ -36,18 +35,22 @@ class _VanillaAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         q, k, v, out, lse = ctx.saved_tensors
-        need_dk = ctx.needs_input_grad[1]
-        if ctx.needs_input_grad[2]:
-            raise NotImplementedError("gradient w.r.t. v is never needed on the GeoDiffuser path (v is detached)")
-        dq, dk = ops.attn_bwd(q, k, v, out, lse, g.contiguous(), ctx.scale, need_dk)
-        return dq, (dk.to(k.dtype) if dk is not None else None), None, None
+        g = g.contiguous()
+        dq = dk = dv = None
+        if ctx.needs_input_grad[0]:
+            dq, _ = ops.attn_bwd(q, k, v, out, lse, g, ctx.scale, False)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dk32, dv32 = ops.attn_bwd_dkv(q, k, v, out, lse, g, ctx.scale)
+            dk = dk32.to(k.dtype) if ctx.needs_input_grad[1] else None
+            dv = dv32.to(v.dtype) if ctx.needs_input_grad[2] else None
+        return dq, dk, dv, None
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
     """softmax(scale q k^T) v, [BH,N,D] x [BH,M,D] -> [BH,N,D] (HIP, flash-style)."""
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad):
-        return _VanillaAttention.apply(q, k, v.detach(), scale)
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        return _VanillaAttention.apply(q, k, v, scale)
     out = torch.empty_like(q)
     ops.attn_fwd([(q, k, v, out, None)], scale)
     return out

@@ -230,6 +230,158 @@ __global__ void k_attn_bwd_dk_reduce(const float* __restrict__ part, int nchunks
     dk[(size_t)bh * MD + o] += acc;
 }
 
+// ---- dK and dV for any key count (the full backward of vanilla attention) -------------------------------------------------
+// k_attn_bwd_dk's geometry with a key-block grid dimension and a second accumulator pair:
+//   dV^T[d, key] += dO_tile^T P        (A = hardware-transposed read of the dO tile, B = P as it leaves the accumulators)
+//   dK^T[d, key] += Q_tile^T dS
+// One workgroup per (query chunk, block of 128 keys, head); a chunk is `qchunk` queries — ALL queries when the key count is large
+// (self-attention: no partial sums at all), 128 for short key lists (cross-attention: more workgroups, per-chunk partials).  The
+// partials [BH, chunks, M, 64] f32 x 2 are summed in chunk order by k_attn_bwd_dk_reduce (no atomics).  Used by the autograd of the
+// vanilla attention op (null-text optimisation differentiates the UNet w.r.t. its text context: U/inversion.py:213-259); the edit
+// path itself never needs dV or self-attention dK (those tensors are detached in the reference, U/attention_sharing.py:242).
+struct DkvArgs {
+    const void* q; const void* k; const void* v; const void* o; const float* lse; const void* dout;
+    float* dk_part; float* dv_part;
+    int N, M, qchunk, nchunks;
+    float c, scale, l2e;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, 1)
+k_attn_bwd_dkv(const DkvArgs a) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    __shared__ __attribute__((aligned(16))) char lds[2][ATT_TILE_BYTES];      // [Q | dO] tile images
+    __shared__ float s_lse2[ATT_BN], s_delta[ATT_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int chunk = blockIdx.x, kblk = blockIdx.y, bh = blockIdx.z;
+    const int N = a.N, M = a.M;
+    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * ATT_D;
+    const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * ATT_D;
+    const T* __restrict__ vp = (const T*)a.v + (size_t)bh * M * ATT_D;
+    const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * ATT_D;
+    const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * ATT_D;
+
+    const int key = kblk * 128 + wave * 32 + (lane & 31);
+    const int kld = key < M ? key : M - 1;
+    V8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        kf[s] = *(const V8*)(kp + (size_t)kld * ATT_D + 16 * s + 8 * h);
+        vf[s] = *(const V8*)(vp + (size_t)kld * ATT_D + 16 * s + 8 * h);
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+
+    const int q_begin = chunk * a.qchunk;
+    const int q_end = (q_begin + a.qchunk) < N ? (q_begin + a.qchunk) : N;
+    for (int q0 = q_begin; q0 < q_end; q0 += ATT_BN) {
+        u32x4 qr[2], gr[2], orr[2];
+        tile_load<T>(qp, q0, N, tid, qr);
+        tile_load<T>(gp, q0, N, tid, gr);
+        tile_load<T>(op, q0, N, tid, orr);
+        __syncthreads();                                  // the previous tile's reads are done
+        tile_store(lds[0], tid, qr);
+        tile_store(lds[1], tid, gr);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                     // delta[row] = sum_d dO o O (see k_attn_bwd_dk)
+            const V8 g8 = __builtin_bit_cast(V8, gr[i]), o8 = __builtin_bit_cast(V8, orr[i]);
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d = __builtin_fmaf(TR::to_f32(g8[j]), TR::to_f32(o8[j]), d);
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            if ((tid & 7) == 0) {
+                const int row = (tid >> 3) + 32 * i, qi = q0 + row;
+                s_delta[row] = d;
+                s_lse2[row] = qi < N ? a.lse[(size_t)bh * N + qi] * a.l2e : INFINITY;     // exp2(-inf) = 0 for padding queries
+            }
+        }
+        __syncthreads();
+        V8 dsf[4], pf[4];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            f32x16 s_acc, p_acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s_acc[i] = 0.f; p_acc[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(read_row_frag<T>(lds[0], blk, s, lane), kf[s], s_acc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) p_acc = TR::mfma32(read_row_frag<T>(lds[1], blk, s, lane), vf[s], p_acc);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = blk * 32 + acc_key(i, h);                 // query row of accumulator register i
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], a.c, -s_lse2[row]));
+                if (key >= M) p = 0.f;
+                s_acc[i] = p;
+                p_acc[i] = p * (p_acc[i] - s_delta[row]);
+            }
+            pf[2 * blk] = acc_to_frag<T>(s_acc, 0);
+            pf[2 * blk + 1] = acc_to_frag<T>(s_acc, 1);
+            dsf[2 * blk] = acc_to_frag<T>(p_acc, 0);
+            dsf[2 * blk + 1] = acc_to_frag<T>(p_acc, 1);
+        }
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                dk[dblk] = TR::mfma32(read_tr_frag<T>(lds[0], dblk, ks, lane), dsf[ks], dk[dblk]);
+                dv[dblk] = TR::mfma32(read_tr_frag<T>(lds[1], dblk, ks, lane), pf[ks], dv[dblk]);
+            }
+    }
+    if (key < M) {            // partials of this query chunk (plain stores; summed by k_attn_bwd_dk_reduce)
+        const size_t off = (((size_t)bh * a.nchunks + chunk) * M + key) * ATT_D;
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 wk, wv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { wk[j] = dk[dblk][4 * g + j] * a.scale; wv[j] = dv[dblk][4 * g + j]; }
+                *(f32x4*)(a.dk_part + off + dblk * 32 + 8 * g + 4 * h) = wk;
+                *(f32x4*)(a.dv_part + off + dblk * 32 + 8 * g + 4 * h) = wv;
+            }
+    }
+}
+
+static int dkv_qchunk(int N, int M) { return M >= 1024 ? N : DK_QCHUNK; }
+
+extern "C" size_t gd_attn_bwd_dkv_workspace_bytes(int BH, int N, int M, int D) {
+    const int qc = dkv_qchunk(N, M);
+    const size_t chunks = (size_t)(N + qc - 1) / qc;
+    return 2 * (size_t)BH * chunks * M * D * sizeof(float);
+}
+
+extern "C" int gd_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* out, const float* lse, const void* dout,
+                               int BH, int N, int M, int D, float scale, float* dk_f32, float* dv_f32,
+                               void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    GD_REQUIRE(q && k && v && out && lse && dout && dk_f32 && dv_f32, GD_EINVAL, "gd_attn_bwd_dkv: null pointer");
+    GD_REQUIRE(D == ATT_D, GD_EUNSUPPORTED, "gd_attn_bwd_dkv: head dim %d unsupported (only 64)", D);
+    GD_REQUIRE(BH > 0 && N > 0 && M > 0, GD_EINVAL, "gd_attn_bwd_dkv: bad sizes");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_bwd_dkv: dtype must be f16/bf16");
+    GD_REQUIRE(workspace && workspace_bytes >= gd_attn_bwd_dkv_workspace_bytes(BH, N, M, D), GD_EWORKSPACE,
+               "gd_attn_bwd_dkv: needs a workspace of gd_attn_bwd_dkv_workspace_bytes() bytes");
+    DkvArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = out; a.lse = lse; a.dout = dout;
+    a.N = N; a.M = M;
+    a.qchunk = dkv_qchunk(N, M);
+    a.nchunks = (N + a.qchunk - 1) / a.qchunk;
+    a.dk_part = (float*)workspace;
+    a.dv_part = a.dk_part + (size_t)BH * a.nchunks * M * ATT_D;
+    a.scale = scale;
+    a.c = scale * 1.4426950408889634f;
+    a.l2e = 1.4426950408889634f;
+    hipStream_t st = as_stream(stream);
+    dim3 grid(a.nchunks, (M + 127) / 128, BH);
+    if (dtype == GD_F16) k_attn_bwd_dkv<f16_t><<<grid, 256, 0, st>>>(a);
+    else k_attn_bwd_dkv<bf16_t><<<grid, 256, 0, st>>>(a);
+    dim3 rgrid((M * ATT_D + 255) / 256, BH);
+    k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>(a.dk_part, a.nchunks, M * ATT_D, dk_f32);
+    k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>(a.dv_part, a.nchunks, M * ATT_D, dv_f32);
+    GD_CHECK_LAUNCH("gd_attn_bwd_dkv");
+    return GD_OK;
+}
+
 extern "C" size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk) {
     if (!need_dk) return 0;
     const size_t chunks = (size_t)(N + DK_QCHUNK - 1) / DK_QCHUNK;

@@ -6,8 +6,8 @@
 // profile of an edit showed ~18 % of the GPU time there.  HBM-bound: reads x twice, writes y once.
 //
 //   k_gn_stats : one workgroup per (batch, pixel slab): coalesced 16-B reads of whole channel rows, per-channel partial sums
-//                in registers, per-group reduction through LDS atomics, ONE plain store of the slab's [G,2] partial moments
-//                (no global atomics, no zero-fill launch)
+//                in registers, per-group reduction through LDS in a FIXED order (column slots, then the columns of a group: no float
+//                atomics anywhere, the kernels are bit-reproducible), ONE plain store of the slab's [G,2] partial moments
 //   k_gn_apply : every workgroup first folds the <= 64 slab partials of its batch entry into mean / rstd in LDS, then
 //                y = (x - mean) * rstd * gamma + beta, optional SiLU, 8 channels (16 B) per thread
 // Optional add_bc [B,C]: the norm is taken of x + add_bc[b,c] (the ResNet block's time-embedding add folded in).
@@ -19,9 +19,11 @@
 // Sum the slab partials of batch entry b into s_out[G*2] (LDS): all 256 threads take part — (256 / (2G)) threads per value, each
 // adding every (256 / 2G)-th slab with independent loads (a single thread per value walked <= 64 dependent-looking loads: 6 us).
 __device__ __forceinline__ void gn_fold_partials(const float* __restrict__ partial, int nslab, int G, int b, float* s_out) {
+    // Deterministic: the `parts` partial sums of a value go through LDS and are added in ascending order by ONE thread (no LDS float
+    // atomics: their arrival order changed the last bits from launch to launch, and a random-init UNet amplifies that to 1e-2).
+    __shared__ float s_fold[256];
     const int tid = threadIdx.x, nv = G * 2, parts = 256 / nv;          // G <= 64 -> parts >= 2
-    if (tid < nv) s_out[tid] = 0.f;
-    __syncthreads();
+    __syncthreads();                                                    // s_fold may still be read by a previous fold
     if (tid < nv * parts) {
         const int v = tid % nv, p = tid / nv;
         const float* pp = partial + (size_t)b * nslab * nv + v;
@@ -29,7 +31,55 @@ __device__ __forceinline__ void gn_fold_partials(const float* __restrict__ parti
         int s = p;
         for (; s + parts < nslab; s += 2 * parts) { a0 += pp[(size_t)s * nv]; a1 += pp[(size_t)(s + parts) * nv]; }
         if (s < nslab) a0 += pp[(size_t)s * nv];
-        atomicAdd(&s_out[v], a0 + a1);
+        s_fold[p * nv + v] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < nv) {
+        float t = 0.f;
+        for (int p = 0; p < parts; ++p) t += s_fold[p * nv + tid];
+        s_out[tid] = t;
+    }
+    __syncthreads();
+}
+
+// Deterministic per-group reduction of the threads' column sums (replaces atomicAdd(&s_g[...]) from every thread).  A thread owns the
+// 8-channel column k of pixel-row slot r and holds (a0, q0) for the column's first group g0 and (a1, q1) for its second group g1 (an
+// 8-channel column touches at most two groups).  The slots of a column are added in ascending r, the columns of a group in ascending k.
+#define GN_MAX_CV 512
+struct GnRed {
+    float rc[256][4];            // per-thread contributions (cv <= 256)
+    float col[GN_MAX_CV][4];     // per-column totals
+};
+
+__device__ __forceinline__ void gn_store_contrib(GnRed& red, int cv, int k, float a0, float q0, float a1, float q1) {
+    float* d = cv <= 256 ? red.rc[threadIdx.x] : red.col[k];
+    d[0] = a0; d[1] = q0; d[2] = a1; d[3] = q1;
+}
+
+__device__ __forceinline__ void gn_group_reduce(GnRed& red, int cv, int rows, int cpg, int G, float* s_g) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (cv <= 256) {
+        if (tid < cv) {
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+            for (int r = 0; r < rows; ++r) {
+                const float* d = red.rc[r * cv + tid];
+                t0 += d[0]; t1 += d[1]; t2 += d[2]; t3 += d[3];
+            }
+            red.col[tid][0] = t0; red.col[tid][1] = t1; red.col[tid][2] = t2; red.col[tid][3] = t3;
+        }
+        __syncthreads();
+    }
+    if (tid < G * 2) {
+        const int g = tid >> 1, w = tid & 1;
+        const int k_lo = (g * cpg) >> 3, k_hi = ((g + 1) * cpg - 1) >> 3;
+        float t = 0.f;
+        for (int k = k_lo; k <= k_hi; ++k) {
+            const int c0 = k * 8, g0 = c0 / cpg, g1 = (c0 + 7) / cpg;
+            if (g0 == g) t += red.col[k][w];
+            if (g1 != g0 && g1 == g) t += red.col[k][2 + w];
+        }
+        s_g[tid] = t;
     }
     __syncthreads();
 }
@@ -45,11 +95,11 @@ k_gn_stats(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, in
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
     __shared__ float s_g[GN_MAX_G * 2];
+    __shared__ GnRed red;
     const int b = blockIdx.y, p0 = blockIdx.x * pix, tid = threadIdx.x;
     const int cv = C >> 3, cpg = C / G;
     const T* xb = x + (size_t)b * HW * C;
-    if (tid < G * 2) s_g[tid] = 0.f;
-    __syncthreads();
+    if (cv <= 256) gn_store_contrib(red, cv, 0, 0.f, 0.f, 0.f, 0.f);       // threads without a column contribute zeros
     const int p1 = (p0 + pix) < HW ? (p0 + pix) : HW;
     // Every thread owns one 8-channel column k of the slab and walks pixels with a fixed stride, so its partial sums stay in
     // registers; consecutive threads read consecutive 16-B chunks (coalesced).  cv <= 256: (256 / cv) pixel rows in flight;
@@ -92,12 +142,11 @@ k_gn_stats(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, in
             for (int i = 0; i < 8; ++i) {
                 if (g1 != g0 && i >= split) { a1 += sum[i]; q1 += sq[i]; } else { a0 += sum[i]; q0 += sq[i]; }
             }
-            atomicAdd(&s_g[g0 * 2], a0); atomicAdd(&s_g[g0 * 2 + 1], q0);
-            if (g1 != g0) { atomicAdd(&s_g[g1 * 2], a1); atomicAdd(&s_g[g1 * 2 + 1], q1); }
+            gn_store_contrib(red, cv, k, a0, q0, a1, q1);
         }
         if (cv <= 256) break;
     }
-    __syncthreads();
+    gn_group_reduce(red, cv, rows, cpg, G, s_g);
     if (tid < G * 2) partial[((size_t)b * gridDim.x + blockIdx.x) * G * 2 + tid] = s_g[tid];
 }
 
@@ -149,8 +198,8 @@ extern "C" int gd_group_norm_nhwc(const void* x, const void* add_bc, int add_ld,
                                   float eps, int silu, float* scratch, void* y, int dtype, void* stream) {
     GD_REQUIRE(x && gamma && beta && scratch && y, GD_EINVAL, "gd_group_norm_nhwc: null pointer");
     // an 8-channel vector may touch at most two groups: C/G >= 8, or exactly 4 (the VAE's 128-channel norms)
-    GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && (C / G >= 8 || C / G == 4), GD_EINVAL,
-               "gd_group_norm_nhwc: unsupported shape B=%d HW=%d C=%d G=%d (need C %% 8 == 0, C/G >= 8 or == 4, G <= %d)", B, HW, C, G, GN_MAX_G);
+    GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && (C / G >= 8 || C / G == 4) && C <= 8 * GN_MAX_CV, GD_EINVAL,
+               "gd_group_norm_nhwc: unsupported shape B=%d HW=%d C=%d G=%d (need C %% 8 == 0, C <= %d, C/G >= 8 or == 4, G <= %d)", B, HW, C, G, 8 * GN_MAX_CV, GN_MAX_G);
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_group_norm_nhwc: dtype must be f16/bf16");
     GD_REQUIRE(!add_bc || add_ld == 0 || (add_ld >= C && (add_ld & 7) == 0), GD_EINVAL, "gd_group_norm_nhwc: add_ld must be >= C and a multiple of 8");
     if (add_ld == 0) add_ld = C;
@@ -217,10 +266,11 @@ k_gn_bwd_stats(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld
     using V8 = typename TR::vec8;
     __shared__ float s_mr[GN_MAX_G * 2];
     __shared__ float s_g[GN_MAX_G * 2];
+    __shared__ GnRed red;
     const int b = blockIdx.y, p0 = blockIdx.x * pix, tid = threadIdx.x;
     const int cv = C >> 3, cpg = C / G;
     const float inv_n = 1.0f / ((float)HW * (float)cpg);
-    if (tid < G * 2) s_g[tid] = 0.f;
+    if (cv <= 256) gn_store_contrib(red, cv, 0, 0.f, 0.f, 0.f, 0.f);
     gn_fold_fwd_stats<T>(fwd_partial, nslab, G, b, inv_n, eps, s_mr);
     const size_t boff = (size_t)b * HW * C;
     const int p1 = (p0 + pix) < HW ? (p0 + pix) : HW;
@@ -251,12 +301,11 @@ k_gn_bwd_stats(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld
                     if (hi) { a1 += g; q1 = __builtin_fmaf(g, xh, q1); } else { a0 += g; q0 = __builtin_fmaf(g, xh, q0); }
                 }
             }
-            atomicAdd(&s_g[g0 * 2], a0); atomicAdd(&s_g[g0 * 2 + 1], q0);
-            if (g1 != g0) { atomicAdd(&s_g[g1 * 2], a1); atomicAdd(&s_g[g1 * 2 + 1], q1); }
+            gn_store_contrib(red, cv, k, a0, q0, a1, q1);
         }
         if (cv <= 256) break;
     }
-    __syncthreads();
+    gn_group_reduce(red, cv, rows, cpg, G, s_g);
     if (tid < G * 2) partial[((size_t)b * gridDim.x + blockIdx.x) * G * 2 + tid] = s_g[tid];
 }
 
@@ -313,7 +362,7 @@ extern "C" int gd_group_norm_nhwc_bwd(const void* x, const void* add_bc, int add
                                       int B, int HW, int C, int G, float eps, int silu, const float* fwd_scratch, float* scratch, void* dx,
                                       int dtype, void* stream) {
     GD_REQUIRE(x && gamma && beta && dy && fwd_scratch && scratch && dx, GD_EINVAL, "gd_group_norm_nhwc_bwd: null pointer");
-    GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && (C / G >= 8 || C / G == 4), GD_EINVAL,
+    GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && (C / G >= 8 || C / G == 4) && C <= 8 * GN_MAX_CV, GD_EINVAL,
                "gd_group_norm_nhwc_bwd: unsupported shape B=%d HW=%d C=%d G=%d", B, HW, C, G);
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_group_norm_nhwc_bwd: dtype must be f16/bf16");
     GD_REQUIRE(!add_bc || add_ld == 0 || (add_ld >= C && (add_ld & 7) == 0), GD_EINVAL, "gd_group_norm_nhwc_bwd: bad add_ld");

@@ -9,6 +9,7 @@ the SGD optimizer branch (``use_optimizer`` is never forwarded), t
 from __future__ import annotations
 
 import logging
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -44,6 +45,7 @@ SCHEDULER = None
 TOKENIZER = None
 UNET_NAME = None
 PROGRESS_BAR = None
+TIE_IDENTICAL_ROWS = os.environ.get("GD_TIE_ROWS", "1") == "1"   # first optimisation pass of an edit: see attention_processors.rows_identical
 SKIP_UNCOND_REF = True      # drop the CFG pass's unused `uncond_ref` batch row (identical edit output)
 
 
@@ -96,7 +98,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
     global_loss_log_dict = {}
     skip_optim_steps = SKIP_OPTIM_STEPS
     batch_size = len(prompt)
-    controller.persistent_tables = True      # lets captured CFG-pass graphs be reused by the next edit (one edit at a time per
+    controller.persistent_tables = os.environ.get("GD_PERSISTENT_TABLES", "1") == "1"      # lets captured CFG-pass graphs be reused by the next edit (one edit at a time per
     #                                          process, like the reference's module-level singletons)
     register_attention_control_diffusers(model, controller, transform_coordinates)
     height = width = image_size or IMAGE_SIZE
@@ -156,6 +158,12 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
             n0 = ops.sumsq(latents[-1].detach().float().contiguous())                                      # orig_norm^2 (:219)
             ctx_cur = context if context_save is None else context_save
             lat_cur = latents
+            # first pass of a REMOVAL edit: reference and edit rows are the same sample and stay the same through the whole UNet (the
+            # remover returns replace_out, which then equals the vanilla output; the editor's blend moves the object in the edit row, so
+            # its rows differ from the second hooked layer on).  One host comparison per edit -> see rows_identical
+            controller.rows_identical = bool(TIE_IDENTICAL_ROWS and i == 0 and is_geo and batch_size == 2 and latents.shape[0] == 2
+                                             and type(controller).__name__ == "AttentionGeometryRemover"
+                                             and torch.equal(latents[0], latents[1]) and torch.equal(ctx_cur[2], ctx_cur[3]))
             # :183-187 — the first optimised step after a fast start runs num_first_optim_steps iterations and keeps the inputs of
             # the lowest-loss one (:236-239); every other step runs one iteration and keeps its updated latents (:252-254)
             if (not first_optim_complete) and fast_start_steps > 0.0:
@@ -187,6 +195,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
                 global_loss_log_dict[i] = out_loss_log_dict
                 clear_controller_loss(controller)
                 controller.cur_step -= 1                                                                   # :307
+                controller.rows_identical = False
             if optimize_latents:                                                                           # :312-316
                 latents = latents_new.detach()
                 last = latents[-1].float().contiguous()

@@ -194,6 +194,24 @@ def attn_bwd(q, k, v, out, lse, dout, scale: float, need_dk: bool):
     return dq, dk
 
 
+def attn_bwd_dkv(q, k, v, out, lse, dout, scale: float):
+    """-> (dk, dv) f32 [BH, M, D]: the key / value gradients of out = softmax(scale q k^T) v for any key count."""
+    lib = _lib.load()
+    dt = _dt16(q, "q")
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
+        _need(t, nm, q.dtype)
+    _need(lse, "lse", torch.float32)
+    BH, N, D = q.shape
+    M = k.shape[1]
+    dk = torch.zeros(BH, M, D, dtype=torch.float32, device=q.device)
+    dv = torch.zeros_like(dk)
+    nbytes = lib.gd_attn_bwd_dkv_workspace_bytes(BH, N, M, D)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    check(lib.gd_attn_bwd_dkv(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), BH, N, M, D, scale, _p(dk), _p(dv), _p(ws), nbytes, dt,
+                              _stream()), "gd_attn_bwd_dkv")
+    return dk, dv
+
+
 def attn_probs(q, k, lse, rows: Optional[torch.Tensor], scale: float):
     """-> P [BH, R, Mpad] 16-bit, Mpad = ceil8(M)."""
     lib = _lib.load()

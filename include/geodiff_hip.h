@@ -150,6 +150,16 @@ int gd_attn_bwd(const void* q, const void* k, const void* v, const void* out, co
                 const void* dout, int BH, int N, int M, int D, float scale,
                 void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
+/* dK and dV of out = softmax(scale q k^T) v for ANY key count (with gd_attn_bwd's dq the full backward of vanilla attention).
+ *   dk_f32, dv_f32 [BH,M,D] f32, ACCUMULATED into (caller zeroes); per-chunk partials go through `workspace`
+ *   (gd_attn_bwd_dkv_workspace_bytes) and are summed in a fixed order — no atomics.
+ * Used by the autograd of the vanilla attention op: null-text optimisation (U/inversion.py:213-259) differentiates the UNet w.r.t.
+ * the text context, i.e. through k and v of every cross-attention layer and q/k/v of every self-attention layer. */
+size_t gd_attn_bwd_dkv_workspace_bytes(int BH, int N, int M, int D);
+int gd_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* out, const float* lse, const void* dout,
+                    int BH, int N, int M, int D, float scale, float* dk_f32, float* dv_f32,
+                    void* workspace, size_t workspace_bytes, int dtype, void* stream);
+
 /* P[bh, r, m] = exp(scale * q[bh, rows[r]] . k[bh, m] - lse[bh, rows[r]])   (rows == NULL: r = row)
  * The opt-pass materialisation of base_att / replace_att rows that removal_loss_geodiff consumes
  * (U/attention_processors.py:250, 307-317).  P is 16-bit [BH, R, Mpad], Mpad = multiple of 8 >= M,

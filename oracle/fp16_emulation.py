@@ -1,0 +1,152 @@
+"""ORACLE experiment (build container only): is the loop-level distance between the HIP path (16-bit storage) and the reference's CPU
+fp32 run ROUNDING, or logic?
+
+The loop fixtures G18 / G19 / G20 are the reference's own driver (U/editor.py:65-423) in fp32 on CPU; the HIP path runs the same call
+with 16-bit weights and activations and lands 0.7 % (G20) / 2.2 % (G18) / 1.8 % (G19) away in L2 after the optimisation loop.  This
+script re-runs the REFERENCE driver on CPU with the UNet's weights rounded to fp16 / bf16 and every module output (and every gradient
+flowing back through a module) rounded through that dtype — i.e. fp32 accumulation + 16-bit storage, which is what the GPU path does —
+and with nothing else changed.  It also probes the loop's sensitivity with a 1e-6 relative perturbation of the start latent in fp32.
+
+    python oracle/fp16_emulation.py            # prints a table, writes tests/golden/fp16_emulation.json
+
+If the emulated-16-bit reference is as far from the fp32 reference as the HIP path is, the HIP-vs-fp32 distance is storage rounding
+amplified by the optimisation loop, not a logic difference.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import cases  # noqa: E402
+import gen_golden  # noqa: E402
+import ref_import  # noqa: E402
+
+
+class _RoundSTE(torch.autograd.Function):
+    """y = round_to(x, dtype) in the forward, gradient rounded the same way in the backward (16-bit storage of activations and of the
+    gradients that flow through them)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+def emulate_16bit(dtype):
+    def prepare(pipe):
+        for mod in (pipe.unet,):
+            with torch.no_grad():
+                for p in mod.parameters():
+                    p.copy_(p.to(dtype).to(p.dtype))
+            for m in mod.modules():
+                if len(list(m.children())) == 0:                      # leaf modules: conv, linear, norms, activations
+                    m.register_forward_hook(lambda _m, _i, out: _RoundSTE.apply(out, dtype) if torch.is_tensor(out) and out.is_floating_point() else out)
+    return prepare
+
+
+class controller_16bit:
+    """Also round what the reference's controllers keep in 16 bits on its own GPU path (autocast): the attention probabilities that
+    feed torch.bmm — attn @ v and the removal loss's correlation (U/attention_processors.py:250-252,428,433) — by wrapping
+    ``compute_attention`` as the reference's attention_processors module sees it."""
+
+    def __init__(self, R, dtype):
+        self.ap, self.dtype = R.attention_processors, dtype
+
+    def __enter__(self):
+        self.orig = self.ap.compute_attention
+        orig, dtype = self.orig, self.dtype
+        self.ap.compute_attention = lambda *a, **k: _RoundSTE.apply(orig(*a, **k), dtype)
+
+    def __exit__(self, *exc):
+        self.ap.compute_attention = self.orig
+
+
+def rel_l2(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+class _CpuVanillaProcessor:
+    """Plain attention in torch (fp32 softmax over materialised scores), the diffusers processor protocol: the formulation of the
+    reference's VanillaAttentionProcessor (U/attention_processors.py:69-139) without diffusers' ``get_attention_scores`` helper."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0):
+        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        q = attn.head_to_batch_dim(attn.to_q(hidden_states))
+        k = attn.head_to_batch_dim(attn.to_k(ctx))
+        v = attn.head_to_batch_dim(attn.to_v(ctx))
+        p = torch.softmax(torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1]), q, k.transpose(-1, -2), beta=0, alpha=attn.scale), -1)
+        out = attn.batch_to_head_dim(torch.bmm(p, v))
+        return attn.to_out[1](attn.to_out[0](out))
+
+
+def unet_pass(R, prepare=None):
+    """One no-grad pass of the narrow UNet (the reference's own VanillaAttentionProcessor on CPU) on seeded inputs, t = 500."""
+    from geodiffuser_amd.pipeline import build_random_sd21
+    pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=True)
+    if prepare is not None:
+        prepare(pipe)
+    pipe.unet.set_attn_processor(_CpuVanillaProcessor())
+    x, ctx = cases.unet_pass_inputs()
+    with torch.no_grad():
+        return pipe.unet(torch.from_numpy(x), 500, encoder_hidden_states=torch.from_numpy(ctx))["sample"], pipe
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    R = ref_import.import_reference()
+    out = {}
+    rows = []
+    # G24: the error budget of ONE UNet pass — fp32 vs ideal 16-bit storage.  The GPU test compares the device pass with both.
+    o32, pipe = unet_pass(R)
+    o16, _ = unet_pass(R, emulate_16bit(torch.float16))
+    ob16, _ = unet_pass(R, emulate_16bit(torch.bfloat16))
+    probe = torch.cat([p.detach().reshape(-1)[:64] for p in pipe.unet.parameters()])
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "G24_unet_pass.npz"), out_fp32=o32.numpy(), out_emul_fp16=o16.numpy(),
+                        out_emul_bf16=ob16.numpy(), weight_probe=probe.numpy())
+    out["G24_unet_pass"] = dict(emulated_fp16=rel_l2(o16, o32), emulated_bf16=rel_l2(ob16, o32))
+    print("G24 one UNet pass: ideal 16-bit storage vs fp32:", out["G24_unet_pass"], flush=True)
+    for name, kind, cfg, fixture in (("G18 editor, 6 steps", "geometry_editor", cases.LOOP, "G18_loop"),
+                                     ("G19 remover, 6 steps", "geometry_remover", cases.LOOP, "G19_loop_remover"),
+                                     ("G20 = configs[0], 20 steps", "geometry_editor", cases.LOOP_CFG0, "G20_loop_cfg0")):
+        ref = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))["latents"])
+        lat32, _, c32, _ = gen_golden.run_reference_loop(R, kind, cfg)
+        up32 = c32._recorded_updates[0]
+        repro = rel_l2(lat32[-1:], ref[-1:])
+        pert, _, _, _ = gen_golden.run_reference_loop(R, kind, cfg, x_T_eps=1e-6)
+        e = dict(fp32_rerun=repro, fp32_xT_perturbed_1e6=rel_l2(pert[-1:], ref[-1:]))
+        for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+            lat, _, ce, _ = gen_golden.run_reference_loop(R, kind, cfg, prepare=emulate_16bit(dt))
+            e["emulated_" + dn] = rel_l2(lat[-1:], ref[-1:])
+            e["emulated_" + dn + "_first_update"] = rel_l2(ce._recorded_updates[0], up32)
+            with controller_16bit(R, dt):
+                lat, _, _, _ = gen_golden.run_reference_loop(R, kind, cfg, prepare=emulate_16bit(dt))
+            e["emulated_" + dn + "_incl_probabilities"] = rel_l2(lat[-1:], ref[-1:])
+        out[fixture] = e
+        rows.append((name, e))
+        print(name, e, flush=True)
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "fp16_emulation.json"), "w"), indent=1)
+    print("\n| loop fixture | fp32 re-run | fp32, x_T perturbed 1e-6 | fp16 storage emulated (UNet) | + 16-bit probabilities | bf16 (UNet) | + probabilities |")
+    print("|---|---|---|---|---|---|---|")
+    for name, e in rows:
+        print(f"first optimisation pass, latent update vs fp32: {name}: fp16 {e['emulated_fp16_first_update']:.2e}, bf16 {e['emulated_bf16_first_update']:.2e}")
+    for name, e in rows:
+        print(f"| {name} | {e['fp32_rerun']:.1e} | {e['fp32_xT_perturbed_1e6']:.1e} | {e['emulated_fp16']:.2e} | "
+              f"{e['emulated_fp16_incl_probabilities']:.2e} | {e['emulated_bf16']:.2e} | {e['emulated_bf16_incl_probabilities']:.2e} |")
+
+
+if __name__ == "__main__":
+    main()

@@ -405,11 +405,13 @@ def g17_attention_store(R, packs):
     save("G17_attention_store", **out)
 
 
-def g18_loop(R, kind="geometry_editor", cfg=None, name=None):
+def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_eps=0.0):
     """The reference's own per-step driver (``text2image_ldm_stable``, U/editor.py:65-423: optimisation pass -> _update_latent ->
     adaptive schedule -> CFG pass -> reference-latent replacement -> latent warp) with its own processors / controller, driving the
     narrow SD-topology UNet of geodiffuser_amd (seeded random weights, fp32, CPU) through a CPU DDIM scheduler built from the
-    reference's closed form.  Records the final latents and the loss log of every optimisation step."""
+    reference's closed form.  -> (final latents, loss log, controller, pipe).
+    ``prepare(pipe)``: optional hook applied to the freshly built model (oracle/fp16_emulation.py installs 16-bit rounding there);
+    ``x_T_eps``: relative perturbation of the start latent (sensitivity probe)."""
     import GeoDiffuser.utils.editor as RE
     from types import SimpleNamespace
     from geodiffuser_amd.pipeline import build_random_sd21
@@ -417,6 +419,8 @@ def g18_loop(R, kind="geometry_editor", cfg=None, name=None):
     c = cfg or cases.LOOP
     inp = cases.loop_inputs(c)
     pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=True)
+    if prepare is not None:
+        prepare(pipe)
 
     class CpuDDIM:
         def __init__(self):
@@ -450,15 +454,37 @@ def g18_loop(R, kind="geometry_editor", cfg=None, name=None):
     ctrl.default_loss_weights = lw
     ctrl.initialize_default_loss_weights()
     ddim = [torch.from_numpy(a) for a in inp["ddim_latents"]]
+    x_T = torch.from_numpy(inp["x_T"])
+    if x_T_eps:
+        g = torch.Generator().manual_seed(5)
+        x_T = x_T * (1.0 + x_T_eps * torch.randn(x_T.shape, generator=g))
+    # record the latent update of every optimisation pass (-step * masked gradient): isolates ONE backward pass from the loop
+    updates = []
+    orig_update = RE._update_latent
+
+    def rec_update(latents, loss, step_size, mask=None, context=None, **kw):
+        res = orig_update(latents, loss, step_size, mask, context, **kw)
+        updates.append((res[0][-1:].detach() - latents[-1:].detach()).clone())
+        return res
+
+    RE._update_latent = rec_update
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        lat, _, log = RE.text2image_ldm_stable(model, ["", ""], ctrl, latent=torch.from_numpy(inp["x_T"]), num_inference_steps=c["steps"],
+        lat, _, log = RE.text2image_ldm_stable(model, ["", ""], ctrl, latent=x_T, num_inference_steps=c["steps"],
                                                guidance_scale=c["guidance"], uncond_embeddings=None, transform_coordinates=coords,
                                                mask_obj=mask, optimize_steps=c["optimize_steps"], latent_replace=c["latent_replace"], lr=c["lr"],
                                                optimize_embeddings=True, optimize_latents=True, ddim_latents=ddim, ddim_noise=None,
                                                edit_type=kind, fast_start_steps=0.0, num_first_optim_steps=1,
                                                use_adaptive_optimization=True, return_type="latents")
     ap.reshape_transform_coords = orig_rtc
+    RE._update_latent = orig_update
+    ctrl._recorded_updates = updates
+    return lat.detach(), log, ctrl, pipe
+
+
+def g18_loop(R, kind="geometry_editor", cfg=None, name=None):
+    """Records the final latents and the loss log of every optimisation step of run_reference_loop."""
+    lat, log, ctrl, pipe = run_reference_loop(R, kind, cfg)
     out = {"latents": lat.detach(), "steps": np.array(sorted(log))}
     for i, d in log.items():
         for att in ("self", "cross"):
@@ -468,6 +494,7 @@ def g18_loop(R, kind="geometry_editor", cfg=None, name=None):
     w = torch.cat([p.detach().reshape(-1)[:64] for p in pipe.unet.parameters()])
     out["weight_probe"] = w                                         # to recognise the same seeded weights on the test machine
     out["final_weights_self_removal"] = np.array(float(ctrl.loss_weight_dict["self"]["removal"]))
+    out["first_update"] = ctrl._recorded_updates[0].numpy()          # latent update of the first optimisation pass
     save(name or ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover"), **out)
 
 

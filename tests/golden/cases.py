@@ -250,3 +250,11 @@ def mesh_masks(size=64) -> dict:
     m[10:50, 52] = 1.0               # one-pixel-wide column: no faces
     out["thin"] = m
     return out
+
+
+def unet_pass_inputs(seed=91, size=32):
+    """One UNet pass of the narrow model: latents [2,4,size,size], text context [2,77,64] (G24)."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((2, 4, size, size)).astype(np.float32)
+    ctx = rng.standard_normal((2, 77, 64)).astype(np.float32)
+    return x, ctx

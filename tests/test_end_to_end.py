@@ -312,8 +312,15 @@ def test_edits_are_independent_of_history(pipe):
     assert rel_l2(lat_b, lat_a) < max(5 * noise, 5e-2)
 
 
+def _emulation():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp16_emulation.json")))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0"])
-def test_loop_matches_reference_driver_g18(pipe, kind):
+def test_loop_matches_reference_driver_g18(kind, dtype):
     """Loop-level parity: fixture G18 is the REFERENCE's own text2image_ldm_stable (its processors, controller, _update_latent,
     adaptive schedule, latent replacement / warp) run on CPU in fp32 over the same narrow SD-topology UNet (same seeded weights) and the
     same seeded trajectory.  Here the same call runs through the HIP path in fp16.  Differences are rounding only (16-bit storage, the
@@ -326,10 +333,20 @@ def test_loop_matches_reference_driver_g18(pipe, kind):
     cfg0 = kind == "cfg0"                # BASELINE configs[0]: 256 x 256, 2-D translation, 20-step DDIM (7 optimisation passes)
     if cfg0:
         kind = "geometry_editor"
-    g = load("G20_loop_cfg0" if cfg0 else ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover"))
-    p, tok, sched = pipe
+    fixture = "G20_loop_cfg0" if cfg0 else ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover")
+    g = load(fixture)
+    # What IDEAL 16-bit storage alone does to the reference's own driver (oracle/fp16_emulation.py: the reference loop on CPU with the
+    # UNet's weights, activations and gradients rounded through the dtype): the yardstick for the distances below.  The 1e-3 relative
+    # tolerance of the north star holds per layer (tests/test_controller_parity.py); at loop level the same rounding is amplified by the
+    # optimisation (an L1 loss differentiates to sign(x): a 1e-3 change of x near 0 flips a unit gradient), by 430x for the editor
+    # (x_T perturbed by 1e-6 -> 4.3e-4) and 2x for the remover — in the reference's own arithmetic.
+    dn = "fp16" if dtype == torch.float16 else "bf16"
+    emu = _emulation()[fixture]
+    emu_final, emu_update = emu["emulated_" + dn], emu["emulated_" + dn + "_first_update"]
+    from geodiffuser_amd.diffusion import load_model
+    p, tok, sched = load_model(device="cuda:0", tiny=True, dtype=dtype)
     probe = torch.cat([q.detach().float().reshape(-1)[:64] for q in p.unet.parameters()]).cpu()
-    if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=2e-3):
+    if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=2e-3 if dtype == torch.float16 else 2e-2):
         pytest.skip("seeded weights differ from the fixture's (different torch build): the fixture does not apply")
     c = cases.LOOP_CFG0 if cfg0 else cases.LOOP
     inp = cases.loop_inputs(c)
@@ -349,27 +366,42 @@ def test_loop_matches_reference_driver_g18(pipe, kind):
     prev = (editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS, editor.SKIP_UNCOND_REF)
     editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS = c["steps"], c["guidance"], c["skip_optim"]
     runs = []
+    updates = []
+    orig_apply = editor._apply_latent_update
+
+    def rec_apply(latents_in, g_lat, context_in, g_ctx, l_eff, mask):
+        res = orig_apply(latents_in, g_lat, context_in, g_ctx, l_eff, mask)
+        updates.append((res[0][-1:].detach().float() - latents_in[-1:].detach().float()).cpu())
+        return res
+
+    editor._apply_latent_update = rec_apply
     try:
         for skip_ref in (False, True):                      # the reference's 4-row CFG batch, and the 3-row shortcut
             editor.SKIP_UNCOND_REF = skip_ref
+            updates.clear()
             ctrl.reset() if hasattr(ctrl, "reset") else None
             ctrl.masks_cache_dict = {}
             ctrl.default_loss_weights = {k: dict(v) for k, v in lw.items()}
             ctrl.initialize_default_loss_weights()
-            ddim = [torch.from_numpy(a).to("cuda").half() for a in inp["ddim_latents"]]
+            ddim = [torch.from_numpy(a).to("cuda").to(dtype) for a in inp["ddim_latents"]]
             lat, _, log = editor.text2image_ldm_stable(
-                p, ["", ""], ctrl, latent=torch.from_numpy(inp["x_T"]).to("cuda").half(), num_inference_steps=c["steps"],
+                p, ["", ""], ctrl, latent=torch.from_numpy(inp["x_T"]).to("cuda").to(dtype), num_inference_steps=c["steps"],
                 guidance_scale=c["guidance"], uncond_embeddings=None, transform_coordinates=coords, mask_obj=torch.from_numpy(inp["mask"]),
                 optimize_steps=c["optimize_steps"], latent_replace=c["latent_replace"], lr=c["lr"], optimize_embeddings=True,
                 optimize_latents=True, ddim_latents=ddim, ddim_noise=None, edit_type=kind, fast_start_steps=0.0,
                 num_first_optim_steps=1, use_adaptive_optimization=True, return_type="latents", image_size=c["size"])
-            runs.append((lat.float().cpu(), log, float(ctrl.loss_weight_dict["self"]["removal"])))
+            runs.append((lat.float().cpu(), log, float(ctrl.loss_weight_dict["self"]["removal"]), updates[0].clone()))
     finally:
+        editor._apply_latent_update = orig_apply
         editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS, editor.SKIP_UNCOND_REF = prev
         p.unet.set_attn_processor(VanillaAttentionProcessor())
     ref_lat = torch.from_numpy(g["latents"])
-    for lat, log, w_rm in runs:
+    for lat, log, w_rm, first_update in runs:
         assert sorted(log) == list(g["steps"])                                          # optimisation ran at the same steps
+        # ONE backward pass, no loop amplification: the latent update of the first optimisation pass (-step * masked gradient)
+        e_up = rel_l2(first_update, torch.from_numpy(g["first_update"]))
+        print(f"[G18] {dn} first optimisation pass, latent update rel_l2 vs the reference driver: {e_up:.4f} (ideal {dn} storage: {emu_update:.4f})")
+        assert e_up < 2.0 * emu_update + 0.01
         first = int(g["steps"][0])
         for kind in ("self", "cross"):
             for k, v in log[first][kind].items():                                       # first pass: inputs identical -> 16-bit rounding only
@@ -377,15 +409,45 @@ def test_loop_matches_reference_driver_g18(pipe, kind):
                 print(f"[G18] first pass {kind}/{k}: {float(v):.5f} vs {ref:.5f}")
                 # (absolute floor: an L1 mean of two 16-bit-rounded attention outputs that are EQUAL in exact arithmetic — the remover's
                 #  background term, which is 0.0 in the fp32 reference — sits at the rounding noise, ~1.5e-4)
-                assert abs(float(v) - ref) <= 2e-2 * abs(ref) + 5e-4, (kind, k, float(v), ref)
+                #  — 8x that in bf16)
+                assert abs(float(v) - ref) <= (2e-2 if dtype == torch.float16 else 6e-2) * abs(ref) + (5e-4 if dtype == torch.float16 else 4e-3), (kind, k, float(v), ref)
             assert log[first]["num_layers"] == int(g[f"log_{first}_num_layers"])
         last = int(g["steps"][-1])
         for kind in ("self", "cross"):
             for k, v in log[last][kind].items():
                 ref = float(g[f"log_{last}_{kind}_{k}"])
-                assert abs(float(v) - ref) <= (0.3 if cfg0 else 0.15) * abs(ref) + 1e-3, (kind, k, float(v), ref)
+                print(f"[G18] last pass (step {last}) {kind}/{k}: {float(v):.5f} vs {ref:.5f}")
+                assert abs(float(v) - ref) <= (0.3 if cfg0 else 0.15) * (1.0 if dtype == torch.float16 else 2.0) * abs(ref) + 1e-3, (kind, k, float(v), ref)
         assert w_rm == pytest.approx(float(g["final_weights_self_removal"]), rel=1e-6)   # the adaptive schedule took the same branches
         assert lat.shape == ref_lat.shape
-        assert torch.equal(lat[0], ref_lat[0].half().float())                           # reference row = the trajectory's last replacement
-        print(f"[G18] edit-latent rel_l2 vs the reference driver: {rel_l2(lat[1], ref_lat[1]):.4f}")
-        assert rel_l2(lat[1], ref_lat[1]) < (0.04 if cfg0 else 0.06)     # measured 0.007 (cfg0, 20 steps) / 0.022 / 0.018; fp16 HIP path vs fp32 CPU reference
+        assert torch.equal(lat[0], ref_lat[0].to(dtype).float())                        # reference row = the trajectory's last replacement
+        e_fin = rel_l2(lat[1], ref_lat[1])
+        print(f"[G18] {dn} edit-latent rel_l2 vs the reference driver: {e_fin:.4f} (ideal {dn} storage: {emu_final:.4f})")
+        # "rounding, not logic": the device path is no further from the fp32 reference than 2x what ideal 16-bit storage alone gives
+        assert e_fin < 2.0 * emu_final + 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_unet_pass_error_budget_g24(dtype):
+    """One UNet pass of the narrow model on the device (16-bit weights / activations, HIP attention + fused norms, MIOpen / rocBLAS)
+    against the CPU fp32 pass on the same seeded weights and inputs (G24), next to the error that IDEAL 16-bit storage alone produces
+    (the same CPU pass with every module output rounded through the dtype, oracle/fp16_emulation.py).  The loop-level bounds of
+    test_loop_matches_reference_driver_g18 are these per-pass errors amplified by the optimisation loop."""
+    import cases
+    from geodiffuser_amd.attention_processors import VanillaAttentionProcessor
+    from geodiffuser_amd.diffusion import load_model
+    g = load("G24_unet_pass")
+    p, _, _ = load_model(device="cuda:0", tiny=True, dtype=dtype)
+    probe = torch.cat([q.detach().float().reshape(-1)[:64] for q in p.unet.parameters()]).cpu()
+    if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=2e-2):
+        pytest.skip("seeded weights differ from the fixture's (different torch build)")
+    p.unet.set_attn_processor(VanillaAttentionProcessor())
+    x, ctx = cases.unet_pass_inputs()
+    with torch.no_grad():
+        out = p.unet(torch.from_numpy(x).cuda().to(dtype), 500, encoder_hidden_states=torch.from_numpy(ctx).cuda().to(dtype))["sample"]
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g["out_fp32"])
+    ideal = rel_l2(torch.from_numpy(g["out_emul_fp16" if dtype == torch.float16 else "out_emul_bf16"]), ref)
+    dev = rel_l2(out.float().cpu(), ref)
+    print(f"[G24] one UNet pass, {dtype}: device vs fp32 {dev:.2e}; ideal 16-bit storage vs fp32 {ideal:.2e}")
+    assert dev < 3.0 * ideal

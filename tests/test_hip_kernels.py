@@ -823,3 +823,43 @@ def test_mesh_coverage_bit_exact_vs_oracle(ops, S):
         assert np.array_equal(got[None, None], O.splatter_mesh(vv, fo, S)) and got.sum() == 0
     got = ops.mesh_coverage(torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, dtype=torch.int32, device=DEV), S)
     assert float(got.sum()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("BH,N,M", [(2, 256, 256), (2, 1024, 77), (1, 1000, 1024), (2, 320, 200), (1, 4096, 4096)])
+def test_attention_backward_dk_dv_any_key_count(ops, dtype, BH, N, M):
+    """gd_attn_bwd_dkv (+ gd_attn_bwd's dq) = the full backward of out = softmax(scale q k^T) v, against torch autograd in fp64 on
+    the same 16-bit inputs: self-attention sizes (one query chunk, no partial sums), cross-attention (77 keys, chunked partials),
+    ragged query / key counts."""
+    torch.manual_seed(N * 3 + M)
+    q = (torch.randn(BH, N, 64, device=DEV) * 1.2).to(dtype); k = (torch.randn(BH, M, 64, device=DEV) * 1.2).to(dtype)
+    v = torch.randn(BH, M, 64, device=DEV).to(dtype); g = (torch.randn(BH, N, 64, device=DEV) * 0.1).to(dtype)
+    out = torch.empty_like(q); lse = torch.empty(BH, N, device=DEV)
+    ops.attn_fwd([(q, k, v, out, lse)], 0.125)
+    dk, dv = ops.attn_bwd_dkv(q, k, v, out, lse, g, 0.125)
+    dq, _ = ops.attn_bwd(q, k, v, out, lse, g, 0.125, False)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bnd,bmd->bnm", qd, kd) * 0.125
+    o = torch.einsum("bnm,bmd->bnd", torch.softmax(s, -1), vd)
+    rq, rk, rv = torch.autograd.grad((o * g.double()).sum(), [qd, kd, vd])
+    lim = 1.5e-2 if dtype == torch.float16 else 5e-2             # 16-bit P / dS fragments; gradients are sums of many signed terms
+    assert rel_l2(dk.double(), rk) < lim and rel_l2(dv.double(), rv) < lim and rel_l2(dq.double(), rq) < lim
+    assert rel_err(dv.double().cpu(), rv.cpu()) < 10 * lim and rel_err(dk.double().cpu(), rk.cpu()) < 10 * lim
+
+
+def test_vanilla_attention_autograd_is_complete():
+    """attention() under autograd returns dq, dk AND dv (what null-text optimisation needs: the text context reaches the loss only
+    through k / v of the cross-attention layers)."""
+    from geodiffuser_amd.attention_sharing import attention
+    torch.manual_seed(3)
+    q = (torch.randn(4, 256, 64, device=DEV)).half().requires_grad_(True)
+    k = (torch.randn(4, 77, 64, device=DEV)).half().requires_grad_(True)
+    v = (torch.randn(4, 77, 64, device=DEV)).half().requires_grad_(True)
+    with torch.enable_grad():
+        out = attention(q, k, v, 0.125)
+        gq, gk, gv = torch.autograd.grad((out.float() ** 2).sum(), [q, k, v])
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    o = torch.einsum("bnm,bmd->bnd", torch.softmax(torch.einsum("bnd,bmd->bnm", qd, kd) * 0.125, -1), vd)
+    rq, rk, rv = torch.autograd.grad((o ** 2).sum(), [qd, kd, vd])
+    for a, b in ((gq, rq), (gk, rk), (gv, rv)):
+        assert a is not None and rel_l2(a.double(), b) < 2e-2

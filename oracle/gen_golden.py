@@ -498,6 +498,52 @@ def g18_loop(R, kind="geometry_editor", cfg=None, name=None):
     save(name or ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover"), **out)
 
 
+def g25_null_text(R):
+    """Null-text optimisation (U/inversion.py:213-259): the reference's own ``NullInversion.null_optimization`` on CPU (fp32) over the
+    narrow UNet (plain torch attention processor), a seeded 4-step trajectory, 3 inner Adam steps per DDIM step."""
+    from types import SimpleNamespace
+    import GeoDiffuser.utils.inversion as RI
+    from geodiffuser_amd.pipeline import build_random_sd21
+    import ref_cpu as O
+    from fp16_emulation import _CpuVanillaProcessor
+    pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=True)
+    pipe.unet.set_attn_processor(_CpuVanillaProcessor())
+    c = cases.NULL_TEXT
+    traj = cases.null_text_inputs()
+
+    class CpuDDIM:
+        def __init__(self, n):
+            self.alphas_cumprod = O.alphas_cumprod()
+            self.final_alpha_cumprod = self.alphas_cumprod[0]
+            self.config = SimpleNamespace(num_train_timesteps=1000)
+            self.num_inference_steps = n
+            self.timesteps = torch.from_numpy(O.ddim_timesteps(n))
+
+    model = SimpleNamespace(unet=pipe.unet, scheduler=CpuDDIM(c["steps"]), tokenizer=pipe.tokenizer, text_encoder=pipe.text_encoder,
+                            device=torch.device("cpu"))
+    import tqdm as _tqdm
+    RI.tqdm = _tqdm.std.tqdm                 # the reference imports the notebook progress bar (needs ipywidgets)
+    # The reference never imports the optimiser it names (U/inversion.py:223 raises NameError: its own default
+    # perform_inversion=True cannot run; every driver passes False).  The prompt-to-prompt code this method was taken from uses
+    # torch.optim.adam.Adam and torch.nn.functional as nnf: supplied here so that the method's arithmetic can be recorded.
+    if not hasattr(RI, "Adam"):
+        RI.Adam = torch.optim.Adam
+    if not hasattr(RI, "nnf"):
+        RI.nnf = torch.nn.functional
+    ni = object.__new__(RI.NullInversion)
+    ni.model, ni.num_ddim_steps, ni.guidance_scale = model, c["steps"], c["guidance"]
+    tok = pipe.tokenizer
+    ids = tok([""], padding="max_length", max_length=tok.model_max_length, return_tensors="pt").input_ids
+    with torch.no_grad():
+        e = pipe.text_encoder(ids)[0]
+    ni.context = torch.cat([e, e])
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        out = ni.null_optimization([torch.from_numpy(a) for a in traj], c["inner"], c["eps"])
+    save("G25_null_text", uncond=torch.cat(out).detach().numpy(), context0=e.detach().numpy(),
+         weight_probe=torch.cat([p.detach().reshape(-1)[:64] for p in pipe.unet.parameters()]).numpy())
+
+
 def g16_batch_config():
     """What ``perform_exp`` hands to ``perform_geometric_edit`` for each live edit type (call intercepted) -> JSON."""
     import json
@@ -540,6 +586,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "G17":
         R = ref_import.import_reference()
         print("G17"); g17_attention_store(R, g_masks_and_warp(R))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "G25":
+        R = ref_import.import_reference()
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        print("G25"); g25_null_text(R)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "G12":
         R = ref_import.import_reference()

@@ -258,3 +258,18 @@ def unet_pass_inputs(seed=91, size=32):
     x = rng.standard_normal((2, 4, size, size)).astype(np.float32)
     ctx = rng.standard_normal((2, 77, 64)).astype(np.float32)
     return x, ctx
+
+
+NULL_TEXT = dict(steps=4, inner=3, guidance=3.0, eps=1e-5, seed=83, size=32)
+
+
+def null_text_inputs():
+    """A seeded 'inversion trajectory' of steps + 1 latents [1,4,32,32] for the null-text fixture (G25)."""
+    c = NULL_TEXT
+    rng = np.random.default_rng(c["seed"])
+    x0 = rng.standard_normal((1, 4, c["size"], c["size"])).astype(np.float32)
+    # a smooth trajectory (each latent a small step from the previous one), like a real inversion
+    traj = [x0]
+    for _ in range(c["steps"]):
+        traj.append((traj[-1] + 0.05 * rng.standard_normal(x0.shape)).astype(np.float32))
+    return traj

@@ -344,3 +344,24 @@ def test_identical_reference_and_edit_rows(kind, cross):
     assert abs(res["loss"] - float(co.loss)) <= 2e-3 * abs(float(co.loss))
     (dq,) = torch.autograd.grad(co.loss, [qo])
     assert rel_l2(res["dq"][f:], dq[f:]) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("name", ["edit_self_opt_32_d64", "edit_cross_opt_32_d64", "edit_self_opt_64_d64", "rem_self_opt_32_d64"])
+def test_edit_layer_is_bit_reproducible(name, dtype):
+    """One hooked layer of an optimisation pass — forward with all five losses and the backward to q / k — gives the same BITS on every
+    run: no floating-point atomics anywhere on the path (loss sums, removal-loss reduction, removal backward, dK partials are folded
+    in fixed orders)."""
+    case = ORACLE_CASES[name]
+    q, k, v, mask, coords = case_inputs(case)
+    runs = []
+    for rep in range(3):
+        ch = _make_hip_controller(case, mask)
+        _prebuild_tables(ch, case, q, coords, dtype)
+        gout = case_gout(case, (q.shape[0] if not case["cfg"] else q.shape[0], q.shape[1], q.shape[2]))
+        res = _run_hip(ch, case, q, k, v, coords, 0.125, gout, dtype)
+        runs.append((res["out"], res["loss"], res["dq"], res["dk"], {kk: float(vv) for kk, vv in ch.loss_log_dict["cross" if case["cross"] else "self"].items()}))
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and r[1] == runs[0][1]
+        assert torch.equal(r[2], runs[0][2]) and torch.equal(r[3], runs[0][3])
+        assert r[4] == runs[0][4]

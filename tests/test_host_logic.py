@@ -140,3 +140,40 @@ def test_two_process_gloo_shard_and_broadcast(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def test_diffusion_step_with_a_foreign_scheduler():
+    """a scheduler object that is not the repo's own (e.g. a diffusers DDIMScheduler passed as scheduler_in) has
+    the plain ``step(model_output, t, sample, eta=0.0)`` signature: diffusion_step must do the classifier-free-guidance combine itself
+    (diffusion.py:47-49) instead of passing the fused-kernel keywords."""
+    import torch
+    from types import SimpleNamespace
+    from geodiffuser_amd.diffusion import diffusion_step
+
+    class ForeignScheduler:
+        def step(self, model_output, timestep, sample, eta=0.0):           # no **kwargs, like diffusers 0.25.1
+            return {"prev_sample": sample - 0.5 * model_output}
+
+    class FakeUNet:
+        def __call__(self, x, t, encoder_hidden_states=None):
+            return {"sample": x * 2.0 + encoder_hidden_states.mean(dim=(1, 2))[:, None, None, None]}
+
+    class Ctrl:
+        def step_callback(self, x, coords=None):
+            return x
+
+    model = SimpleNamespace(unet=FakeUNet(), scheduler=ForeignScheduler())
+    torch.manual_seed(0)
+    lat = torch.randn(2, 4, 8, 8)
+    ctx = torch.randn(4, 77, 16)
+    g = 3.0
+    eps = model.unet(torch.cat([lat] * 2), 500, encoder_hidden_states=ctx)["sample"]
+    eu, ec = eps.chunk(2)
+    want = lat - 0.5 * (eu + g * (ec - eu))
+    got = diffusion_step(model, Ctrl(), lat, ctx, 500, g)
+    assert torch.allclose(got, want, atol=1e-6)
+    got2, noise = diffusion_step(model, Ctrl(), lat, ctx, 500, g, return_noise=True)
+    assert torch.allclose(got2, want, atol=1e-6) and torch.allclose(noise, eu + g * (ec - eu), atol=1e-6)
+    # 3-row shortcut (uncond_edit, cond_ref, cond_edit)
+    got3 = diffusion_step(model, Ctrl(), lat, ctx, 500, g, skip_uncond_ref=True)
+    assert torch.allclose(got3[1:], want[1:], atol=1e-6) and torch.equal(got3[:1], lat[:1])

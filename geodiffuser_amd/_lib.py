@@ -63,7 +63,7 @@ SIGNATURES = {
     "gd_edit_losses_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gd_edit_losses_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
-    "gd_removal_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "gd_removal_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "gd_edit_losses_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gd_blend_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -31,7 +31,7 @@ import torch
 from . import ops
 from . import warp_utils
 from ._lib import GD_TOKEN_MAJOR
-from .attention_sharing import attention_tok, AttentionStore, attention, compute_attention, get_base_edit_qkv
+from .attention_sharing import attention_tok, AttentionStore, attention, compute_attention, get_base_edit_qkv, pad_head_dim
 from .generic_torch import (CoordinateDistances, binarize_tensor, reshape_attention_mask,
                             reshape_transform_coords, torch_dilate)
 
@@ -476,9 +476,12 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         self.coords_dtype = torch.float16
 
     # -- per-resolution device tables --------------------------------------------------------------------
-    def _tables(self, S: int, f: int, q: torch.Tensor, transform_coords):
+    def _tables(self, S: int, f: int, q: torch.Tensor, transform_coords, D: int = 64):
+        """D: the TRUE head dim (loss normalisers, U/attention_processors.py:231-305); only q's device / dtype are read."""
         c = self.masks_cache_dict.get(S)
         if c is not None and "f" in c:
+            if c["D"] != D:
+                raise ValueError(f"layers of latent size {S} disagree on the head dim ({c['D']} vs {D})")
             return c
         dev = q.device
         N = S * S
@@ -541,7 +544,6 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         c["rows"] = rows
         # reciprocals of the loss denominators (U/attention_processors.py:231-305) on the device: sim, movement, amodal, smooth_h,
         # smooth_w, removal
-        D = 64
         use_amodal = (not rem) and N > 32 ** 2
         cnt = float(f * S * (S - 1) * D)
         inv = torch.tensor([1.0 / (f * D * c["s_wo"] + 1e-8), 1.0 / (f * D * c["s_edit"] + 1e-8), 1.0 / (f * D * c["s_am"] + 1e-8),
@@ -551,7 +553,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         if not use_amodal:
             tb[2] = 0.0
         c["inv5_bwd"] = _persist(pt, ("inv5_bwd", S, rem), tb)
-        c["S"], c["f"] = S, f
+        c["S"], c["f"], c["D"] = S, f, D
         if N >= 32 ** 2:                                                       # :413-415,575-576 / :778-780
             self.mask_wo_edit = m_wo.detach()
             self.mask_1_empty = m_empty.detach()
@@ -567,13 +569,13 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
                             for S, c in self.masks_cache_dict.items() if "f" in c))
 
     def tables_built(self, layers) -> bool:
-        return all(S in self.masks_cache_dict and "f" in self.masks_cache_dict[S] for S, _ in layers)
+        return all(S in self.masks_cache_dict and "f" in self.masks_cache_dict[S] for S, *_ in layers)
 
     def prebuild_tables(self, layers, q_like: torch.Tensor, transform_coords):
         """Build the per-resolution tables for the (S, heads) pairs of a previous pass now (one host sync each) instead of lazily
         inside the first hooked call, so that a captured pass can be replayed as the very first pass of an edit."""
-        for S, f in layers:
-            self._tables(S, f, q_like, transform_coords)
+        for S, f, *rest in layers:
+            self._tables(S, f, q_like, transform_coords, rest[0] if rest else 64)
 
     def graph_key(self):
         """Everything a no-grad UNet pass of this controller branches on (the launch sequence is static for a given key)."""
@@ -664,10 +666,14 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         if is_cross:
             _ = self.cross_replace_alpha[self.cur_step]                        # :654 (indexing only; value unused)
         S = int(math.isqrt(q.shape[1]))
-        c = self._tables(S, f, q, transform_coords)
+        D = q.shape[2]
+        c = self._tables(S, f, q, transform_coords, D)
         if self.rows_identical and torch.is_grad_enabled():
             q, k, v = (self._tie_rows(t, f) for t in (q, k, v))
+        if D % 64:      # SD1.x heads (40 / 80 / 160): zero columns up to the kernels' 64 / 128 / 192; the loss normalisers keep the true D
+            q, k, v = pad_head_dim(q), pad_head_dim(k), pad_head_dim(v)
         out, loss, terms = _EditLayer.apply(q.contiguous(), k.contiguous(), v.contiguous(), self, is_cross, float(scale), c)
+        out = out[..., :D]
         if (q.shape[1] >= 32 ** 2) and (not self.use_cfg):
             kind = "cross" if is_cross else "self"
             self.loss = self.loss + loss                                       # :494,604 / :822,914

@@ -46,8 +46,20 @@ class _VanillaAttention(torch.autograd.Function):
         return dq, dk, dv, None
 
 
+def pad_head_dim(t: torch.Tensor) -> torch.Tensor:
+    """[..., D] -> [..., ceil(D / 64) * 64] with zero columns (differentiable)."""
+    D = t.shape[-1]
+    return t if D % 64 == 0 else torch.nn.functional.pad(t, (0, -D % 64))
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
-    """softmax(scale q k^T) v, [BH,N,D] x [BH,M,D] -> [BH,N,D] (HIP, flash-style)."""
+    """softmax(scale q k^T) v, [BH,N,D] x [BH,M,D] -> [BH,N,D] (HIP, flash-style).  Head dims that are not a multiple of 64 (SD1.x:
+    40 / 80 / 160) are zero-padded to the next multiple — the kernels exist for 64 / 128 / 192; zero columns change no score and
+    give zero outputs / gradients; ``scale`` stays the true head dim's."""
+    D = q.shape[-1]
+    if D % 64:
+        q, k, v = pad_head_dim(q), pad_head_dim(k), pad_head_dim(v)
+        return attention(q, k, v, scale)[..., :D]
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
         return _VanillaAttention.apply(q, k, v, scale)

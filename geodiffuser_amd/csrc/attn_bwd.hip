@@ -1,4 +1,4 @@
-// Attention backward for the edit path (gfx950 MFMA), D = 64.
+// Attention backward for the edit path (gfx950 MFMA), D = 64 NCH (NCH = 1: SD2.1; 2, 3: zero-padded 80 / 160-wide SD1.x heads).
 //
 // Reference: torch.autograd through compute_attention + torch.bmm (GeoDiffuser/utils/attention_sharing.py:30-47,
 // GeoDiffuser/utils/attention_processors.py:432-433,555-557) as driven by torch.autograd.grad in
@@ -20,56 +20,65 @@ struct BwdArgs {
     float c, scale, l2e;
 };
 
-template <typename T>
-__global__ void __launch_bounds__(256, 2)
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256, NCH == 1 ? 2 : 1)
 k_attn_bwd_dq(const BwdArgs a) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
-    __shared__ __attribute__((aligned(16))) char lds[2][2][ATT_TILE_BYTES];   // [buf][K|V]
+    constexpr int D = ATT_D * NCH;
+    __shared__ __attribute__((aligned(16))) char lds[2][2][NCH * ATT_TILE_BYTES];   // [buf][K|V][64-column chunk]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int wg = xcd_remap(blockIdx.x, a.nwg);
     const int bh = wg / a.tiles, tile = wg - bh * a.tiles;
     const int N = a.N, M = a.M;
-    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * ATT_D;
-    const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * ATT_D;
-    const T* __restrict__ vp = (const T*)a.v + (size_t)bh * M * ATT_D;
-    const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * ATT_D;
-    const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * ATT_D;
+    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * D;
+    const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * D;
+    const T* __restrict__ vp = (const T*)a.v + (size_t)bh * M * D;
+    const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * D;
+    const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * D;
 
     const int qrow = tile * ATT_BM + wave * 32 + (lane & 31);
     const int qld = qrow < N ? qrow : N - 1;
-    V8 qf[4], gf[4];
+    V8 qf[4 * NCH], gf[4 * NCH];
     float dpart = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        qf[s] = *(const V8*)(qp + (size_t)qld * ATT_D + 16 * s + 8 * h);
-        gf[s] = *(const V8*)(gp + (size_t)qld * ATT_D + 16 * s + 8 * h);
-        const V8 of = *(const V8*)(op + (size_t)qld * ATT_D + 16 * s + 8 * h);
+    for (int s = 0; s < 4 * NCH; ++s) {
+        qf[s] = *(const V8*)(qp + (size_t)qld * D + 16 * s + 8 * h);
+        gf[s] = *(const V8*)(gp + (size_t)qld * D + 16 * s + 8 * h);
+        const V8 of = *(const V8*)(op + (size_t)qld * D + 16 * s + 8 * h);
 #pragma unroll
         for (int j = 0; j < 8; ++j) dpart = __builtin_fmaf(TR::to_f32(gf[s][j]), TR::to_f32(of[j]), dpart);
     }
     const float delta = dpart + __shfl_xor(dpart, 32, 64);         // rowsum(dO o O)
     const float lse2 = a.lse[(size_t)bh * N + qld] * a.l2e;
 
-    f32x16 dq[2];
+    f32x16 dq[2 * NCH];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
+    for (int j = 0; j < 2 * NCH; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[j][i] = 0.f;
 
     const int T_tiles = (M + ATT_BN - 1) / ATT_BN;
-    u32x4 kr[2], vr[2];
-    tile_load<T>(kp, 0, M, tid, kr);
-    tile_load<T>(vp, 0, M, tid, vr);
-    tile_store(lds[0][0], tid, kr);
-    tile_store(lds[0][1], tid, vr);
+    u32x4 kr[NCH][2], vr[NCH][2];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        tile_load<T>(kp + ch * ATT_D, 0, M, tid, kr[ch], D);
+        tile_load<T>(vp + ch * ATT_D, 0, M, tid, vr[ch], D);
+        tile_store(lds[0][0] + ch * ATT_TILE_BYTES, tid, kr[ch]);
+        tile_store(lds[0][1] + ch * ATT_TILE_BYTES, tid, vr[ch]);
+    }
     __syncthreads();
 
     for (int t = 0; t < T_tiles; ++t) {
         const int cur = t & 1;
         const bool more = (t + 1) < T_tiles;
         if (more) {
-            tile_load<T>(kp, (t + 1) * ATT_BN, M, tid, kr);
-            tile_load<T>(vp, (t + 1) * ATT_BN, M, tid, vr);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                tile_load<T>(kp + ch * ATT_D, (t + 1) * ATT_BN, M, tid, kr[ch], D);
+                tile_load<T>(vp + ch * ATT_D, (t + 1) * ATT_BN, M, tid, vr[ch], D);
+            }
         }
         const char* lk = lds[cur][0];
         const char* lv = lds[cur][1];
@@ -81,9 +90,13 @@ k_attn_bwd_dq(const BwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s_acc[i] = 0.f; p_acc[i] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(read_row_frag<T>(lk, blk, s, lane), qf[s], s_acc);
+            for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) p_acc = TR::mfma32(read_row_frag<T>(lv, blk, s, lane), gf[s], p_acc);
+                for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(read_row_frag<T>(lk + ch * ATT_TILE_BYTES, blk, s, lane), qf[4 * ch + s], s_acc);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) p_acc = TR::mfma32(read_row_frag<T>(lv + ch * ATT_TILE_BYTES, blk, s, lane), gf[4 * ch + s], p_acc);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[i], a.c, -lse2));
@@ -95,20 +108,26 @@ k_attn_bwd_dq(const BwdArgs a) {
         }
         // dQ^T += K^T dS^T
 #pragma unroll
-        for (int dblk = 0; dblk < 2; ++dblk)
+        for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dq[dblk] = TR::mfma32(read_tr_frag<T>(lk, dblk, ks, lane), dsf[ks], dq[dblk]);
+            for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    dq[2 * ch + dblk] = TR::mfma32(read_tr_frag<T>(lk + ch * ATT_TILE_BYTES, dblk, ks, lane), dsf[ks], dq[2 * ch + dblk]);
 
         if (more) {
-            tile_store(lds[cur ^ 1][0], tid, kr);
-            tile_store(lds[cur ^ 1][1], tid, vr);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                tile_store(lds[cur ^ 1][0] + ch * ATT_TILE_BYTES, tid, kr[ch]);
+                tile_store(lds[cur ^ 1][1] + ch * ATT_TILE_BYTES, tid, vr[ch]);
+            }
         }
         __syncthreads();
     }
     if (qrow < N) {
-        T* __restrict__ dp = (T*)a.dq + ((size_t)bh * N + qrow) * ATT_D;
+        T* __restrict__ dp = (T*)a.dq + ((size_t)bh * N + qrow) * D;
 #pragma unroll
-        for (int dblk = 0; dblk < 2; ++dblk)
+        for (int dblk = 0; dblk < 2 * NCH; ++dblk)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 typename TR::vec4 w;
@@ -128,51 +147,63 @@ k_attn_bwd_dq(const BwdArgs a) {
 //                                                                  leaves the accumulators — the forward's P.V trick)
 // One workgroup per (head, DK_QCHUNK queries); the per-chunk partials are summed by k_attn_bwd_dk_reduce (no atomics).
 #define DK_QCHUNK 128
-template <typename T>
-__global__ void __launch_bounds__(256, 2)
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256, NCH == 1 ? 2 : 1)
 k_attn_bwd_dk(const BwdArgs a) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
-    __shared__ __attribute__((aligned(16))) char lds[2][ATT_TILE_BYTES];      // [Q | dO] tile images
+    constexpr int D = ATT_D * NCH;
+    __shared__ __attribute__((aligned(16))) char lds[2][NCH * ATT_TILE_BYTES];      // [Q | dO] tile images
     __shared__ float s_lse2[ATT_BN], s_delta[ATT_BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int bh = blockIdx.y, chunk = blockIdx.x;
     const int N = a.N, M = a.M;
-    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * ATT_D;
-    const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * ATT_D;
-    const T* __restrict__ vp = (const T*)a.v + (size_t)bh * M * ATT_D;
-    const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * ATT_D;
-    const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * ATT_D;
+    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * D;
+    const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * D;
+    const T* __restrict__ vp = (const T*)a.v + (size_t)bh * M * D;
+    const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * D;
+    const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * D;
 
     const int key = wave * 32 + (lane & 31);
     const int kld = key < M ? key : M - 1;
-    V8 kf[4], vf[4];
+    V8 kf[4 * NCH], vf[4 * NCH];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        kf[s] = *(const V8*)(kp + (size_t)kld * ATT_D + 16 * s + 8 * h);
-        vf[s] = *(const V8*)(vp + (size_t)kld * ATT_D + 16 * s + 8 * h);
+    for (int s = 0; s < 4 * NCH; ++s) {
+        kf[s] = *(const V8*)(kp + (size_t)kld * D + 16 * s + 8 * h);
+        vf[s] = *(const V8*)(vp + (size_t)kld * D + 16 * s + 8 * h);
     }
-    f32x16 dk[2];
+    f32x16 dk[2 * NCH];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; }
+    for (int j = 0; j < 2 * NCH; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dk[j][i] = 0.f;
 
     const int q_begin = chunk * DK_QCHUNK;
     const int q_end = (q_begin + DK_QCHUNK) < N ? (q_begin + DK_QCHUNK) : N;
     for (int q0 = q_begin; q0 < q_end; q0 += ATT_BN) {
-        u32x4 qr[2], gr[2], orr[2];
-        tile_load<T>(qp, q0, N, tid, qr);
-        tile_load<T>(gp, q0, N, tid, gr);
-        tile_load<T>(op, q0, N, tid, orr);
+        u32x4 qr[NCH][2], gr[NCH][2], orr[NCH][2];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            tile_load<T>(qp + ch * ATT_D, q0, N, tid, qr[ch], D);
+            tile_load<T>(gp + ch * ATT_D, q0, N, tid, gr[ch], D);
+            tile_load<T>(op + ch * ATT_D, q0, N, tid, orr[ch], D);
+        }
         __syncthreads();                                  // the previous tile's reads are done
-        tile_store(lds[0], tid, qr);
-        tile_store(lds[1], tid, gr);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            tile_store(lds[0] + ch * ATT_TILE_BYTES, tid, qr[ch]);
+            tile_store(lds[1] + ch * ATT_TILE_BYTES, tid, gr[ch]);
+        }
         // delta[row] = sum_d dO o O: this thread holds chunk (tid & 7) of rows (tid >> 3) and (tid >> 3) + 32
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const V8 g8 = __builtin_bit_cast(V8, gr[i]), o8 = __builtin_bit_cast(V8, orr[i]);
             float d = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d = __builtin_fmaf(TR::to_f32(g8[j]), TR::to_f32(o8[j]), d);
+            for (int ch = 0; ch < NCH; ++ch) {
+                const V8 g8 = __builtin_bit_cast(V8, gr[ch][i]), o8 = __builtin_bit_cast(V8, orr[ch][i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d = __builtin_fmaf(TR::to_f32(g8[j]), TR::to_f32(o8[j]), d);
+            }
             d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
             if ((tid & 7) == 0) {
                 const int row = (tid >> 3) + 32 * i, qi = q0 + row;
@@ -188,9 +219,13 @@ k_attn_bwd_dk(const BwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s_acc[i] = 0.f; p_acc[i] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(read_row_frag<T>(lds[0], blk, s, lane), kf[s], s_acc);
+            for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) p_acc = TR::mfma32(read_row_frag<T>(lds[1], blk, s, lane), vf[s], p_acc);
+                for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(read_row_frag<T>(lds[0] + ch * ATT_TILE_BYTES, blk, s, lane), kf[4 * ch + s], s_acc);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) p_acc = TR::mfma32(read_row_frag<T>(lds[1] + ch * ATT_TILE_BYTES, blk, s, lane), vf[4 * ch + s], p_acc);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = blk * 32 + acc_key(i, h);                 // query row of accumulator register i
@@ -202,14 +237,17 @@ k_attn_bwd_dk(const BwdArgs a) {
             dsf[2 * blk + 1] = acc_to_frag<T>(s_acc, 1);
         }
 #pragma unroll
-        for (int dblk = 0; dblk < 2; ++dblk)
+        for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dk[dblk] = TR::mfma32(read_tr_frag<T>(lds[0], dblk, ks, lane), dsf[ks], dk[dblk]);
+            for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    dk[2 * ch + dblk] = TR::mfma32(read_tr_frag<T>(lds[0] + ch * ATT_TILE_BYTES, dblk, ks, lane), dsf[ks], dk[2 * ch + dblk]);
     }
     if (key < M) {            // partial dK of this query chunk (plain stores; summed by k_attn_bwd_dk_reduce)
-        float* dst = a.dk_part + (((size_t)bh * gridDim.x + chunk) * M + key) * ATT_D;
+        float* dst = a.dk_part + (((size_t)bh * gridDim.x + chunk) * M + key) * D;
 #pragma unroll
-        for (int dblk = 0; dblk < 2; ++dblk)
+        for (int dblk = 0; dblk < 2 * NCH; ++dblk)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 w;
@@ -246,50 +284,62 @@ struct DkvArgs {
     float c, scale, l2e;
 };
 
-template <typename T>
+template <typename T, int NCH>
 __global__ void __launch_bounds__(256, 1)
 k_attn_bwd_dkv(const DkvArgs a) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
-    __shared__ __attribute__((aligned(16))) char lds[2][ATT_TILE_BYTES];      // [Q | dO] tile images
+    constexpr int D = ATT_D * NCH;
+    __shared__ __attribute__((aligned(16))) char lds[2][NCH * ATT_TILE_BYTES];      // [Q | dO] tile images
     __shared__ float s_lse2[ATT_BN], s_delta[ATT_BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int chunk = blockIdx.x, kblk = blockIdx.y, bh = blockIdx.z;
     const int N = a.N, M = a.M;
-    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * ATT_D;
-    const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * ATT_D;
-    const T* __restrict__ vp = (const T*)a.v + (size_t)bh * M * ATT_D;
-    const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * ATT_D;
-    const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * ATT_D;
+    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * D;
+    const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * D;
+    const T* __restrict__ vp = (const T*)a.v + (size_t)bh * M * D;
+    const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * D;
+    const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * D;
 
     const int key = kblk * 128 + wave * 32 + (lane & 31);
     const int kld = key < M ? key : M - 1;
-    V8 kf[4], vf[4];
+    V8 kf[4 * NCH], vf[4 * NCH];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        kf[s] = *(const V8*)(kp + (size_t)kld * ATT_D + 16 * s + 8 * h);
-        vf[s] = *(const V8*)(vp + (size_t)kld * ATT_D + 16 * s + 8 * h);
+    for (int s = 0; s < 4 * NCH; ++s) {
+        kf[s] = *(const V8*)(kp + (size_t)kld * D + 16 * s + 8 * h);
+        vf[s] = *(const V8*)(vp + (size_t)kld * D + 16 * s + 8 * h);
     }
-    f32x16 dk[2], dv[2];
+    f32x16 dk[2 * NCH], dv[2 * NCH];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+    for (int j = 0; j < 2 * NCH; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[j][i] = 0.f; dv[j][i] = 0.f; }
 
     const int q_begin = chunk * a.qchunk;
     const int q_end = (q_begin + a.qchunk) < N ? (q_begin + a.qchunk) : N;
     for (int q0 = q_begin; q0 < q_end; q0 += ATT_BN) {
-        u32x4 qr[2], gr[2], orr[2];
-        tile_load<T>(qp, q0, N, tid, qr);
-        tile_load<T>(gp, q0, N, tid, gr);
-        tile_load<T>(op, q0, N, tid, orr);
+        u32x4 qr[NCH][2], gr[NCH][2], orr[NCH][2];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            tile_load<T>(qp + ch * ATT_D, q0, N, tid, qr[ch], D);
+            tile_load<T>(gp + ch * ATT_D, q0, N, tid, gr[ch], D);
+            tile_load<T>(op + ch * ATT_D, q0, N, tid, orr[ch], D);
+        }
         __syncthreads();                                  // the previous tile's reads are done
-        tile_store(lds[0], tid, qr);
-        tile_store(lds[1], tid, gr);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            tile_store(lds[0] + ch * ATT_TILE_BYTES, tid, qr[ch]);
+            tile_store(lds[1] + ch * ATT_TILE_BYTES, tid, gr[ch]);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {                     // delta[row] = sum_d dO o O (see k_attn_bwd_dk)
-            const V8 g8 = __builtin_bit_cast(V8, gr[i]), o8 = __builtin_bit_cast(V8, orr[i]);
             float d = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d = __builtin_fmaf(TR::to_f32(g8[j]), TR::to_f32(o8[j]), d);
+            for (int ch = 0; ch < NCH; ++ch) {
+                const V8 g8 = __builtin_bit_cast(V8, gr[ch][i]), o8 = __builtin_bit_cast(V8, orr[ch][i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d = __builtin_fmaf(TR::to_f32(g8[j]), TR::to_f32(o8[j]), d);
+            }
             d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
             if ((tid & 7) == 0) {
                 const int row = (tid >> 3) + 32 * i, qi = q0 + row;
@@ -305,9 +355,13 @@ k_attn_bwd_dkv(const DkvArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s_acc[i] = 0.f; p_acc[i] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(read_row_frag<T>(lds[0], blk, s, lane), kf[s], s_acc);
+            for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) p_acc = TR::mfma32(read_row_frag<T>(lds[1], blk, s, lane), vf[s], p_acc);
+                for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(read_row_frag<T>(lds[0] + ch * ATT_TILE_BYTES, blk, s, lane), kf[4 * ch + s], s_acc);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) p_acc = TR::mfma32(read_row_frag<T>(lds[1] + ch * ATT_TILE_BYTES, blk, s, lane), vf[4 * ch + s], p_acc);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = blk * 32 + acc_key(i, h);                 // query row of accumulator register i
@@ -322,17 +376,19 @@ k_attn_bwd_dkv(const DkvArgs a) {
             dsf[2 * blk + 1] = acc_to_frag<T>(p_acc, 1);
         }
 #pragma unroll
-        for (int dblk = 0; dblk < 2; ++dblk)
+        for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                dk[dblk] = TR::mfma32(read_tr_frag<T>(lds[0], dblk, ks, lane), dsf[ks], dk[dblk]);
-                dv[dblk] = TR::mfma32(read_tr_frag<T>(lds[1], dblk, ks, lane), pf[ks], dv[dblk]);
-            }
+            for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    dk[2 * ch + dblk] = TR::mfma32(read_tr_frag<T>(lds[0] + ch * ATT_TILE_BYTES, dblk, ks, lane), dsf[ks], dk[2 * ch + dblk]);
+                    dv[2 * ch + dblk] = TR::mfma32(read_tr_frag<T>(lds[1] + ch * ATT_TILE_BYTES, dblk, ks, lane), pf[ks], dv[2 * ch + dblk]);
+                }
     }
     if (key < M) {            // partials of this query chunk (plain stores; summed by k_attn_bwd_dk_reduce)
-        const size_t off = (((size_t)bh * a.nchunks + chunk) * M + key) * ATT_D;
+        const size_t off = (((size_t)bh * a.nchunks + chunk) * M + key) * D;
 #pragma unroll
-        for (int dblk = 0; dblk < 2; ++dblk)
+        for (int dblk = 0; dblk < 2 * NCH; ++dblk)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 wk, wv;
@@ -343,6 +399,22 @@ k_attn_bwd_dkv(const DkvArgs a) {
             }
     }
 }
+
+// launch K<f16_t / bf16_t, D / 64>
+#define GD_LAUNCH_NCH(K, GRID, ARGS)                                                                   \
+    do {                                                                                               \
+        const int nch_ = D / ATT_D;                                                                    \
+        if (dtype == GD_F16) {                                                                         \
+            if (nch_ == 1) K<f16_t, 1><<<GRID, 256, 0, st>>>(ARGS);                                    \
+            else if (nch_ == 2) K<f16_t, 2><<<GRID, 256, 0, st>>>(ARGS);                               \
+            else K<f16_t, 3><<<GRID, 256, 0, st>>>(ARGS);                                              \
+        } else {                                                                                       \
+            if (nch_ == 1) K<bf16_t, 1><<<GRID, 256, 0, st>>>(ARGS);                                   \
+            else if (nch_ == 2) K<bf16_t, 2><<<GRID, 256, 0, st>>>(ARGS);                              \
+            else K<bf16_t, 3><<<GRID, 256, 0, st>>>(ARGS);                                             \
+        }                                                                                              \
+    } while (0)
+#define GD_HEAD_DIM_OK(D) ((D) == 64 || (D) == 128 || (D) == 192)
 
 static int dkv_qchunk(int N, int M) { return M >= 1024 ? N : DK_QCHUNK; }
 
@@ -356,7 +428,7 @@ extern "C" int gd_attn_bwd_dkv(const void* q, const void* k, const void* v, cons
                                int BH, int N, int M, int D, float scale, float* dk_f32, float* dv_f32,
                                void* workspace, size_t workspace_bytes, int dtype, void* stream) {
     GD_REQUIRE(q && k && v && out && lse && dout && dk_f32 && dv_f32, GD_EINVAL, "gd_attn_bwd_dkv: null pointer");
-    GD_REQUIRE(D == ATT_D, GD_EUNSUPPORTED, "gd_attn_bwd_dkv: head dim %d unsupported (only 64)", D);
+    GD_REQUIRE(GD_HEAD_DIM_OK(D), GD_EUNSUPPORTED, "gd_attn_bwd_dkv: head dim %d unsupported (64, 128, 192)", D);
     GD_REQUIRE(BH > 0 && N > 0 && M > 0, GD_EINVAL, "gd_attn_bwd_dkv: bad sizes");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_bwd_dkv: dtype must be f16/bf16");
     GD_REQUIRE(workspace && workspace_bytes >= gd_attn_bwd_dkv_workspace_bytes(BH, N, M, D), GD_EWORKSPACE,
@@ -367,17 +439,16 @@ extern "C" int gd_attn_bwd_dkv(const void* q, const void* k, const void* v, cons
     a.qchunk = dkv_qchunk(N, M);
     a.nchunks = (N + a.qchunk - 1) / a.qchunk;
     a.dk_part = (float*)workspace;
-    a.dv_part = a.dk_part + (size_t)BH * a.nchunks * M * ATT_D;
+    a.dv_part = a.dk_part + (size_t)BH * a.nchunks * M * D;
     a.scale = scale;
     a.c = scale * 1.4426950408889634f;
     a.l2e = 1.4426950408889634f;
     hipStream_t st = as_stream(stream);
     dim3 grid(a.nchunks, (M + 127) / 128, BH);
-    if (dtype == GD_F16) k_attn_bwd_dkv<f16_t><<<grid, 256, 0, st>>>(a);
-    else k_attn_bwd_dkv<bf16_t><<<grid, 256, 0, st>>>(a);
-    dim3 rgrid((M * ATT_D + 255) / 256, BH);
-    k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>(a.dk_part, a.nchunks, M * ATT_D, dk_f32);
-    k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>(a.dv_part, a.nchunks, M * ATT_D, dv_f32);
+    GD_LAUNCH_NCH(k_attn_bwd_dkv, grid, a);
+    dim3 rgrid((M * D + 255) / 256, BH);
+    k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>(a.dk_part, a.nchunks, M * D, dk_f32);
+    k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>(a.dv_part, a.nchunks, M * D, dv_f32);
     GD_CHECK_LAUNCH("gd_attn_bwd_dkv");
     return GD_OK;
 }
@@ -392,7 +463,7 @@ extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const vo
                            const void* dout, int BH, int N, int M, int D, float scale,
                            void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
     GD_REQUIRE(q && k && v && out && lse && dout && dq, GD_EINVAL, "gd_attn_bwd: null pointer");
-    GD_REQUIRE(D == ATT_D, GD_EUNSUPPORTED, "gd_attn_bwd: head dim %d unsupported (only 64)", D);
+    GD_REQUIRE(GD_HEAD_DIM_OK(D), GD_EUNSUPPORTED, "gd_attn_bwd: head dim %d unsupported (64, 128, 192)", D);
     GD_REQUIRE(BH > 0 && N > 0 && M > 0, GD_EINVAL, "gd_attn_bwd: bad sizes");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_bwd: dtype must be f16/bf16");
     GD_REQUIRE(!dk_f32 || M <= 128, GD_EUNSUPPORTED, "gd_attn_bwd: dK is only implemented for M <= 128 keys (cross-attention); M=%d", M);
@@ -407,14 +478,12 @@ extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const vo
     a.c = scale * 1.4426950408889634f;
     a.l2e = 1.4426950408889634f;
     hipStream_t st = as_stream(stream);
-    if (dtype == GD_F16) k_attn_bwd_dq<f16_t><<<a.nwg, 256, 0, st>>>(a);
-    else k_attn_bwd_dq<bf16_t><<<a.nwg, 256, 0, st>>>(a);
+    GD_LAUNCH_NCH(k_attn_bwd_dq, a.nwg, a);
     if (dk_f32) {
         dim3 grid((N + DK_QCHUNK - 1) / DK_QCHUNK, BH);
-        if (dtype == GD_F16) k_attn_bwd_dk<f16_t><<<grid, 256, 0, st>>>(a);
-        else k_attn_bwd_dk<bf16_t><<<grid, 256, 0, st>>>(a);
-        dim3 rgrid((M * ATT_D + 255) / 256, BH);
-        k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>((const float*)workspace, (int)grid.x, M * ATT_D, dk_f32);
+        GD_LAUNCH_NCH(k_attn_bwd_dk, grid, a);
+        dim3 rgrid((M * D + 255) / 256, BH);
+        k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>((const float*)workspace, (int)grid.x, M * D, dk_f32);
     }
     GD_CHECK_LAUNCH("gd_attn_bwd");
     return GD_OK;

@@ -22,8 +22,8 @@
 // only 16 score + 8 probability registers live, which fits 4 waves per SIMD (<= 128 VGPRs): on this kernel latency
 // hiding by occupancy is worth more than the few extra max/rescale checks.
 // softmax of one 32-key half step: probabilities of s_acc against the row's reference value -> two 16-bit B fragments, l_run updated
-template <typename T>
-__device__ __forceinline__ void softmax_half(const f32x16& s_acc, f32x16 (&o)[2], float& m_run, float& l_run, float c,
+template <typename T, int NO>
+__device__ __forceinline__ void softmax_half(const f32x16& s_acc, f32x16 (&o)[NO], float& m_run, float& l_run, float c,
                                              typename elem_traits<T>::vec8& pf0, typename elem_traits<T>::vec8& pf1) {
     using TR = elem_traits<T>;
     // Probabilities against the CURRENT reference maximum, no per-step row maximum: p = exp2(c*s - c*m_run).  A row maximum is
@@ -59,7 +59,9 @@ __device__ __forceinline__ void softmax_half(const f32x16& s_acc, f32x16 (&o)[2]
         l_run *= alpha;
         m_run = m_new;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int j = 0; j < NO; ++j) o[j][i] *= alpha;
         mc = m_run * c;
         ps = 0.f;
 #pragma unroll
@@ -76,18 +78,23 @@ __device__ __forceinline__ void softmax_half(const f32x16& s_acc, f32x16 (&o)[2]
 // one 64-key tile as two 32-key half steps (S^T = K Q^T, online softmax, O^T += V^T P^T), software-pipelined inside the tile: both
 // score GEMMs are issued up front and the first half's P.V before the second half's softmax, so that within ONE wave the matrix
 // pipe has independent work (QK^T of half 1, PV of half 0) while the vector pipe runs the exponentials of the other half.
-template <typename T, bool MASKED>
-__device__ __forceinline__ void fwd_tile(const char* lk, const char* lv, const FragOffs& fo, const typename elem_traits<T>::vec8 (&qf)[4],
-                                         f32x16 (&o)[2], float& m_run, float& l_run, float c, int kv0, int M, int h) {
+// NCH = head dim / 64: the K / V tiles are NCH consecutive 64-column images, qf / o carry NCH x 4 fragments / NCH x 2 accumulators.
+template <typename T, bool MASKED, int NCH>
+__device__ __forceinline__ void fwd_tile(const char* lk, const char* lv, const FragOffs& fo, const typename elem_traits<T>::vec8 (&qf)[4 * NCH],
+                                         f32x16 (&o)[2 * NCH], float& m_run, float& l_run, float c, int kv0, int M, int h) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
     f32x16 s0, s1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) s0 = TR::mfma32(rd_row<T>(lk, fo, 0, s), qf[s], s0);
+    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) s1 = TR::mfma32(rd_row<T>(lk, fo, 1, s), qf[s], s1);
+        for (int s = 0; s < 4; ++s) s0 = TR::mfma32(rd_row<T>(lk + ch * ATT_TILE_BYTES, fo, 0, s), qf[4 * ch + s], s0);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) s1 = TR::mfma32(rd_row<T>(lk + ch * ATT_TILE_BYTES, fo, 1, s), qf[4 * ch + s], s1);
     if (MASKED) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -96,26 +103,32 @@ __device__ __forceinline__ void fwd_tile(const char* lk, const char* lv, const F
         }
     }
     V8 pa0, pa1, pb0, pb1;
-    softmax_half<T>(s0, o, m_run, l_run, c, pa0, pa1);
+    softmax_half<T, 2 * NCH>(s0, o, m_run, l_run, c, pa0, pa1);
 #pragma unroll
-    for (int dblk = 0; dblk < 2; ++dblk) {
-        o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 0), pa0, o[dblk]);
-        o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 1), pa1, o[dblk]);
-    }
-    softmax_half<T>(s1, o, m_run, l_run, c, pb0, pb1);
+    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-    for (int dblk = 0; dblk < 2; ++dblk) {
-        o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 2), pb0, o[dblk]);
-        o[dblk] = TR::mfma32(rd_tr<T>(lv, fo, dblk, 3), pb1, o[dblk]);
-    }
+        for (int dblk = 0; dblk < 2; ++dblk) {
+            o[2 * ch + dblk] = TR::mfma32(rd_tr<T>(lv + ch * ATT_TILE_BYTES, fo, dblk, 0), pa0, o[2 * ch + dblk]);
+            o[2 * ch + dblk] = TR::mfma32(rd_tr<T>(lv + ch * ATT_TILE_BYTES, fo, dblk, 1), pa1, o[2 * ch + dblk]);
+        }
+    softmax_half<T, 2 * NCH>(s1, o, m_run, l_run, c, pb0, pb1);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk) {
+            o[2 * ch + dblk] = TR::mfma32(rd_tr<T>(lv + ch * ATT_TILE_BYTES, fo, dblk, 2), pb0, o[2 * ch + dblk]);
+            o[2 * ch + dblk] = TR::mfma32(rd_tr<T>(lv + ch * ATT_TILE_BYTES, fo, dblk, 3), pb1, o[2 * ch + dblk]);
+        }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256, 2)
+// NCH = head dim / 64 (1: the SD2.1 / SDXL head; 2, 3: the zero-padded 80- and 160-wide SD1.x heads, one workgroup per CU)
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256, NCH == 1 ? 2 : 1)
 k_attn_fwd(const FwdArgs a) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
-    __shared__ __attribute__((aligned(16))) char lds[2][2][ATT_TILE_BYTES];   // [buf][K|V]
+    constexpr int D = ATT_D * NCH;
+    __shared__ __attribute__((aligned(16))) char lds[2][2][NCH * ATT_TILE_BYTES];   // [buf][K|V][64-column chunk]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int wg0 = xcd_remap(blockIdx.x, a.nwg);
@@ -129,16 +142,16 @@ k_attn_fwd(const FwdArgs a) {
     const int bh = gbh - (sidx ? a.bh_end[sidx - 1] : 0);
     const gd_attn_seg_t sg = a.seg[sidx];
     const int N = a.N, M = a.M;
-    // row stride / base offsets: head-major [bh, N, 64] or token-major [B, N, heads*64]
-    const int rs = sg.heads > 0 ? sg.heads * ATT_D : ATT_D;
+    // row stride / base offsets: head-major [bh, N, D] or token-major [B, N, heads*D]
+    const int rs = sg.heads > 0 ? sg.heads * D : D;
     size_t qoff, koff;
     if (sg.heads > 0) {
         const int b = bh / sg.heads, hh = bh - b * sg.heads;
-        qoff = (size_t)b * N * rs + (size_t)hh * ATT_D;
-        koff = (size_t)b * M * rs + (size_t)hh * ATT_D;
+        qoff = (size_t)b * N * rs + (size_t)hh * D;
+        koff = (size_t)b * M * rs + (size_t)hh * D;
     } else {
-        qoff = (size_t)bh * N * ATT_D;
-        koff = (size_t)bh * M * ATT_D;
+        qoff = (size_t)bh * N * D;
+        koff = (size_t)bh * M * D;
     }
     const T* __restrict__ qp = (const T*)sg.q + qoff;
     const T* __restrict__ kp = (const T*)sg.k + koff;
@@ -147,24 +160,35 @@ k_attn_fwd(const FwdArgs a) {
     // this lane's query (B operand column); lanes l and l^32 share the query, split d / keys
     const int qrow = tile * ATT_BM + wave * 32 + (lane & 31);
     const int qld = qrow < N ? qrow : N - 1;
-    V8 qf[4];
-    load_q_frags<T>(sg, qp, rs, qld, h, qf);
+    V8 qf[4 * NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        V8 f4[4];
+        load_q_frags<T>(sg, qp + ch * ATT_D, rs, qld, h, f4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[4 * ch + s] = f4[s];
+    }
     const FragOffs fo = make_frag_offs(lane);
 
-    f32x16 o[2];
+    f32x16 o[2 * NCH];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    for (int j = 0; j < 2 * NCH; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[j][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
     const int T_all = (M + ATT_BN - 1) / ATT_BN;
     const int t0 = sp * a.tps;                          // this split's key tiles [t0, T_tiles)
     const int T_tiles = (t0 + a.tps) < T_all ? (t0 + a.tps) : T_all;
     const int T_full = (M / ATT_BN) < T_tiles ? (M / ATT_BN) : T_tiles;     // tiles without a key tail
-    u32x4 kr[2], vr[2];
-    tile_load<T>(kp, t0 * ATT_BN, M, tid, kr, rs);
-    tile_load<T>(vp, t0 * ATT_BN, M, tid, vr, rs);
-    tile_store(lds[0][0], tid, kr);
-    tile_store(lds[0][1], tid, vr);
+    u32x4 kr[NCH][2], vr[NCH][2];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        tile_load<T>(kp + ch * ATT_D, t0 * ATT_BN, M, tid, kr[ch], rs);
+        tile_load<T>(vp + ch * ATT_D, t0 * ATT_BN, M, tid, vr[ch], rs);
+        tile_store(lds[0][0] + ch * ATT_TILE_BYTES, tid, kr[ch]);
+        tile_store(lds[0][1] + ch * ATT_TILE_BYTES, tid, vr[ch]);
+    }
     __syncthreads();
     // this thread's chunk of the NEXT tile (rows tid/8 and tid/8 + 32 of tile t0 + 1); advanced by one tile per iteration
     const T* kq = kp + (size_t)((t0 + 1) * ATT_BN + (tid >> 3)) * rs + (tid & 7) * 8;
@@ -175,25 +199,34 @@ k_attn_fwd(const FwdArgs a) {
         const int cur = (t - t0) & 1;
         const bool more = (t + 1) < T_tiles;
         if (t + 1 < T_full) {                      // next tile is full: no clamping
-            kr[0] = *(const u32x4*)kq; kr[1] = *(const u32x4*)(kq + (size_t)32 * rs);
-            vr[0] = *(const u32x4*)vq; vr[1] = *(const u32x4*)(vq + (size_t)32 * rs);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                kr[ch][0] = *(const u32x4*)(kq + ch * ATT_D); kr[ch][1] = *(const u32x4*)(kq + ch * ATT_D + (size_t)32 * rs);
+                vr[ch][0] = *(const u32x4*)(vq + ch * ATT_D); vr[ch][1] = *(const u32x4*)(vq + ch * ATT_D + (size_t)32 * rs);
+            }
             kq += (size_t)ATT_BN * rs; vq += (size_t)ATT_BN * rs;
         } else if (more) {
-            tile_load<T>(kp, (t + 1) * ATT_BN, M, tid, kr, rs);
-            tile_load<T>(vp, (t + 1) * ATT_BN, M, tid, vr, rs);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                tile_load<T>(kp + ch * ATT_D, (t + 1) * ATT_BN, M, tid, kr[ch], rs);
+                tile_load<T>(vp + ch * ATT_D, (t + 1) * ATT_BN, M, tid, vr[ch], rs);
+            }
         }
-        fwd_tile<T, false>(lds[cur][0], lds[cur][1], fo, qf, o, m_run, l_run, a.c, t * ATT_BN, M, h);
+        fwd_tile<T, false, NCH>(lds[cur][0], lds[cur][1], fo, qf, o, m_run, l_run, a.c, t * ATT_BN, M, h);
         if (more) {
-            tile_store(lds[cur ^ 1][0], tid, kr);
-            tile_store(lds[cur ^ 1][1], tid, vr);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                tile_store(lds[cur ^ 1][0] + ch * ATT_TILE_BYTES, tid, kr[ch]);
+                tile_store(lds[cur ^ 1][1] + ch * ATT_TILE_BYTES, tid, vr[ch]);
+            }
         }
         __syncthreads();
     }
     if (T_full < T_tiles)        // key tail (M % 64 != 0): one masked tile, always the last tile of the last split
-        fwd_tile<T, true>(lds[(T_full - t0) & 1][0], lds[(T_full - t0) & 1][1], fo, qf, o, m_run, l_run, a.c, T_full * ATT_BN, M, h);
+        fwd_tile<T, true, NCH>(lds[(T_full - t0) & 1][0], lds[(T_full - t0) & 1][1], fo, qf, o, m_run, l_run, a.c, T_full * ATT_BN, M, h);
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    if (a.nsplit > 1) {                                  // partial result of this split, merged by k_attn_combine
+    if (NCH == 1 && a.nsplit > 1) {                      // partial result of this split, merged by k_attn_combine
         if (qrow < N) {
             const size_t r = ((size_t)sp * a.tot_bh + gbh) * N + qrow;
             float* wo = a.ws_o + r * ATT_D;
@@ -214,7 +247,7 @@ k_attn_fwd(const FwdArgs a) {
     if (qrow < N) {
         T* __restrict__ op = (T*)sg.out + qoff + (size_t)qrow * rs;
 #pragma unroll
-        for (int dblk = 0; dblk < 2; ++dblk)
+        for (int dblk = 0; dblk < 2 * NCH; ++dblk)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 typename TR::vec4 w;
@@ -346,7 +379,9 @@ extern "C" int gd_attn_fwd_splitkv(const gd_attn_seg_t* segs, int nseg, int N, i
 static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
                            size_t workspace_bytes, int dtype, void* stream) {
     GD_REQUIRE(segs && nseg >= 1 && nseg <= GD_ATTN_MAX_SEGS, GD_EINVAL, "gd_attn_fwd: nseg=%d (1..%d)", nseg, GD_ATTN_MAX_SEGS);
-    GD_REQUIRE(D == ATT_D, GD_EUNSUPPORTED, "gd_attn_fwd: head dim %d unsupported (only 64)", D);
+    GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED,
+               "gd_attn_fwd: head dim %d unsupported (64, 128, 192; zero-pad 40 / 80 / 160 and pass the true scale)", D);
+    GD_REQUIRE(D == ATT_D || nsplit == 1, GD_EUNSUPPORTED, "gd_attn_fwd_splitkv: head dim %d unsupported (only 64)", D);
     GD_REQUIRE(N > 0 && M > 0, GD_EINVAL, "gd_attn_fwd: bad sizes N=%d M=%d", N, M);
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_fwd: dtype must be f16/bf16");
     FwdArgs a;
@@ -381,14 +416,20 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
         a.ws_ml = a.ws_o + (size_t)nsplit * tot * N * ATT_D;
     }
     hipStream_t st = as_stream(stream);
-    if (nsplit == 1) {
+    if (nsplit == 1 && D == ATT_D) {
         int qb = 0, ks = 0;
         mp_config(tot, N, M, &qb, &ks);
         if (qb > 0) return gd_attn_fwd_mp_launch(a, qb, ks, dtype, st);       // software-pipelined kernels (attn_fwd_mp.hip)
     }
     a.nwg = a.tiles * tot * nsplit;
-    if (dtype == GD_F16) k_attn_fwd<f16_t><<<a.nwg, 256, 0, st>>>(a);
-    else k_attn_fwd<bf16_t><<<a.nwg, 256, 0, st>>>(a);
+    if (D == 128) {
+        if (dtype == GD_F16) k_attn_fwd<f16_t, 2><<<a.nwg, 256, 0, st>>>(a);
+        else k_attn_fwd<bf16_t, 2><<<a.nwg, 256, 0, st>>>(a);
+    } else if (D == 192) {
+        if (dtype == GD_F16) k_attn_fwd<f16_t, 3><<<a.nwg, 256, 0, st>>>(a);
+        else k_attn_fwd<bf16_t, 3><<<a.nwg, 256, 0, st>>>(a);
+    } else if (dtype == GD_F16) k_attn_fwd<f16_t, 1><<<a.nwg, 256, 0, st>>>(a);
+    else k_attn_fwd<bf16_t, 1><<<a.nwg, 256, 0, st>>>(a);
     if (nsplit > 1) {
         const long long total = (long long)tot * N * (ATT_D / 4);
         const int blocks = (int)((total + 255) / 256);
@@ -411,39 +452,46 @@ struct ProbsArgs {
     float l2e;
 };
 
-template <typename T>
+template <typename T, int NCH>
 __global__ void __launch_bounds__(256, 2)
 k_attn_probs(const ProbsArgs a) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
-    __shared__ __attribute__((aligned(16))) char ldsk[2][ATT_TILE_BYTES];
+    constexpr int D = ATT_D * NCH;
+    __shared__ __attribute__((aligned(16))) char ldsk[2][NCH * ATT_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) T stage[4][32][ATT_BN + 8];     // per-wave P tile, padded rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int wg = xcd_remap(blockIdx.x, a.nwg);
     const int bh = wg / a.tiles, tile = wg - bh * a.tiles;
     const int N = a.N, M = a.M, R = a.R;
-    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * ATT_D;
-    const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * ATT_D;
+    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * D;
+    const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * D;
     T* __restrict__ Pp = (T*)a.P + (size_t)bh * R * a.Mpad;
 
     const int r_out = tile * ATT_BM + wave * 32 + (lane & 31);
     const int r_c = r_out < R ? r_out : R - 1;
     const int qrow = a.rows ? a.rows[r_c] : r_c;
-    V8 qf[4];
+    V8 qf[4 * NCH];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const V8*)(qp + (size_t)qrow * ATT_D + 16 * s + 8 * h);
+    for (int s = 0; s < 4 * NCH; ++s) qf[s] = *(const V8*)(qp + (size_t)qrow * D + 16 * s + 8 * h);
     const float lse2 = a.lse[(size_t)bh * N + qrow] * a.l2e;
 
     const int T_tiles = (a.Mpad + ATT_BN - 1) / ATT_BN;
-    u32x4 kr[2];
-    tile_load<T>(kp, 0, M, tid, kr);
-    tile_store(ldsk[0], tid, kr);
+    u32x4 kr[NCH][2];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        tile_load<T>(kp + ch * ATT_D, 0, M, tid, kr[ch], D);
+        tile_store(ldsk[0] + ch * ATT_TILE_BYTES, tid, kr[ch]);
+    }
     __syncthreads();
     for (int t = 0; t < T_tiles; ++t) {
         const int cur = t & 1;
         const bool more = (t + 1) < T_tiles;
-        if (more) tile_load<T>(kp, (t + 1) * ATT_BN, M, tid, kr);
+        if (more) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) tile_load<T>(kp + ch * ATT_D, (t + 1) * ATT_BN, M, tid, kr[ch], D);
+        }
         const int kv0 = t * ATT_BN;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
@@ -451,7 +499,10 @@ k_attn_probs(const ProbsArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) s_acc[i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) s_acc = TR::mfma32(read_row_frag<T>(ldsk[cur], blk, s, lane), qf[s], s_acc);
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    s_acc = TR::mfma32(read_row_frag<T>(ldsk[cur] + ch * ATT_TILE_BYTES, blk, s, lane), qf[4 * ch + s], s_acc);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 typename TR::vec4 w;
@@ -473,7 +524,10 @@ k_attn_probs(const ProbsArgs a) {
             if (rg < R && kv0 + cc < a.Mpad)
                 *(u32x4*)(Pp + (size_t)rg * a.Mpad + kv0 + cc) = *(const u32x4*)(&stage[wave][rr][cc]);
         }
-        if (more) tile_store(ldsk[cur ^ 1], tid, kr);
+        if (more) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) tile_store(ldsk[cur ^ 1] + ch * ATT_TILE_BYTES, tid, kr[ch]);
+        }
         __syncthreads();
     }
 }
@@ -481,7 +535,7 @@ k_attn_probs(const ProbsArgs a) {
 extern "C" int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t* rows,
                              int BH, int N, int R, int M, int Mpad, int D, float scale, void* P, int dtype, void* stream) {
     GD_REQUIRE(q && k && lse && P, GD_EINVAL, "gd_attn_probs: null pointer");
-    GD_REQUIRE(D == ATT_D, GD_EUNSUPPORTED, "gd_attn_probs: head dim %d unsupported (only 64)", D);
+    GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED, "gd_attn_probs: head dim %d unsupported (64, 128, 192)", D);
     GD_REQUIRE(BH > 0 && N > 0 && R > 0 && M > 0 && Mpad >= M && (Mpad & 7) == 0, GD_EINVAL,
                "gd_attn_probs: bad sizes (Mpad must be a multiple of 8 and >= M)");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_probs: dtype must be f16/bf16");
@@ -492,8 +546,13 @@ extern "C" int gd_attn_probs(const void* q, const void* k, const float* lse, con
     a.nwg = a.tiles * BH;
     a.c = scale * 1.4426950408889634f;
     a.l2e = 1.4426950408889634f;
-    if (dtype == GD_F16) k_attn_probs<f16_t><<<a.nwg, 256, 0, as_stream(stream)>>>(a);
-    else k_attn_probs<bf16_t><<<a.nwg, 256, 0, as_stream(stream)>>>(a);
+    hipStream_t st = as_stream(stream);
+    const int nch = D / ATT_D;
+#define GD_PROBS(NCH)                                                            \
+    if (dtype == GD_F16) k_attn_probs<f16_t, NCH><<<a.nwg, 256, 0, st>>>(a);     \
+    else k_attn_probs<bf16_t, NCH><<<a.nwg, 256, 0, st>>>(a)
+    if (nch == 1) { GD_PROBS(1); } else if (nch == 2) { GD_PROBS(2); } else { GD_PROBS(3); }
+#undef GD_PROBS
     GD_CHECK_LAUNCH("gd_attn_probs");
     return GD_OK;
 }

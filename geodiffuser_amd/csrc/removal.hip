@@ -200,7 +200,7 @@ struct RmBwdArgs {
     const void* Pe; const void* Pb; const void* q; const void* k; const int32_t* rows;
     const float* p_in; const int32_t* j_in; const float* p_wo; const int32_t* j_wo; const float* wgt;
     const float* m_inp; const float* m_wo; float coef; const float* gscale;
-    int H, R, N, M, Mpad; float scale; float* dq; float* dk; float* ds_ws; const float* rowdot; float* dq_part;
+    int H, R, N, M, Mpad, D; float scale; float* dq; float* dk; float* ds_ws; const float* rowdot; float* dq_part;
 };
 
 // rowdot[h, r] = sum_m A[h,r,m] * dA[h,r,m]   (one wave per inpaint row; feeds the softmax backward below)
@@ -236,13 +236,15 @@ k_removal_bwd(const RmBwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int blocks_per_head = (a.R + RM_RB - 1) / RM_RB;
     const int msplit = (a.M + RM_MCH - 1) / RM_MCH;
-    int wb = blockIdx.x * 4 + (threadIdx.x >> 6);                 // one wave per (head, block of RM_RB inpaint rows, key chunk)
-    if (wb >= a.H * blocks_per_head * msplit) return;
+    const int nch = a.D / ATT_D;                                  // 64-wide slices of the head dim (1 for SD2.1)
+    int wb = blockIdx.x * 4 + (threadIdx.x >> 6);                 // one wave per (head, block of RM_RB inpaint rows, key chunk, d slice)
+    if (wb >= a.H * blocks_per_head * msplit * nch) return;
+    const int dch = wb % nch; wb /= nch;
     const int mc = wb % msplit; wb /= msplit;
     const int m_lo = mc * RM_MCH, m_hi = (m_lo + RM_MCH) < a.M ? (m_lo + RM_MCH) : a.M;
     const int hd = wb / blocks_per_head, r0 = (wb - hd * blocks_per_head) * RM_RB;
     const float cf = a.gscale ? a.coef * a.gscale[0] : a.coef;
-    const T* __restrict__ kp = (const T*)a.k + (size_t)hd * a.M * ATT_D;
+    const T* __restrict__ kp = (const T*)a.k + (size_t)hd * a.M * a.D + dch * ATT_D;
     const T* pe[RM_RB]; const T* pbw[RM_RB]; const T* pbi[RM_RB];
     float cw[RM_RB], ci[RM_RB], dot[RM_RB], acc[RM_RB];
     int qrow[RM_RB];
@@ -271,7 +273,7 @@ k_removal_bwd(const RmBwdArgs a) {
                 const float A = TR::to_f32(pe[i][m]);
                 ds[i] = A * (cw[i] * TR::to_f32(pbw[i][m]) + ci[i] * TR::to_f32(pbi[i][m]) - dot[i]) * a.scale;
             }
-            if (a.ds_ws && (r0 + i) < a.R && m < m_hi) a.ds_ws[((size_t)hd * a.R + r0 + i) * a.Mpad + m] = ds[i];
+            if (a.ds_ws && dch == 0 && (r0 + i) < a.R && m < m_hi) a.ds_ws[((size_t)hd * a.R + r0 + i) * a.Mpad + m] = ds[i];
         }
         // 16 key rows of K in flight at a time (a load-use chain per key made this loop latency-bound); keys past the chunk
         // end have dS = 0, their (clamped) K rows contribute nothing
@@ -282,7 +284,7 @@ k_removal_bwd(const RmBwdArgs a) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int mk = (m0 + mb + u) < a.M ? (m0 + mb + u) : (a.M - 1);
-                kv[u] = TR::to_f32(kp[(size_t)mk * ATT_D + lane]);
+                kv[u] = TR::to_f32(kp[(size_t)mk * a.D + lane]);
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u)
@@ -294,33 +296,33 @@ k_removal_bwd(const RmBwdArgs a) {
     // per-(key chunk) partial of dq; the chunks of a row are summed in index order by k_removal_dq_fold (no f32 atomics: bit-reproducible)
 #pragma unroll
     for (int i = 0; i < RM_RB; ++i)
-        if ((r0 + i) < a.R) a.dq_part[(((size_t)mc * a.H + hd) * a.R + r0 + i) * ATT_D + lane] = acc[i];
+        if ((r0 + i) < a.R) a.dq_part[(((size_t)mc * a.H + hd) * a.R + r0 + i) * a.D + dch * ATT_D + lane] = acc[i];
 }
 
 // dq[h, rows[r], :] += sum_c dq_part[c, h, r, :]  (c ascending).  Padding slots of the row list (weight 0, contribution exactly 0) are
 // skipped, so every live row has exactly one writer.
 __global__ void k_removal_dq_fold(const float* __restrict__ dq_part, const int32_t* __restrict__ rows, const float* __restrict__ wgt,
-                                  int msplit, int H, int R, int N, float* __restrict__ dq) {
+                                  int msplit, int H, int R, int N, int D, float* __restrict__ dq) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= H * R * ATT_D) return;
-    const int d = gid % ATT_D, hr = gid / ATT_D;
+    if (gid >= H * R * D) return;
+    const int d = gid % D, hr = gid / D;
     if (wgt[hr] == 0.f) return;
     const int hd = hr / R, r = hr - hd * R;
     float s = 0.f;
-    for (int c = 0; c < msplit; ++c) s += dq_part[((size_t)c * H * R + hr) * ATT_D + d];
-    dq[((size_t)hd * N + rows[r]) * ATT_D + d] += s;
+    for (int c = 0; c < msplit; ++c) s += dq_part[((size_t)c * H * R + hr) * D + d];
+    dq[((size_t)hd * N + rows[r]) * D + d] += s;
 }
 
 // dk[h, m, d] += sum_r dS[h, r, m] * q[h, rows[r], d]   (cross-attention: few keys; one thread per (m, d) of a head)
 template <typename T>
 __global__ void k_removal_dk(const float* __restrict__ ds_ws, const T* __restrict__ q, const int32_t* __restrict__ rows,
-                             int R, int N, int M, int Mpad, float* __restrict__ dk) {
+                             int R, int N, int M, int Mpad, int D, float* __restrict__ dk) {
     const int hd = blockIdx.y;
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= M * ATT_D) return;
-    const int m = o / ATT_D, d = o - m * ATT_D;
+    if (o >= M * D) return;
+    const int m = o / D, d = o - m * D;
     const float* dsh = ds_ws + (size_t)hd * R * Mpad + m;
-    const T* qh = q + (size_t)hd * N * ATT_D + d;
+    const T* qh = q + (size_t)hd * N * D + d;
     float acc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc[u] = 0.f;
@@ -328,15 +330,15 @@ __global__ void k_removal_dk(const float* __restrict__ ds_ws, const T* __restric
     for (; r + 8 <= R; r += 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            acc[u] = __builtin_fmaf(dsh[(size_t)(r + u) * Mpad], elem_traits<T>::to_f32(qh[(size_t)rows[r + u] * ATT_D]), acc[u]);
+            acc[u] = __builtin_fmaf(dsh[(size_t)(r + u) * Mpad], elem_traits<T>::to_f32(qh[(size_t)rows[r + u] * D]), acc[u]);
     }
-    for (; r < R; ++r) acc[0] = __builtin_fmaf(dsh[(size_t)r * Mpad], elem_traits<T>::to_f32(qh[(size_t)rows[r] * ATT_D]), acc[0]);
-    dk[((size_t)hd * M + m) * ATT_D + d] += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    for (; r < R; ++r) acc[0] = __builtin_fmaf(dsh[(size_t)r * Mpad], elem_traits<T>::to_f32(qh[(size_t)rows[r] * D]), acc[0]);
+    dk[((size_t)hd * M + m) * D + d] += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
-extern "C" size_t gd_removal_bwd_workspace_bytes(int H, int R, int M, int Mpad, int need_dk) {
+extern "C" size_t gd_removal_bwd_workspace_bytes(int H, int R, int M, int Mpad, int D, int need_dk) {
     const size_t msplit = (size_t)(M + RM_MCH - 1) / RM_MCH;
-    return ((size_t)H * R * (1 + msplit * ATT_D + (need_dk ? (size_t)Mpad : 0))) * sizeof(float);
+    return ((size_t)H * R * (1 + msplit * D + (need_dk ? (size_t)Mpad : 0))) * sizeof(float);
 }
 
 extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
@@ -346,31 +348,31 @@ extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, con
                               float* dq_f32, float* dk_f32, float* ds_ws, int dtype, void* stream) {
     GD_REQUIRE(Pe && Pb && q && k && rows && p_in && j_in && p_wo && j_wo && wgt && m_inp && m_wo && dq_f32, GD_EINVAL,
                "gd_removal_bwd: null pointer");
-    GD_REQUIRE(D == ATT_D, GD_EUNSUPPORTED, "gd_removal_bwd: head dim %d unsupported (only 64)", D);
+    GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED, "gd_removal_bwd: head dim %d unsupported (64, 128, 192)", D);
     GD_REQUIRE(H > 0 && R > 0 && N > 0 && M > 0 && Mpad >= M, GD_EINVAL, "gd_removal_bwd: bad sizes");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_bwd: dtype must be f16/bf16");
     RmBwdArgs a;
     a.Pe = Pe; a.Pb = Pb; a.q = q; a.k = k; a.rows = rows; a.p_in = p_in; a.j_in = j_in; a.p_wo = p_wo; a.j_wo = j_wo;
-    a.wgt = wgt; a.m_inp = m_inp; a.m_wo = m_wo; a.coef = coef; a.gscale = gscale_dev; a.H = H; a.R = R; a.N = N; a.M = M; a.Mpad = Mpad;
+    a.wgt = wgt; a.m_inp = m_inp; a.m_wo = m_wo; a.coef = coef; a.gscale = gscale_dev; a.H = H; a.R = R; a.N = N; a.M = M; a.Mpad = Mpad; a.D = D;
     GD_REQUIRE(ds_ws, GD_EINVAL, "gd_removal_bwd: workspace of gd_removal_bwd_workspace_bytes() required");
-    // workspace: rowdot [H*R] | dq partials [msplit, H, R, 64] | dS [H, R, Mpad] (only with dk_f32)
+    // workspace: rowdot [H*R] | dq partials [msplit, H, R, D] | dS [H, R, Mpad] (only with dk_f32)
     const int msplit = (M + RM_MCH - 1) / RM_MCH;
     float* rowdot = ds_ws;
     a.dq_part = ds_ws + (size_t)H * R;
     a.scale = scale; a.dq = dq_f32; a.dk = dk_f32; a.rowdot = rowdot;
-    a.ds_ws = dk_f32 ? a.dq_part + (size_t)msplit * H * R * ATT_D : nullptr;
-    const int waves = H * ((R + RM_RB - 1) / RM_RB) * ((M + RM_MCH - 1) / RM_MCH);
+    a.ds_ws = dk_f32 ? a.dq_part + (size_t)msplit * H * R * D : nullptr;
+    const int waves = H * ((R + RM_RB - 1) / RM_RB) * ((M + RM_MCH - 1) / RM_MCH) * (D / ATT_D);
     const int blocks = (waves + 3) / 4;
     hipStream_t st = as_stream(stream);
     if (dtype == GD_F16) k_removal_rowdot<f16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rowdot);
     else k_removal_rowdot<bf16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rowdot);
     if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, st>>>(a);
     else k_removal_bwd<bf16_t><<<blocks, 256, 0, st>>>(a);
-    k_removal_dq_fold<<<(H * R * ATT_D + 255) / 256, 256, 0, st>>>(a.dq_part, rows, wgt, msplit, H, R, N, dq_f32);
+    k_removal_dq_fold<<<(H * R * D + 255) / 256, 256, 0, st>>>(a.dq_part, rows, wgt, msplit, H, R, N, D, dq_f32);
     if (dk_f32) {
-        dim3 grid((M * ATT_D + 255) / 256, H);
-        if (dtype == GD_F16) k_removal_dk<f16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const f16_t*)q, rows, R, N, M, Mpad, dk_f32);
-        else k_removal_dk<bf16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const bf16_t*)q, rows, R, N, M, Mpad, dk_f32);
+        dim3 grid((M * D + 255) / 256, H);
+        if (dtype == GD_F16) k_removal_dk<f16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const f16_t*)q, rows, R, N, M, Mpad, D, dk_f32);
+        else k_removal_dk<bf16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const bf16_t*)q, rows, R, N, M, Mpad, D, dk_f32);
     }
     GD_CHECK_LAUNCH("gd_removal_bwd");
     return GD_OK;

@@ -30,7 +30,7 @@ def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None):
     layers = seen.get(lk)
     if layers is None:                                    # first hooked no-grad pass at this latent size: eager, learn the layers
         out = model.unet(x, t, encoder_hidden_states=ctx)["sample"]
-        seen[lk] = sorted((S, c["f"]) for S, c in controller.masks_cache_dict.items() if "f" in c)
+        seen[lk] = sorted((S, c["f"], c["D"]) for S, c in controller.masks_cache_dict.items() if "f" in c)
         return out
     if not controller.tables_built(layers):
         q_like = torch.empty(1, device=x.device, dtype=model.unet.dtype)

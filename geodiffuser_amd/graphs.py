@@ -131,10 +131,10 @@ class GraphedOptPass:
         if seen is None:                                                       # very first pass on this UNet: eager, learn the layers
             out = self._eager(controller, lat, ctx, t)
             _SEEN_LAYERS[uid] = (weakref.ref(self.model.unet),
-                                 sorted((S, c["f"]) for S, c in controller.masks_cache_dict.items() if "f" in c))
+                                 sorted((S, c["f"], c["D"]) for S, c in controller.masks_cache_dict.items() if "f" in c))
             return out + (lat, ctx)
         layers = seen[1]
-        if not all(S in controller.masks_cache_dict and "f" in controller.masks_cache_dict[S] for S, _ in layers):
+        if not all(S in controller.masks_cache_dict and "f" in controller.masks_cache_dict[S] for S, *_ in layers):
             q_like = torch.empty(1, device=lat.device, dtype=self.model.unet.dtype)
             controller.prebuild_tables(layers, q_like, self.transform_coords)
         dev = lat.device

@@ -257,7 +257,7 @@ def removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, scale
     N, D = q.shape[1], q.shape[2]
     M = k.shape[1]
     _need(dq_f32, "dq_f32", torch.float32)
-    ds_ws = torch.empty(lib.gd_removal_bwd_workspace_bytes(H, R, M, Mpad, int(dk_f32 is not None)) // 4, dtype=torch.float32,
+    ds_ws = torch.empty(lib.gd_removal_bwd_workspace_bytes(H, R, M, Mpad, D, int(dk_f32 is not None)) // 4, dtype=torch.float32,
                         device=Pe.device)
     check(lib.gd_removal_bwd(_p(Pe), _p(Pb), _p(q), _p(k), _p(rows), _p(aux["p_in"]), _p(aux["j_in"]), _p(aux["p_wo"]),
                              _p(aux["j_wo"]), _p(aux["wgt"]), _p(m_inp), _p(m_wo), coef, _p(gscale), H, R, N, M, Mpad, D, scale,

@@ -198,7 +198,7 @@ int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, 
  * dq_f32 [H,N,D] f32 accumulated (caller zeroes).  ds_ws: scratch of gd_removal_bwd_workspace_bytes() bytes (row dots, per-key-chunk dq partials that are folded in a fixed order — no f32 atomics, bit-reproducible — and dS when dk_f32 != NULL).  gscale_dev: optional DEVICE scalar multiplied into coef (the
  * upstream gradient of the loss, so that no host sync is needed to read it).
  */
-size_t gd_removal_bwd_workspace_bytes(int H, int R, int M, int Mpad, int need_dk);
+size_t gd_removal_bwd_workspace_bytes(int H, int R, int M, int Mpad, int D, int need_dk);
 int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
                    const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
                    const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,

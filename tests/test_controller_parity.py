@@ -106,7 +106,7 @@ def _cpu_topk_table(c_hip, S):
 
 def _prebuild_tables(c, case, q, coords, dtype=torch.float16):
     f, S = case["f"], case["S"]
-    c._tables(S, f, q.to(dtype).to(DEV), coords)
+    c._tables(S, f, q.to(dtype).to(DEV), coords, case.get("D", 64) if q.shape[-1] != 64 else 64)
     if case["kind"] == "edit" and S * S > 32 ** 2:
         _cpu_topk_table(c, S)
 
@@ -194,13 +194,7 @@ ORACLE_CASES = {
 }
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
-@pytest.mark.parametrize("name", list(ORACLE_CASES))
-def test_controller_vs_oracle_d64(name, dtype):
-    """Every controller regime at the real head dim, in fp16 (the reference's autocast dtype) AND in bf16 (the dtype bench.py times).
-    Both sides start from the SAME 16-bit-representable q/k/v (rounded through ``dtype`` once), so the comparison measures the
-    kernels' arithmetic and their 16-bit intermediates, not the input rounding."""
-    case = ORACLE_CASES[name]
+def _oracle_case(case, dtype):
     q, k, v, mask, coords = case_inputs(case)
     q, k, v = (t.to(dtype).float() for t in (q, k, v))
     tols = TOLS[dtype]
@@ -211,6 +205,7 @@ def test_controller_vs_oracle_d64(name, dtype):
     ch = _make_hip_controller(case, mask)
     _prebuild_tables(ch, case, q, coords, dtype)
     res = _run_hip(ch, case, q, k, v, coords, scale, gout, dtype)
+    assert res["out"].shape == out_ref.shape
     assert rel_err(res["out"], out_ref.detach()) < tols["out"]
     assert (ch.cur_att_layer, ch.cur_step) == (co.cur_att_layer, co.cur_step)
     if not case["cfg"]:
@@ -223,6 +218,54 @@ def test_controller_vs_oracle_d64(name, dtype):
             log_ref = {key: float(val) for key, val in co.loss_log_dict["cross" if case["cross"] else "self"].items()}
         dq, dk = torch.autograd.grad(total, [qo, ko], allow_unused=True)
         _check_losses_and_grads(case, ch, co, res, loss_ref, log_ref, dq, dk, 1.0, tols)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("name", list(ORACLE_CASES))
+def test_controller_vs_oracle_d64(name, dtype):
+    """Every controller regime at the real head dim, in fp16 (the reference's autocast dtype) AND in bf16 (the dtype bench.py times).
+    Both sides start from the SAME 16-bit-representable q/k/v (rounded through ``dtype`` once), so the comparison measures the
+    kernels' arithmetic and their 16-bit intermediates, not the input rounding."""
+    _oracle_case(ORACLE_CASES[name], dtype)
+
+
+# The SD1.x head dims (BASELINE configs[2]: CompVis/stable-diffusion-v1-4, 8 heads over 320 / 640 / 1280 channels): the controller
+# zero-pads 40 -> 64, 80 -> 128, 160 -> 192 internally and keeps the true D in the loss normalisers and the softmax scale.
+SD1_CASES = {
+    "edit_self_opt_32_d40": dict(kind="edit", S=32, f=2, D=40, cross=False, cfg=False, cur_step=3, coords="rotate", quant=True, seed=51),
+    "edit_cross_opt_32_d40": dict(kind="edit", S=32, f=2, D=40, cross=True, cfg=False, cur_step=3, coords="scale", quant=True, seed=52),
+    "edit_self_opt_32_d80": dict(kind="edit", S=32, f=2, D=80, cross=False, cfg=False, cur_step=3, coords="translate", quant=True, seed=53),
+    "edit_cross_opt_32_d80": dict(kind="edit", S=32, f=2, D=80, cross=True, cfg=False, cur_step=3, coords="rotate", quant=True, seed=54),
+    "edit_self_cfg_16_d160": dict(kind="edit", S=16, f=3, D=160, cross=False, cfg=True, cur_step=10, coords="translate", quant=True, seed=55),
+    "edit_cross_opt_32_d160": dict(kind="edit", S=32, f=1, D=160, cross=True, cfg=False, cur_step=3, coords="scale", quant=True, seed=56),
+    "rem_self_opt_32_d80": dict(kind="remover", S=32, f=2, D=80, cross=False, cfg=False, cur_step=3, coords="translate", quant=False, seed=57),
+    "rem_cross_opt_32_d160": dict(kind="remover", S=32, f=1, D=160, cross=True, cfg=False, cur_step=3, coords="translate", quant=False, seed=58),
+}
+
+
+@pytest.mark.parametrize("name", list(SD1_CASES))
+def test_controller_vs_oracle_sd1_head_dims(name):
+    _oracle_case(SD1_CASES[name], torch.float16)
+
+
+@pytest.mark.parametrize("name", [n for n, c in cases.CONTROLLER_CASES.items() if not c["cfg"]][:4])
+def test_controller_vs_golden_native_head_dim(name):
+    """The G6 fixtures (head dims 16 / 8, recorded from the reference) through the controller's OWN zero-padding: no manual padding
+    and no loss-weight rescaling as in test_controller_vs_golden — loss and gradient must come out as recorded."""
+    case = cases.CONTROLLER_CASES[name]
+    g = load("G6_" + name)
+    q, k, v, mask, coords = case_inputs(case)
+    D = case["D"]
+    c = _make_hip_controller(case, mask)
+    c._tables(case["S"], case["f"], q.half().to(DEV), coords, D)
+    if case["kind"] == "edit" and case["S"] ** 2 > 32 ** 2:
+        _cpu_topk_table(c, case["S"])
+    gout = case_gout(case, g["out"].shape)
+    res = _run_hip(c, case, q, k, v, coords, D ** -0.5, gout)
+    assert res["out"].shape == g["out"].shape and rel_err(res["out"], g["out"]) < TOL_OUT
+    co, _, _, _ = _oracle_run(case, q, k, v, mask, coords, D ** -0.5, gout)
+    log_ref = {key[4:]: g[key] for key in g if key.startswith("log_")}
+    _check_losses_and_grads(case, c, co, res, g.get("loss"), log_ref, torch.from_numpy(g["dq"]), torch.from_numpy(g["dk"]), 1.0)
 
 
 def test_amodal_table_choice_is_the_only_difference():

@@ -863,3 +863,56 @@ def test_vanilla_attention_autograd_is_complete():
     rq, rk, rv = torch.autograd.grad((o ** 2).sum(), [qd, kd, vd])
     for a, b in ((gq, rq), (gk, rk), (gv, rv)):
         assert a is not None and rel_l2(a.double(), b) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ SD1.x head dims (40 / 80 / 160)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("D,BH,N,M", [(128, 2, 256, 256), (192, 2, 300, 77), (128, 3, 1024, 1024), (192, 1, 1000, 1100), (192, 8, 64, 64)])
+def test_attention_wide_heads_forward_backward_probs(ops, dtype, D, BH, N, M):
+    """The 128- and 192-wide instantiations (zero-padded 80 / 160 heads) of forward, probs, dq, cross dK and dK/dV against fp64 on
+    the same 16-bit inputs, ragged query / key counts included."""
+    torch.manual_seed(D + N + M)
+    sc = 80 ** -0.5 if D == 128 else 160 ** -0.5
+    q = (torch.randn(BH, N, D, device=DEV) * 1.2).to(dtype); k = (torch.randn(BH, M, D, device=DEV) * 1.2).to(dtype)
+    v = torch.randn(BH, M, D, device=DEV).to(dtype); g = (torch.randn(BH, N, D, device=DEV) * 0.1).to(dtype)
+    out = torch.empty_like(q); lse = torch.empty(BH, N, device=DEV)
+    ops.attn_fwd([(q, k, v, out, lse)], sc)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bnd,bmd->bnm", qd, kd) * sc
+    p = torch.softmax(s, -1)
+    o = torch.einsum("bnm,bmd->bnd", p, vd)
+    assert rel_err(out.double().cpu(), o.detach().cpu()) < tol(dtype)
+    assert float((lse.double() - torch.logsumexp(s, -1)).abs().max()) < 1e-4
+    rows = torch.arange(1, N, 3, dtype=torch.int32, device=DEV)
+    P = ops.attn_probs(q, k, lse, rows, sc)
+    assert rel_err(P[:, :, :M].double().cpu(), p[:, rows.long()].detach().cpu()) < (TOL16 if dtype == torch.float16 else 8 * TOL16)
+    rq, rk, rv = torch.autograd.grad((o * g.double()).sum(), [qd, kd, vd])
+    lim = 1.5e-2 if dtype == torch.float16 else 5e-2
+    dq, dk_x = ops.attn_bwd(q, k, v, out, lse, g, sc, M <= 128)
+    assert rel_l2(dq.double(), rq) < lim
+    if M <= 128:
+        assert rel_l2(dk_x.double(), rk) < lim
+    dk, dv = ops.attn_bwd_dkv(q, k, v, out, lse, g, sc)
+    assert rel_l2(dk.double(), rk) < lim and rel_l2(dv.double(), rv) < lim
+
+
+@pytest.mark.parametrize("D", [40, 80, 160])
+def test_attention_pads_sd1_head_dims(D):
+    """attention() on a head dim that is not a multiple of 64: zero-padded internally, outputs / gradients of the true width."""
+    from geodiffuser_amd.attention_sharing import attention
+    torch.manual_seed(D)
+    q = torch.randn(4, 256, D, device=DEV).half().requires_grad_(True)
+    k = torch.randn(4, 77, D, device=DEV).half().requires_grad_(True)
+    v = torch.randn(4, 77, D, device=DEV).half().requires_grad_(True)
+    with torch.enable_grad():
+        out = attention(q, k, v, D ** -0.5)
+        gq, gk, gv = torch.autograd.grad((out.float() ** 2).sum(), [q, k, v])
+    assert out.shape == q.shape and gq.shape == q.shape and gk.shape == k.shape
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    o = torch.einsum("bnm,bmd->bnd", torch.softmax(torch.einsum("bnd,bmd->bnm", qd, kd) * D ** -0.5, -1), vd)
+    assert rel_err(out.double().cpu(), o.detach().cpu()) < TOL16
+    rq, rk, rv = torch.autograd.grad((o ** 2).sum(), [qd, kd, vd])
+    for a, b in ((gq, rq), (gk, rk), (gv, rv)):
+        assert rel_l2(a.double(), b) < 2e-2
+    with torch.no_grad():
+        assert torch.equal(attention(q, k, v, D ** -0.5), out)

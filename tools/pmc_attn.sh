@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes over tools/attn_one.py (one process per pass; counters only, no tracing domains).  Usage: tools/pmc_attn.sh <tag> [BH] [cfg]
 # Writes gpurun_out/pmc_<tag>/pass*/ and gpurun_out/pmc_<tag>.md
-TAG=${1:-x}; export BH=${2:-32}; export GD_ATTN_CFG=${3:-4x1}
+TAG=${1:-x}; export BH=${2:-32}; if [ -n "$3" ]; then export GD_ATTN_CFG=$3; fi; export QS=${4:-0}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 i=0

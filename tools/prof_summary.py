@@ -35,7 +35,8 @@ def main():
         if "k_attn_fwd" in n:
             g = by_grid[wgs]
             g[0] += 1; g[1] += (e - s) * 1e-3
-            if wgs >= 320 and (e - s) >= 35000:
+            # r02: the pipelined kernels serve every self-attention launch; 64^2 launches run >= 28 us (5 heads), 32^2 ones <= 22 us
+            if ("k_attn_fwd_mp" in n and (e - s) >= 26000) or ("k_attn_fwd_mp" not in n and wgs >= 320 and (e - s) >= 35000):
                 big[0] += 1; big[1] += (e - s) * 1e-3
         a = agg[n]
         d = (e - s) * 1e-3

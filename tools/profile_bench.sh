@@ -1,0 +1,12 @@
+#!/bin/bash
+# rocprofv3 kernel trace of the benchmark's timed region + summary.  Usage: tools/profile_bench.sh <tag>   (run on the GPU box)
+TAG=${1:-r02}
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+export GD_BENCH_MARK=1
+rocprofv3 --kernel-trace --stats -d $OUT -o bench --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
+cd $ROOT
+TR=$(find $OUT -name "*kernel_trace.csv" | head -1)
+python3 tools/prof_summary.py $TR gpurun_out/${TAG}_bench_summary.md gpurun_out/${TAG}_bench_kernel_stats.csv "$TAG - rocprofv3 --kernel-trace --stats of bench.py --steps 2 --warmup 1 --no-cpu-baseline (MI355X, bf16)"
+rm -f $TR   # hundreds of MB
+head -60 gpurun_out/${TAG}_bench_summary.md

@@ -79,6 +79,7 @@ SIGNATURES = {
     "gd_softsplat_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gd_hist_match": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int64, c_int, c_void_p]),
+    "gd_ddim_step_v": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int64, c_int, c_void_p]),
     "gd_masked_latent_update": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p]),
     "gd_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "gd_norm_rescale": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -6,34 +6,53 @@
 // to remove ~10 separate torch launches per step from a launch-bound loop.
 #include "common.hpp"
 
-template <typename T>
+// VPRED: the model output is v = sqrt(a_t) eps - sqrt(1-a_t) x0 (SD2.1-768, BASELINE configs[3]); isa_t then carries sqrt(a_t).
+template <typename T, bool VPRED>
 __global__ void k_ddim_step(const T* __restrict__ x, const T* __restrict__ eu, const T* __restrict__ ec, float g,
                             float sb_t, float isa_t, float sa_to, float sb_to, T* __restrict__ out, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float e = (float)eu[i];
     if (ec) e = e + g * ((float)ec[i] - e);
-    const float x0 = ((float)x[i] - sb_t * e) * isa_t;
+    float x0;
+    if (VPRED) {
+        const float xv = (float)x[i], v = e;
+        x0 = isa_t * xv - sb_t * v;
+        e = isa_t * v + sb_t * xv;
+    } else {
+        x0 = ((float)x[i] - sb_t * e) * isa_t;
+    }
     out[i] = (T)(sa_to * x0 + sb_to * e);
 }
 
-extern "C" int gd_ddim_step(const void* x, const void* eps_u, const void* eps_c, float guidance, float a_t, float a_to,
+template <bool VPRED>
+static int ddim_step_launch(const void* x, const void* eps_u, const void* eps_c, float guidance, float a_t, float a_to,
                             void* out, int64_t n, int dtype, void* stream) {
     GD_REQUIRE(x && eps_u && out && n > 0, GD_EINVAL, "gd_ddim_step: null pointer or n<=0");
     GD_REQUIRE(a_t > 0.f && a_t <= 1.f && a_to > 0.f && a_to <= 1.f, GD_EINVAL, "gd_ddim_step: alphas out of (0,1]");
-    const float sb_t = sqrtf(1.f - a_t), isa_t = 1.f / sqrtf(a_t), sa_to = sqrtf(a_to), sb_to = sqrtf(1.f - a_to);
+    const float sb_t = sqrtf(1.f - a_t), isa_t = VPRED ? sqrtf(a_t) : 1.f / sqrtf(a_t), sa_to = sqrtf(a_to), sb_to = sqrtf(1.f - a_to);
     const int blocks = (int)((n + 255) / 256);
     hipStream_t st = as_stream(stream);
     if (dtype == GD_F32)
-        k_ddim_step<float><<<blocks, 256, 0, st>>>((const float*)x, (const float*)eps_u, (const float*)eps_c, guidance, sb_t, isa_t, sa_to, sb_to, (float*)out, n);
+        k_ddim_step<float, VPRED><<<blocks, 256, 0, st>>>((const float*)x, (const float*)eps_u, (const float*)eps_c, guidance, sb_t, isa_t, sa_to, sb_to, (float*)out, n);
     else if (dtype == GD_F16)
-        k_ddim_step<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, (const f16_t*)eps_u, (const f16_t*)eps_c, guidance, sb_t, isa_t, sa_to, sb_to, (f16_t*)out, n);
+        k_ddim_step<f16_t, VPRED><<<blocks, 256, 0, st>>>((const f16_t*)x, (const f16_t*)eps_u, (const f16_t*)eps_c, guidance, sb_t, isa_t, sa_to, sb_to, (f16_t*)out, n);
     else if (dtype == GD_BF16)
-        k_ddim_step<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)eps_u, (const bf16_t*)eps_c, guidance, sb_t, isa_t, sa_to, sb_to, (bf16_t*)out, n);
+        k_ddim_step<bf16_t, VPRED><<<blocks, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)eps_u, (const bf16_t*)eps_c, guidance, sb_t, isa_t, sa_to, sb_to, (bf16_t*)out, n);
     else
         GD_REQUIRE(false, GD_EINVAL, "gd_ddim_step: bad dtype %d", dtype);
     GD_CHECK_LAUNCH("gd_ddim_step");
     return GD_OK;
+}
+
+extern "C" int gd_ddim_step(const void* x, const void* eps_u, const void* eps_c, float guidance, float a_t, float a_to,
+                            void* out, int64_t n, int dtype, void* stream) {
+    return ddim_step_launch<false>(x, eps_u, eps_c, guidance, a_t, a_to, out, n, dtype, stream);
+}
+
+extern "C" int gd_ddim_step_v(const void* x, const void* v_u, const void* v_c, float guidance, float a_t, float a_to,
+                              void* out, int64_t n, int dtype, void* stream) {
+    return ddim_step_launch<true>(x, v_u, v_c, guidance, a_t, a_to, out, n, dtype, stream);
 }
 
 __global__ void k_masked_update(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ m,

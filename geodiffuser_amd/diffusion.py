@@ -115,8 +115,9 @@ def image2latent(image, model, mask=None, device="cuda:0"):
 
 
 def load_model(diffusion_model="stabilityai/stable-diffusion-2-1-base", unet_path="", device="cuda:0", random_init=None,
-               dtype=torch.float16, tiny=False):
-    """diffusion.py:99-149.  With diffusers + weights available this would wrap ``StableDiffusionPipeline.from_pretrained``;
+               dtype=torch.float16, tiny=False, prediction_type=None):
+    """diffusion.py:99-149.  ``prediction_type``: "epsilon" / "v_prediction"; default: the checkpoint's scheduler config when a
+    pipeline is loaded ("stabilityai/stable-diffusion-2-1" at 768^2 is a v-prediction model, BASELINE configs[3]), else "epsilon".  With diffusers + weights available this would wrap ``StableDiffusionPipeline.from_pretrained``;
     in this environment neither exists (no network), so a seeded random-init model of the same shape is built.
     Returns (ldm_stable, tokenizer, scheduler) like the reference."""
     try:  # pragma: no cover
@@ -130,10 +131,15 @@ def load_model(diffusion_model="stabilityai/stable-diffusion-2-1-base", unet_pat
         pipe = _SDP.from_pretrained(unet_path or diffusion_model, torch_dtype=dtype).to(device)
         # the repo's own scheduler (same betas / alphas / 'leading' timestep table as the diffusers object the reference builds at
         # diffusion.py:110): its step runs the fused CFG + DDIM kernel and accepts the keywords diffusion_step passes
+        if prediction_type is None:
+            prediction_type = getattr(getattr(pipe.scheduler, "config", None), "prediction_type", "epsilon")
         pipe.scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
-                                       set_alpha_to_one=False)
+                                       set_alpha_to_one=False, prediction_type=prediction_type)
         pipe.unet.set_attn_processor(VanillaAttentionProcessor())
         pipe.unet.eval()
         return pipe, pipe.tokenizer, pipe.scheduler
     pipe = build_random_sd21(device=device, dtype=dtype, tiny=tiny)
+    if prediction_type not in (None, "epsilon"):
+        pipe.scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                                       set_alpha_to_one=False, prediction_type=prediction_type)
     return pipe, pipe.tokenizer, pipe.scheduler

@@ -116,7 +116,11 @@ class NullInversion:
         tp = t - sch.config.num_train_timesteps // sch.num_inference_steps
         a_t = float(sch.alphas_cumprod[t])
         a_p = float(sch.alphas_cumprod[tp]) if tp >= 0 else float(sch.final_alpha_cumprod)
-        x0 = (sample - (1 - a_t) ** 0.5 * model_output) / a_t ** 0.5
+        if getattr(sch, "_v", False):                         # v-prediction: recover x0 / eps from v first
+            x0 = a_t ** 0.5 * sample - (1 - a_t) ** 0.5 * model_output
+            model_output = a_t ** 0.5 * model_output + (1 - a_t) ** 0.5 * sample
+        else:
+            x0 = (sample - (1 - a_t) ** 0.5 * model_output) / a_t ** 0.5
         return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * model_output
 
     def get_noise_pred_single(self, latents, t, context):

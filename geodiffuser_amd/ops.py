@@ -366,14 +366,16 @@ def hist_match(src, tmpl, m_src, m_tmpl):
 # ---------------------------------------------------------------------------------------------------
 # R10-R12 scheduler / latent arithmetic
 # ---------------------------------------------------------------------------------------------------
-def ddim_step(x, eps_u, eps_c, guidance: float, a_t: float, a_to: float, out=None):
+def ddim_step(x, eps_u, eps_c, guidance: float, a_t: float, a_to: float, out=None, v_prediction: bool = False):
+    """CFG combine + DDIM closed form; ``v_prediction``: eps_u / eps_c hold the v-prediction of an SD2.1-768-style UNet."""
     lib = _lib.load()
     _need(x, "x"); _need(eps_u, "eps_u", x.dtype)
     if eps_c is not None:
         _need(eps_c, "eps_c", x.dtype)
     if out is None:
         out = torch.empty_like(x)
-    check(lib.gd_ddim_step(_p(x), _p(eps_u), _p(eps_c), guidance, a_t, a_to, _p(out), x.numel(), _DT[x.dtype], _stream()), "gd_ddim_step")
+    fn = lib.gd_ddim_step_v if v_prediction else lib.gd_ddim_step
+    check(fn(_p(x), _p(eps_u), _p(eps_c), guidance, a_t, a_to, _p(out), x.numel(), _DT[x.dtype], _stream()), "gd_ddim_step")
     return out
 
 

@@ -2,7 +2,9 @@
 ``DDIMInverseScheduler`` as constructed at GeoDiffuser/utils/diffusion.py:110 and inversion.py:143):
 ``set_timesteps``, ``timesteps``, ``alphas_cumprod``, ``config.num_train_timesteps``, ``final_alpha_cumprod``,
 ``step(model_output, t, sample, eta=0.0)``.  The step arithmetic is the reference's own closed form
-(inversion.py:47-65) executed by the ``gd_ddim_step`` HIP kernel.
+(inversion.py:47-65) executed by the ``gd_ddim_step`` HIP kernel.  ``prediction_type="v_prediction"`` (not in the reference: its
+README.md:61 lists v-prediction models as to do) runs the same step on x0 / eps recovered from v (``gd_ddim_step_v``), as needed by
+SD2.1-768 (BASELINE configs[3]).
 
 Parity note: diffusers is absent, so the timestep table ('leading' spacing, steps_offset 0) is unpinned.
 """
@@ -35,8 +37,10 @@ class _Out(dict):
 class DDIMScheduler:
     def __init__(self, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                  set_alpha_to_one=False, num_train_timesteps=1000, prediction_type="epsilon"):
-        if beta_schedule != "scaled_linear" or clip_sample or prediction_type != "epsilon":
-            raise NotImplementedError("only the configuration the reference builds (diffusion.py:110) is supported")
+        if beta_schedule != "scaled_linear" or clip_sample or prediction_type not in ("epsilon", "v_prediction"):
+            raise NotImplementedError("only the configuration the reference builds (diffusion.py:110) is supported, plus "
+                                      "prediction_type='v_prediction' (SD2.1-768, BASELINE configs[3])")
+        self._v = prediction_type == "v_prediction"
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                                       prediction_type=prediction_type)
         self.alphas_cumprod = make_alphas_cumprod(num_train_timesteps, beta_start, beta_end)
@@ -70,7 +74,7 @@ class DDIMScheduler:
         dt = sample.dtype
         eps = model_output.to(dt).contiguous()
         epc = None if eps_cond is None else eps_cond.to(dt).contiguous()
-        out = ops.ddim_step(sample.contiguous(), eps, epc, float(guidance_scale), self._alpha(t), self._alpha(tp))
+        out = ops.ddim_step(sample.contiguous(), eps, epc, float(guidance_scale), self._alpha(t), self._alpha(tp), v_prediction=self._v)
         return _Out(prev_sample=out)
 
 
@@ -88,5 +92,5 @@ class DDIMInverseScheduler(DDIMScheduler):
         dt = sample.dtype
         eps = model_output.to(dt).contiguous()
         epc = None if eps_cond is None else eps_cond.to(dt).contiguous()
-        out = ops.ddim_step(sample.contiguous(), eps, epc, float(guidance_scale), self._alpha(tc), self._alpha(t))
+        out = ops.ddim_step(sample.contiguous(), eps, epc, float(guidance_scale), self._alpha(tc), self._alpha(t), v_prediction=self._v)
         return _Out(prev_sample=out) if return_dict else (out,)

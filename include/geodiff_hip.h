@@ -261,6 +261,12 @@ int gd_blend_tokens(const void* a, const void* b, const float* m, int H, int N, 
 int gd_ddim_step(const void* x, const void* eps_u, const void* eps_c, float guidance, float a_t, float a_to,
                  void* out, int64_t n, int dtype, void* stream);
 
+/* The same step for a v-prediction UNet (SD2.1-768, BASELINE configs[3]; the reference has no such path — README.md:61 lists it as
+ * to do — so the arithmetic is the published DDIM step of diffusers' DDIMScheduler with prediction_type="v_prediction"):
+ *   v = v_u + g*(v_c-v_u);  x0 = sqrt(a_t) x - sqrt(1-a_t) v;  eps = sqrt(a_t) v + sqrt(1-a_t) x;  out = sqrt(a_to) x0 + sqrt(1-a_to) eps. */
+int gd_ddim_step_v(const void* x, const void* v_u, const void* v_c, float guidance, float a_t, float a_to,
+                   void* out, int64_t n, int dtype, void* stream);
+
 /* U/optimization.py:228-231: x1 <- x1 - step*(1+m)*nan_to_num(g)  (the two chained updates), m [hw] f32
  * broadcast over C channels; x, g, out f32 [C*hw]. */
 int gd_masked_latent_update(const float* x, const float* g, const float* m, float step, int C, int hw,

@@ -916,3 +916,30 @@ def test_attention_pads_sd1_head_dims(D):
         assert rel_l2(a.double(), b) < 2e-2
     with torch.no_grad():
         assert torch.equal(attention(q, k, v, D ** -0.5), out)
+
+
+def test_ddim_step_v_prediction(ops):
+    """gd_ddim_step_v against the oracle's restatement of the published v-prediction DDIM step (BASELINE configs[3], SD2.1-768;
+    parity unpinned — the reference has no v-prediction path); v -> (x0, eps) -> v is the identity; the scheduler classes route to it."""
+    from geodiffuser_amd.scheduler import DDIMInverseScheduler, DDIMScheduler
+    ac = O.alphas_cumprod()
+    rng = np.random.default_rng(12)
+    x, vu, vc = (torch.from_numpy(rng.standard_normal((2, 4, 96, 96), dtype=np.float32)) for _ in range(3))
+    for t in (980, 500, 20, 0):
+        v = O.cfg_combine(vu, vc, 7.5)
+        a_t, a_p = float(ac[t]), float(ac[t - 20] if t >= 20 else ac[0])
+        got = ops.ddim_step(x.to(DEV), vu.to(DEV), vc.to(DEV), 7.5, a_t, a_p, v_prediction=True).cpu()
+        assert rel_err(got, O.prev_step_v(v, t, x, ac, 50)) < 1e-5
+        gotn = ops.ddim_step(x.to(DEV), vu.to(DEV), vc.to(DEV), 7.5, a_p, a_t, v_prediction=True).cpu()
+        assert rel_err(gotn, O.next_step_v(v, t, x, ac, 50)) < 1e-5
+    # an epsilon step on the eps recovered from v gives the same sample
+    x0, eps = O.v_to_x0_eps(vu, x, ac[500])
+    assert rel_err(O.prev_step_v(vu, 500, x, ac, 50), O.prev_step(eps, 500, x, ac, 50)) < 1e-5
+    sch = DDIMScheduler(prediction_type="v_prediction"); sch.set_timesteps(50)
+    inv = DDIMInverseScheduler(prediction_type="v_prediction"); inv.set_timesteps(50)
+    for dt, tl in ((torch.float32, 1e-5), (torch.float16, TOL16), (torch.bfloat16, 8 * TOL16)):
+        xs, vs = x.to(dt), vu.to(dt)
+        out = sch.step(vs.to(DEV), 500, xs.to(DEV), eta=0.0)["prev_sample"]
+        assert out.dtype == dt and rel_err(out.float().cpu(), O.prev_step_v(vs.float(), 500, xs.float(), ac, 50)) < tl
+        outn = inv.step(vs.to(DEV), 500, xs.to(DEV))["prev_sample"]
+        assert rel_err(outn.float().cpu(), O.next_step_v(vs.float(), 500, xs.float(), ac, 50)) < tl

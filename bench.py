@@ -356,6 +356,10 @@ def main():
     # favours split-K igemm kernels with an fp32 workspace + cast kernels here): -7 % per edit, ~90 s more warm-up on a fresh box.
     if os.environ.get("GD_MIOPEN_FIND", "1") == "1":
         torch.backends.cudnn.benchmark = True
+    # ... and keep what it found: the find-db lives in the package (geodiffuser_amd/miopen_db, committed with this benchmark's shapes),
+    # so a fresh process / rank does not repeat the solver search
+    from geodiffuser_amd import miopen_cache
+    miopen_db = miopen_cache.configure()
     from geodiffuser_amd import dist as gdist
     rank, world, local = gdist.init()
     if world != args.gpus and world > 1:
@@ -381,8 +385,12 @@ def main():
         kw.update(num_ddim_steps=args.ddim_steps, ldm_stable_model=pipe, tokenizer_model=tok, scheduler_in=sched)
         return editor.run_geodiffuser(image, depth, mask, T, **kw)
 
+    warm_s = []
     for j in range(args.warmup):
+        tw = time.perf_counter()
         one_edit(1000 + j)
+        torch.cuda.synchronize()
+        warm_s.append(time.perf_counter() - tw)
     torch.cuda.synchronize()
     gdist.barrier()
     timer.enabled = rank == 0
@@ -400,6 +408,8 @@ def main():
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
     timer.enabled = False
+    per_rank = gdist.gather_over_ranks(elapsed, device=dev)
+    first_edit = gdist.gather_over_ranks(warm_s[0] if warm_s else 0.0, device=dev)
     elapsed = gdist.max_over_ranks(elapsed, device=dev)
     if rank == 0:
         timer.replay()
@@ -414,7 +424,10 @@ def main():
             "config": {"workload": f"configs[1]: single {args.size}x{args.size} image, 3-D {args.kind} edit, {args.ddim_steps}-step DDIM "
                                    f"inversion + edit (17 optimisation passes), SD2.1-base-shaped UNet/VAE/text-encoder, random-init, "
                                    f"one edit per GPU", "edits_per_min": 60.0 * value, "weights_broadcast_bytes": nbytes,
-                       "tiny_debug_model": bool(args.tiny)},
+                       "tiny_debug_model": bool(args.tiny),
+                       # multi-GPU reporting: seconds of the timed region on every rank (value uses their max) and of each rank's
+                       # FIRST warm-up edit (solver search unless the find-db has the shapes, graph captures, allocator growth)
+                       "per_rank_s": per_rank, "first_warmup_edit_s": first_edit, "miopen_db": os.path.relpath(miopen_db, ROOT)},
         }
         if roof:
             line["roofline"] = {"kernel": "k_attn_fwd (64^2 self-attention launches)", "bound": "mfma", "achieved": roof["achieved"] / 1e12,

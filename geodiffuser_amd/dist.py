@@ -96,3 +96,14 @@ def sum_over_ranks(x: float, device=None) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_over_ranks(x: float, device=None) -> List[float]:
+    """[x of rank 0, x of rank 1, ...] on every rank (reporting only: the per-rank seconds of the benchmark line)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [x]
+    world = dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    t[dist.get_rank()] = x
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]

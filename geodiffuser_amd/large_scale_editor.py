@@ -199,9 +199,14 @@ def main(argv=None):
     logging.basicConfig(level=logging.INFO)
     from . import dist as gdist, editor
     from .diffusion import load_model
+    from . import miopen_cache
+    miopen_cache.configure()                                                  # committed find-db: no per-rank solver search
     rank, world, local = gdist.init()
-    dev = f"cuda:{local}"
-    torch.cuda.set_device(local)
+    # (the edit itself needs the HIP extension and fails loudly without a GPU; the driver around it — sharding, broadcast, result
+    #  files — is device-agnostic so that the world-size-2 gloo test can run it on CPU with a stubbed edit)
+    dev = f"cuda:{local}" if torch.cuda.is_available() else "cpu"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
     editor.DEVICE = torch.device(dev)
     pipe, tok, sched = load_model(device=dev, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float16)
     gdist.broadcast_model([pipe.unet, pipe.vae, pipe.text_encoder], src=0)     # one RCCL broadcast; no-op for one rank

@@ -75,10 +75,11 @@ def _log_to_host(d):
 
 def text2image_loop(unet, text_embeddings, uncond_embeddings, controller, x_T, ddim_latents, transform_coordinates, mask_obj, *, num_steps,
                     guidance_scale, skip_optim_steps, optimize_steps, latent_replace, lr, edit_type="geometry_editor",
-                    removal_loss_value_in=-1.5, progress=None, timings=None, max_steps=None):
+                    removal_loss_value_in=-1.5, progress=None, timings=None, max_steps=None, prediction_type="epsilon"):
     """U/editor.py:65-423 with optimize_embeddings = optimize_latents = True, fast_start_steps = 0, use_adaptive_optimization = True,
     an inversion trajectory given (the configuration of every reference driver).  -> (latents [2,4,h,w], {step: loss log}).
-    ``timings`` (dict) accumulates wall seconds / counts of the optimisation and CFG passes; ``max_steps`` stops early (bench sample)."""
+    ``timings`` (dict) accumulates wall seconds / counts of the optimisation and CFG passes; ``max_steps`` stops early (bench sample).
+    ``prediction_type="v_prediction"`` (no reference path, parity unpinned: ref_cpu.prev_step_v): the UNet output is v (SD2.1-768)."""
     import time as _time
     remover = edit_type == "geometry_remover"
     ac = O.alphas_cumprod()
@@ -131,7 +132,8 @@ def text2image_loop(unet, text_embeddings, uncond_embeddings, controller, x_T, d
         with torch.no_grad():
             eps = unet(torch.cat([latents] * 2), t, encoder_hidden_states=context)["sample"]
             eu, ec = eps.chunk(2)
-            latents = O.prev_step(O.cfg_combine(eu, ec, guidance_scale), t, latents, ac, num_steps)
+            step_fn = O.prev_step_v if prediction_type == "v_prediction" else O.prev_step
+            latents = step_fn(O.cfg_combine(eu, ec, guidance_scale), t, latents, ac, num_steps)
         if timings is not None:
             timings["cfg_s"] = timings.get("cfg_s", 0.0) + _time.perf_counter() - t_start
             timings["cfg_n"] = timings.get("cfg_n", 0) + 1

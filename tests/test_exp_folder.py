@@ -126,3 +126,65 @@ def test_save_results_writes_the_reference_file_set(tmp_path):
     # aspect ratio [h, w] = [96, 64] < 1: height stretched by 1/ratio (image_processing.py:100-113)
     assert read_image(os.path.join(folder, "resized_result_ls.png")).shape == (72, 64, 3)
     assert read_image(os.path.join(folder, "experiment.png")).shape == (72, 3 * 64 + 2 * 20, 3)
+
+
+_BATCH_WORKER = r'''
+import os, sys, types
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from geodiffuser_amd import diffusion, editor, large_scale_editor as L
+
+def fake_load_model(device="cpu", dtype=torch.float32, **kw):
+    torch.manual_seed(100 + int(os.environ["RANK"]))            # every rank starts from DIFFERENT weights: only the broadcast aligns them
+    pipe = types.SimpleNamespace(unet=torch.nn.Linear(8, 8), vae=torch.nn.Linear(4, 4), text_encoder=torch.nn.Linear(2, 2))
+    return pipe, None, None
+
+def fake_edit(image, depth, image_mask, transform_in, prompt="", ldm_stable_model=None, edit_type="geometry_editor", **kw):
+    # a deterministic function of the experiment's inputs AND the model weights (so the result files prove which weights were used)
+    w = float(ldm_stable_model.unet.weight.double().sum()) + float(ldm_stable_model.vae.weight.double().sum())
+    out = np.clip(image.astype(np.float64) * 0.5 + 40.0 * (image_mask[..., None] > 0.5) + (w %% 7.0), 0, 255)
+    log = {0: {"self": {"sim": w}, "cross": {"sim": float(np.asarray(transform_in).sum())}, "num_layers": 16}}
+    return [image, out], log
+
+diffusion.load_model = fake_load_model
+editor.perform_geometric_edit = fake_edit
+L.main(["--root", %(data)r])
+print("rank", os.environ["RANK"], "done")
+'''
+
+
+def test_two_rank_gloo_batch_driver_on_experiment_folders(tmp_path):
+    """BASELINE configs[2] without the hardware: ``large_scale_editor.main`` as two gloo ranks over a dataset root (category folders ->
+    edit types, Rotation_2D skipped), the edit itself stubbed (it needs the GPU).  Every experiment is processed exactly once, by rank
+    j mod 2, with RANK 0's weights (the start-up broadcast), and the result files equal those of a single-process run."""
+    import shutil
+    import subprocess
+    import sys
+    from geodiffuser_amd import large_scale_editor as L
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for world in (1, 2):
+        data = tmp_path / f"w{world}"
+        shutil.copytree(ROOT, data)
+        script = tmp_path / f"worker{world}.py"
+        script.write_text(_BATCH_WORKER % dict(root=repo, data=str(data)))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29640 + world), WORLD_SIZE=str(world))
+        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        logs = [p.communicate(timeout=300)[0] for p in procs]
+        for r, (p, o) in enumerate(zip(procs, logs)):
+            assert p.returncode == 0, o
+            assert f"rank {r} done" in o
+        outs[world] = (data, logs)
+    data2, logs2 = outs[2]
+    work = [os.path.relpath(f, data2).rstrip("/") for f, _ in L.list_experiments(str(data2))]
+    assert work == ["Mix/1", "Mix/2", "Removal/1"]
+    for j, rel in enumerate(work):                              # edit j ran on rank j mod 2 only
+        for r in range(2):
+            assert (f"Completed: {data2}/{rel}/" in logs2[r]) == (j % 2 == r), (rel, r)
+    assert not os.path.exists(data2 / "Rotation_2D" / "1" / "result_ls.png")          # skipped category (large_scale_editor.py:378-381)
+    for rel in work:
+        for name in ("result_ls.png", "resized_result_ls.png", "experiment.png", "loss.pkl", "loss.log"):
+            a, b = outs[1][0] / rel / name, data2 / rel / name
+            assert a.exists() and b.exists(), (rel, name)
+            assert a.read_bytes() == b.read_bytes(), (rel, name)      # rank 1's results were computed with rank 0's weights

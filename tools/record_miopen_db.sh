@@ -1,0 +1,17 @@
+#!/bin/bash
+# Records MIOpen's find-db for the benchmark's convolution shapes on an MI355X into gpurun_out/miopen_db/ (copy it to
+# geodiffuser_amd/miopen_db/ and commit).  Runs the bench twice in fresh processes: the second run shows what a warm db saves.
+#   gpurun --timeout 1500 -- 'tools/record_miopen_db.sh'
+cd "$(dirname "$0")/.."
+export GD_MIOPEN_DB=$PWD/gpurun_out/miopen_db
+rm -rf "$GD_MIOPEN_DB"; mkdir -p "$GD_MIOPEN_DB"
+cp -r geodiffuser_amd/miopen_db/. "$GD_MIOPEN_DB"/ 2>/dev/null
+for run in cold warm; do
+  python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline > gpurun_out/miopen_db_$run.json 2> gpurun_out/miopen_db_$run.err
+  python3 - <<PY
+import json
+d = json.load(open("gpurun_out/miopen_db_$run.json"))
+print("$run", "first warm-up edit:", d["config"]["first_warmup_edit_s"], "s; timed edit:", d["ms_per_step"], "ms")
+PY
+done
+du -sh "$GD_MIOPEN_DB"; find "$GD_MIOPEN_DB" -type f | head -20

@@ -329,7 +329,7 @@ class _EditLayer(torch.autograd.Function):
             rm = torch.zeros(1, dtype=torch.float32, device=dev)
             if R > 0:
                 Pb = ops.attn_probs(q_base, k_base, lse_van[b0 * f:b1 * f], None, scale)     # base_att (:307-317)
-                Pe = ops.attn_probs(q_edit, K, lse_e, c["rows"], scale)                      # replace_att[:, inpaint rows]
+                Pe = ops.attn_probs(q_edit, K, lse_e, c["rows"], scale, n_valid=c.get("n_rows"))   # replace_att[:, inpaint rows]
                 aux, rm = ops.removal_fwd(Pe, Pb, c["m_inp"], c["m_wo"], c["rows"], S, n_valid=c.get("n_rows"))
                 ctrl._last_removal_aux = aux          # diagnostics: arg-max indices / values of this layer
             use_amodal = (not remover) and N > 32 ** 2                                       # :479-480,596-597
@@ -388,7 +388,8 @@ class _EditLayer(torch.autograd.Function):
         dq = dq16
         if have_loss and Pe is not None:
             dq32 = torch.zeros(q_edit.shape, dtype=torch.float32, device=dev)
-            ops.removal_bwd(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], 1.0, gscale * rm_coef, m["scale"], dq32, dk32)
+            ops.removal_bwd(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], 1.0, gscale * rm_coef, m["scale"], dq32, dk32,
+                            n_valid=c.get("n_rows"))
             dq = (dq16.float() + dq32).to(dt)
         grad_q = torch.zeros(m["q_shape"], dtype=dt, device=dev)
         grad_q[m["e0"] * f:m["e1"] * f] = dq

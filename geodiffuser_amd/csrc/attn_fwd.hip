@@ -447,6 +447,7 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
 // ---------------------------------------------------------------------------------------------------
 struct ProbsArgs {
     const void* q; const void* k; const float* lse; const int32_t* rows; void* P;
+    const int32_t* n_valid;       // device scalar: rows [n_valid, R) are padding of the row list and are not computed (NULL: all R)
     int N, R, M, Mpad, tiles, nwg;
     float c;      // scale * log2(e)
     float l2e;
@@ -465,6 +466,7 @@ k_attn_probs(const ProbsArgs a) {
     const int wg = xcd_remap(blockIdx.x, a.nwg);
     const int bh = wg / a.tiles, tile = wg - bh * a.tiles;
     const int N = a.N, M = a.M, R = a.R;
+    if (a.n_valid && tile * ATT_BM >= a.n_valid[0]) return;       // a tile of padding slots only
     const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * D;
     const T* __restrict__ kp = (const T*)a.k + (size_t)bh * M * D;
     T* __restrict__ Pp = (T*)a.P + (size_t)bh * R * a.Mpad;
@@ -532,7 +534,7 @@ k_attn_probs(const ProbsArgs a) {
     }
 }
 
-extern "C" int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t* rows,
+extern "C" int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t* rows, const int32_t* n_valid_dev,
                              int BH, int N, int R, int M, int Mpad, int D, float scale, void* P, int dtype, void* stream) {
     GD_REQUIRE(q && k && lse && P, GD_EINVAL, "gd_attn_probs: null pointer");
     GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED, "gd_attn_probs: head dim %d unsupported (64, 128, 192)", D);
@@ -540,7 +542,7 @@ extern "C" int gd_attn_probs(const void* q, const void* k, const float* lse, con
                "gd_attn_probs: bad sizes (Mpad must be a multiple of 8 and >= M)");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_probs: dtype must be f16/bf16");
     ProbsArgs a;
-    a.q = q; a.k = k; a.lse = lse; a.rows = rows; a.P = P;
+    a.q = q; a.k = k; a.lse = lse; a.rows = rows; a.P = P; a.n_valid = n_valid_dev;
     a.N = N; a.R = R; a.M = M; a.Mpad = Mpad;
     a.tiles = (R + ATT_BM - 1) / ATT_BM;
     a.nwg = a.tiles * BH;

@@ -17,6 +17,7 @@
 
 struct CorrArgs {
     const void* Pe; const void* Pb; const float* m_inp; const float* m_wo; unsigned long long* best;
+    const int32_t* n_valid;       // device scalar: rows [n_valid, R) of Pe are padding slots (not computed, `best` stays 0); NULL: all R
     int H, R, N, Mpad, rtiles, jtiles;
 };
 
@@ -49,6 +50,7 @@ k_corr_max(const CorrArgs a) {
     const int hd = blockIdx.y;
     const int jt = blockIdx.x / a.rtiles, rt = blockIdx.x - jt * a.rtiles;
     const int j0 = jt * CM_T, r0 = rt * CM_T;
+    if (a.n_valid && r0 >= a.n_valid[0]) return;
     const T* __restrict__ pb = (const T*)a.Pb + (size_t)hd * a.N * a.Mpad;
     const T* __restrict__ pe = (const T*)a.Pe + (size_t)hd * a.R * a.Mpad;
 
@@ -126,13 +128,13 @@ k_corr_max(const CorrArgs a) {
     }
 }
 
-extern "C" int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo,
+extern "C" int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
                                    int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream) {
     GD_REQUIRE(Pe && Pb && m_inp && m_wo && best, GD_EINVAL, "gd_removal_corr_max: null pointer");
     GD_REQUIRE(H > 0 && R > 0 && N > 0 && Mpad > 0 && (Mpad & 7) == 0, GD_EINVAL, "gd_removal_corr_max: bad sizes");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_corr_max: dtype must be f16/bf16");
     CorrArgs a;
-    a.Pe = Pe; a.Pb = Pb; a.m_inp = m_inp; a.m_wo = m_wo; a.best = best;
+    a.Pe = Pe; a.Pb = Pb; a.m_inp = m_inp; a.m_wo = m_wo; a.best = best; a.n_valid = n_valid_dev;
     a.H = H; a.R = R; a.N = N; a.Mpad = Mpad;
     a.rtiles = (R + CM_T - 1) / CM_T;
     a.jtiles = (N + CM_T - 1) / CM_T;
@@ -201,6 +203,7 @@ struct RmBwdArgs {
     const float* p_in; const int32_t* j_in; const float* p_wo; const int32_t* j_wo; const float* wgt;
     const float* m_inp; const float* m_wo; float coef; const float* gscale;
     int H, R, N, M, Mpad, D; float scale; float* dq; float* dk; float* ds_ws; const float* rowdot; float* dq_part;
+    const int32_t* n_valid;       // device scalar: slots [n_valid, R) of the row list are padding (weight 0) and are skipped; NULL: all R
 };
 
 // rowdot[h, r] = sum_m A[h,r,m] * dA[h,r,m]   (one wave per inpaint row; feeds the softmax backward below)
@@ -212,6 +215,7 @@ k_removal_rowdot(const RmBwdArgs a, float* __restrict__ rowdot) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.H * a.R) return;
     const int hd = row / a.R, r = row - hd * a.R;
+    if (a.n_valid && r >= a.n_valid[0]) return;
     const float cf = a.gscale ? a.coef * a.gscale[0] : a.coef;
     const int ji = a.j_in[row], jw = a.j_wo[row];
     const float cw = -cf * a.wgt[row] * a.m_wo[jw] / (a.p_wo[row] + 1e-4f);
@@ -243,6 +247,8 @@ k_removal_bwd(const RmBwdArgs a) {
     const int mc = wb % msplit; wb /= msplit;
     const int m_lo = mc * RM_MCH, m_hi = (m_lo + RM_MCH) < a.M ? (m_lo + RM_MCH) : a.M;
     const int hd = wb / blocks_per_head, r0 = (wb - hd * blocks_per_head) * RM_RB;
+    const int nv = a.n_valid ? (a.n_valid[0] < a.R ? a.n_valid[0] : a.R) : a.R;      // live slots of the row list
+    if (r0 >= nv) return;
     const float cf = a.gscale ? a.coef * a.gscale[0] : a.coef;
     const T* __restrict__ kp = (const T*)a.k + (size_t)hd * a.M * a.D + dch * ATT_D;
     const T* pe[RM_RB]; const T* pbw[RM_RB]; const T* pbi[RM_RB];
@@ -250,8 +256,8 @@ k_removal_bwd(const RmBwdArgs a) {
     int qrow[RM_RB];
 #pragma unroll
     for (int i = 0; i < RM_RB; ++i) {
-        const int r = (r0 + i) < a.R ? (r0 + i) : (a.R - 1);
-        const bool live = (r0 + i) < a.R;
+        const int r = (r0 + i) < nv ? (r0 + i) : (nv - 1);
+        const bool live = (r0 + i) < nv;
         const int row = hd * a.R + r;
         const int ji = a.j_in[row], jw = a.j_wo[row];
         qrow[i] = a.rows[r];
@@ -273,7 +279,7 @@ k_removal_bwd(const RmBwdArgs a) {
                 const float A = TR::to_f32(pe[i][m]);
                 ds[i] = A * (cw[i] * TR::to_f32(pbw[i][m]) + ci[i] * TR::to_f32(pbi[i][m]) - dot[i]) * a.scale;
             }
-            if (a.ds_ws && dch == 0 && (r0 + i) < a.R && m < m_hi) a.ds_ws[((size_t)hd * a.R + r0 + i) * a.Mpad + m] = ds[i];
+            if (a.ds_ws && dch == 0 && (r0 + i) < nv && m < m_hi) a.ds_ws[((size_t)hd * a.R + r0 + i) * a.Mpad + m] = ds[i];
         }
         // 16 key rows of K in flight at a time (a load-use chain per key made this loop latency-bound); keys past the chunk
         // end have dS = 0, their (clamped) K rows contribute nothing
@@ -296,7 +302,7 @@ k_removal_bwd(const RmBwdArgs a) {
     // per-(key chunk) partial of dq; the chunks of a row are summed in index order by k_removal_dq_fold (no f32 atomics: bit-reproducible)
 #pragma unroll
     for (int i = 0; i < RM_RB; ++i)
-        if ((r0 + i) < a.R) a.dq_part[(((size_t)mc * a.H + hd) * a.R + r0 + i) * a.D + dch * ATT_D + lane] = acc[i];
+        if ((r0 + i) < nv) a.dq_part[(((size_t)mc * a.H + hd) * a.R + r0 + i) * a.D + dch * ATT_D + lane] = acc[i];
 }
 
 // dq[h, rows[r], :] += sum_c dq_part[c, h, r, :]  (c ascending).  Padding slots of the row list (weight 0, contribution exactly 0) are
@@ -316,12 +322,13 @@ __global__ void k_removal_dq_fold(const float* __restrict__ dq_part, const int32
 // dk[h, m, d] += sum_r dS[h, r, m] * q[h, rows[r], d]   (cross-attention: few keys; one thread per (m, d) of a head)
 template <typename T>
 __global__ void k_removal_dk(const float* __restrict__ ds_ws, const T* __restrict__ q, const int32_t* __restrict__ rows,
-                             int R, int N, int M, int Mpad, int D, float* __restrict__ dk) {
+                             const int32_t* __restrict__ n_valid, int R_all, int N, int M, int Mpad, int D, float* __restrict__ dk) {
+    const int R = n_valid ? (n_valid[0] < R_all ? n_valid[0] : R_all) : R_all;      // padding slots hold no dS
     const int hd = blockIdx.y;
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= M * D) return;
     const int m = o / D, d = o - m * D;
-    const float* dsh = ds_ws + (size_t)hd * R * Mpad + m;
+    const float* dsh = ds_ws + (size_t)hd * R_all * Mpad + m;
     const T* qh = q + (size_t)hd * N * D + d;
     float acc[8];
 #pragma unroll
@@ -344,7 +351,7 @@ extern "C" size_t gd_removal_bwd_workspace_bytes(int H, int R, int M, int Mpad, 
 extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
                               const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
                               const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
-                              int H, int R, int N, int M, int Mpad, int D, float scale,
+                              const int32_t* n_valid_dev, int H, int R, int N, int M, int Mpad, int D, float scale,
                               float* dq_f32, float* dk_f32, float* ds_ws, int dtype, void* stream) {
     GD_REQUIRE(Pe && Pb && q && k && rows && p_in && j_in && p_wo && j_wo && wgt && m_inp && m_wo && dq_f32, GD_EINVAL,
                "gd_removal_bwd: null pointer");
@@ -353,7 +360,7 @@ extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, con
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_bwd: dtype must be f16/bf16");
     RmBwdArgs a;
     a.Pe = Pe; a.Pb = Pb; a.q = q; a.k = k; a.rows = rows; a.p_in = p_in; a.j_in = j_in; a.p_wo = p_wo; a.j_wo = j_wo;
-    a.wgt = wgt; a.m_inp = m_inp; a.m_wo = m_wo; a.coef = coef; a.gscale = gscale_dev; a.H = H; a.R = R; a.N = N; a.M = M; a.Mpad = Mpad; a.D = D;
+    a.wgt = wgt; a.m_inp = m_inp; a.m_wo = m_wo; a.coef = coef; a.gscale = gscale_dev; a.H = H; a.R = R; a.N = N; a.M = M; a.Mpad = Mpad; a.D = D; a.n_valid = n_valid_dev;
     GD_REQUIRE(ds_ws, GD_EINVAL, "gd_removal_bwd: workspace of gd_removal_bwd_workspace_bytes() required");
     // workspace: rowdot [H*R] | dq partials [msplit, H, R, D] | dS [H, R, Mpad] (only with dk_f32)
     const int msplit = (M + RM_MCH - 1) / RM_MCH;
@@ -371,8 +378,8 @@ extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, con
     k_removal_dq_fold<<<(H * R * D + 255) / 256, 256, 0, st>>>(a.dq_part, rows, wgt, msplit, H, R, N, D, dq_f32);
     if (dk_f32) {
         dim3 grid((M * D + 255) / 256, H);
-        if (dtype == GD_F16) k_removal_dk<f16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const f16_t*)q, rows, R, N, M, Mpad, D, dk_f32);
-        else k_removal_dk<bf16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const bf16_t*)q, rows, R, N, M, Mpad, D, dk_f32);
+        if (dtype == GD_F16) k_removal_dk<f16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const f16_t*)q, rows, n_valid_dev, R, N, M, Mpad, D, dk_f32);
+        else k_removal_dk<bf16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const bf16_t*)q, rows, n_valid_dev, R, N, M, Mpad, D, dk_f32);
     }
     GD_CHECK_LAUNCH("gd_removal_bwd");
     return GD_OK;

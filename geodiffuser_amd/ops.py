@@ -212,8 +212,9 @@ def attn_bwd_dkv(q, k, v, out, lse, dout, scale: float):
     return dk, dv
 
 
-def attn_probs(q, k, lse, rows: Optional[torch.Tensor], scale: float):
-    """-> P [BH, R, Mpad] 16-bit, Mpad = ceil8(M)."""
+def attn_probs(q, k, lse, rows: Optional[torch.Tensor], scale: float, n_valid: Optional[torch.Tensor] = None):
+    """-> P [BH, R, Mpad] 16-bit, Mpad = ceil8(M).  n_valid (device int32[1]): slots [n_valid, R) of ``rows`` are padding; whole
+    128-row tiles of padding are not computed (those rows of P stay uninitialised)."""
     lib = _lib.load()
     dt = _dt16(q, "q")
     _need(q, "q"); _need(k, "k", q.dtype); _need(lse, "lse", torch.float32)
@@ -224,7 +225,9 @@ def attn_probs(q, k, lse, rows: Optional[torch.Tensor], scale: float):
     if rows is not None:
         _need(rows, "rows", torch.int32)
     P = torch.empty(BH, R, Mpad, dtype=q.dtype, device=q.device)
-    check(lib.gd_attn_probs(_p(q), _p(k), _p(lse), _p(rows), BH, N, R, M, Mpad, D, scale, _p(P), dt, _stream()), "gd_attn_probs")
+    if n_valid is not None:
+        _need(n_valid, "n_valid", torch.int32)
+    check(lib.gd_attn_probs(_p(q), _p(k), _p(lse), _p(rows), _p(n_valid), BH, N, R, M, Mpad, D, scale, _p(P), dt, _stream()), "gd_attn_probs")
     return P
 
 
@@ -241,7 +244,7 @@ def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int, n_valid=None):
     N = Pb.shape[1]
     dev = Pe.device
     best = torch.empty(H, R, 2, dtype=torch.int64, device=dev)
-    check(lib.gd_removal_corr_max(_p(Pe), _p(Pb), _p(m_inp), _p(m_wo), H, R, N, Mpad, _p(best), dt, _stream()), "gd_removal_corr_max")
+    check(lib.gd_removal_corr_max(_p(Pe), _p(Pb), _p(m_inp), _p(m_wo), _p(n_valid), H, R, N, Mpad, _p(best), dt, _stream()), "gd_removal_corr_max")
     p_in = torch.empty(H, R, dtype=torch.float32, device=dev); p_wo = torch.empty_like(p_in); wgt = torch.empty_like(p_in)
     j_in = torch.empty(H, R, dtype=torch.int32, device=dev); j_wo = torch.empty_like(j_in)
     loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -250,7 +253,7 @@ def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int, n_valid=None):
     return dict(p_in=p_in, j_in=j_in, p_wo=p_wo, j_wo=j_wo, wgt=wgt), loss
 
 
-def removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, scale: float, dq_f32, dk_f32):
+def removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, scale: float, dq_f32, dk_f32, n_valid=None):
     lib = _lib.load()
     dt = _dt16(Pe, "Pe")
     H, R, Mpad = Pe.shape
@@ -260,7 +263,7 @@ def removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, scale
     ds_ws = torch.empty(lib.gd_removal_bwd_workspace_bytes(H, R, M, Mpad, D, int(dk_f32 is not None)) // 4, dtype=torch.float32,
                         device=Pe.device)
     check(lib.gd_removal_bwd(_p(Pe), _p(Pb), _p(q), _p(k), _p(rows), _p(aux["p_in"]), _p(aux["j_in"]), _p(aux["p_wo"]),
-                             _p(aux["j_wo"]), _p(aux["wgt"]), _p(m_inp), _p(m_wo), coef, _p(gscale), H, R, N, M, Mpad, D, scale,
+                             _p(aux["j_wo"]), _p(aux["wgt"]), _p(m_inp), _p(m_wo), coef, _p(gscale), _p(n_valid), H, R, N, M, Mpad, D, scale,
                              _p(dq_f32), _p(dk_f32), _p(ds_ws), dt, _stream()), "gd_removal_bwd")
 
 

@@ -163,8 +163,10 @@ int gd_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* out
 /* P[bh, r, m] = exp(scale * q[bh, rows[r]] . k[bh, m] - lse[bh, rows[r]])   (rows == NULL: r = row)
  * The opt-pass materialisation of base_att / replace_att rows that removal_loss_geodiff consumes
  * (U/attention_processors.py:250, 307-317).  P is 16-bit [BH, R, Mpad], Mpad = multiple of 8 >= M,
- * padding columns are written as 0. */
-int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t* rows,
+ * padding columns are written as 0.  n_valid_dev (DEVICE int32[1], may be NULL = R): only rows[0 .. n_valid) are wanted — the rest of
+ * the list is padding that keeps launch dimensions identical across edits; 128-row tiles made of padding only are skipped (their P
+ * rows stay unwritten and are not read by gd_removal_corr_max / gd_removal_bwd given the same n_valid_dev).  D: 64, 128 or 192. */
+int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t* rows, const int32_t* n_valid_dev,
                   int BH, int N, int R, int M, int Mpad, int D, float scale, void* P, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -176,9 +178,10 @@ int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t*
  *   corr[h,r,j] = sum_m Pe[h,r,m] * Pb[h,j,m];  (p_in,j_in) = max_j corr*m_inp[j];  (p_wo,j_wo) = max_j corr*m_wo[j]
  * Pe [H,R,Mpad], Pb [H,N,Mpad] 16-bit (gd_attn_probs); m_inp, m_wo [N] f32.
  * best [H,R,2] u64 scratch: (value bits << 32 | ~j) for the inpaint / wo-edit mask (first index wins ties);
- * it is cleared by the call and unpacked by gd_removal_loss_reduce.
+ * it is cleared by the call and unpacked by gd_removal_loss_reduce.  n_valid_dev (DEVICE int32[1] or NULL): 128-row tiles of Pe at or
+ * beyond n_valid are padding and are skipped (their `best` stays 0).
  */
-int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo,
+int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
                         int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream);
 
 /* Unpacks best -> p_in,p_wo [H,R] f32, j_in,j_wo [H,R] i32, writes wgt[h,r] = exp(-dist(rows[r], j_wo)) and
@@ -196,13 +199,14 @@ int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, 
  *   dA[h,r,m] = coef * wgt[h,r] * ( -Pb[h,j_wo,m] * m_wo[j_wo]/(p_wo+1e-4) + Pb[h,j_in,m] * m_inp[j_in]/(p_in+1e-4) )
  *   dS = A o (dA - rowsum(A o dA));  dq[h,rows[r]] += scale * dS K;  dk_f32[h] += scale * dS^T q   (dk_f32 may be NULL)
  * dq_f32 [H,N,D] f32 accumulated (caller zeroes).  ds_ws: scratch of gd_removal_bwd_workspace_bytes() bytes (row dots, per-key-chunk dq partials that are folded in a fixed order — no f32 atomics, bit-reproducible — and dS when dk_f32 != NULL).  gscale_dev: optional DEVICE scalar multiplied into coef (the
- * upstream gradient of the loss, so that no host sync is needed to read it).
+ * upstream gradient of the loss, so that no host sync is needed to read it).  n_valid_dev (DEVICE int32[1] or NULL): slots
+ * [n_valid, R) of the row list are padding and are skipped.
  */
 size_t gd_removal_bwd_workspace_bytes(int H, int R, int M, int Mpad, int D, int need_dk);
 int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
                    const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
                    const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
-                   int H, int R, int N, int M, int Mpad, int D, float scale,
+                   const int32_t* n_valid_dev, int H, int R, int N, int M, int Mpad, int D, float scale,
                    float* dq_f32, float* dk_f32, float* ds_ws, int dtype, void* stream);
 
 /*

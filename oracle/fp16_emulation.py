@@ -104,7 +104,43 @@ def unet_pass(R, prepare=None):
         return pipe.unet(torch.from_numpy(x), 500, encoder_hidden_states=torch.from_numpy(ctx))["sample"], pipe
 
 
+def vpred_loop():
+    """The same yardstick for the v-prediction remover loop (BASELINE configs[3]; there is no reference driver for it, so the fp32 side
+    is the oracle loop oracle/ref_loop.py, pinned to the reference's driver for epsilon models by G18-G20)."""
+    import ref_loop
+    from geodiffuser_amd.pipeline import build_random_sd21
+    c = cases.LOOP
+    inp = cases.loop_inputs(c)
+
+    def run(dtype):
+        pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=True)
+        if dtype is not None:
+            emulate_16bit(dtype)(pipe)
+        tok = pipe.tokenizer
+        ids = tok(["", ""], padding="max_length", max_length=tok.model_max_length, return_tensors="pt").input_ids
+        with torch.no_grad():
+            emb = pipe.text_encoder(ids)[0]
+        co = ref_loop.make_controller("geometry_remover", inp["mask"], c)
+        lat, _ = ref_loop.text2image_loop(
+            pipe.unet, emb, emb, co, torch.from_numpy(inp["x_T"]), [torch.from_numpy(a) for a in inp["ddim_latents"]],
+            torch.from_numpy(inp["coords"]), torch.from_numpy(inp["mask"]), num_steps=c["steps"], guidance_scale=c["guidance"],
+            skip_optim_steps=c["skip_optim"], optimize_steps=c["optimize_steps"], latent_replace=c["latent_replace"], lr=c["lr"],
+            edit_type="geometry_remover", prediction_type="v_prediction")
+        return lat
+
+    ref = run(None)
+    return dict(emulated_fp16=rel_l2(run(torch.float16)[-1:], ref[-1:]), emulated_bf16=rel_l2(run(torch.bfloat16)[-1:], ref[-1:]))
+
+
 def main():
+    path = os.path.join(ROOT, "tests", "golden", "fp16_emulation.json")
+    if "--vpred-only" in sys.argv:                 # add / refresh only the v-prediction entry of the committed table
+        torch.set_num_threads(8)
+        out = json.load(open(path))
+        out["vpred_remover_loop"] = vpred_loop()
+        print("v-prediction remover loop: ideal 16-bit storage vs fp32 (oracle loop):", out["vpred_remover_loop"])
+        json.dump(out, open(path, "w"), indent=1)
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_import.import_reference()
@@ -138,6 +174,7 @@ def main():
         out[fixture] = e
         rows.append((name, e))
         print(name, e, flush=True)
+    out["vpred_remover_loop"] = vpred_loop()
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "fp16_emulation.json"), "w"), indent=1)
     print("\n| loop fixture | fp32 re-run | fp32, x_T perturbed 1e-6 | fp16 storage emulated (UNet) | + 16-bit probabilities | bf16 (UNet) | + probabilities |")
     print("|---|---|---|---|---|---|---|")

@@ -547,6 +547,25 @@ def test_removal_loss_nan_rows_keep_indices_valid(ops):
     ops.removal_bwd(ok, Pb, q, k, rows, aux1, m_inp, m_wo, 1.0, None, 0.125, d1, None)
     ops.removal_bwd(ok_p, Pb, q, k, rows_p, aux2, m_inp, m_wo, 1.0, None, 0.125, d2, None)
     assert rel_err(d2.cpu(), d1.cpu()) < 1e-5
+    # ... and with n_valid handed to every kernel the padding slots are not even computed: a list padded to 3 tiles of 128 whose padding
+    # rows of P are NaN garbage (as left behind by a skipped tile) gives the same loss, indices and gradients, dK included
+    pad = 3 * 128 - R
+    nv = torch.tensor([R], dtype=torch.int32, device=DEV)
+    rows_p = torch.cat([rows, rows[:1].expand(pad)]).contiguous()
+    Pm = ops.attn_probs(q, k, torch.zeros(H, N, device=DEV), rows_p, 0.125, n_valid=nv)
+    assert Pm.shape == (H, 3 * 128, N)
+    ok_p = torch.cat([ok, torch.full((H, pad, N), float("nan"), device=DEV, dtype=ok.dtype)], 1).contiguous()
+    aux3, loss3 = ops.removal_fwd(ok_p, Pb, m_inp, m_wo, rows_p, S, n_valid=nv)
+    assert torch.allclose(loss1, loss3, rtol=1e-6) and torch.equal(aux1["j_in"], aux3["j_in"][:, :R]) and torch.equal(aux1["p_wo"], aux3["p_wo"][:, :R])
+    k77 = torch.randn(H, 77, 64, device=DEV).half()
+    Pb77 = torch.softmax(torch.randn(H, N, 80, device=DEV), -1).half(); ok77 = torch.softmax(torch.randn(H, R, 80, device=DEV), -1).half()
+    ok77_p = torch.cat([ok77, torch.full((H, pad, 80), float("nan"), device=DEV, dtype=ok.dtype)], 1).contiguous()
+    a1, _ = ops.removal_fwd(ok77, Pb77, m_inp, m_wo, rows, S)
+    a3, _ = ops.removal_fwd(ok77_p, Pb77, m_inp, m_wo, rows_p, S, n_valid=nv)
+    g1 = [torch.zeros(H, N, 64, device=DEV), torch.zeros(H, 77, 64, device=DEV)]; g3 = [torch.zeros_like(g1[0]), torch.zeros_like(g1[1])]
+    ops.removal_bwd(ok77, Pb77, q, k77, rows, a1, m_inp, m_wo, 1.0, None, 0.125, g1[0], g1[1])
+    ops.removal_bwd(ok77_p, Pb77, q, k77, rows_p, a3, m_inp, m_wo, 1.0, None, 0.125, g3[0], g3[1], n_valid=nv)
+    assert rel_err(g3[0].cpu(), g1[0].cpu()) < 1e-5 and torch.isfinite(g3[1]).all() and rel_err(g3[1].cpu(), g1[1].cpu()) < 1e-5
 
 
 def test_ddim_and_latent_update(ops):

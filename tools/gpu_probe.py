@@ -48,7 +48,7 @@ for (BH, N, M) in ((2, 256, 256), (2, 1024, 77)):
     Mpad = (M + 7) // 8 * 8
     rows = torch.arange(5, N, 3, device=dev, dtype=torch.int32); R = rows.numel()
     Pm = torch.full((BH, R, Mpad), -1, device=dev, dtype=dtype)
-    rc = lib.gd_attn_probs(P(q), P(k), P(lse), P(rows), BH, N, R, M, Mpad, 64, ctypes.c_float(0.125), P(Pm), 0, None)
+    rc = lib.gd_attn_probs(P(q), P(k), P(lse), P(rows), None, BH, N, R, M, Mpad, 64, ctypes.c_float(0.125), P(Pm), 0, None)
     assert rc == 0, lib.gd_last_error()
     torch.cuda.synchronize()
     s = torch.einsum("bnd,bmd->bnm", q.float(), k.float()) * 0.125

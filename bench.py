@@ -350,6 +350,8 @@ def main():
     ap.add_argument("--kind", default="rotate", choices=["rotate", "translate", "mixed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="narrow model (debug only; the result is not a benchmark number)")
+    ap.add_argument("--model", default="sd21", choices=["sd21", "sdxl"],
+                    help="sd21 = BASELINE configs[1] (the benchmark); sdxl = SDXL-base-shaped UNet, use with --size 1024 (configs[4] shape, bf16 path)")
     args = ap.parse_args()
 
     # Let MIOpen time its convolution solvers per shape during the warm-up edit instead of taking the heuristic pick (which
@@ -372,10 +374,11 @@ def main():
     _lib.load()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     editor.DEVICE = torch.device(dev)
-    pipe, tok, sched = load_model(device=dev, dtype=dtype, tiny=args.tiny)
+    pipe, tok, sched = load_model("stabilityai/stable-diffusion-xl-base-1.0" if args.model == "sdxl" else "stabilityai/stable-diffusion-2-1-base",
+                                  device=dev, dtype=dtype, tiny=args.tiny)
     nbytes = gdist.broadcast_model([pipe.unet, pipe.vae, pipe.text_encoder], src=0)
 
-    timer = AttnTimer((args.size // 8) ** 2)
+    timer = AttnTimer((args.size // (16 if args.model == "sdxl" else 8)) ** 2)      # the largest hooked self-attention layer
     timer.install()
     def one_edit(j):
         image, depth, mask, T = make_edit(j * world + rank, size=args.size, kind=args.kind)
@@ -418,12 +421,16 @@ def main():
         value = args.steps * world / elapsed
         roof = timer.summary()
         line = {
-            "metric": "geometry edits/sec (512^2, 50-step DDIM, SD2.1)", "value": value, "unit": "edits/sec",
+            "metric": "geometry edits/sec (512^2, 50-step DDIM, SD2.1)" if args.model == "sd21" else f"geometry edits/sec ({args.size}^2, SDXL shape)",
+            "value": value, "unit": "edits/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"configs[1]: single {args.size}x{args.size} image, 3-D {args.kind} edit, {args.ddim_steps}-step DDIM "
-                                   f"inversion + edit (17 optimisation passes), SD2.1-base-shaped UNet/VAE/text-encoder, random-init, "
-                                   f"one edit per GPU", "edits_per_min": 60.0 * value, "weights_broadcast_bytes": nbytes,
+            "config": {"workload": (f"configs[1]: single {args.size}x{args.size} image, 3-D {args.kind} edit, {args.ddim_steps}-step DDIM "
+                                    f"inversion + edit (17 optimisation passes), SD2.1-base-shaped UNet/VAE/text-encoder, random-init, "
+                                    f"one edit per GPU") if args.model == "sd21" else
+                                   (f"configs[4] shape on the bf16 path: single {args.size}x{args.size} image, 3-D {args.kind} edit, "
+                                    f"{args.ddim_steps}-step DDIM inversion + edit, SDXL-base-shaped UNet (2.57 B parameters) / two text towers / "
+                                    f"VAE, random-init, one edit per GPU"), "edits_per_min": 60.0 * value, "weights_broadcast_bytes": nbytes,
                        "tiny_debug_model": bool(args.tiny),
                        # multi-GPU reporting: seconds of the timed region on every rank (value uses their max) and of each rank's
                        # FIRST warm-up edit (solver search unless the find-db has the shapes, graph captures, allocator growth)

@@ -138,7 +138,11 @@ def load_model(diffusion_model="stabilityai/stable-diffusion-2-1-base", unet_pat
         pipe.unet.set_attn_processor(VanillaAttentionProcessor())
         pipe.unet.eval()
         return pipe, pipe.tokenizer, pipe.scheduler
-    pipe = build_random_sd21(device=device, dtype=dtype, tiny=tiny)
+    if "xl" in str(diffusion_model).lower():                       # SDXL-base shape (BASELINE configs[4]); 1024^2 micro-conditioning
+        from .pipeline import build_random_sdxl
+        pipe = build_random_sdxl(device=device, dtype=dtype, tiny=tiny)
+    else:
+        pipe = build_random_sd21(device=device, dtype=dtype, tiny=tiny)
     if prediction_type not in (None, "epsilon"):
         pipe.scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                                        set_alpha_to_one=False, prediction_type=prediction_type)

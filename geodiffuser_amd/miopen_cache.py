@@ -31,4 +31,10 @@ def configure(path: str = None, per_rank_copy: bool = True) -> str:
         shutil.copytree(src, use, dirs_exist_ok=True)
     os.environ["MIOPEN_USER_DB_PATH"] = use
     os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(use, "cache"))
+    # Keep MIOpen's reference ("naive") direct convolutions out of the search: they are 1000x slower than the implicit-GEMM solvers on
+    # these shapes (34 ms vs 33 us), each costs the search seconds, and — decisive for persistence — a find-db record that lists a solver
+    # whose compiled kernel is not in the kernel cache is thrown away and regenerated ("Kernel cache entry not found for solver:
+    # ConvDirectNaiveConvFwd ... Find-db regenerating", MIOPEN_LOG_LEVEL=6), and the naive kernels are never in the cache.
+    for k in ("FWD", "BWD", "WRW"):
+        os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + k, "0")
     return use

@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .scheduler import DDIMScheduler
-from .unet_sd21 import GroupNormAct, UNet2DConditionModel, tiny_unet
+from .unet_sd21 import GroupNormAct, UNet2DConditionModel, sdxl_unet, tiny_unet
 
 
 # ------------------------------------------------------------------------------------------------ tokenizer
@@ -70,6 +70,25 @@ class TextEncoder(nn.Module):
         for l in self.layers:
             x = l(x, mask)
         return (self.ln_f(x),)
+
+
+class DualTextEncoder(nn.Module):
+    """SDXL's two text towers behind the one ``text_encoder(ids)[0]`` call the reference's drivers make (U/editor.py:156-163): the
+    context is the two towers' hidden states concatenated on the feature axis (768 + 1280 = 2048); the second tower's pooled output
+    (its EOS position, projected) is kept in ``last_pooled`` for the UNet's text_time embedding."""
+
+    def __init__(self, width_1=768, layers_1=12, heads_1=12, width_2=1280, layers_2=32, heads_2=20):
+        super().__init__()
+        self.encoder_1 = TextEncoder(width_1, layers_1, heads_1)
+        self.encoder_2 = TextEncoder(width_2, layers_2, heads_2)
+        self.text_projection = nn.Linear(width_2, width_2, bias=False)
+        self.last_pooled = None
+
+    def forward(self, input_ids):
+        h1, h2 = self.encoder_1(input_ids)[0], self.encoder_2(input_ids)[0]
+        eos = (input_ids == SimpleTokenizer.eos).float().argmax(dim=1)
+        self.last_pooled = self.text_projection(h2[torch.arange(h2.shape[0], device=h2.device), eos])
+        return (torch.cat([h1, h2], dim=-1), self.last_pooled)
 
 
 # ------------------------------------------------------------------------------------------------ VAE
@@ -188,3 +207,39 @@ def build_random_sd21(device="cuda:0", dtype=torch.float16, seed=1234, tiny=Fals
             p.requires_grad_(False)
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)
     return StableDiffusionPipeline(unet, vae, te, SimpleTokenizer(), sched, device)
+
+
+def build_random_sdxl(device="cuda:0", dtype=torch.float16, seed=4321, tiny=False, image_size=1024) -> StableDiffusionPipeline:
+    """Seeded random-init SDXL-base-shaped model (BASELINE configs[4]; the reference's own SDXL line is commented out,
+    U/diffusion.py:106): UNet ``sdxl_unet``, two text towers behind one ``text_encoder`` call, the VAE of the SD family with SDXL's scaling
+    factor.  The UNet's text_time conditioning defaults to the pooled embedding of the empty prompt and the micro-conditioning ids
+    (original size, crop 0, target size) of an un-cropped ``image_size`` square — every driver of the reference edits with the empty
+    prompt; pass ``added_cond_kwargs`` to the UNet for anything else."""
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        if tiny:
+            te = DualTextEncoder(32, 2, 2, 64, 2, 2)
+            unet = sdxl_unet(tiny=True, ctx_dim=96, text_embed_dim=64)
+            vae = AutoencoderKL(ch=(32, 32, 64, 64), scaling_factor=0.13025)
+        else:
+            te = DualTextEncoder()
+            unet = sdxl_unet()
+            vae = AutoencoderKL(scaling_factor=0.13025)
+    finally:
+        torch.random.set_rng_state(g)
+    import os
+    cl = os.environ.get("GD_CHANNELS_LAST", "1") == "1"
+    for m in (unet, vae, te):
+        m.to(device=device, dtype=dtype).eval()
+        if cl and m is not te:
+            m.to(memory_format=torch.channels_last)
+        for p in m.parameters():
+            p.requires_grad_(False)
+    tok = SimpleTokenizer()
+    with torch.no_grad():
+        te(tok([""]).input_ids.to(device))
+    unet.default_added_cond = (te.last_pooled.detach().clone(),
+                               torch.tensor([[image_size, image_size, 0, 0, image_size, image_size]], dtype=torch.float32, device=device))
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)
+    return StableDiffusionPipeline(unet, vae, te, tok, sched, device)

@@ -196,11 +196,11 @@ class BasicTransformerBlock(nn.Module):
 class Transformer2DModel(nn.Module):
     """use_linear_projection=True variant (SD2.x)."""
 
-    def __init__(self, channels, heads, dim_head, cross_attention_dim):
+    def __init__(self, channels, heads, dim_head, cross_attention_dim, depth=1):
         super().__init__()
         self.norm = GroupNormAct(32, channels, eps=1e-6)
         self.proj_in = nn.Linear(channels, channels)
-        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(channels, heads, dim_head, cross_attention_dim)])
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(channels, heads, dim_head, cross_attention_dim) for _ in range(depth)])
         self.proj_out = nn.Linear(channels, channels)
 
     def forward(self, x, ctx):
@@ -282,10 +282,10 @@ class Upsample2D(nn.Module):
 
 
 class DownBlock(nn.Module):
-    def __init__(self, cin, cout, heads, ctx_dim, n_layers=2, attn=True, down=True, temb_ch=1280):
+    def __init__(self, cin, cout, heads, ctx_dim, n_layers=2, attn=True, down=True, temb_ch=1280, depth=1):
         super().__init__()
         self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_ch) for i in range(n_layers)])
-        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cout // heads, ctx_dim) for _ in range(n_layers)]) if attn else None
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cout // heads, ctx_dim, depth) for _ in range(n_layers)]) if attn else None
         self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if down else None
 
     def forward(self, x, temb, ctx):
@@ -302,10 +302,10 @@ class DownBlock(nn.Module):
 
 
 class MidBlock(nn.Module):
-    def __init__(self, ch, heads, ctx_dim, temb_ch=1280):
+    def __init__(self, ch, heads, ctx_dim, temb_ch=1280, depth=1):
         super().__init__()
         self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb_ch), ResnetBlock2D(ch, ch, temb_ch)])
-        self.attentions = nn.ModuleList([Transformer2DModel(ch, heads, ch // heads, ctx_dim)])
+        self.attentions = nn.ModuleList([Transformer2DModel(ch, heads, ch // heads, ctx_dim, depth)])
 
     def forward(self, x, temb, ctx):
         x = self.resnets[0](x, temb)
@@ -314,7 +314,7 @@ class MidBlock(nn.Module):
 
 
 class UpBlock(nn.Module):
-    def __init__(self, cin, cout, prev, heads, ctx_dim, n_layers=3, attn=True, up=True, temb_ch=1280):
+    def __init__(self, cin, cout, prev, heads, ctx_dim, n_layers=3, attn=True, up=True, temb_ch=1280, depth=1):
         super().__init__()
         res = []
         for i in range(n_layers):
@@ -322,7 +322,7 @@ class UpBlock(nn.Module):
             r_in = prev if i == 0 else cout
             res.append(ResnetBlock2D(r_in + skip, cout, temb_ch))
         self.resnets = nn.ModuleList(res)
-        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cout // heads, ctx_dim) for _ in range(n_layers)]) if attn else None
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cout // heads, ctx_dim, depth) for _ in range(n_layers)]) if attn else None
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if up else None
 
     def forward(self, x, skips, temb, ctx):
@@ -359,25 +359,40 @@ class UNet2DConditionModel(nn.Module):
     processors (16 transformer blocks x {attn1, attn2})."""
 
     def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), heads=(5, 10, 20, 20),
-                 cross_attention_dim=1024, layers_per_block=2):
+                 cross_attention_dim=1024, layers_per_block=2, attn_levels=None, transformer_depth=None, mid_depth=None,
+                 addition_time_embed_dim=None, addition_text_embed_dim=None):
+        """Defaults: SD2.1-base.  SDXL-base (``sdxl_unet``): three levels (320, 640, 1280), attention on levels 1 and 2 only with 2 and
+        10 transformer blocks per Transformer2DModel, context 2048 (two text encoders), and the "text_time" additional embedding
+        (pooled text embedding + 6 micro-conditioning ids through a second TimestepEmbedding, added to the time embedding)."""
         super().__init__()
         ch = block_out_channels
+        L = len(ch)
+        attn_levels = tuple(attn_levels) if attn_levels is not None else tuple(i < L - 1 for i in range(L))
+        depth = tuple(transformer_depth) if transformer_depth is not None else (1,) * L
+        mid_depth = mid_depth if mid_depth is not None else depth[-1]
+        temb_ch = ch[0] * 4
         self.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
-        self.time_embedding = TimestepEmbedding(ch[0], ch[0] * 4)
+        self.time_embedding = TimestepEmbedding(ch[0], temb_ch)
+        self.add_time_dim = addition_time_embed_dim
+        if addition_time_embed_dim:
+            self.add_embedding = TimestepEmbedding(addition_text_embed_dim + 6 * addition_time_embed_dim, temb_ch)
+        self.default_added_cond = None         # (text_embeds [1 | B, E], time_ids [1 | B, 6]) used when the caller passes no added_cond_kwargs
         self.down_blocks = nn.ModuleList()
         cin = ch[0]
         for i, cout in enumerate(ch):
-            last = i == len(ch) - 1
-            self.down_blocks.append(DownBlock(cin, cout, heads[i], cross_attention_dim, layers_per_block, attn=not last, down=not last, temb_ch=ch[0] * 4))
+            last = i == L - 1
+            self.down_blocks.append(DownBlock(cin, cout, heads[i], cross_attention_dim, layers_per_block, attn=attn_levels[i], down=not last,
+                                              temb_ch=temb_ch, depth=depth[i]))
             cin = cout
-        self.mid_block = MidBlock(ch[-1], heads[-1], cross_attention_dim, temb_ch=ch[0] * 4)
+        self.mid_block = MidBlock(ch[-1], heads[-1], cross_attention_dim, temb_ch=temb_ch, depth=mid_depth)
         self.up_blocks = nn.ModuleList()
-        rev, rheads = list(reversed(ch)), list(reversed(heads))
+        rev, rheads, rattn, rdepth = list(reversed(ch)), list(reversed(heads)), list(reversed(attn_levels)), list(reversed(depth))
         prev = rev[0]
         for i, cout in enumerate(rev):
-            cin_skip = rev[min(i + 1, len(ch) - 1)]
-            last = i == len(ch) - 1
-            self.up_blocks.append(UpBlock(cin_skip, cout, prev, rheads[i], cross_attention_dim, layers_per_block + 1, attn=i > 0, up=not last, temb_ch=ch[0] * 4))
+            cin_skip = rev[min(i + 1, L - 1)]
+            last = i == L - 1
+            self.up_blocks.append(UpBlock(cin_skip, cout, prev, rheads[i], cross_attention_dim, layers_per_block + 1, attn=rattn[i], up=not last,
+                                          temb_ch=temb_ch, depth=rdepth[i]))
             prev = cout
         self.conv_norm_out = GroupNormAct(32, ch[0], eps=1e-5)
         self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
@@ -441,6 +456,16 @@ class UNet2DConditionModel(nn.Module):
         t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep], device=x.device)
         t = t.reshape(-1).to(x.device).expand(x.shape[0])
         temb = self.time_embedding(timestep_embedding(t, self.t_dim).to(dt))
+        if self.add_time_dim:                  # SDXL "text_time" conditioning (diffusers UNet2DConditionModel.get_aug_embed)
+            cond = kw.get("added_cond_kwargs") or self.default_added_cond
+            if cond is None:
+                raise ValueError("this UNet needs added_cond_kwargs={'text_embeds', 'time_ids'} (or unet.default_added_cond)")
+            text_embeds, time_ids = (cond["text_embeds"], cond["time_ids"]) if isinstance(cond, dict) else cond
+            B = x.shape[0]
+            text_embeds = text_embeds.to(x.device, dt).expand(B, -1) if text_embeds.shape[0] == 1 else text_embeds.to(x.device, dt)
+            time_ids = time_ids.to(x.device).expand(B, -1) if time_ids.shape[0] == 1 else time_ids.to(x.device)
+            tid = timestep_embedding(time_ids.reshape(-1), self.add_time_dim).reshape(B, -1).to(dt)
+            temb = temb + self.add_embedding(torch.cat([text_embeds, tid], dim=-1))
         if self.conv_in.weight.is_contiguous(memory_format=torch.channels_last) and not self.conv_in.weight.is_contiguous():
             x = x.contiguous(memory_format=torch.channels_last)
         if _fast(x, grad_ok=self._frozen()) and x.is_contiguous(memory_format=torch.channels_last):
@@ -457,6 +482,21 @@ class UNet2DConditionModel(nn.Module):
         if not return_dict:
             return (x,)
         return UNetOutput(sample=x)
+
+
+def sdxl_unet(tiny: bool = False, ctx_dim: int = None, text_embed_dim: int = None) -> UNet2DConditionModel:
+    """SDXL-base topology (public ``stabilityai/stable-diffusion-xl-base-1.0`` UNet config; NOT in /root/reference, whose SDXL line is
+    commented out, U/diffusion.py:106): block_out_channels (320, 640, 1280), head dim 64 (5 / 10 / 20 heads), attention on the two
+    lower levels only with 2 / 10 transformer blocks each (mid: 10), context 2048, text_time additional embedding (1280 + 6 x 256).
+    At 1024^2 (latent 128^2) the hooked attention layers sit at 64^2 tokens (10 heads) and 32^2 tokens (20 heads): shapes the D = 64
+    kernels already serve.  ``tiny``: same topology, narrow."""
+    if tiny:
+        return UNet2DConditionModel(block_out_channels=(64, 128, 128), heads=(1, 2, 2), cross_attention_dim=ctx_dim or 96,
+                                    attn_levels=(False, True, True), transformer_depth=(0, 1, 2), mid_depth=2,
+                                    addition_time_embed_dim=32, addition_text_embed_dim=text_embed_dim or 64)
+    return UNet2DConditionModel(block_out_channels=(320, 640, 1280), heads=(5, 10, 20), cross_attention_dim=ctx_dim or 2048,
+                                attn_levels=(False, True, True), transformer_depth=(0, 2, 10), mid_depth=10,
+                                addition_time_embed_dim=256, addition_text_embed_dim=text_embed_dim or 1280)
 
 
 def tiny_unet(ctx_dim=64) -> UNet2DConditionModel:

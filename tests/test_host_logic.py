@@ -177,3 +177,16 @@ def test_diffusion_step_with_a_foreign_scheduler():
     # 3-row shortcut (uncond_edit, cond_ref, cond_edit)
     got3 = diffusion_step(model, Ctrl(), lat, ctx, 500, g, skip_uncond_ref=True)
     assert torch.allclose(got3[1:], want[1:], atol=1e-6) and torch.equal(got3[:1], lat[:1])
+
+
+def test_sdxl_harness_topology():
+    """The SDXL-base-shaped UNet harness (BASELINE configs[4]): the public model's parameter count and attention-module census
+    (70 transformer blocks x {attn1, attn2}), built on the meta device (no memory)."""
+    from geodiffuser_amd.unet_sd21 import sdxl_unet
+    with torch.device("meta"):
+        u = sdxl_unet()
+    assert sum(p.numel() for p in u.parameters()) == 2_567_463_684
+    names = list(u.attn_processors)
+    assert len(names) == 140 and not any(n.startswith("down_blocks.0") or n.startswith("up_blocks.2") for n in names)
+    heads = {m.heads for _, m in u._attn_modules()}
+    assert heads == {10, 20}

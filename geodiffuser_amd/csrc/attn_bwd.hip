@@ -18,6 +18,10 @@ struct BwdArgs {
     void* dq; float* dk; float* dk_part;
     int N, M, tiles, nwg;
     float c, scale, l2e;
+    // dq with few workgroups: the key tiles are cut into kchunks ranges of tpc tiles (one workgroup each); the f32 partials
+    // dq_part [kchunks, BH, N, D] are summed in chunk order by k_attn_bwd_dq_fold (no atomics)
+    int kchunks, tpc;
+    float* dq_part;
 };
 
 template <typename T, int NCH>
@@ -29,7 +33,8 @@ k_attn_bwd_dq(const BwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2][2][NCH * ATT_TILE_BYTES];   // [buf][K|V][64-column chunk]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int wg = xcd_remap(blockIdx.x, a.nwg);
+    const int wg0 = xcd_remap(blockIdx.x, a.nwg);
+    const int kc = wg0 % a.kchunks, wg = wg0 / a.kchunks;
     const int bh = wg / a.tiles, tile = wg - bh * a.tiles;
     const int N = a.N, M = a.M;
     const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * D;
@@ -59,19 +64,21 @@ k_attn_bwd_dq(const BwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[j][i] = 0.f;
 
-    const int T_tiles = (M + ATT_BN - 1) / ATT_BN;
+    const int T_all = (M + ATT_BN - 1) / ATT_BN;
+    const int t_lo = kc * a.tpc;
+    const int T_tiles = (t_lo + a.tpc) < T_all ? (t_lo + a.tpc) : T_all;        // launcher: every chunk holds at least one tile
     u32x4 kr[NCH][2], vr[NCH][2];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        tile_load<T>(kp + ch * ATT_D, 0, M, tid, kr[ch], D);
-        tile_load<T>(vp + ch * ATT_D, 0, M, tid, vr[ch], D);
+        tile_load<T>(kp + ch * ATT_D, t_lo * ATT_BN, M, tid, kr[ch], D);
+        tile_load<T>(vp + ch * ATT_D, t_lo * ATT_BN, M, tid, vr[ch], D);
         tile_store(lds[0][0] + ch * ATT_TILE_BYTES, tid, kr[ch]);
         tile_store(lds[0][1] + ch * ATT_TILE_BYTES, tid, vr[ch]);
     }
     __syncthreads();
 
-    for (int t = 0; t < T_tiles; ++t) {
-        const int cur = t & 1;
+    for (int t = t_lo; t < T_tiles; ++t) {
+        const int cur = (t - t_lo) & 1;
         const bool more = (t + 1) < T_tiles;
         if (more) {
 #pragma unroll
@@ -124,6 +131,22 @@ k_attn_bwd_dq(const BwdArgs a) {
         }
         __syncthreads();
     }
+    if (a.kchunks > 1) {                 // f32 partial of this key range
+        if (qrow < N) {
+            const int n_bh = a.nwg / (a.kchunks * a.tiles);
+            float* __restrict__ pp = a.dq_part + (((size_t)kc * n_bh + bh) * N + qrow) * D;
+#pragma unroll
+            for (int dblk = 0; dblk < 2 * NCH; ++dblk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = dq[dblk][4 * g + j] * a.scale;
+                    *(f32x4*)(pp + dblk * 32 + 8 * g + 4 * h) = w;
+                }
+        }
+        return;
+    }
     if (qrow < N) {
         T* __restrict__ dp = (T*)a.dq + ((size_t)bh * N + qrow) * D;
 #pragma unroll
@@ -136,6 +159,34 @@ k_attn_bwd_dq(const BwdArgs a) {
                 *(typename TR::vec4*)(dp + dblk * 32 + 8 * g + 4 * h) = w;
             }
     }
+}
+
+// dq[i] = 16-bit( sum_c dq_part[c][i] ), c ascending (4 elements per thread)
+template <typename T>
+__global__ void k_attn_bwd_dq_fold(const float* __restrict__ part, int kchunks, long long n4, T* __restrict__ dq) {
+    using TR = elem_traits<T>;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 acc = *(const f32x4*)(part + i * 4);
+    for (int c = 1; c < kchunks; ++c) {
+        const f32x4 p = *(const f32x4*)(part + ((long long)c * n4 + i) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += p[j];
+    }
+    typename TR::vec4 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = TR::from_f32(acc[j]);
+    *(typename TR::vec4*)(dq + i * 4) = w;
+}
+
+// How many key ranges the dq kernel is cut into: launches under two workgroups per CU (5 heads x 32 query tiles at 64^2 = 160
+// workgroups of one wave per SIMD: 96 us, 13 % MFMA busy) are split until there are >= 512, keeping >= 8 key tiles per range.
+static int dq_kchunks(int BH, int N, int M) {
+    const long long wgs = (long long)((N + ATT_BM - 1) / ATT_BM) * BH;
+    const int t_all = (M + ATT_BN - 1) / ATT_BN;
+    int kc = 1;
+    while (wgs * kc < 512 && t_all / (kc * 2) >= 8 && kc < 8) kc *= 2;
+    return kc;
 }
 
 // ---- dK for cross-attention (M <= 128 keys) on the matrix cores ------------------------------------------
@@ -453,10 +504,16 @@ extern "C" int gd_attn_bwd_dkv(const void* q, const void* k, const void* v, cons
     return GD_OK;
 }
 
-extern "C" size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk) {
+// workspace: [dK partials (need_dk)] [dq partials (when the dq kernel is split over the keys)]
+static size_t bwd_dk_ws_bytes(int BH, int N, int M, int D, int need_dk) {
     if (!need_dk) return 0;
     const size_t chunks = (size_t)(N + DK_QCHUNK - 1) / DK_QCHUNK;
     return (size_t)BH * chunks * M * D * sizeof(float);
+}
+
+extern "C" size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk) {
+    const int kc = dq_kchunks(BH, N, M);
+    return bwd_dk_ws_bytes(BH, N, M, D, need_dk) + (kc > 1 ? (size_t)kc * BH * N * D * sizeof(float) : 0);
 }
 
 extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
@@ -468,17 +525,27 @@ extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const vo
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_bwd: dtype must be f16/bf16");
     GD_REQUIRE(!dk_f32 || M <= 128, GD_EUNSUPPORTED, "gd_attn_bwd: dK is only implemented for M <= 128 keys (cross-attention); M=%d", M);
     BwdArgs a;
-    GD_REQUIRE(!dk_f32 || (workspace && workspace_bytes >= gd_attn_bwd_workspace_bytes(BH, N, M, D, 1)), GD_EWORKSPACE,
-               "gd_attn_bwd: dK needs a workspace of gd_attn_bwd_workspace_bytes() bytes");
+    const size_t need_ws = gd_attn_bwd_workspace_bytes(BH, N, M, D, dk_f32 != nullptr);
+    GD_REQUIRE(need_ws == 0 || (workspace && workspace_bytes >= need_ws), GD_EWORKSPACE,
+               "gd_attn_bwd: needs a workspace of gd_attn_bwd_workspace_bytes() = %zu bytes", need_ws);
     a.q = q; a.k = k; a.v = v; a.o = out; a.lse = lse; a.dout = dout; a.dq = dq; a.dk = dk_f32; a.dk_part = (float*)workspace;
     a.N = N; a.M = M;
     a.tiles = (N + ATT_BM - 1) / ATT_BM;
-    a.nwg = a.tiles * BH;
+    a.kchunks = dq_kchunks(BH, N, M);
+    a.tpc = ((M + ATT_BN - 1) / ATT_BN + a.kchunks - 1) / a.kchunks;
+    a.dq_part = (float*)((char*)workspace + bwd_dk_ws_bytes(BH, N, M, D, dk_f32 != nullptr));
+    a.nwg = a.tiles * BH * a.kchunks;
     a.scale = scale;
     a.c = scale * 1.4426950408889634f;
     a.l2e = 1.4426950408889634f;
     hipStream_t st = as_stream(stream);
     GD_LAUNCH_NCH(k_attn_bwd_dq, a.nwg, a);
+    if (a.kchunks > 1) {
+        const long long n4 = (long long)BH * N * D / 4;
+        const int fb = (int)((n4 + 255) / 256);
+        if (dtype == GD_F16) k_attn_bwd_dq_fold<f16_t><<<fb, 256, 0, st>>>(a.dq_part, a.kchunks, n4, (f16_t*)dq);
+        else k_attn_bwd_dq_fold<bf16_t><<<fb, 256, 0, st>>>(a.dq_part, a.kchunks, n4, (bf16_t*)dq);
+    }
     if (dk_f32) {
         dim3 grid((N + DK_QCHUNK - 1) / DK_QCHUNK, BH);
         GD_LAUNCH_NCH(k_attn_bwd_dk, grid, a);

@@ -48,7 +48,11 @@ k_corr_max(const CorrArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int wj = wave >> 1, wr = wave & 1;
     const int hd = blockIdx.y;
-    const int jt = blockIdx.x / a.rtiles, rt = blockIdx.x - jt * a.rtiles;
+    // The r-tiles of one j-tile read the same 128 rows of Pb (1 MB at M = 4096).  Consecutive block ids land on DIFFERENT XCDs (round
+    // robin), each with its own L2, so without a remap every r-tile re-fetched its Pb rows from HBM (PMC: 539 MB fetched per launch against
+    // 194 MB of operands).  xcd_remap hands each XCD a contiguous range of logical ids, i.e. all r-tiles of a j-tile, dispatched together.
+    const int lid = xcd_remap(blockIdx.x, a.rtiles * a.jtiles);
+    const int jt = lid / a.rtiles, rt = lid - jt * a.rtiles;
     const int j0 = jt * CM_T, r0 = rt * CM_T;
     if (a.n_valid && r0 >= a.n_valid[0]) return;
     const T* __restrict__ pb = (const T*)a.Pb + (size_t)hd * a.N * a.Mpad;

@@ -142,8 +142,9 @@ int gd_attn_fwd_splitkv(const gd_attn_seg_t* segs, int nseg, int N, int M, int D
  *   dout [BH,N,D] 16-bit; lse from the forward; dq [BH,N,D] 16-bit (overwritten);
  *   dk_f32 [BH,M,D] f32, ACCUMULATED into (caller zeroes) — used by cross-attention where k_edit
  *   carries gradient (U/attention_processors.py:432).  v never receives gradient on this path
- *   (v_base.detach(), :433,557).  workspace: gd_attn_bwd_workspace_bytes() bytes when dk_f32 != NULL (per-chunk partials,
- *   summed without atomics), else NULL.
+ *   (v_base.detach(), :433,557).  workspace: gd_attn_bwd_workspace_bytes() bytes (may be 0 -> NULL): per-chunk dK partials when
+ *   dk_f32 != NULL, and f32 dQ partials per key range when a launch of few workgroups is split over the keys to fill the chip; both
+ *   are summed in a fixed order, without atomics.  D: 64, 128 or 192.
  */
 size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk);
 int gd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,

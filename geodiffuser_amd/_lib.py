@@ -48,6 +48,13 @@ SIGNATURES = {
     "gd_attn_bwd_dkv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gd_attn_bwd_dkv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "gd_fp8_absmax_heads": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "gd_fp8_quant_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p]),
+    "gd_fp8_quant_vt": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "gd_fp8_quantize_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_void_p]),
+    "gd_attn_fwd_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                c_void_p, c_void_p, c_int, c_void_p]),
     "gd_attn_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_float, c_void_p, c_int, c_void_p]),
     "gd_removal_corr_max": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -6,6 +6,8 @@ materialised unless a caller explicitly asks for one.
 """
 from __future__ import annotations
 
+import os
+
 import abc
 from typing import Optional
 
@@ -68,10 +70,21 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -
     return out
 
 
+# Opt-in (GD_ATTN_FP8=1, BASELINE configs[4]): vanilla no-grad self-attention on the fp8 matrix instruction.  An APPROXIMATION (e4m3 has 3
+# mantissa bits: ~5e-2 on an attention output against the 1e-3 of the 16-bit path); its parity contract is oracle/ref_cpu.py:
+# attention_fp8_oracle.  The hooked edit layers (warped queries, losses) always run the 16-bit kernels.
+FP8_ATTENTION = os.environ.get("GD_ATTN_FP8", "0") == "1"
+_LN2 = 0.6931471805599453
+
+
 def attention_tok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, heads: int, q_scaled: bool = False) -> torch.Tensor:
     """No-grad attention on the projections' own layout: q [B,N,heads*64], k/v [B,M,heads*64] -> [B,N,heads*64].
     q_scaled: q already carries scale*log2(e) (attention_processors._project_qkv)."""
     out = torch.empty_like(q)
+    if FP8_ATTENTION and k.shape[1] % 64 == 0 and k.shape[1] >= 256:
+        s_eff = _LN2 if q_scaled else float(scale)                      # pre-scaled queries: the scores already are exponents of 2
+        ops.attn_fwd_fp8(ops.fp8_quantize(q, k, v, s_eff, heads=heads), s_eff, out, heads=heads)
+        return out
     ops.attn_fwd([(q, k, v, out, None)], scale, heads=heads, q_scaled=q_scaled)
     return out
 

@@ -177,6 +177,45 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
         check(lib.gd_attn_fwd(arr, n, N, M, D, scale, dt, _stream()), "gd_attn_fwd")
 
 
+def fp8_quantize(q, k, v, scale: float, heads: int = 0):
+    """Per-head e4m3 quantisation for ``attn_fwd_fp8`` (``scale``: the softmax scale, whose mantissa is folded into q8): q, k, v 16-bit, head-major [BH, N | M, 64] (heads = 0) or token-major
+    [B, N | M, heads*64].  -> dict(q8 [BH,N,64] u8, k8 [BH,M,64] u8, vt8 [BH, M/64, 64, 64] u8, aq, ak, av [BH] f32)."""
+    lib = _lib.load()
+    dt = _dt16(q, "q")
+    for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+        _need(t, nm, q.dtype)
+    B = q.shape[0]
+    BH = B * heads if heads else B
+    N, M = q.shape[1], k.shape[1]
+    if (q.shape[2] != (heads or 1) * 64) or k.shape[2] != q.shape[2] or v.shape != k.shape:
+        raise _lib.GeodiffError("fp8_quantize: head dim must be 64")
+    dev = q.device
+    amax3 = torch.empty(3, BH, dtype=torch.float32, device=dev)
+    aq, ak, av = amax3[0], amax3[1], amax3[2]
+    q8 = torch.empty(BH, N, 64, dtype=torch.uint8, device=dev)
+    k8 = torch.empty(BH, M, 64, dtype=torch.uint8, device=dev)
+    vt8 = torch.empty(BH, (M + 63) // 64, 64, 64, dtype=torch.uint8, device=dev)
+    check(lib.gd_fp8_quantize_qkv(_p(q), _p(k), _p(v), BH, heads, N, M, scale, _p(amax3), _p(q8), _p(k8), _p(vt8), dt, _stream()),
+          "gd_fp8_quantize_qkv")
+    return dict(q8=q8, k8=k8, vt8=vt8, aq=aq, ak=ak, av=av, scale=float(scale))
+
+
+def attn_fwd_fp8(qz: dict, scale: float, out: torch.Tensor, lse: Optional[torch.Tensor] = None, heads: int = 0) -> None:
+    """out = softmax(scale q k^T) v on the fp8 matrix instruction from ``fp8_quantize`` output; out 16-bit [BH,N,64] (heads = 0) or
+    [B,N,heads*64].  Opt-in (parity is the oracle's, not the 1e-3 of the 16-bit path)."""
+    lib = _lib.load()
+    dt = _dt16(out, "out")
+    _need(out, "out")
+    BH, N, _ = qz["q8"].shape
+    M = qz["k8"].shape[1]
+    if float(scale) != qz["scale"]:
+        raise _lib.GeodiffError("attn_fwd_fp8: scale differs from the one folded into q8 by fp8_quantize")
+    if lse is not None:
+        _need(lse, "lse", torch.float32)
+    check(lib.gd_attn_fwd_fp8(_p(qz["q8"]), _p(qz["k8"]), _p(qz["vt8"]), _p(qz["aq"]), _p(qz["ak"]), _p(qz["av"]), BH, heads, N, M, 64, scale,
+                              _p(out), _p(lse), dt, _stream()), "gd_attn_fwd_fp8")
+
+
 def attn_bwd(q, k, v, out, lse, dout, scale: float, need_dk: bool):
     lib = _lib.load()
     dt = _dt16(q, "q")

@@ -171,6 +171,30 @@ int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t*
                   int BH, int N, int R, int M, int Mpad, int D, float scale, void* P, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * fp8 (OCP e4m3) attention forward on the block-scaled K = 64 matrix instruction — opt-in, no-grad passes only (BASELINE configs[4]).
+ * The reference has no fp8 path (attention is fp16 compute_attention + torch.bmm, U/attention_sharing.py:30-47; its SDXL line is
+ * commented out, U/diffusion.py:106); parity is defined by oracle/ref_cpu.py:attention_fp8_oracle.
+ *   gd_fp8_absmax_heads : amax[bh] = max |x[bh]|                       (x 16-bit, [BH,N,64] head-major or [B,N,heads*64] with heads > 0)
+ *   gd_fp8_quant_rows   : out8[bh,n,:] = e4m3(clamp(x * 448 / amax[bh], +-448))     [BH,N,64] bytes, head-major.  For the QUERY tensor pass
+ *                         amax_k (the keys' absmax) and the softmax scale: c = scale log2(e) (aq/448) (ak/448) is split by frexp into
+ *                         mant 2^ex, the multiplier becomes mant * 448 / aq and the attention kernel applies 2^ex as the instruction's
+ *                         block scale — the score product then yields exponents of 2 directly.  Keys: amax_k = NULL.
+ *   gd_fp8_quant_vt     : V transposed per 64-key tile in the slot order the second product needs: vt8 [BH, ceil(M/64), 64 d, 64 slots]
+ *   gd_attn_fwd_fp8     : out = softmax(scale q k^T) v from those, M % 64 == 0, D = 64; out 16-bit head-major (heads = 0) or token-major;
+ *                         lse [BH,N] f32 or NULL.  Probabilities are re-quantised to e4m3 (x 64) in registers.
+ * ---------------------------------------------------------------------------------------------- */
+int gd_fp8_absmax_heads(const void* x, int BH, int heads, int N, float* amax, int dtype, void* stream);
+int gd_fp8_quant_rows(const void* x, int BH, int heads, int N, const float* amax, const float* amax_k, float scale, void* out8,
+                      int dtype, void* stream);
+int gd_fp8_quant_vt(const void* v, int BH, int heads, int M, const float* amax, void* vt8, int dtype, void* stream);
+/* gd_fp8_absmax_heads x 3 + gd_fp8_quant_rows (q, with the keys' absmax and the scale) + gd_fp8_quant_rows (k) + gd_fp8_quant_vt (v) in three
+ * launches.  amax3: [3, BH] f32 (q | k | v), written. */
+int gd_fp8_quantize_qkv(const void* q, const void* k, const void* v, int BH, int heads, int N, int M, float scale, float* amax3,
+                        void* q8, void* k8, void* vt8, int dtype, void* stream);
+int gd_attn_fwd_fp8(const void* q8, const void* k8, const void* vt8, const float* amax_q, const float* amax_k, const float* amax_v,
+                    int BH, int heads, int N, int M, int D, float scale, void* out, float* lse, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * R8  losses.
  * ---------------------------------------------------------------------------------------------- */
 

@@ -616,3 +616,29 @@ def test_sdxl_shaped_edit_1024():
     assert log_a[first]["num_layers"] == log_b[first]["num_layers"] > 0
     for k in ("sim", "movement", "smoothness"):
         assert abs(log_a[first]["self"][k] - log_b[first]["self"][k]) <= 5e-2 * abs(log_a[first]["self"][k]) + 1e-5, k
+
+
+def test_fp8_vanilla_attention_mode_on_the_sdxl_harness():
+    """GD_ATTN_FP8: one no-grad pass of the SDXL-shaped UNet with the vanilla processor, self-attention on the fp8 kernels, against the same
+    pass on the 16-bit kernels.  An approximation by contract (3 mantissa bits): the pass must agree to a few per cent, not to 1e-3."""
+    from geodiffuser_amd import attention_sharing
+    from geodiffuser_amd.attention_processors import VanillaAttentionProcessor
+    from geodiffuser_amd.diffusion import load_model
+    p, tok, _ = load_model("stabilityai/stable-diffusion-xl-base-1.0", device="cuda:0", tiny=True, dtype=torch.bfloat16)
+    p.unet.set_attn_processor(VanillaAttentionProcessor())
+    torch.manual_seed(0)
+    x = torch.randn(2, 4, 128, 128, device="cuda").bfloat16()
+    ctx = p.text_encoder(tok(["", ""]).input_ids.to("cuda"))[0]
+    outs = []
+    prev = attention_sharing.FP8_ATTENTION
+    try:
+        for fp8 in (False, True):
+            attention_sharing.FP8_ATTENTION = fp8
+            with torch.no_grad():
+                outs.append(p.unet(x, 500, encoder_hidden_states=ctx)["sample"].float().cpu())
+    finally:
+        attention_sharing.FP8_ATTENTION = prev
+    assert torch.isfinite(outs[1]).all()
+    e = rel_l2(outs[1], outs[0])
+    print(f"[fp8] SDXL-shaped UNet pass, fp8 vs 16-bit self-attention: rel_l2 {e:.4f}")
+    assert 0.0 < e < 0.1

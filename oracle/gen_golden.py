@@ -405,7 +405,7 @@ def g17_attention_store(R, packs):
     save("G17_attention_store", **out)
 
 
-def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_eps=0.0):
+def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_eps=0.0, tiny=True):
     """The reference's own per-step driver (``text2image_ldm_stable``, U/editor.py:65-423: optimisation pass -> _update_latent ->
     adaptive schedule -> CFG pass -> reference-latent replacement -> latent warp) with its own processors / controller, driving the
     narrow SD-topology UNet of geodiffuser_amd (seeded random weights, fp32, CPU) through a CPU DDIM scheduler built from the
@@ -418,7 +418,7 @@ def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_ep
     import ref_cpu as O
     c = cfg or cases.LOOP
     inp = cases.loop_inputs(c)
-    pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=True)
+    pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=tiny)       # tiny=False: the full SD2.1-base width (865 M parameters)
     if prepare is not None:
         prepare(pipe)
 
@@ -482,9 +482,9 @@ def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_ep
     return lat.detach(), log, ctrl, pipe
 
 
-def g18_loop(R, kind="geometry_editor", cfg=None, name=None):
+def g18_loop(R, kind="geometry_editor", cfg=None, name=None, tiny=True):
     """Records the final latents and the loss log of every optimisation step of run_reference_loop."""
-    lat, log, ctrl, pipe = run_reference_loop(R, kind, cfg)
+    lat, log, ctrl, pipe = run_reference_loop(R, kind, cfg, tiny=tiny)
     out = {"latents": lat.detach(), "steps": np.array(sorted(log))}
     for i, d in log.items():
         for att in ("self", "cross"):
@@ -582,6 +582,14 @@ def main():
         print("G18"); g18_loop(R)
         print("G19"); g18_loop(R, "geometry_remover")
         print("G20"); g18_loop(R, "geometry_editor", cases.LOOP_CFG0, "G20_loop_cfg0")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "G21":
+        # BASELINE configs[0] (256^2, 2-D translation, 20-step DDIM) through the reference's driver at the FULL SD2.1-base width
+        # (865 M-parameter random-init UNet, fp32, CPU: a few minutes on 8 cores)
+        R = ref_import.import_reference()
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        torch.set_num_threads(8)
+        print("G21"); g18_loop(R, "geometry_editor", cases.LOOP_CFG0, "G21_loop_cfg0_full", tiny=False)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "G17":
         R = ref_import.import_reference()

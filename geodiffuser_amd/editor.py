@@ -87,6 +87,13 @@ def _resize_mask(m, s):
 
 
 @torch.no_grad()
+def _coords_dtype(like: torch.Tensor):
+    """Dtype the warp coordinates are rounded through where the reference writes ``.type_as(<a model tensor>)`` (U/editor.py:148,389): fp16
+    on its GPU path.  A bf16 model must NOT round pixel coordinates through bf16 (8 mantissa bits = 2 pixels at 512^2 — found by the
+    full-width 512^2 loop test: the inpaint region lost its only 64^2 pixel); it keeps the reference's fp16 rounding."""
+    return torch.float16 if like.dtype == torch.bfloat16 else like.dtype
+
+
 def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_steps: int = 20, guidance_scale: Optional[float] = 7.5,
                           generator=None, latent=None, uncond_embeddings=None, start_time=50, return_type="image",
                           transform_coordinates=None, mask_obj=None, optimize_steps=0.2, latent_replace=0.2, lr=0.0,
@@ -123,7 +130,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
 
     if transform_coordinates is not None:                                            # :147-149 (512^2 mask warp, once)
         t_coords_m = reshape_transform_coords(transform_coordinates.to(model.device).float(), in_mat_shape=controller.image_mask.shape)
-        t_coords_m = t_coords_m.tile(controller.image_mask.shape[0], 1, 1, 1).type_as(text_embeddings)
+        t_coords_m = t_coords_m.tile(controller.image_mask.shape[0], 1, 1, 1).to(_coords_dtype(text_embeddings))
         controller.mask_new_warped = binarize_tensor(
             warp_grid_edit(controller.image_mask[:, None].to(model.device).float(), t_coords_m)).type_as(text_embeddings)
 
@@ -218,7 +225,8 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
         if type(controller).__name__ != "AttentionGeometryRemover":                                        # :382-399 latent warp
             if (i < T * latent_replace and mask_obj is not None) or (i < T * fast_start_steps):
                 s = latents.shape[-1]
-                t_coords = reshape_transform_coords(transform_coordinates.to(model.device).float(), in_mat_shape=latents[1:].shape).type_as(latents)
+                t_coords = reshape_transform_coords(transform_coordinates.to(model.device).float(), in_mat_shape=latents[1:].shape)
+                t_coords = t_coords.to(_coords_dtype(latents))
                 i_mask = (_resize_mask(controller.mask_new_warped[:1].detach().float(), s) > 0.5) * 1.0
                 i_mask = i_mask.type_as(latents)
                 warped = warp_grid_edit(latents[-2:-1].detach().clone(), t_coords)

@@ -141,21 +141,23 @@ def main():
         print("v-prediction remover loop: ideal 16-bit storage vs fp32 (oracle loop):", out["vpred_remover_loop"])
         json.dump(out, open(path, "w"), indent=1)
         return
-    if "--g21-only" in sys.argv:                   # the full-width configs[0] loop (fixture G21): add / refresh its entry only
-        torch.set_num_threads(8)
-        R = ref_import.import_reference()
-        out = json.load(open(path))
-        ref = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "G21_loop_cfg0_full.npz"))["latents"])
-        up32 = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "G21_loop_cfg0_full.npz"))["first_update"])
-        e = {}
-        for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
-            lat, _, ce, _ = gen_golden.run_reference_loop(R, "geometry_editor", cases.LOOP_CFG0, prepare=emulate_16bit(dt), tiny=False)
-            e["emulated_" + dn] = rel_l2(lat[-1:], ref[-1:])
-            e["emulated_" + dn + "_first_update"] = rel_l2(ce._recorded_updates[0], up32)
-            print("G21", dn, e, flush=True)
-        out["G21_loop_cfg0_full"] = e
-        json.dump(out, open(path, "w"), indent=1)
-        return
+    for flag, fixture, cfg in (("--g21-only", "G21_loop_cfg0_full", cases.LOOP_CFG0), ("--g22-only", "G22_loop_cfg1_full", cases.LOOP_CFG1)):
+        if flag in sys.argv:                       # the full-width loops (fixtures G21 / G22): add / refresh that entry only
+            torch.set_num_threads(8)
+            R = ref_import.import_reference()
+            out = json.load(open(path))
+            g = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
+            ref, up32 = torch.from_numpy(g["latents"]), torch.from_numpy(g["first_update"])
+            e = out.get(fixture, {})
+            for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+                if ("--" + dn) in sys.argv or not any(a in sys.argv for a in ("--fp16", "--bf16")):
+                    lat, _, ce, _ = gen_golden.run_reference_loop(R, "geometry_editor", cfg, prepare=emulate_16bit(dt), tiny=False)
+                    e["emulated_" + dn] = rel_l2(lat[-1:], ref[-1:])
+                    e["emulated_" + dn + "_first_update"] = rel_l2(ce._recorded_updates[0], up32)
+                    print(fixture, dn, e, flush=True)
+                    out[fixture] = e
+                    json.dump(out, open(path, "w"), indent=1)
+            return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_import.import_reference()

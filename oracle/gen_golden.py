@@ -446,7 +446,7 @@ def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_ep
               "cross": {"sim": 45, "movement": 30.34, "removal": 2.6, "smoothness": 15.0, "amodal": 3.5}}
         ctrl = ap.AttentionGeometryEdit(["", ""], c["steps"], {"default_": c["cross_replace"]}, c["self_replace"], image_mask=inp["mask"],
                                         obj_edit_step=c["obj_edit_step"], device="cpu")
-        ctrl.amodal_mask = R.generic_torch.torch_erode(torch.from_numpy(cases.amodal_input(inp["mask"], dx=32, dy=-12)))
+        ctrl.amodal_mask = R.generic_torch.torch_erode(torch.from_numpy(cases.amodal_input(inp["mask"], *c.get("amodal_shift", (32, -12)))))
     else:
         lw = {"self": {"sim": 55, "removal": 4.6, "smoothness": 30.0}, "cross": {"sim": 45, "removal": 4.6, "smoothness": 15.0}}
         ctrl = ap.AttentionGeometryRemover(["", ""], c["steps"], {"default_": 0.9}, 0.9, image_mask=inp["mask"], obj_edit_step=1.0,
@@ -590,6 +590,14 @@ def main():
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         torch.set_num_threads(8)
         print("G21"); g18_loop(R, "geometry_editor", cases.LOOP_CFG0, "G21_loop_cfg0_full", tiny=False)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "G22":
+        # BASELINE configs[1] SHAPE (512^2, 3-D rotation) through the reference's driver at the full SD2.1-base width, 4 DDIM steps
+        # (2 optimisation passes + 4 CFG passes; the reference materialises [10, 4096, 4096] fp32 maps per 64^2 layer: ~25 GB, minutes)
+        R = ref_import.import_reference()
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        torch.set_num_threads(8)
+        print("G22"); g18_loop(R, "geometry_editor", cases.LOOP_CFG1, "G22_loop_cfg1_full", tiny=False)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "G17":
         R = ref_import.import_reference()

@@ -221,12 +221,21 @@ LOOP = dict(size=256, steps=6, guidance=3.0, skip_optim=2, optimize_steps=0.65, 
 LOOP_CFG0 = dict(LOOP, steps=20, seed=78)
 
 
+# BASELINE configs[1] shape: single 512 x 512 image, 3-D rotation edit (a bounded number of DDIM steps: the reference's formulation on CPU
+# materialises [10, 4096, 4096] fp32 maps for every 64^2 layer of an optimisation pass)
+LOOP_CFG1 = dict(LOOP, size=512, steps=4, seed=79, transform="rotate", amodal_shift=(64, -24))
+
+
 def loop_inputs(c=None):
-    """-> dict(mask [256,256] f32, coords [1,256,256,3] f32, x_T [1,4,32,32], ddim_latents list of steps+1 [1,4,32,32])."""
+    """-> dict(mask [S,S] f32, coords [1,S,S,3] f32, x_T [1,4,S/8,S/8], ddim_latents list of steps+1 [1,4,S/8,S/8])."""
     c = c or LOOP
     size = c["size"]
-    mask = ellipse_mask(cx=118.0, cy=131.0, ax=35.0, ay=29.0, size=size)
-    coords = coords_translate(dx_px=32.0, dy_px=-12.0, z=0.5, size=size)
+    if c.get("transform") == "rotate":                     # the 512^2 ellipse and the 3-D rotation about its centroid of the controller cases
+        mask = ellipse_mask(size=size)
+        coords = coords_rotate_y(mask=mask, size=size)
+    else:
+        mask = ellipse_mask(cx=118.0, cy=131.0, ax=35.0, ay=29.0, size=size)
+        coords = coords_translate(dx_px=32.0, dy_px=-12.0, z=0.5, size=size)
     rng = np.random.default_rng(c["seed"])
     traj = [rng.standard_normal((1, 4, size // 8, size // 8)).astype(np.float32) for _ in range(c["steps"] + 1)]
     return dict(mask=mask.astype(np.float32), coords=coords.astype(np.float32), x_T=traj[-1], ddim_latents=traj)       # coords [1,256,256,3]

@@ -320,7 +320,7 @@ def _emulation():
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
-@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0", "cfg0_full"])
+@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0", "cfg0_full", "cfg1_full"])
 def test_loop_matches_reference_driver_g18(kind, dtype):
     """Loop-level parity: fixture G18 is the REFERENCE's own text2image_ldm_stable (its processors, controller, _update_latent,
     adaptive schedule, latent replacement / warp) run on CPU in fp32 over the same narrow SD-topology UNet (same seeded weights) and the
@@ -331,11 +331,12 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
     from geodiffuser_amd import editor
     from geodiffuser_amd.attention_processors import AttentionGeometryEdit, AttentionGeometryRemover, VanillaAttentionProcessor
     from geodiffuser_amd.generic_torch import torch_erode
-    full = kind == "cfg0_full"           # ... the same at the FULL SD2.1-base width (865 M-parameter UNet, 5 / 10 / 20 heads): fixture G21
+    full = kind in ("cfg0_full", "cfg1_full")    # ... at the FULL SD2.1-base width (865 M-parameter UNet, 5 / 10 / 20 heads): fixtures G21, G22
+    cfg1 = kind == "cfg1_full"           # BASELINE configs[1] SHAPE: 512 x 512, 3-D rotation (4 DDIM steps, 2 optimisation passes; 64^2-token layers)
     cfg0 = kind in ("cfg0", "cfg0_full")  # BASELINE configs[0]: 256 x 256, 2-D translation, 20-step DDIM (7 optimisation passes)
-    if cfg0:
+    if cfg0 or cfg1:
         kind = "geometry_editor"
-    fixture = "G21_loop_cfg0_full" if full else ("G20_loop_cfg0" if cfg0 else ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover"))
+    fixture = "G22_loop_cfg1_full" if cfg1 else ("G21_loop_cfg0_full" if full else ("G20_loop_cfg0" if cfg0 else ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover")))
     g = load(fixture)
     # What IDEAL 16-bit storage alone does to the reference's own driver (oracle/fp16_emulation.py: the reference loop on CPU with the
     # UNet's weights, activations and gradients rounded through the dtype): the yardstick for the distances below.  The 1e-3 relative
@@ -350,7 +351,7 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
     probe = torch.cat([q.detach().float().reshape(-1)[:64] for q in p.unet.parameters()]).cpu()
     if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=2e-3 if dtype == torch.float16 else 2e-2):
         pytest.skip("seeded weights differ from the fixture's (different torch build): the fixture does not apply")
-    c = cases.LOOP_CFG0 if cfg0 else cases.LOOP
+    c = cases.LOOP_CFG1 if cfg1 else (cases.LOOP_CFG0 if cfg0 else cases.LOOP)
     inp = cases.loop_inputs(c)
     coords = torch.from_numpy(inp["coords"])
     if kind == "geometry_editor":
@@ -358,7 +359,7 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
               "cross": {"sim": 45, "movement": 30.34, "removal": 2.6, "smoothness": 15.0, "amodal": 3.5}}
         ctrl = AttentionGeometryEdit(["", ""], c["steps"], {"default_": c["cross_replace"]}, c["self_replace"], image_mask=inp["mask"],
                                      obj_edit_step=c["obj_edit_step"], device="cuda:0")
-        ctrl.amodal_mask = torch_erode(torch.from_numpy(cases.amodal_input(inp["mask"], dx=32, dy=-12)))
+        ctrl.amodal_mask = torch_erode(torch.from_numpy(cases.amodal_input(inp["mask"], *c.get("amodal_shift", (32, -12)))))
     else:
         lw = {"self": {"sim": 55, "removal": 4.6, "smoothness": 30.0}, "cross": {"sim": 45, "removal": 4.6, "smoothness": 15.0}}
         ctrl = AttentionGeometryRemover(["", ""], c["steps"], {"default_": 0.9}, 0.9, image_mask=inp["mask"], obj_edit_step=1.0,

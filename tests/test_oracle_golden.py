@@ -342,7 +342,7 @@ def test_oracle_loop_matches_the_reference_driver(kind, fixture, cfgname):
     if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=1e-6):
         pytest.skip("seeded weights differ from the fixture's (different torch build)")
     inp = cases.loop_inputs(c)
-    ctrl = ref_loop.make_controller(kind, inp["mask"], c, cases.amodal_input(inp["mask"], dx=32, dy=-12))
+    ctrl = ref_loop.make_controller(kind, inp["mask"], c, cases.amodal_input(inp["mask"], *c.get("amodal_shift", (32, -12))))
     tok = pipe.tokenizer
     ids = tok(["", ""], padding="max_length", max_length=tok.model_max_length, return_tensors="pt").input_ids
     with torch.no_grad():

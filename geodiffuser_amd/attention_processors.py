@@ -90,6 +90,10 @@ def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_
         hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
     lin_args = args if getattr(attn, "linear_takes_scale", False) else ()
     q_scaled = False
+    if token_major and BATCHED_QKV and SCALED_Q and not lin_args and getattr(attn, "norm_cross", None) in (None, False):
+        fused = _batched_qkv(attn, hidden_states, encoder_hidden_states)
+        if fused is not None:
+            return fused[:4] + (shape4,) + fused[5:]
     if token_major and SCALED_Q and not lin_args and type(attn.to_q) is torch.nn.Linear and attn.to_q.bias is None:
         # q' = 16-bit(scale*log2(e) * (x W^T)): the softmax scale and the base change applied as the GEMM's alpha in its fp32
         # epilogue, BEFORE the one rounding to 16 bits (no extra rounding, unlike scaling a rounded q).  The attention kernels
@@ -118,7 +122,54 @@ def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_
     return query, key, value, is_cross, shape4, lin_args, False
 
 
+def _stacked_weights(attn, names, alpha0):
+    """[len(names), out, in] stack of the projections' weights (cached on the module, refreshed when a weight changes); the first one is
+    multiplied by ``alpha0`` in fp32 before the ONE rounding to the storage dtype."""
+    mods = [getattr(attn, n) for n in names]
+    if any(type(m) is not torch.nn.Linear or m.bias is not None for m in mods) or len({m.weight.shape for m in mods}) != 1:
+        return None
+    ver = tuple(m.weight._version for m in mods) + (mods[0].weight.dtype, mods[0].weight.device, alpha0)
+    c = attn.__dict__.get("_gd_stack_" + "".join(names))
+    if c is None or c[0] != ver:
+        with torch.no_grad():
+            ws = [m.weight.detach() for m in mods]
+            if alpha0 != 1.0:
+                ws[0] = (ws[0].float() * alpha0).to(ws[0].dtype)
+            c = attn.__dict__["_gd_stack_" + "".join(names)] = (ver, torch.stack(ws, 0).transpose(1, 2).contiguous())     # [n, in, out]
+    return c[1]
+
+
+def _batched_qkv(attn, hidden_states, encoder_hidden_states):
+    """No-grad token-major passes: the three (self-attention) or two (cross-attention k, v) bias-free projections of one input as ONE
+    batched GEMM ``[n, M, in] x [n, in, out]`` (the input broadcast over the batch with stride 0: no copy), so their outputs are separate
+    contiguous [B, N, C] tensors the attention kernels take as they are.  The query's ``scale*log2(e)`` is folded into its weight in fp32
+    before the weight's one rounding (``q_scaled``).  Returns None when the module's projections do not qualify."""
+    alpha = float(attn.scale) * LOG2E
+    x2 = hidden_states.reshape(-1, hidden_states.shape[-1])
+    if encoder_hidden_states is None:
+        if x2.shape[0] * x2.shape[1] > 3_000_000:     # measured (tools/bench_qkv.py): at M = 12288, C = 320 three GEMMs beat the batched one
+            return None
+        w3 = _stacked_weights(attn, ("to_q", "to_k", "to_v"), alpha)
+        if w3 is None or w3.shape[1] != x2.shape[1]:
+            return None
+        qkv = torch.bmm(x2.unsqueeze(0).expand(3, -1, -1), w3)
+        shp = (*hidden_states.shape[:-1], w3.shape[2])
+        return qkv[0].view(shp), qkv[1].view(shp), qkv[2].view(shp), False, None, (), True
+    wq = _stacked_weights(attn, ("to_q",), alpha)
+    w2 = _stacked_weights(attn, ("to_k", "to_v"), 1.0)
+    if wq is None or w2 is None or wq.shape[1] != x2.shape[1]:
+        return None
+    e2 = encoder_hidden_states.reshape(-1, encoder_hidden_states.shape[-1])
+    if w2.shape[1] != e2.shape[1]:
+        return None
+    q = torch.mm(x2, wq[0]).view(*hidden_states.shape[:-1], wq.shape[2])
+    kv = torch.bmm(e2.unsqueeze(0).expand(2, -1, -1), w2)
+    shp = (*encoder_hidden_states.shape[:-1], w2.shape[2])
+    return q, kv[0].view(shp), kv[1].view(shp), True, None, (), True
+
+
 TOKEN_MAJOR = os.environ.get("GD_TOKEN_MAJOR", "1") == "1"
+BATCHED_QKV = os.environ.get("GD_BATCHED_QKV", "1") == "1"   # no-grad passes: q / k / v projections of one input as one batched GEMM
 SCALED_Q = os.environ.get("GD_SCALED_Q", "1") == "1"      # token-major passes: scale*log2(e) folded into the query projection
 LOG2E = 1.4426950408889634
 FUSED_WARP = os.environ.get("GD_FUSED_WARP", "1") == "1"   # build the warped queries inside the attention launch

@@ -283,6 +283,17 @@ def _flat(m: torch.Tensor) -> torch.Tensor:
 # Device buffers that outlive a controller: a captured hipGraph of a CFG pass reads the per-resolution tables by address, so an
 # edit that wants to reuse the graphs of the previous edit copies its tables INTO these buffers instead of allocating new ones.
 _PERSISTENT_TABLES: Dict[tuple, torch.Tensor] = {}
+# ... which makes them process-wide state: ONE controller at a time may own them (the reference is one edit at a time per process as well: its
+# model cache, DISTANCE_CLASS, SPLATTER and GAUSSIAN_FEATURE_SMOOTHER are module globals).  The owner is the controller that built
+# its tables last; a hooked call of any other controller whose tables live in these buffers raises instead of reading the owner's geometry.
+_TABLE_OWNER = None            # weakref to the owning controller
+
+
+def _check_table_owner(ctrl):
+    owner = _TABLE_OWNER() if _TABLE_OWNER is not None else None
+    if owner is not None and owner is not ctrl:
+        raise RuntimeError("two live edit controllers share the persistent per-resolution tables (GD_PERSISTENT_TABLES=1): another controller "
+                           "rebuilt them after this one did; run one edit at a time per process, or set controller.persistent_tables = False")
 
 
 def _persist(enabled: bool, key: tuple, t: torch.Tensor) -> torch.Tensor:
@@ -530,11 +541,20 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
     # -- per-resolution device tables --------------------------------------------------------------------
     def _tables(self, S: int, f: int, q: torch.Tensor, transform_coords, D: int = 64):
         """D: the TRUE head dim (loss normalisers, U/attention_processors.py:231-305); only q's device / dtype are read."""
+        global _TABLE_OWNER
         c = self.masks_cache_dict.get(S)
         if c is not None and "f" in c:
             if c["D"] != D:
                 raise ValueError(f"layers of latent size {S} disagree on the head dim ({c['D']} vs {D})")
+            if getattr(self, "persistent_tables", False):
+                _check_table_owner(self)
             return c
+        if getattr(self, "persistent_tables", False):
+            import weakref
+            if not any("f" in t for t in self.masks_cache_dict.values()):      # first table of this controller: it takes the buffers over
+                _TABLE_OWNER = weakref.ref(self)
+            else:
+                _check_table_owner(self)
         dev = q.device
         N = S * S
         q_base_like = torch.empty(1, f, N, 1, device=dev, dtype=q.dtype)

@@ -408,3 +408,26 @@ def test_edit_layer_is_bit_reproducible(name, dtype):
         assert torch.equal(r[0], runs[0][0]) and r[1] == runs[0][1]
         assert torch.equal(r[2], runs[0][2]) and torch.equal(r[3], runs[0][3])
         assert r[4] == runs[0][4]
+
+
+def test_two_live_controllers_cannot_share_the_persistent_tables():
+    """the per-resolution tables live in process-wide buffers (so that captured graphs can be reused across edits);
+    a second controller that builds its tables takes them over, and the first one must then refuse to run rather than read the other's
+    geometry."""
+    mask = cases.ellipse_mask()
+    case = dict(kind="edit", S=16, f=2, D=64, cross=False, cfg=True, cur_step=3, coords="translate", quant=True, seed=5)
+    q, k, v, _, coords = case_inputs(case)
+    a, b = _make_hip_controller(case, mask), _make_hip_controller(dict(case, coords="rotate"), mask)
+    coords_b = torch.from_numpy(cases.make_coords("rotate", mask))
+    a.persistent_tables = b.persistent_tables = True
+    args = dict(is_cross=False, place_in_unet="up", scale=0.125)
+    qd, kd, vd = (t.half().to(DEV) for t in (q, k, v))
+    with torch.no_grad():
+        out_a = a(qd, kd, vd, transform_coords=coords, **args)
+        b(qd, kd, vd, transform_coords=coords_b, **args)               # b rebuilds the shared buffers
+        with pytest.raises(RuntimeError, match="two live edit controllers"):
+            a(qd, kd, vd, transform_coords=coords, **args)
+        b(qd, kd, vd, transform_coords=coords_b, **args)               # the owner keeps working
+        c = _make_hip_controller(case, mask)                           # without persistent tables controllers are independent
+        c.persistent_tables = False
+        assert torch.equal(c(qd, kd, vd, transform_coords=coords, **args), out_a)

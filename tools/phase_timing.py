@@ -2,6 +2,7 @@
 import os, sys, time, torch, collections
 torch.backends.cudnn.benchmark = os.environ.get('GD_MIOPEN_FIND', '1') == '1'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from geodiffuser_amd import miopen_cache; miopen_cache.configure()
 from geodiffuser_amd import editor, inversion, diffusion, optimization, vis_utils
 from geodiffuser_amd.diffusion import load_model
 from geodiffuser_amd.synthetic import editor_kwargs, make_edit

@@ -63,7 +63,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_removal_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                               c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gd_nn_table": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_amodal_target": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_int, c_void_p]),

@@ -446,15 +446,19 @@ class _EditLayer(torch.autograd.Function):
         dro = ops.edit_losses_bwd(eo, replace_out, tgt if have_loss else None, c["m_wo"], m_edit_l, c.get("w_dist"),
                                   c.get("m_amodal"), gout, coefs if have_loss else _zeros5(dev), gscale,
                                   blend=(m["blend"] and not m["remover"]), S=S)
-        dq16, dk32 = ops.attn_bwd(q_edit, K, v_base, replace_out, lse_e, dro, m["scale"], need_dk=m["is_cross"] and not m["remover"])
-        dq = dq16
+        # the reference rows receive no gradient (they are detached in the reference as well): dq is written straight into the edit rows of
+        # the full-size gradient, the removal loss's contribution is folded into it in place (one rounding, as adding an f32 tensor would)
+        e0f, e1f = m["e0"] * f, m["e1"] * f
+        grad_q = torch.empty(m["q_shape"], dtype=dt, device=dev)
+        if e0f:
+            grad_q[:e0f].zero_()
+        if e1f < grad_q.shape[0]:
+            grad_q[e1f:].zero_()
+        dq_view = grad_q[e0f:e1f]
+        _, dk32 = ops.attn_bwd(q_edit, K, v_base, replace_out, lse_e, dro, m["scale"], need_dk=m["is_cross"] and not m["remover"], dq_out=dq_view)
         if have_loss and Pe is not None:
-            dq32 = torch.zeros(q_edit.shape, dtype=torch.float32, device=dev)
-            ops.removal_bwd(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], 1.0, gscale * rm_coef, m["scale"], dq32, dk32,
-                            n_valid=c.get("n_rows"))
-            dq = (dq16.float() + dq32).to(dt)
-        grad_q = torch.zeros(m["q_shape"], dtype=dt, device=dev)
-        grad_q[m["e0"] * f:m["e1"] * f] = dq
+            ops.removal_bwd(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], 1.0, gscale * rm_coef, m["scale"], None, dk32,
+                            n_valid=c.get("n_rows"), dq16=dq_view)
         grad_k = None
         if dk32 is not None:
             grad_k = torch.zeros(m["k_shape"], dtype=dt, device=dev)

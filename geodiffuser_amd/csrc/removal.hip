@@ -311,8 +311,11 @@ k_removal_bwd(const RmBwdArgs a) {
 
 // dq[h, rows[r], :] += sum_c dq_part[c, h, r, :]  (c ascending).  Padding slots of the row list (weight 0, contribution exactly 0) are
 // skipped, so every live row has exactly one writer.
+// T16 != void: the sum is added IN PLACE to a 16-bit gradient (dq16 = T16(float(dq16) + s): the rounding of adding an f32 tensor and
+// casting, without the f32 tensor, its zero fill and three element-wise launches).
+template <typename T16>
 __global__ void k_removal_dq_fold(const float* __restrict__ dq_part, const int32_t* __restrict__ rows, const float* __restrict__ wgt,
-                                  int msplit, int H, int R, int N, int D, float* __restrict__ dq) {
+                                  int msplit, int H, int R, int N, int D, float* __restrict__ dq, T16* __restrict__ dq16) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= H * R * D) return;
     const int d = gid % D, hr = gid / D;
@@ -320,7 +323,9 @@ __global__ void k_removal_dq_fold(const float* __restrict__ dq_part, const int32
     const int hd = hr / R, r = hr - hd * R;
     float s = 0.f;
     for (int c = 0; c < msplit; ++c) s += dq_part[((size_t)c * H * R + hr) * D + d];
-    dq[((size_t)hd * N + rows[r]) * D + d] += s;
+    const size_t o = ((size_t)hd * N + rows[r]) * D + d;
+    if (dq) dq[o] += s;
+    if (dq16) dq16[o] = (T16)((float)dq16[o] + s);
 }
 
 // dk[h, m, d] += sum_r dS[h, r, m] * q[h, rows[r], d]   (cross-attention: few keys; one thread per (m, d) of a head)
@@ -356,8 +361,8 @@ extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, con
                               const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
                               const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
                               const int32_t* n_valid_dev, int H, int R, int N, int M, int Mpad, int D, float scale,
-                              float* dq_f32, float* dk_f32, float* ds_ws, int dtype, void* stream) {
-    GD_REQUIRE(Pe && Pb && q && k && rows && p_in && j_in && p_wo && j_wo && wgt && m_inp && m_wo && dq_f32, GD_EINVAL,
+                              float* dq_f32, float* dk_f32, float* ds_ws, void* dq16_inout, int dtype, void* stream) {
+    GD_REQUIRE(Pe && Pb && q && k && rows && p_in && j_in && p_wo && j_wo && wgt && m_inp && m_wo && (dq_f32 || dq16_inout), GD_EINVAL,
                "gd_removal_bwd: null pointer");
     GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED, "gd_removal_bwd: head dim %d unsupported (64, 128, 192)", D);
     GD_REQUIRE(H > 0 && R > 0 && N > 0 && M > 0 && Mpad >= M, GD_EINVAL, "gd_removal_bwd: bad sizes");
@@ -379,7 +384,8 @@ extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, con
     else k_removal_rowdot<bf16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rowdot);
     if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, st>>>(a);
     else k_removal_bwd<bf16_t><<<blocks, 256, 0, st>>>(a);
-    k_removal_dq_fold<<<(H * R * D + 255) / 256, 256, 0, st>>>(a.dq_part, rows, wgt, msplit, H, R, N, D, dq_f32);
+    if (dtype == GD_F16) k_removal_dq_fold<f16_t><<<(H * R * D + 255) / 256, 256, 0, st>>>(a.dq_part, rows, wgt, msplit, H, R, N, D, dq_f32, (f16_t*)dq16_inout);
+    else k_removal_dq_fold<bf16_t><<<(H * R * D + 255) / 256, 256, 0, st>>>(a.dq_part, rows, wgt, msplit, H, R, N, D, dq_f32, (bf16_t*)dq16_inout);
     if (dk_f32) {
         dim3 grid((M * D + 255) / 256, H);
         if (dtype == GD_F16) k_removal_dk<f16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const f16_t*)q, rows, n_valid_dev, R, N, M, Mpad, D, dk_f32);

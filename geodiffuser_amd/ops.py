@@ -216,7 +216,8 @@ def attn_fwd_fp8(qz: dict, scale: float, out: torch.Tensor, lse: Optional[torch.
                               _p(out), _p(lse), dt, _stream()), "gd_attn_fwd_fp8")
 
 
-def attn_bwd(q, k, v, out, lse, dout, scale: float, need_dk: bool):
+def attn_bwd(q, k, v, out, lse, dout, scale: float, need_dk: bool, dq_out=None):
+    """-> (dq 16-bit [BH,N,D], dk f32 [BH,M,D] | None).  dq_out: write dq into this contiguous tensor (e.g. a row slice of a larger gradient)."""
     lib = _lib.load()
     dt = _dt16(q, "q")
     for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
@@ -224,7 +225,11 @@ def attn_bwd(q, k, v, out, lse, dout, scale: float, need_dk: bool):
     _need(lse, "lse", torch.float32)
     BH, N, D = q.shape
     M = k.shape[1]
-    dq = torch.empty_like(q)
+    if dq_out is not None:
+        _need(dq_out, "dq_out", q.dtype)
+        if dq_out.shape != q.shape:
+            raise _lib.GeodiffError("attn_bwd: dq_out must have q's shape")
+    dq = dq_out if dq_out is not None else torch.empty_like(q)
     dk = torch.zeros(BH, M, D, dtype=torch.float32, device=q.device) if need_dk else None
     nbytes = lib.gd_attn_bwd_workspace_bytes(BH, N, M, D, int(need_dk))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device) if nbytes else None
@@ -292,18 +297,22 @@ def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int, n_valid=None):
     return dict(p_in=p_in, j_in=j_in, p_wo=p_wo, j_wo=j_wo, wgt=wgt), loss
 
 
-def removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, scale: float, dq_f32, dk_f32, n_valid=None):
+def removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, scale: float, dq_f32, dk_f32, n_valid=None, dq16=None):
+    """dq_f32 (f32, accumulated) and / or dq16 (16-bit, added in place with one rounding) receive the query gradient."""
     lib = _lib.load()
     dt = _dt16(Pe, "Pe")
     H, R, Mpad = Pe.shape
     N, D = q.shape[1], q.shape[2]
     M = k.shape[1]
-    _need(dq_f32, "dq_f32", torch.float32)
+    if dq_f32 is not None:
+        _need(dq_f32, "dq_f32", torch.float32)
+    if dq16 is not None:
+        _need(dq16, "dq16", q.dtype)
     ds_ws = torch.empty(lib.gd_removal_bwd_workspace_bytes(H, R, M, Mpad, D, int(dk_f32 is not None)) // 4, dtype=torch.float32,
                         device=Pe.device)
     check(lib.gd_removal_bwd(_p(Pe), _p(Pb), _p(q), _p(k), _p(rows), _p(aux["p_in"]), _p(aux["j_in"]), _p(aux["p_wo"]),
                              _p(aux["j_wo"]), _p(aux["wgt"]), _p(m_inp), _p(m_wo), coef, _p(gscale), _p(n_valid), H, R, N, M, Mpad, D, scale,
-                             _p(dq_f32), _p(dk_f32), _p(ds_ws), dt, _stream()), "gd_removal_bwd")
+                             _p(dq_f32), _p(dk_f32), _p(ds_ws), _p(dq16), dt, _stream()), "gd_removal_bwd")
 
 
 def nn_table(fg, S: int):

@@ -225,14 +225,15 @@ int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, 
  *   dS = A o (dA - rowsum(A o dA));  dq[h,rows[r]] += scale * dS K;  dk_f32[h] += scale * dS^T q   (dk_f32 may be NULL)
  * dq_f32 [H,N,D] f32 accumulated (caller zeroes).  ds_ws: scratch of gd_removal_bwd_workspace_bytes() bytes (row dots, per-key-chunk dq partials that are folded in a fixed order — no f32 atomics, bit-reproducible — and dS when dk_f32 != NULL).  gscale_dev: optional DEVICE scalar multiplied into coef (the
  * upstream gradient of the loss, so that no host sync is needed to read it).  n_valid_dev (DEVICE int32[1] or NULL): slots
- * [n_valid, R) of the row list are padding and are skipped.
+ * [n_valid, R) of the row list are padding and are skipped.  dq16_inout (may be NULL): a 16-bit [H,N,D] gradient the contribution is
+ * added to in place, element = T(float(element) + contribution) (dq_f32 may then be NULL).
  */
 size_t gd_removal_bwd_workspace_bytes(int H, int R, int M, int Mpad, int D, int need_dk);
 int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
                    const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
                    const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
                    const int32_t* n_valid_dev, int H, int R, int N, int M, int Mpad, int D, float scale,
-                   float* dq_f32, float* dk_f32, float* ds_ws, int dtype, void* stream);
+                   float* dq_f32, float* dk_f32, float* ds_ws, void* dq16_inout, int dtype, void* stream);
 
 /*
  * The mask-only half of interpolate_from_mask (U/attention_sharing.py:81-83,103), once per edit and resolution:

@@ -142,7 +142,9 @@ def load_model(diffusion_model="stabilityai/stable-diffusion-2-1-base", unet_pat
         from .pipeline import build_random_sdxl
         pipe = build_random_sdxl(device=device, dtype=dtype, tiny=tiny)
     else:
-        pipe = build_random_sd21(device=device, dtype=dtype, tiny=tiny)
+        name = str(diffusion_model).lower()
+        sd14 = "v1-" in name or "v1." in name or "sd14" in name            # e.g. "CompVis/stable-diffusion-v1-4", the reference's default
+        pipe = build_random_sd21(device=device, dtype=dtype, tiny=tiny, sd14=sd14)
     if prediction_type not in (None, "epsilon"):
         pipe.scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                                        set_alpha_to_one=False, prediction_type=prediction_type)

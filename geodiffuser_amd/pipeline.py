@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .scheduler import DDIMScheduler
-from .unet_sd21 import GroupNormAct, UNet2DConditionModel, sdxl_unet, tiny_unet
+from .unet_sd21 import GroupNormAct, UNet2DConditionModel, sd14_unet, sdxl_unet, tiny_unet
 
 
 # ------------------------------------------------------------------------------------------------ tokenizer
@@ -182,12 +182,17 @@ class StableDiffusionPipeline:
             yield from m.parameters()
 
 
-def build_random_sd21(device="cuda:0", dtype=torch.float16, seed=1234, tiny=False) -> StableDiffusionPipeline:
-    """Seeded random-init SD2.1-base-shaped model.  ``tiny``: same topology, narrow (for smoke tests)."""
+def build_random_sd21(device="cuda:0", dtype=torch.float16, seed=1234, tiny=False, sd14=False) -> StableDiffusionPipeline:
+    """Seeded random-init SD2.1-base-shaped model.  ``tiny``: same topology, narrow (for smoke tests).  ``sd14``: the SD1.x head layout
+    (8 heads per level: head dims 40 / 80 / 160) and text width (768) of the reference's default model."""
     g = torch.random.get_rng_state()
     torch.manual_seed(seed)
     try:
-        if tiny:
+        if sd14:
+            unet = sd14_unet(tiny=tiny, ctx_dim=64 if tiny else 768)
+            vae = AutoencoderKL(ch=(32, 32, 64, 64)) if tiny else AutoencoderKL()
+            te = TextEncoder(width=64, layers=2, heads=2) if tiny else TextEncoder(width=768, layers=12, heads=12)
+        elif tiny:
             unet = tiny_unet(ctx_dim=64)
             vae = AutoencoderKL(ch=(32, 32, 64, 64))
             te = TextEncoder(width=64, layers=2, heads=2)

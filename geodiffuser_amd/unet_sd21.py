@@ -499,6 +499,15 @@ def sdxl_unet(tiny: bool = False, ctx_dim: int = None, text_embed_dim: int = Non
                                 addition_time_embed_dim=256, addition_text_embed_dim=text_embed_dim or 1280)
 
 
+def sd14_unet(tiny: bool = False, ctx_dim: int = None) -> UNet2DConditionModel:
+    """SD1.x topology — the reference's DEFAULT model (CompVis/stable-diffusion-v1-4, U/editor.py:58): the SD2.1 block structure with
+    8 heads on every level, i.e. head dims 40 / 80 / 160 / 160, and a 768-wide text context.  ``tiny``: 4 heads over 160 / 320 / 640 / 640
+    channels — the same head dims."""
+    if tiny:
+        return UNet2DConditionModel(block_out_channels=(160, 320, 640, 640), heads=(4, 4, 4, 4), cross_attention_dim=ctx_dim or 64)
+    return UNet2DConditionModel(block_out_channels=(320, 640, 1280, 1280), heads=(8, 8, 8, 8), cross_attention_dim=ctx_dim or 768)
+
+
 def tiny_unet(ctx_dim=64) -> UNet2DConditionModel:
     """A small model with the same topology (head dim 64) for smoke tests."""
     return UNet2DConditionModel(block_out_channels=(64, 128, 128, 128), heads=(1, 2, 2, 2), cross_attention_dim=ctx_dim)

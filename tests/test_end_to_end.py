@@ -644,3 +644,68 @@ def test_fp8_vanilla_attention_mode_on_the_sdxl_harness():
     e = rel_l2(outs[1], outs[0])
     print(f"[fp8] SDXL-shaped UNet pass, fp8 vs 16-bit self-attention: rel_l2 {e:.4f}")
     assert 0.0 < e < 0.1
+
+
+def test_sd14_head_dims_through_the_whole_loop():
+    """The reference's DEFAULT model is SD1.4 (U/editor.py:58): 8 heads per level, head dims 40 / 80 / 160.  On an SD1.x-topology UNet
+    (narrow, same head dims) the whole driver loop — hooked layers padded to 64 / 128 / 192 inside the controllers, optimisation passes with
+    backward, CFG passes — runs on the HIP path and agrees with the oracle loop (fp32, the reference's formulation; pinned to the reference's
+    driver by G18-G20) like the 64-wide models do."""
+    import cases
+    import ref_loop
+    from geodiffuser_amd import editor
+    from geodiffuser_amd.attention_processors import AttentionGeometryEdit, VanillaAttentionProcessor
+    from geodiffuser_amd.diffusion import load_model
+    from geodiffuser_amd.generic_torch import torch_erode
+    from geodiffuser_amd.pipeline import build_random_sd21
+    c = cases.LOOP
+    inp = cases.loop_inputs(c)
+    kind = "geometry_editor"
+    torch.set_num_threads(8)
+    cpu = build_random_sd21(device="cpu", dtype=torch.float32, tiny=True, sd14=True)
+    dims = sorted({m.to_q.out_features // m.heads for _, m in cpu.unet._attn_modules()})
+    assert dims == [40, 80, 160]
+    tok = cpu.tokenizer
+    ids = tok(["", ""], padding="max_length", max_length=tok.model_max_length, return_tensors="pt").input_ids
+    with torch.no_grad():
+        emb = cpu.text_encoder(ids)[0]
+    amodal = cases.amodal_input(inp["mask"], *c.get("amodal_shift", (32, -12)))
+    co = ref_loop.make_controller(kind, inp["mask"], c, amodal)
+    ref_lat, ref_logs = ref_loop.text2image_loop(
+        cpu.unet, emb, emb, co, torch.from_numpy(inp["x_T"]), [torch.from_numpy(a) for a in inp["ddim_latents"]],
+        torch.from_numpy(inp["coords"]), torch.from_numpy(inp["mask"]), num_steps=c["steps"], guidance_scale=c["guidance"],
+        skip_optim_steps=c["skip_optim"], optimize_steps=c["optimize_steps"], latent_replace=c["latent_replace"], lr=c["lr"], edit_type=kind)
+    p, _, _ = load_model("CompVis/stable-diffusion-v1-4", device="cuda:0", tiny=True, dtype=torch.float16)
+    lw = {"self": {"sim": 55, "movement": 30.5, "removal": 2.6, "smoothness": 30.0, "amodal": 80.5},
+          "cross": {"sim": 45, "movement": 30.34, "removal": 2.6, "smoothness": 15.0, "amodal": 3.5}}
+    ctrl = AttentionGeometryEdit(["", ""], c["steps"], {"default_": c["cross_replace"]}, c["self_replace"], image_mask=inp["mask"],
+                                 obj_edit_step=c["obj_edit_step"], device="cuda:0")
+    ctrl.amodal_mask = torch_erode(torch.from_numpy(amodal))
+    ctrl.default_loss_weights = lw
+    ctrl.initialize_default_loss_weights()
+    prev = (editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS)
+    editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS = c["steps"], c["guidance"], c["skip_optim"]
+    try:
+        ddim = [torch.from_numpy(a).to("cuda").half() for a in inp["ddim_latents"]]
+        lat, _, log = editor.text2image_ldm_stable(
+            p, ["", ""], ctrl, latent=torch.from_numpy(inp["x_T"]).to("cuda").half(), num_inference_steps=c["steps"],
+            guidance_scale=c["guidance"], uncond_embeddings=None, transform_coordinates=torch.from_numpy(inp["coords"]),
+            mask_obj=torch.from_numpy(inp["mask"]), optimize_steps=c["optimize_steps"], latent_replace=c["latent_replace"], lr=c["lr"],
+            optimize_embeddings=True, optimize_latents=True, ddim_latents=ddim, ddim_noise=None, edit_type=kind, fast_start_steps=0.0,
+            num_first_optim_steps=1, use_adaptive_optimization=True, return_type="latents", image_size=c["size"])
+    finally:
+        editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS = prev
+        p.unet.set_attn_processor(VanillaAttentionProcessor())
+    lat = lat.float().cpu()
+    assert sorted(log) == sorted(ref_logs)
+    first = sorted(log)[0]
+    assert log[first]["num_layers"] == ref_logs[first]["num_layers"]
+    for att in ("self", "cross"):
+        for k, v in log[first][att].items():
+            ref = ref_logs[first][att][k]
+            print(f"[sd14] first pass {att}/{k}: {float(v):.5f} vs {ref:.5f}")
+            assert abs(float(v) - ref) <= 2e-2 * abs(ref) + 5e-4, (att, k, float(v), ref)
+    e = rel_l2(lat[1], ref_lat[1])
+    emu = _emulation()["G18_loop"]["emulated_fp16"]        # the 64-wide narrow editor loop's yardstick (same loop, same sizes)
+    print(f"[sd14] fp16 edit-latent rel_l2 vs the oracle loop: {e:.4f} (ideal fp16 storage on the 64-wide narrow loop: {emu:.4f})")
+    assert e < 3.0 * emu + 1e-3

@@ -190,3 +190,14 @@ def test_sdxl_harness_topology():
     assert len(names) == 140 and not any(n.startswith("down_blocks.0") or n.startswith("up_blocks.2") for n in names)
     heads = {m.heads for _, m in u._attn_modules()}
     assert heads == {10, 20}
+
+
+def test_sd14_harness_topology():
+    """The SD1.x-shaped harness (the reference's default model, U/editor.py:58): CompVis/stable-diffusion-v1-4's UNet parameter count and
+    its 8-head layout (head dims 40 / 80 / 160), on the meta device."""
+    from geodiffuser_amd.unet_sd21 import sd14_unet
+    with torch.device("meta"):
+        u = sd14_unet()
+    assert sum(p.numel() for p in u.parameters()) == 859_520_964
+    assert sorted({m.to_q.out_features // m.heads for _, m in u._attn_modules()}) == [40, 80, 160]
+    assert {m.heads for _, m in u._attn_modules()} == {8} and len(u.attn_processors) == 32

@@ -405,7 +405,7 @@ def g17_attention_store(R, packs):
     save("G17_attention_store", **out)
 
 
-def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_eps=0.0, tiny=True):
+def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_eps=0.0, tiny=True, sd14=False):
     """The reference's own per-step driver (``text2image_ldm_stable``, U/editor.py:65-423: optimisation pass -> _update_latent ->
     adaptive schedule -> CFG pass -> reference-latent replacement -> latent warp) with its own processors / controller, driving the
     narrow SD-topology UNet of geodiffuser_amd (seeded random weights, fp32, CPU) through a CPU DDIM scheduler built from the
@@ -418,7 +418,8 @@ def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_ep
     import ref_cpu as O
     c = cfg or cases.LOOP
     inp = cases.loop_inputs(c)
-    pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=tiny)       # tiny=False: the full SD2.1-base width (865 M parameters)
+    # tiny=False: the full SD2.1-base width (865 M parameters); sd14: the SD1.x head layout (head dims 40 / 80 / 160) of the reference's default model
+    pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=tiny, sd14=sd14)
     if prepare is not None:
         prepare(pipe)
 
@@ -482,9 +483,9 @@ def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_ep
     return lat.detach(), log, ctrl, pipe
 
 
-def g18_loop(R, kind="geometry_editor", cfg=None, name=None, tiny=True):
+def g18_loop(R, kind="geometry_editor", cfg=None, name=None, tiny=True, sd14=False):
     """Records the final latents and the loss log of every optimisation step of run_reference_loop."""
-    lat, log, ctrl, pipe = run_reference_loop(R, kind, cfg, tiny=tiny)
+    lat, log, ctrl, pipe = run_reference_loop(R, kind, cfg, tiny=tiny, sd14=sd14)
     out = {"latents": lat.detach(), "steps": np.array(sorted(log))}
     for i, d in log.items():
         for att in ("self", "cross"):
@@ -590,6 +591,14 @@ def main():
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         torch.set_num_threads(8)
         print("G21"); g18_loop(R, "geometry_editor", cases.LOOP_CFG0, "G21_loop_cfg0_full", tiny=False)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "G23":
+        # the reference's driver over an SD1.x-topology UNet (narrow; 4 heads per level = head dims 40 / 80 / 160, the layout of its default
+        # model CompVis/stable-diffusion-v1-4, U/editor.py:58)
+        R = ref_import.import_reference()
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        torch.set_num_threads(8)
+        print("G23"); g18_loop(R, "geometry_editor", cases.LOOP, "G23_loop_sd14", tiny=True, sd14=True)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "G22":
         # BASELINE configs[1] SHAPE (512^2, 3-D rotation) through the reference's driver at the full SD2.1-base width, 4 DDIM steps

@@ -320,7 +320,7 @@ def _emulation():
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
-@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0", "cfg0_full", "cfg1_full"])
+@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0", "cfg0_full", "cfg1_full", "sd14"])
 def test_loop_matches_reference_driver_g18(kind, dtype):
     """Loop-level parity: fixture G18 is the REFERENCE's own text2image_ldm_stable (its processors, controller, _update_latent,
     adaptive schedule, latent replacement / warp) run on CPU in fp32 over the same narrow SD-topology UNet (same seeded weights) and the
@@ -334,9 +334,10 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
     full = kind in ("cfg0_full", "cfg1_full")    # ... at the FULL SD2.1-base width (865 M-parameter UNet, 5 / 10 / 20 heads): fixtures G21, G22
     cfg1 = kind == "cfg1_full"           # BASELINE configs[1] SHAPE: 512 x 512, 3-D rotation (4 DDIM steps, 2 optimisation passes; 64^2-token layers)
     cfg0 = kind in ("cfg0", "cfg0_full")  # BASELINE configs[0]: 256 x 256, 2-D translation, 20-step DDIM (7 optimisation passes)
-    if cfg0 or cfg1:
+    sd14 = kind == "sd14"                # the reference's default model layout: head dims 40 / 80 / 160 (narrow SD1.x-topology UNet): fixture G23
+    if cfg0 or cfg1 or sd14:
         kind = "geometry_editor"
-    fixture = "G22_loop_cfg1_full" if cfg1 else ("G21_loop_cfg0_full" if full else ("G20_loop_cfg0" if cfg0 else ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover")))
+    fixture = "G23_loop_sd14" if sd14 else "G22_loop_cfg1_full" if cfg1 else ("G21_loop_cfg0_full" if full else ("G20_loop_cfg0" if cfg0 else ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover")))
     g = load(fixture)
     # What IDEAL 16-bit storage alone does to the reference's own driver (oracle/fp16_emulation.py: the reference loop on CPU with the
     # UNet's weights, activations and gradients rounded through the dtype): the yardstick for the distances below.  The 1e-3 relative
@@ -347,7 +348,8 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
     emu = _emulation()[fixture]
     emu_final, emu_update = emu["emulated_" + dn], emu["emulated_" + dn + "_first_update"]
     from geodiffuser_amd.diffusion import load_model
-    p, tok, sched = load_model(device="cuda:0", tiny=not full, dtype=dtype)
+    p, tok, sched = load_model("CompVis/stable-diffusion-v1-4" if sd14 else "stabilityai/stable-diffusion-2-1-base", device="cuda:0",
+                               tiny=not full, dtype=dtype)
     probe = torch.cat([q.detach().float().reshape(-1)[:64] for q in p.unet.parameters()]).cpu()
     if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=2e-3 if dtype == torch.float16 else 2e-2):
         pytest.skip("seeded weights differ from the fixture's (different torch build): the fixture does not apply")

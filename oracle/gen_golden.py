@@ -592,6 +592,13 @@ def main():
         torch.set_num_threads(8)
         print("G21"); g18_loop(R, "geometry_editor", cases.LOOP_CFG0, "G21_loop_cfg0_full", tiny=False)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "G26":
+        # the removal edit through the reference's driver at the full SD2.1-base width (256^2, 6 steps)
+        R = ref_import.import_reference()
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        torch.set_num_threads(8)
+        print("G26"); g18_loop(R, "geometry_remover", cases.LOOP, "G26_loop_remover_full", tiny=False)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "G23":
         # the reference's driver over an SD1.x-topology UNet (narrow; 4 heads per level = head dims 40 / 80 / 160, the layout of its default
         # model CompVis/stable-diffusion-v1-4, U/editor.py:58)

@@ -320,7 +320,7 @@ def _emulation():
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
-@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0", "cfg0_full", "cfg1_full", "sd14"])
+@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0", "cfg0_full", "cfg1_full", "sd14", "remover_full"])
 def test_loop_matches_reference_driver_g18(kind, dtype):
     """Loop-level parity: fixture G18 is the REFERENCE's own text2image_ldm_stable (its processors, controller, _update_latent,
     adaptive schedule, latent replacement / warp) run on CPU in fp32 over the same narrow SD-topology UNet (same seeded weights) and the
@@ -331,13 +331,16 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
     from geodiffuser_amd import editor
     from geodiffuser_amd.attention_processors import AttentionGeometryEdit, AttentionGeometryRemover, VanillaAttentionProcessor
     from geodiffuser_amd.generic_torch import torch_erode
-    full = kind in ("cfg0_full", "cfg1_full")    # ... at the FULL SD2.1-base width (865 M-parameter UNet, 5 / 10 / 20 heads): fixtures G21, G22
+    rem_full = kind == "remover_full"    # the removal edit at the full SD2.1-base width: fixture G26
+    if rem_full:
+        kind = "geometry_remover"
+    full = rem_full or kind in ("cfg0_full", "cfg1_full")    # ... at the FULL SD2.1-base width (865 M-parameter UNet, 5 / 10 / 20 heads): fixtures G21, G22
     cfg1 = kind == "cfg1_full"           # BASELINE configs[1] SHAPE: 512 x 512, 3-D rotation (4 DDIM steps, 2 optimisation passes; 64^2-token layers)
     cfg0 = kind in ("cfg0", "cfg0_full")  # BASELINE configs[0]: 256 x 256, 2-D translation, 20-step DDIM (7 optimisation passes)
     sd14 = kind == "sd14"                # the reference's default model layout: head dims 40 / 80 / 160 (narrow SD1.x-topology UNet): fixture G23
     if cfg0 or cfg1 or sd14:
         kind = "geometry_editor"
-    fixture = "G23_loop_sd14" if sd14 else "G22_loop_cfg1_full" if cfg1 else ("G21_loop_cfg0_full" if full else ("G20_loop_cfg0" if cfg0 else ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover")))
+    fixture = "G26_loop_remover_full" if rem_full else "G23_loop_sd14" if sd14 else "G22_loop_cfg1_full" if cfg1 else ("G21_loop_cfg0_full" if full else ("G20_loop_cfg0" if cfg0 else ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover")))
     g = load(fixture)
     # What IDEAL 16-bit storage alone does to the reference's own driver (oracle/fp16_emulation.py: the reference loop on CPU with the
     # UNet's weights, activations and gradients rounded through the dtype): the yardstick for the distances below.  The 1e-3 relative

@@ -313,14 +313,31 @@ def test_edits_are_independent_of_history(pipe):
     assert rel_l2(lat_b, lat_a) < max(5 * noise, 5e-2)
 
 
+_MODELS = {}
+
+
+def _cached_model(name, tiny, dtype):
+    """The full-width models take ~10 s to build: one instance per (architecture, width, dtype) for the loop tests (they restore the
+    processor and set the scheduler's timesteps themselves)."""
+    from geodiffuser_amd.diffusion import load_model
+    key = (name, tiny, dtype)
+    if key not in _MODELS:
+        if not tiny:
+            for k in [k for k in _MODELS if not k[1]]:          # keep at most one 865 M-parameter model resident
+                del _MODELS[k]
+            torch.cuda.empty_cache()
+        _MODELS[key] = load_model(name, device="cuda:0", tiny=tiny, dtype=dtype)
+    return _MODELS[key]
+
+
 def _emulation():
     import json
     import os
     return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp16_emulation.json")))
 
 
+@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0", "sd14", "cfg0_full", "cfg1_full", "remover_full"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
-@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0", "cfg0_full", "cfg1_full", "sd14", "remover_full"])
 def test_loop_matches_reference_driver_g18(kind, dtype):
     """Loop-level parity: fixture G18 is the REFERENCE's own text2image_ldm_stable (its processors, controller, _update_latent,
     adaptive schedule, latent replacement / warp) run on CPU in fp32 over the same narrow SD-topology UNet (same seeded weights) and the
@@ -351,8 +368,8 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
     emu = _emulation()[fixture]
     emu_final, emu_update = emu["emulated_" + dn], emu["emulated_" + dn + "_first_update"]
     from geodiffuser_amd.diffusion import load_model
-    p, tok, sched = load_model("CompVis/stable-diffusion-v1-4" if sd14 else "stabilityai/stable-diffusion-2-1-base", device="cuda:0",
-                               tiny=not full, dtype=dtype)
+    name = "CompVis/stable-diffusion-v1-4" if sd14 else "stabilityai/stable-diffusion-2-1-base"
+    p, tok, sched = _cached_model(name, not full, dtype)
     probe = torch.cat([q.detach().float().reshape(-1)[:64] for q in p.unet.parameters()]).cpu()
     if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=2e-3 if dtype == torch.float16 else 2e-2):
         pytest.skip("seeded weights differ from the fixture's (different torch build): the fixture does not apply")

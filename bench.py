@@ -437,7 +437,7 @@ def main():
                        "per_rank_s": per_rank, "first_warmup_edit_s": first_edit, "miopen_db": os.path.relpath(miopen_db, ROOT)},
         }
         if roof:
-            line["roofline"] = {"kernel": "k_attn_fwd_mp (attention forward, N = M = 4096 self-attention launches)", "bound": "mfma", "achieved": roof["achieved"] / 1e12,
+            line["roofline"] = {"kernel": f"k_attn_fwd_mp (attention forward, N = M = {timer.n} self-attention launches)", "bound": "mfma", "achieved": roof["achieved"] / 1e12,
                                 "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s", "frac": roof["achieved"] / PEAK_MFMA_16BIT,
                                 "traffic": roof["traffic"], "launches": roof["launches"], "avg_launch_us": roof["avg_us"],
                                 "configs": roof["configs"],

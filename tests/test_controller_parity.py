@@ -243,6 +243,22 @@ SD1_CASES = {
 }
 
 
+# BASELINE configs[3]: object removal at 768 x 768 — latent 96^2, hooked layers at 96^2 / 48^2 / 24^2 / 12^2 tokens ("stresses the 48 x 48
+# attention-map warp + inpaint loss"); N is not a power of two here (9216, 2304: 72 / 18 query tiles, 144 / 36 key tiles).
+REMOVAL_768_CASES = {
+    "rem_self_opt_48": dict(kind="remover", S=48, f=2, D=64, cross=False, cfg=False, cur_step=3, coords="translate", quant=False, seed=61),
+    "rem_cross_opt_48": dict(kind="remover", S=48, f=2, D=64, cross=True, cfg=False, cur_step=3, coords="translate", quant=False, seed=62),
+    "rem_self_opt_96": dict(kind="remover", S=96, f=1, D=64, cross=False, cfg=False, cur_step=3, coords="translate", quant=False, seed=63),
+    "rem_self_cfg_96": dict(kind="remover", S=96, f=1, D=64, cross=False, cfg=True, cur_step=10, coords="translate", quant=False, seed=64),
+    "edit_self_opt_48": dict(kind="edit", S=48, f=2, D=64, cross=False, cfg=False, cur_step=3, coords="rotate", quant=True, seed=65),
+}
+
+
+@pytest.mark.parametrize("name", list(REMOVAL_768_CASES))
+def test_controller_vs_oracle_768_shapes(name):
+    _oracle_case(REMOVAL_768_CASES[name], torch.float16)
+
+
 @pytest.mark.parametrize("name", list(SD1_CASES))
 def test_controller_vs_oracle_sd1_head_dims(name):
     _oracle_case(SD1_CASES[name], torch.float16)

@@ -126,8 +126,10 @@ def _oracle_run(case, q, k, v, mask, coords, scale, gout):
 # against fp16's 11, i.e. 8x the rounding step on every stored q/k/v/output/probability.
 # Measured with tools/parity_report.py (profiles/r02_parity_report.md): fp16 out <= 5.0e-4, loss <= 1.4e-5, dq L2 <= 3.4e-3, dq max <= 6.6e-3;
 # bf16 out <= 3.7e-3, loss <= 9.6e-5, dq L2 <= 1.8e-2, dq max <= 1.1e-2.
-TOLS = {torch.float16: dict(out=1e-3, loss=5e-4, gl2=8e-3, gmax=2.5e-2),
-        torch.bfloat16: dict(out=8e-3, loss=1e-3, gl2=4e-2, gmax=5e-2)}
+# ``tie``: how close (relative) two correlation candidates of the removal loss's arg-max may be for either to count as the maximiser — the
+# precision of the stored probabilities (16 bits: 11 / 8 mantissa bits).
+TOLS = {torch.float16: dict(out=1e-3, loss=5e-4, gl2=8e-3, gmax=2.5e-2, tie=2e-3),
+        torch.bfloat16: dict(out=8e-3, loss=1e-3, gl2=4e-2, gmax=5e-2, tie=1.6e-2)}
 TOLS_GOLDEN = dict(out=1e-3, loss=5e-3, gl2=1.5e-2, gmax=0.1)      # fixtures: fp32 inputs on the reference side, fp16-rounded here
 
 
@@ -144,7 +146,7 @@ def _check_losses_and_grads(case, ch, co, res, loss_ref, log_ref, dq_ref, dk_ref
         rm_expected = rm_ref
         if getattr(ch, "_last_removal_aux", None) is not None and co.aux.get("corr_in") is not None:
             tab = ch.masks_cache_dict[S]
-            same, rm_expected = removal_consistency(ch._last_removal_aux, co.aux, S, f, tab["s_inp"])
+            same, rm_expected = removal_consistency(ch._last_removal_aux, co.aux, S, f, tab["s_inp"], tie_tol=tols.get("tie", 2e-3))
         lw_rm = float(ch.loss_weight_dict[kind]["removal"])
         loss_expected = float(loss_ref) + lw_rm * (rm_expected - rm_ref)
         assert abs(res["loss"] - loss_expected) <= TOL_GRAD * max(1.0, abs(loss_expected))
@@ -252,6 +254,19 @@ REMOVAL_768_CASES = {
     "rem_self_cfg_96": dict(kind="remover", S=96, f=1, D=64, cross=False, cfg=True, cur_step=10, coords="translate", quant=False, seed=64),
     "edit_self_opt_48": dict(kind="edit", S=48, f=2, D=64, cross=False, cfg=False, cur_step=3, coords="rotate", quant=True, seed=65),
 }
+
+
+# BASELINE configs[4] shapes: the SDXL-base hooked layers (latent 128^2): 64^2 tokens x 10 heads and 32^2 tokens x 20 heads, head dim 64
+SDXL_CASES = {
+    "edit_self_cfg_64_f10": dict(kind="edit", S=64, f=10, D=64, cross=False, cfg=True, cur_step=10, coords="rotate", quant=True, seed=66),
+    "edit_self_opt_32_f20": dict(kind="edit", S=32, f=20, D=64, cross=False, cfg=False, cur_step=3, coords="rotate", quant=True, seed=67),
+    "edit_cross_opt_64_f10": dict(kind="edit", S=64, f=10, D=64, cross=True, cfg=False, cur_step=3, coords="scale", quant=True, seed=68),
+}
+
+
+@pytest.mark.parametrize("name", list(SDXL_CASES))
+def test_controller_vs_oracle_sdxl_shapes(name):
+    _oracle_case(SDXL_CASES[name], torch.bfloat16)
 
 
 @pytest.mark.parametrize("name", list(REMOVAL_768_CASES))

@@ -142,7 +142,8 @@ def main():
         json.dump(out, open(path, "w"), indent=1)
         return
     for flag, fixture, cfg in (("--g21-only", "G21_loop_cfg0_full", cases.LOOP_CFG0), ("--g22-only", "G22_loop_cfg1_full", cases.LOOP_CFG1),
-                               ("--g23-only", "G23_loop_sd14", cases.LOOP), ("--g26-only", "G26_loop_remover_full", cases.LOOP)):
+                               ("--g23-only", "G23_loop_sd14", cases.LOOP), ("--g26-only", "G26_loop_remover_full", cases.LOOP),
+                               ("--g27-only", "G27_loop_sdxl", cases.LOOP_SDXL)):
         if flag in sys.argv:                       # the full-width loops (fixtures G21 / G22): add / refresh that entry only
             torch.set_num_threads(8)
             R = ref_import.import_reference()
@@ -153,7 +154,7 @@ def main():
             for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
                 if ("--" + dn) in sys.argv or not any(a in sys.argv for a in ("--fp16", "--bf16")):
                     lat, _, ce, _ = gen_golden.run_reference_loop(R, "geometry_remover" if "remover" in fixture else "geometry_editor", cfg,
-                                                                  prepare=emulate_16bit(dt), tiny=fixture.startswith("G23"),
+                                                                  prepare=emulate_16bit(dt), tiny=fixture.startswith(("G23", "G27")), sdxl=fixture.startswith("G27"),
                                                                   sd14=fixture.startswith("G23"))
                     e["emulated_" + dn] = rel_l2(lat[-1:], ref[-1:])
                     e["emulated_" + dn + "_first_update"] = rel_l2(ce._recorded_updates[0], up32)

@@ -405,7 +405,7 @@ def g17_attention_store(R, packs):
     save("G17_attention_store", **out)
 
 
-def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_eps=0.0, tiny=True, sd14=False):
+def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_eps=0.0, tiny=True, sd14=False, sdxl=False):
     """The reference's own per-step driver (``text2image_ldm_stable``, U/editor.py:65-423: optimisation pass -> _update_latent ->
     adaptive schedule -> CFG pass -> reference-latent replacement -> latent warp) with its own processors / controller, driving the
     narrow SD-topology UNet of geodiffuser_amd (seeded random weights, fp32, CPU) through a CPU DDIM scheduler built from the
@@ -419,7 +419,11 @@ def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_ep
     c = cfg or cases.LOOP
     inp = cases.loop_inputs(c)
     # tiny=False: the full SD2.1-base width (865 M parameters); sd14: the SD1.x head layout (head dims 40 / 80 / 160) of the reference's default model
-    pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=tiny, sd14=sd14)
+    if sdxl:      # SDXL-base topology (narrow): its text_time conditioning comes from unet.default_added_cond, the reference's call signature is unchanged
+        from geodiffuser_amd.pipeline import build_random_sdxl
+        pipe = build_random_sdxl(device="cpu", dtype=torch.float32, tiny=True, image_size=c["size"])
+    else:
+        pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=tiny, sd14=sd14)
     if prepare is not None:
         prepare(pipe)
 
@@ -483,9 +487,9 @@ def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_ep
     return lat.detach(), log, ctrl, pipe
 
 
-def g18_loop(R, kind="geometry_editor", cfg=None, name=None, tiny=True, sd14=False):
+def g18_loop(R, kind="geometry_editor", cfg=None, name=None, tiny=True, sd14=False, sdxl=False):
     """Records the final latents and the loss log of every optimisation step of run_reference_loop."""
-    lat, log, ctrl, pipe = run_reference_loop(R, kind, cfg, tiny=tiny, sd14=sd14)
+    lat, log, ctrl, pipe = run_reference_loop(R, kind, cfg, tiny=tiny, sd14=sd14, sdxl=sdxl)
     out = {"latents": lat.detach(), "steps": np.array(sorted(log))}
     for i, d in log.items():
         for att in ("self", "cross"):
@@ -591,6 +595,14 @@ def main():
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         torch.set_num_threads(8)
         print("G21"); g18_loop(R, "geometry_editor", cases.LOOP_CFG0, "G21_loop_cfg0_full", tiny=False)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "G27":
+        # the reference's driver over an SDXL-topology UNet (narrow: three levels, attention on the lower two with stacked transformer
+        # blocks, text_time conditioning) at 512^2: hooked layers at 32^2 (losses) and 16^2 tokens
+        R = ref_import.import_reference()
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        torch.set_num_threads(8)
+        print("G27"); g18_loop(R, "geometry_editor", cases.LOOP_SDXL, "G27_loop_sdxl", sdxl=True)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "G26":
         # the removal edit through the reference's driver at the full SD2.1-base width (256^2, 6 steps)

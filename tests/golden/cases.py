@@ -226,6 +226,10 @@ LOOP_CFG0 = dict(LOOP, steps=20, seed=78)
 LOOP_CFG1 = dict(LOOP, size=512, steps=4, seed=79, transform="rotate", amodal_shift=(64, -24))
 
 
+# SDXL-topology loop case (BASELINE configs[4] topology, narrow model): 512^2 so that the hooked 32^2-token layers evaluate the losses
+LOOP_SDXL = dict(LOOP_CFG1, seed=80)
+
+
 def loop_inputs(c=None):
     """-> dict(mask [S,S] f32, coords [1,S,S,3] f32, x_T [1,4,S/8,S/8], ddim_latents list of steps+1 [1,4,S/8,S/8])."""
     c = c or LOOP

@@ -336,7 +336,7 @@ def _emulation():
     return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp16_emulation.json")))
 
 
-@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0", "sd14", "cfg0_full", "cfg1_full", "remover_full"])
+@pytest.mark.parametrize("kind", ["geometry_editor", "geometry_remover", "cfg0", "sd14", "sdxl", "cfg0_full", "cfg1_full", "remover_full"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 def test_loop_matches_reference_driver_g18(kind, dtype):
     """Loop-level parity: fixture G18 is the REFERENCE's own text2image_ldm_stable (its processors, controller, _update_latent,
@@ -355,9 +355,10 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
     cfg1 = kind == "cfg1_full"           # BASELINE configs[1] SHAPE: 512 x 512, 3-D rotation (4 DDIM steps, 2 optimisation passes; 64^2-token layers)
     cfg0 = kind in ("cfg0", "cfg0_full")  # BASELINE configs[0]: 256 x 256, 2-D translation, 20-step DDIM (7 optimisation passes)
     sd14 = kind == "sd14"                # the reference's default model layout: head dims 40 / 80 / 160 (narrow SD1.x-topology UNet): fixture G23
-    if cfg0 or cfg1 or sd14:
+    sdxl = kind == "sdxl"                # SDXL-base topology (narrow), 512^2: fixture G27
+    if cfg0 or cfg1 or sd14 or sdxl:
         kind = "geometry_editor"
-    fixture = "G26_loop_remover_full" if rem_full else "G23_loop_sd14" if sd14 else "G22_loop_cfg1_full" if cfg1 else ("G21_loop_cfg0_full" if full else ("G20_loop_cfg0" if cfg0 else ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover")))
+    fixture = "G27_loop_sdxl" if sdxl else "G26_loop_remover_full" if rem_full else "G23_loop_sd14" if sd14 else "G22_loop_cfg1_full" if cfg1 else ("G21_loop_cfg0_full" if full else ("G20_loop_cfg0" if cfg0 else ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover")))
     g = load(fixture)
     # What IDEAL 16-bit storage alone does to the reference's own driver (oracle/fp16_emulation.py: the reference loop on CPU with the
     # UNet's weights, activations and gradients rounded through the dtype): the yardstick for the distances below.  The 1e-3 relative
@@ -368,12 +369,14 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
     emu = _emulation()[fixture]
     emu_final, emu_update = emu["emulated_" + dn], emu["emulated_" + dn + "_first_update"]
     from geodiffuser_amd.diffusion import load_model
-    name = "CompVis/stable-diffusion-v1-4" if sd14 else "stabilityai/stable-diffusion-2-1-base"
+    name = "CompVis/stable-diffusion-v1-4" if sd14 else ("stabilityai/stable-diffusion-xl-base-1.0" if sdxl else "stabilityai/stable-diffusion-2-1-base")
     p, tok, sched = _cached_model(name, not full, dtype)
+    if sdxl:                             # the fixture's model was built for 512^2 micro-conditioning ids
+        p.unet.default_added_cond = (p.unet.default_added_cond[0], torch.tensor([[512, 512, 0, 0, 512, 512]], dtype=torch.float32, device="cuda"))
     probe = torch.cat([q.detach().float().reshape(-1)[:64] for q in p.unet.parameters()]).cpu()
     if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=2e-3 if dtype == torch.float16 else 2e-2):
         pytest.skip("seeded weights differ from the fixture's (different torch build): the fixture does not apply")
-    c = cases.LOOP_CFG1 if cfg1 else (cases.LOOP_CFG0 if cfg0 else cases.LOOP)
+    c = cases.LOOP_SDXL if sdxl else cases.LOOP_CFG1 if cfg1 else (cases.LOOP_CFG0 if cfg0 else cases.LOOP)
     inp = cases.loop_inputs(c)
     coords = torch.from_numpy(inp["coords"])
     if kind == "geometry_editor":

@@ -201,3 +201,27 @@ def test_sd14_harness_topology():
     assert sum(p.numel() for p in u.parameters()) == 859_520_964
     assert sorted({m.to_q.out_features // m.heads for _, m in u._attn_modules()}) == [40, 80, 160]
     assert {m.heads for _, m in u._attn_modules()} == {8} and len(u.attn_processors) == 32
+
+
+def test_batched_qkv_projection_equals_separate_linears():
+    """The one-GEMM projection of the no-grad passes (stride-0 broadcast input, stacked weights, the query's scale*log2(e) folded into its
+    weight) against the three / two separate linears, on CPU in fp32; the weight cache follows in-place weight updates."""
+    from geodiffuser_amd import attention_processors as AP
+    from geodiffuser_amd.unet_sd21 import Attention
+    torch.manual_seed(0)
+    for ctx_dim in (None, 24):
+        attn = Attention(32, ctx_dim, heads=2, dim_head=16)
+        x = torch.randn(2, 10, 32)
+        ctx = None if ctx_dim is None else torch.randn(2, 7, ctx_dim)
+        q, k, v, is_cross, _, _, q_scaled = AP._batched_qkv(attn, x, ctx)
+        src = x if ctx is None else ctx
+        assert q_scaled and is_cross == (ctx is not None)
+        assert torch.allclose(q, attn.to_q(x) * (attn.scale * AP.LOG2E), atol=1e-5)
+        assert torch.allclose(k, attn.to_k(src), atol=1e-5) and torch.allclose(v, attn.to_v(src), atol=1e-5)
+        assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+        with torch.no_grad():
+            attn.to_k.weight.mul_(2.0)                             # the stack is rebuilt when a weight changes
+        k2 = AP._batched_qkv(attn, x, ctx)[1]
+        assert torch.allclose(k2, attn.to_k(src), atol=1e-5) and not torch.allclose(k2, k, atol=1e-3)
+    attn.to_q.bias = torch.nn.Parameter(torch.zeros(32))          # projections with a bias do not qualify
+    assert AP._batched_qkv(attn, x, ctx) is None

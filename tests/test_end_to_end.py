@@ -734,3 +734,32 @@ def test_sd14_head_dims_through_the_whole_loop():
     emu = _emulation()["G18_loop"]["emulated_fp16"]        # the 64-wide narrow editor loop's yardstick (same loop, same sizes)
     print(f"[sd14] fp16 edit-latent rel_l2 vs the oracle loop: {e:.4f} (ideal fp16 storage on the 64-wide narrow loop: {emu:.4f})")
     assert e < 3.0 * emu + 1e-3
+
+
+def test_removal_edit_768_full_width_v_prediction():
+    """BASELINE configs[3] at its stated workload shape: object removal at 768 x 768 with the FULL SD2.1-width UNet (865 M parameters; hooked
+    layers at 96^2 x 5, 48^2 x 10, 24^2 x 20, 12^2 x 20 heads) and a v-prediction scheduler (SD2.1-768 is a v-prediction model), 6 DDIM
+    steps incl. inversion.  No reference exists for this configuration (the reference has no v-prediction path and its formulation needs
+    ~3.4 GB per 96^2 map on the host): the parity of the pieces is tested elsewhere (controller at S = 48 / 96, v-prediction loop against the
+    oracle loop, full-width loops G21 / G22 / G26); here the edit must run, stay finite, log every optimisation step's loss terms over all
+    hooked layers and leave the reference row equal to the inversion trajectory's start."""
+    from geodiffuser_amd import editor
+    from geodiffuser_amd.scheduler import DDIMScheduler
+    from geodiffuser_amd.synthetic import editor_kwargs, make_edit
+    p, tok, sched = _cached_model("stabilityai/stable-diffusion-2-1-base", False, torch.bfloat16)
+    prev = p.scheduler
+    p.scheduler = DDIMScheduler(prediction_type="v_prediction")
+    try:
+        image, depth, mask, T = make_edit(3, size=768, kind="translate")
+        kw = editor_kwargs("geometry_remover")
+        kw.update(num_ddim_steps=6, ldm_stable_model=p, tokenizer_model=tok, scheduler_in=p.scheduler, return_latents=True, return_loss_log_dict=True)
+        images, log, lat = editor.run_geodiffuser(image, depth, mask, T, **kw)
+        torch.cuda.synchronize()
+    finally:
+        p.scheduler = prev
+    assert images[1].shape == (768, 768, 3) and lat.shape == (2, 4, 96, 96) and torch.isfinite(lat.float()).all()
+    assert len(log) >= 2
+    for d in log.values():
+        assert d["num_layers"] == 20                       # 10 self + 10 cross layers with N >= 32^2 (96^2 and 48^2 levels)
+        assert all(np.isfinite(v) for att in ("self", "cross") for v in d[att].values())
+        assert d["self"]["removal"] != 0.0

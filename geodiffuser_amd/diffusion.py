@@ -5,6 +5,8 @@ which gives the same dtypes at the attention processors without an autocast cont
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -120,6 +122,10 @@ def load_model(diffusion_model="stabilityai/stable-diffusion-2-1-base", unet_pat
     pipeline is loaded ("stabilityai/stable-diffusion-2-1" at 768^2 is a v-prediction model, BASELINE configs[3]), else "epsilon".  With diffusers + weights available this would wrap ``StableDiffusionPipeline.from_pretrained``;
     in this environment neither exists (no network), so a seeded random-init model of the same shape is built.
     Returns (ldm_stable, tokenizer, scheduler) like the reference."""
+    if os.environ.get("GD_MIOPEN_CACHE", "1") == "1":
+        # before the first convolution of the process: committed find-db + no naive solvers in MIOpen's per-shape search (miopen_cache.py)
+        from . import miopen_cache
+        miopen_cache.configure()
     try:  # pragma: no cover
         import diffusers  # noqa: F401
         have_diffusers = True

@@ -1,0 +1,301 @@
+// UNet harness: 3x3 convolution (padding 1; stride 1 or 2; optionally over the nearest-neighbour 2x upsampling of its input) on NHWC
+// 16-bit tensors as an implicit GEMM on the gfx950 matrix cores.  Not a SURVEY §8 row of its own: it is the library call
+// (torch.nn.functional.conv2d -> MIOpen) that the reference's UNet makes ~60 times per pass around the attention hooks, and after round 2
+// the largest single share of an edit (31 % of the kernel time; MIOpen's kernels for these shapes issue the 32x32x8 matrix instruction
+// and leave 100-160 of 256 CUs idle at batch 1-3).
+//
+//   out[p, k] = bias[k] + sum_{ky, kx, c} in[img, y*stride + ky - 1, x*stride + kx - 1, c] * w[k, ky, kx, c]
+//
+// GEMM view: the reduction index (tap, c) is contiguous in BOTH operands — w is [K, 3, 3, C] ("KYXC", what a channels_last
+// torch weight holds) and an input pixel's C channels are contiguous — so a reduction step of 64 channels of one tap is a 64-row x 128-B
+// tile of each operand, the shape the attention kernels already stage (attn_common.hpp: swizzled 8 KB LDS image, conflict-free
+// ds_read_b128 fragments).  A = weights (row = output channel), B = pixels (column = MFMA lane), v_mfma_f32_32x32x16: a lane ends up
+// with 16 output channels of ITS pixel, stored as 8-byte pieces.
+//
+// Workgroup = 4 waves = (64 PI) pixels x (64 KI) output channels; wave (wp, wk) owns PI x KI accumulator blocks.  Halo / padding /
+// tails are out-of-range buffer-load offsets (the buffer returns zeros).  Global -> register loads run two reduction steps ahead of the
+// matrix work, LDS is double-buffered, one barrier per step.  Launches that cannot fill the chip split the REDUCTION over workgroups
+// (f32 partials, folded in a fixed order by k_conv_fold: deterministic).
+#include "attn_common.hpp"
+
+struct ConvArgs {
+    const void* in; const void* w; const void* bias; void* out; float* ws;
+    int n, Hi, Wi, C, K, Ho, Wo, stride, up;
+    int P;                       // n * Ho * Wo output pixels
+    int Hv, Wv;                  // extent of the (virtual) input grid the taps index: 2 Hi x 2 Wi when upsampling
+    int tiles_p, tiles_k, ksplit, steps, spc, nwg;     // steps = 9 C / 64 reduction steps, spc of them per split
+    int cpt;                     // steps per tap = C / 64
+};
+
+template <typename T, int PI, int KI>
+__global__ void __launch_bounds__(256, 2)
+k_conv3x3(const ConvArgs a) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    constexpr int NT = PI + KI;                  // 64-row tiles per stage: PI pixel tiles then KI weight tiles
+    __shared__ __attribute__((aligned(16))) char lds[2][NT][ATT_TILE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 1, wk = wave >> 1;
+    int wg = xcd_remap(blockIdx.x, a.nwg);
+    const int sp = wg % a.ksplit; wg /= a.ksplit;
+    const int tk = wg % a.tiles_k, tp = wg / a.tiles_k;
+    const int p0 = tp * (64 * PI), k0 = tk * (64 * KI);
+    const int s_lo = sp * a.spc;
+    const int s_hi = (s_lo + a.spc) < a.steps ? (s_lo + a.spc) : a.steps;
+    const int ns = s_hi - s_lo;
+
+    const int C = a.C;
+    const __amdgpu_buffer_rsrc_t ib = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.n * a.Hi * a.Wi * C * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wb = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.K * 9 * C * 2), 0x00020000);
+
+    // this thread's chunks: rows (tid >> 3) + 32 i of every tile, 16-B chunk tid & 7
+    const int crow = tid >> 3, cch = tid & 7;
+    int pbase[2 * PI], vy[2 * PI], vx[2 * PI];
+#pragma unroll
+    for (int r = 0; r < 2 * PI; ++r) {
+        const int p = p0 + (r >> 1) * 64 + (r & 1) * 32 + crow;
+        const int hw = a.Ho * a.Wo;
+        const int img = p / hw, rem = p - img * hw;
+        const int y = rem / a.Wo, x = rem - y * a.Wo;
+        pbase[r] = img * a.Hi * a.Wi;
+        vy[r] = p < a.P ? y * a.stride - 1 : -(1 << 20);
+        vx[r] = x * a.stride - 1;
+    }
+    uint32_t woff[2 * KI];
+#pragma unroll
+    for (int r = 0; r < 2 * KI; ++r)
+        woff[r] = (uint32_t)(((size_t)(k0 + (r >> 1) * 64 + (r & 1) * 32 + crow) * 9 * C + cch * 8) * 2);
+    int loff[2];
+    loff[0] = img_off(crow, cch);
+    loff[1] = img_off(crow + 32, cch);
+
+    // reduction step s: tap = s / cpt, channels [64 (s % cpt), +64)
+#define GD_CONV_LOAD(R, S)                                                                                               \
+    {                                                                                                                    \
+        const int s_ = (S);                                                                                              \
+        const int tap_ = s_ / a.cpt, c0_ = (s_ - tap_ * a.cpt) * 64;                                                     \
+        const int ky_ = tap_ / 3, kx_ = tap_ - ky_ * 3;                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 2 * PI; ++r) {                                                             \
+            int y_ = vy[r] + ky_, x_ = vx[r] + kx_;                                                                      \
+            const bool ok_ = (unsigned)y_ < (unsigned)a.Hv && (unsigned)x_ < (unsigned)a.Wv;                             \
+            if (a.up) { y_ >>= 1; x_ >>= 1; }                                                                            \
+            const uint32_t o_ = ok_ ? (uint32_t)(((pbase[r] + y_ * a.Wi + x_) * C + c0_ + cch * 8) * 2) : 0x80000000u;   \
+            R[r] = __builtin_amdgcn_raw_buffer_load_b128(ib, o_, 0, 0);                                                  \
+        }                                                                                                                \
+        _Pragma("unroll") for (int r = 0; r < 2 * KI; ++r)                                                               \
+            R[2 * PI + r] = __builtin_amdgcn_raw_buffer_load_b128(wb, woff[r], s_ * 128, 0);                             \
+    }
+#define GD_CONV_STORE(R, BUF)                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < 2 * NT; ++r) *(u32x4*)(lds[BUF][r >> 1] + loff[r & 1]) = R[r]
+
+    f32x16 acc[KI][PI];
+#pragma unroll
+    for (int j = 0; j < KI; ++j)
+#pragma unroll
+        for (int i = 0; i < PI; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+    const FragOffs fo = make_frag_offs(lane);
+
+#define GD_CONV_COMPUTE(BUF)                                                                                             \
+    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                                   \
+        V8 wf[KI], pf[PI];                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < KI; ++j) {                                                                 \
+            const int b_ = wk * KI + j;                                                                                  \
+            wf[j] = rd_row<T>(lds[BUF][PI + (b_ >> 1)], fo, b_ & 1, s4);                                                 \
+        }                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < PI; ++i) {                                                                 \
+            const int b_ = wp * PI + i;                                                                                  \
+            pf[i] = rd_row<T>(lds[BUF][b_ >> 1], fo, b_ & 1, s4);                                                        \
+        }                                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < KI; ++j)                                                                   \
+            _Pragma("unroll") for (int i = 0; i < PI; ++i) acc[j][i] = TR::mfma32(wf[j], pf[i], acc[j][i]);              \
+    }
+
+    u32x4 R0[2 * NT], R1[2 * NT];
+    GD_CONV_LOAD(R0, s_lo);
+    if (ns > 1) GD_CONV_LOAD(R1, s_lo + 1);
+    GD_CONV_STORE(R0, 0);
+    if (ns > 2) GD_CONV_LOAD(R0, s_lo + 2);
+    __syncthreads();
+    int it = 0;
+#pragma unroll 1
+    for (; it + 2 <= ns; it += 2) {
+        GD_CONV_COMPUTE(0);
+        GD_CONV_STORE(R1, 1);
+        __syncthreads();
+        if (it + 3 < ns) GD_CONV_LOAD(R1, s_lo + it + 3);
+        GD_CONV_COMPUTE(1);
+        if (it + 2 < ns) GD_CONV_STORE(R0, 0);
+        __syncthreads();
+        if (it + 4 < ns) GD_CONV_LOAD(R0, s_lo + it + 4);
+    }
+    if (it < ns) { GD_CONV_COMPUTE(0); }
+#undef GD_CONV_LOAD
+#undef GD_CONV_STORE
+#undef GD_CONV_COMPUTE
+
+    // epilogue: lane = pixel, 16 output channels per block in 4 groups of 4 consecutive ones
+#pragma unroll
+    for (int ii = 0; ii < PI; ++ii) {
+        const int p = p0 + (wp * PI + ii) * 32 + (lane & 31);
+        if (p >= a.P) continue;
+#pragma unroll
+        for (int j = 0; j < KI; ++j) {
+            const int kb = k0 + (wk * KI + j) * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = kb + 8 * g + 4 * h;
+                if (ch >= a.K) continue;
+                if (a.ksplit > 1) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][ii][4 * g + e];
+                    *(f32x4*)(a.ws + ((size_t)sp * a.P + p) * a.K + ch) = v;
+                } else {
+                    typename TR::vec4 v;
+                    if (a.bias) {
+                        const typename TR::vec4 b = *(const typename TR::vec4*)((const T*)a.bias + ch);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = TR::from_f32(acc[j][ii][4 * g + e] + TR::to_f32(b[e]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = TR::from_f32(acc[j][ii][4 * g + e]);
+                    }
+                    *(typename TR::vec4*)((T*)a.out + (size_t)p * a.K + ch) = v;
+                }
+            }
+        }
+    }
+}
+
+// fold the reduction splits in a fixed order, add the bias, round once: 4 channels per thread
+template <typename T>
+__global__ void k_conv_fold(const ConvArgs a) {
+    using TR = elem_traits<T>;
+    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t tot = (size_t)a.P * a.K / 4;
+    if (i4 >= tot) return;
+    f32x4 s = *(const f32x4*)(a.ws + i4 * 4);
+    for (int sp = 1; sp < a.ksplit; ++sp) {
+        const f32x4 t = *(const f32x4*)(a.ws + (size_t)sp * a.P * a.K + i4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += t[e];
+    }
+    const int ch = (int)((i4 * 4) % a.K);
+    typename TR::vec4 v;
+    if (a.bias) {
+        const typename TR::vec4 b = *(const typename TR::vec4*)((const T*)a.bias + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = TR::from_f32(s[e] + TR::to_f32(b[e]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = TR::from_f32(s[e]);
+    }
+    *(typename TR::vec4*)((T*)a.out + i4 * 4) = v;
+}
+
+// configuration of a launch: tile shape (PI, KI) and reduction split.  cfg > 0 forces PI*100 + KI*10... (development): see below.
+static int g_conv_force = -1;      // -1: heuristic; otherwise PI * 1000 + KI * 100 + ksplit
+
+extern "C" int gd_conv3x3_set_config(int pi, int ki, int ksplit) {
+    if (pi <= 0) { g_conv_force = -1; return GD_OK; }
+    GD_REQUIRE((pi == 1 || pi == 2) && (ki == 1 || ki == 2) && ksplit >= 1 && ksplit <= 64, GD_EINVAL,
+               "gd_conv3x3_set_config: PI, KI in {1, 2}, ksplit in 1..64");
+    g_conv_force = pi * 1000 + ki * 100 + ksplit;
+    return GD_OK;
+}
+
+static void conv_plan(int P, int K, int steps, int* pi, int* ki, int* ksplit) {
+    if (g_conv_force > 0) {
+        *pi = g_conv_force / 1000; *ki = (g_conv_force / 100) % 10; *ksplit = g_conv_force % 100;
+        if (*ksplit > steps) *ksplit = steps;
+        return;
+    }
+    // Measured on MI355X over the UNet's shapes at batch 1 and 3 (tools/bench_conv.py --sweep): the best configuration is, almost
+    // everywhere, the LARGEST tile for which tiles x splits reaches ~480 workgroups (two per CU) with at least 15 reduction steps
+    // left per split; 128-channel tiles need K % 128 == 0 (K = 320 would waste a fifth of them).
+    static const int cand[4][2] = {{2, 2}, {1, 2}, {2, 1}, {1, 1}};
+    int sp = 1;
+    *pi = 1; *ki = 1;
+    bool found = false;
+    for (int c = 0; c < 4 && !found; ++c) {
+        const int cp = cand[c][0], ck = cand[c][1];
+        if ((ck == 2 && K % 128 != 0) || (cp == 2 && P < 128)) continue;
+        const long long tiles = (long long)((P + 64 * cp - 1) / (64 * cp)) * ((K + 64 * ck - 1) / (64 * ck));
+        int s2 = tiles >= 384 ? 1 : (int)(512 / tiles);
+        if (s2 > 1 && steps / s2 < 15) continue;
+        *pi = cp; *ki = ck; sp = s2; found = true;
+    }
+    if (!found) {                       // tiny launches: 64 x 64 tiles, ~15 steps per split
+        const long long tiles = (long long)((P + 63) / 64) * ((K + 63) / 64);
+        sp = steps / 15;
+        if ((long long)sp * tiles > 512) sp = (int)(512 / tiles);
+    }
+    if (sp < 1) sp = 1;
+    if (sp > 64) sp = 64;
+    *ksplit = sp;
+}
+
+extern "C" size_t gd_conv3x3_workspace_bytes(int n, int Ho, int Wo, int C, int K) {
+    int pi, ki, sp;
+    const int P = n * Ho * Wo;
+    if (P <= 0 || C <= 0 || K <= 0 || C % 64) return 0;
+    conv_plan(P, K, 9 * C / 64, &pi, &ki, &sp);
+    return sp > 1 ? (size_t)sp * P * K * sizeof(float) : 0;
+}
+
+extern "C" int gd_conv3x3(const void* in, const void* w, const void* bias, void* out, int n, int Hi, int Wi, int C, int K, int stride,
+                          int upsample, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    GD_REQUIRE(in && w && out, GD_EINVAL, "gd_conv3x3: null pointer");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_conv3x3: dtype must be f16/bf16");
+    GD_REQUIRE(n > 0 && Hi > 0 && Wi > 0 && C > 0 && K > 0, GD_EINVAL, "gd_conv3x3: bad sizes");
+    GD_REQUIRE(C % 64 == 0 && K % 8 == 0, GD_EUNSUPPORTED, "gd_conv3x3: C=%d must be a multiple of 64 and K=%d of 8", C, K);
+    GD_REQUIRE((stride == 1 || stride == 2) && (upsample == 0 || (upsample == 1 && stride == 1)), GD_EUNSUPPORTED,
+               "gd_conv3x3: stride %d / upsample %d unsupported", stride, upsample);
+    GD_REQUIRE((size_t)n * Hi * Wi * C * 2 < 0x7FFFFFFFull && (size_t)K * 9 * C * 2 < 0x7FFFFFFFull, GD_EUNSUPPORTED,
+               "gd_conv3x3: operand larger than 2 GiB");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.w = w; a.bias = bias; a.out = out;
+    a.n = n; a.Hi = Hi; a.Wi = Wi; a.C = C; a.K = K; a.stride = stride; a.up = upsample;
+    a.Hv = upsample ? 2 * Hi : Hi; a.Wv = upsample ? 2 * Wi : Wi;
+    a.Ho = upsample ? 2 * Hi : (Hi - 1) / stride + 1;          // padding 1, kernel 3
+    a.Wo = upsample ? 2 * Wi : (Wi - 1) / stride + 1;
+    a.P = n * a.Ho * a.Wo;
+    a.cpt = C / 64;
+    a.steps = 9 * a.cpt;
+    int pi, ki, sp;
+    conv_plan(a.P, K, a.steps, &pi, &ki, &sp);
+    a.tiles_p = (a.P + 64 * pi - 1) / (64 * pi);
+    a.tiles_k = (K + 64 * ki - 1) / (64 * ki);
+    a.spc = (a.steps + sp - 1) / sp;
+    a.ksplit = (a.steps + a.spc - 1) / a.spc;                  // no empty split
+    a.nwg = a.tiles_p * a.tiles_k * a.ksplit;
+    if (a.ksplit > 1) {
+        const size_t need = (size_t)a.ksplit * a.P * K * sizeof(float);
+        GD_REQUIRE(workspace && workspace_bytes >= need, GD_EWORKSPACE, "gd_conv3x3: workspace %zu B < %zu B", workspace_bytes, need);
+        a.ws = (float*)workspace;
+    }
+    hipStream_t st = as_stream(stream);
+#define GD_CONV(PI_, KI_)                                                              \
+    {                                                                                  \
+        if (dtype == GD_F16) k_conv3x3<f16_t, PI_, KI_><<<a.nwg, 256, 0, st>>>(a);     \
+        else k_conv3x3<bf16_t, PI_, KI_><<<a.nwg, 256, 0, st>>>(a);                    \
+    }
+    if (pi == 2 && ki == 2) GD_CONV(2, 2)
+    else if (pi == 2) GD_CONV(2, 1)
+    else if (ki == 2) GD_CONV(1, 2)
+    else GD_CONV(1, 1)
+#undef GD_CONV
+    if (a.ksplit > 1) {
+        const size_t tot = (size_t)a.P * K / 4;
+        const unsigned blocks = (unsigned)((tot + 255) / 256);
+        if (dtype == GD_F16) k_conv_fold<f16_t><<<blocks, 256, 0, st>>>(a);
+        else k_conv_fold<bf16_t><<<blocks, 256, 0, st>>>(a);
+    }
+    GD_CHECK_LAUNCH("gd_conv3x3");
+    return GD_OK;
+}

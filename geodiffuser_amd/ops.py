@@ -548,3 +548,39 @@ def add_layer_norm(a, b, gamma, beta, eps: float):
     check(lib.gd_add_layer_norm(_p(a), _p(b), _p(gamma), _p(beta), rows, C, eps, _p(s) if b is not None else None, _p(y), _DT[a.dtype],
                                 _stream()), "gd_add_layer_norm")
     return s, y
+
+
+# ---------------------------------------------------------------------------------------------------
+# UNet harness: 3x3 convolution on the matrix cores (conv3x3.hip)
+# ---------------------------------------------------------------------------------------------------
+def conv3x3_supported(x, w, stride=1) -> bool:
+    """True when ``conv3x3`` takes this call: 16-bit channels_last activations [n, C, H, W] and weight [K, C, 3, 3], C % 64 == 0,
+    K % 8 == 0, stride 1 / 2."""
+    return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and w.dtype == x.dtype and x.dim() == 4 and w.dim() == 4
+            and tuple(w.shape[2:]) == (3, 3) and w.shape[1] == x.shape[1] and x.shape[1] % 64 == 0 and w.shape[0] % 8 == 0
+            and stride in (1, 2) and x.is_contiguous(memory_format=torch.channels_last)
+            and w.is_contiguous(memory_format=torch.channels_last))
+
+
+def conv3x3(x, w, bias=None, stride: int = 1, upsample: bool = False):
+    """3x3 convolution, padding 1 (F.conv2d(x, w, bias, stride, 1); with ``upsample`` over F.interpolate(x, 2.0, 'nearest') without
+    building it).  x [n, C, H, W] and the result [n, K, Ho, Wo] are channels_last (NHWC memory)."""
+    lib = _lib.load()
+    if not conv3x3_supported(x, w, stride):
+        raise _lib.GeodiffError("conv3x3: needs 16-bit channels_last x [n,C,H,W] / w [K,C,3,3] with C % 64 == 0, K % 8 == 0")
+    n, C, H, W = x.shape
+    K = w.shape[0]
+    if upsample:
+        if stride != 1:
+            raise _lib.GeodiffError("conv3x3: upsample needs stride 1")
+        Ho, Wo = 2 * H, 2 * W
+    else:
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if bias is not None:
+        _need(bias, "bias", x.dtype)
+    out = torch.empty((n, K, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    nb = int(lib.gd_conv3x3_workspace_bytes(n, Ho, Wo, C, K))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
+    check(lib.gd_conv3x3(x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), n, H, W, C, K, stride, int(bool(upsample)),
+                         _p(ws), nb, _DT[x.dtype], _stream()), "gd_conv3x3")
+    return out

@@ -76,6 +76,54 @@ def group_norm_fused(x, weight, bias, groups, eps, silu, add_bc=None):
     return ops.group_norm_nhwc(x, weight, bias, groups, eps, silu, add_bc=add_bc)
 
 
+# 3x3 convolutions on the hand-written implicit-GEMM kernel (conv3x3.hip) instead of the library call; GD_CONV3X3=0 = F.conv2d (MIOpen).
+CONV3X3 = os.environ.get("GD_CONV3X3", "1") == "1"
+_WBWD = {}          # id(weight) -> (version, data_ptr, weight of the backward-data convolution)
+
+
+def _weight_bwd(w):
+    """Weight of the convolution that maps dL/dout to dL/din for a stride-1, padding-1 3x3 convolution: taps flipped, channel roles
+    swapped (w_b[c, k, ky, kx] = w[k, c, 2-ky, 2-kx]); built once per (frozen) weight."""
+    c = _WBWD.get(id(w))
+    if c is None or c[0] != w._version or c[1] != w.data_ptr():
+        wb = w.detach().flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+        c = _WBWD[id(w)] = (w._version, w.data_ptr(), wb)
+    return c[2]
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """Stride-1 3x3 convolution with a frozen weight: the gradient w.r.t. the input is the same kernel on the flipped weight."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import ops
+        ctx.save_for_backward(weight)
+        return ops.conv3x3(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        (weight,) = ctx.saved_tensors
+        return ops.conv3x3(g.contiguous(memory_format=torch.channels_last), _weight_bwd(weight)), None, None
+
+
+def conv3x3(x, weight, bias=None, stride=1, upsample=False):
+    """F.conv2d(x [upsampled 2x nearest], weight, bias, stride, padding=1) — on gd_conv3x3 when the call qualifies (16-bit channels_last
+    GPU tensors, C % 64 == 0, K % 8 == 0, frozen weights), on the library otherwise (conv_in / conv_out, fp32 models, CPU)."""
+    if CONV3X3 and x.is_cuda and not weight.requires_grad and (bias is None or not bias.requires_grad):
+        from . import ops
+        if ops.conv3x3_supported(x, weight, stride):
+            if torch.is_grad_enabled() and x.requires_grad:
+                # the backward-data kernel needs C' = K % 64 == 0; strided / upsampled calls keep autograd's library backward
+                if stride == 1 and not upsample and weight.shape[0] % 64 == 0:
+                    return _Conv3x3Fn.apply(x, weight, bias)
+            else:
+                return ops.conv3x3(x, weight, bias, stride=stride, upsample=upsample)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    return F.conv2d(x, weight, bias, stride=stride, padding=1)
+
+
 class UNetOutput(dict):
     """``out["sample"]`` / ``out.sample`` / ``out[0]`` like diffusers' UNet2DConditionOutput."""
 
@@ -232,9 +280,9 @@ class ResnetBlock2D(nn.Module):
         """no-grad pass: conv biases folded away (conv1's into tb, conv2's + shortcut's into one epilogue with the residual add),
         the time-embedding add folded into GroupNorm 2."""
         from . import ops
-        h = F.conv2d(self.norm1(x, silu=True), self.conv1.weight, None, padding=1)
+        h = conv3x3(self.norm1(x, silu=True), self.conv1.weight)
         h = group_norm_fused(h, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, True, add_bc=tb)
-        h = F.conv2d(h, self.conv2.weight, None, padding=1)
+        h = conv3x3(h, self.conv2.weight)
         if self.conv_shortcut is not None:
             x = F.conv2d(x, self.conv_shortcut.weight, None)
         if torch.is_grad_enabled() and (h.requires_grad or x.requires_grad):
@@ -255,9 +303,9 @@ class ResnetBlock2D(nn.Module):
         tb, self._tb = self._tb, None
         if _DBG["GD_FUSE_RES"] and tb is not None and x.is_contiguous(memory_format=torch.channels_last) and self.norm1.fusable(x) and self.norm2.fusable(x):
             return self._fused(x, tb)
-        h = self.conv1(self.norm1(x, silu=True))
+        h = conv3x3(self.norm1(x, silu=True), self.conv1.weight, self.conv1.bias)
         h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(self.norm2(h, silu=True))
+        h = conv3x3(self.norm2(h, silu=True), self.conv2.weight, self.conv2.bias)
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return x + h
@@ -269,7 +317,7 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=1)
 
     def forward(self, x):
-        return self.conv(x)
+        return conv3x3(x, self.conv.weight, self.conv.bias, stride=2)
 
 
 class Upsample2D(nn.Module):
@@ -278,7 +326,7 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, padding=1)
 
     def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        return conv3x3(x, self.conv.weight, self.conv.bias, upsample=True)
 
 
 class DownBlock(nn.Module):

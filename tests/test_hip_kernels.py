@@ -1034,3 +1034,86 @@ def test_fp8_attention_rejects_what_it_cannot_do(ops):
     qz = ops.fp8_quantize(q, k, k.clone(), 0.125)
     with pytest.raises(GeodiffError):                       # 77 keys: not a multiple of 64 (cross-attention stays on the 16-bit path)
         ops.attn_fwd_fp8(qz, 0.125, torch.empty_like(q))
+
+
+# ------------------------------------------------------------------------------------------------ UNet harness: 3x3 convolution
+def _conv_ref(x, w, b, stride, up):
+    import torch.nn.functional as F
+    xi = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    return F.conv2d(xi, w.float(), None if b is None else b.float(), stride=stride, padding=1)
+
+
+def _conv_inputs(n, C, H, W, K, dtype, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(n, C, H, W, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(K, C, 3, 3, generator=g) / (3.0 * C ** 0.5)).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(K, generator=g).to(DEV).to(dtype)
+    return x, w, b
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,C,H,W,K,stride,up,cfg", [
+    (1, 64, 8, 8, 64, 1, 0, None), (2, 128, 9, 7, 72, 1, 0, None), (3, 320, 16, 16, 320, 1, 0, None), (1, 64, 7, 9, 128, 2, 0, None),
+    (2, 128, 8, 8, 64, 2, 0, None), (2, 64, 5, 6, 64, 1, 1, None), (1, 320, 64, 64, 320, 1, 0, None), (3, 1280, 8, 8, 1280, 1, 0, None),
+    (2, 192, 12, 12, 136, 1, 0, (2, 2, 3)), (2, 192, 12, 12, 136, 1, 0, (1, 1, 5)), (2, 192, 12, 12, 136, 1, 0, (2, 1, 1)),
+    (2, 192, 12, 12, 136, 1, 0, (1, 2, 27)), (1, 640, 32, 32, 640, 1, 1, None), (1, 640, 32, 32, 640, 2, 0, None)])
+def test_conv3x3_matches_fp32_convolution(ops, dtype, n, C, H, W, K, stride, up, cfg):
+    """gd_conv3x3 against F.conv2d in fp32 on the same 16-bit operands (padding 1; stride 2; fused nearest upsampling; ragged pixel /
+    channel tails; every tile shape and reduction splits that do not divide the steps).  Tolerance: one rounding of the result."""
+    from geodiffuser_amd import _lib
+    lib = _lib.load()
+    x, w, b = _conv_inputs(n, C, H, W, K, dtype)
+    for bias in (b, None):
+        if cfg:
+            lib.gd_conv3x3_set_config(*cfg)
+        try:
+            o = ops.conv3x3(x, w, bias, stride=stride, upsample=bool(up))
+            o2 = ops.conv3x3(x, w, bias, stride=stride, upsample=bool(up))
+        finally:
+            lib.gd_conv3x3_set_config(0, 0, 0)
+        r = _conv_ref(x, w, bias, stride, up)
+        assert o.shape == r.shape and o.is_contiguous(memory_format=torch.channels_last)
+        assert rel_err(o.float(), r) < tol(dtype)
+        assert torch.equal(o, o2), "split reductions must fold in a fixed order"
+
+
+def test_conv3x3_rejects_what_it_cannot_do(ops):
+    from geodiffuser_amd._lib import GeodiffError
+    x, w, b = _conv_inputs(1, 64, 8, 8, 64, torch.float16)
+    with pytest.raises(GeodiffError):
+        ops.conv3x3(x.contiguous(), w, b)                                        # NCHW memory
+    x4 = torch.randn(1, 4, 8, 8, device=DEV).half().contiguous(memory_format=torch.channels_last)
+    w4 = torch.randn(64, 4, 3, 3, device=DEV).half().contiguous(memory_format=torch.channels_last)
+    assert not ops.conv3x3_supported(x4, w4)                                     # conv_in keeps the library call
+    with pytest.raises(GeodiffError):
+        ops.conv3x3(x4, w4)
+    with pytest.raises(GeodiffError):
+        ops.conv3x3(x, w, b, stride=2, upsample=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_unet_conv3x3_autograd_matches_library(dtype):
+    """The harness' conv3x3: forward and input gradient (same kernel on the flipped weight) against F.conv2d's autograd in fp32, and
+    the library fallbacks (strided / upsampled calls under autograd, GD_CONV3X3=0)."""
+    import torch.nn.functional as F
+    from geodiffuser_amd import unet_sd21 as U
+    x, w, b = _conv_inputs(2, 128, 12, 10, 192, dtype, seed=3)
+    w.requires_grad_(False); b.requires_grad_(False)
+    xg = x.clone().requires_grad_(True)
+    y = U.conv3x3(xg, w, b)
+    assert y.grad_fn is not None and "Conv3x3Fn" in type(y.grad_fn).__name__
+    gy = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, xg, gy)
+    xr = x.float().requires_grad_(True)
+    yr = F.conv2d(xr, w.float(), b.float(), padding=1)
+    (gr,) = torch.autograd.grad(yr, xr, gy.float())
+    assert rel_err(y.float(), yr) < tol(dtype)
+    assert rel_err(gx.float(), gr) < tol(dtype)
+    # strided call under autograd: library backward, same values
+    y2 = U.conv3x3(xg, w, b, stride=2)
+    assert "Conv3x3Fn" not in type(y2.grad_fn).__name__
+    assert rel_err(y2.float(), F.conv2d(x.float(), w.float(), b.float(), stride=2, padding=1)) < tol(dtype)
+    with torch.no_grad():
+        y3 = U.conv3x3(x, w, b, upsample=True)
+        r3 = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
+    assert rel_err(y3.float(), r3) < tol(dtype)

@@ -16,6 +16,7 @@
 // tails are out-of-range buffer-load offsets (the buffer returns zeros).  Global -> register loads run two reduction steps ahead of the
 // matrix work, LDS is double-buffered, one barrier per step.  Launches that cannot fill the chip split the REDUCTION over workgroups
 // (f32 partials, folded in a fixed order by k_conv_fold: deterministic).
+#include <math.h>
 #include "attn_common.hpp"
 
 struct ConvArgs {
@@ -25,6 +26,7 @@ struct ConvArgs {
     int Hv, Wv;                  // extent of the (virtual) input grid the taps index: 2 Hi x 2 Wi when upsampling
     int tiles_p, tiles_k, ksplit, steps, spc, nwg;     // steps = 9 C / 64 reduction steps, spc of them per split
     int cpt;                     // steps per tap = C / 64
+    int order;                   // workgroup order inside an XCD's chunk: 0 = pixel tile slowest, 1 = pixel tile fastest (see gd_conv3x3)
 };
 
 template <typename T, int PI, int KI>
@@ -39,8 +41,14 @@ k_conv3x3(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave & 1, wk = wave >> 1;
     int wg = xcd_remap(blockIdx.x, a.nwg);
-    const int sp = wg % a.ksplit; wg /= a.ksplit;
-    const int tk = wg % a.tiles_k, tp = wg / a.tiles_k;
+    int sp, tk, tp;
+    if (a.order == 0) {
+        sp = wg % a.ksplit; wg /= a.ksplit;
+        tk = wg % a.tiles_k; tp = wg / a.tiles_k;
+    } else {
+        tp = wg % a.tiles_p; wg /= a.tiles_p;
+        sp = wg % a.ksplit; tk = wg / a.ksplit;
+    }
     const int p0 = tp * (64 * PI), k0 = tk * (64 * KI);
     const int s_lo = sp * a.spc;
     const int s_hi = (s_lo + a.spc) < a.steps ? (s_lo + a.spc) : a.steps;
@@ -71,21 +79,40 @@ k_conv3x3(const ConvArgs a) {
     loff[0] = img_off(crow, cch);
     loff[1] = img_off(crow + 32, cch);
 
-    // reduction step s: tap = s / cpt, channels [64 (s % cpt), +64)
-#define GD_CONV_LOAD(R, S)                                                                                               \
+    // Load stream.  Steps are loaded in ascending order, so the position inside the reduction is running SCALAR state: the byte offset of
+    // the 64-channel chunk inside the tap (c0b, the buffer loads' scalar offset), the tap (ky, kx) and the weight tiles' step offset.
+    // The per-thread part — which input pixel a tile row reads for this tap, or out of range for the halo — changes only when the tap
+    // does (every C / 64 steps) and is recomputed there; a step itself costs no vector address arithmetic.  (The first version
+    // re-derived everything per step: ~100 vector / scalar instructions with two integer divisions, 0.5 us per step and CU — more than
+    // the loads, LDS traffic and MFMAs together; tools/price_conv.py.)
+    uint32_t roff[2 * PI];
+    int ld_ky, ld_kx, ld_c0b, ld_wso;
+    {
+        const int tap0 = s_lo / a.cpt;
+        ld_ky = tap0 / 3; ld_kx = tap0 - ld_ky * 3;
+        ld_c0b = (s_lo - tap0 * a.cpt) * 128;
+        ld_wso = s_lo * 128;
+    }
+#define GD_CONV_SET_TAP()                                                                                                \
+    _Pragma("unroll") for (int r = 0; r < 2 * PI; ++r) {                                                                 \
+        int y_ = vy[r] + ld_ky, x_ = vx[r] + ld_kx;                                                                      \
+        const bool ok_ = (unsigned)y_ < (unsigned)a.Hv && (unsigned)x_ < (unsigned)a.Wv;                                 \
+        if (a.up) { y_ >>= 1; x_ >>= 1; }                                                                                \
+        roff[r] = ok_ ? (uint32_t)(((pbase[r] + y_ * a.Wi + x_) * C + cch * 8) * 2) : 0x80000000u;                       \
+    }
+    GD_CONV_SET_TAP();
+#define GD_CONV_LOAD(R)                                                                                                  \
     {                                                                                                                    \
-        const int s_ = (S);                                                                                              \
-        const int tap_ = s_ / a.cpt, c0_ = (s_ - tap_ * a.cpt) * 64;                                                     \
-        const int ky_ = tap_ / 3, kx_ = tap_ - ky_ * 3;                                                                  \
-        _Pragma("unroll") for (int r = 0; r < 2 * PI; ++r) {                                                             \
-            int y_ = vy[r] + ky_, x_ = vx[r] + kx_;                                                                      \
-            const bool ok_ = (unsigned)y_ < (unsigned)a.Hv && (unsigned)x_ < (unsigned)a.Wv;                             \
-            if (a.up) { y_ >>= 1; x_ >>= 1; }                                                                            \
-            const uint32_t o_ = ok_ ? (uint32_t)(((pbase[r] + y_ * a.Wi + x_) * C + c0_ + cch * 8) * 2) : 0x80000000u;   \
-            R[r] = __builtin_amdgcn_raw_buffer_load_b128(ib, o_, 0, 0);                                                  \
-        }                                                                                                                \
+        _Pragma("unroll") for (int r = 0; r < 2 * PI; ++r) R[r] = __builtin_amdgcn_raw_buffer_load_b128(ib, roff[r], ld_c0b, 0); \
         _Pragma("unroll") for (int r = 0; r < 2 * KI; ++r)                                                               \
-            R[2 * PI + r] = __builtin_amdgcn_raw_buffer_load_b128(wb, woff[r], s_ * 128, 0);                             \
+            R[2 * PI + r] = __builtin_amdgcn_raw_buffer_load_b128(wb, woff[r], ld_wso, 0);                               \
+        ld_wso += 128;                                                                                                   \
+        ld_c0b += 128;                                                                                                   \
+        if (ld_c0b == 2 * C) {                                                                                           \
+            ld_c0b = 0;                                                                                                  \
+            if (++ld_kx == 3) { ld_kx = 0; ++ld_ky; }                                                                    \
+            GD_CONV_SET_TAP();                                                                                           \
+        }                                                                                                                \
     }
 #define GD_CONV_STORE(R, BUF)                                                                                            \
     _Pragma("unroll") for (int r = 0; r < 2 * NT; ++r) *(u32x4*)(lds[BUF][r >> 1] + loff[r & 1]) = R[r]
@@ -99,41 +126,60 @@ k_conv3x3(const ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
     const FragOffs fo = make_frag_offs(lane);
 
+// all fragment reads of the step first (the MFMAs then wait on them with counted lgkmcnt, not one LDS latency each)
 #define GD_CONV_COMPUTE(BUF)                                                                                             \
-    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                                   \
-        V8 wf[KI], pf[PI];                                                                                               \
-        _Pragma("unroll") for (int j = 0; j < KI; ++j) {                                                                 \
-            const int b_ = wk * KI + j;                                                                                  \
-            wf[j] = rd_row<T>(lds[BUF][PI + (b_ >> 1)], fo, b_ & 1, s4);                                                 \
+    {                                                                                                                    \
+        V8 wf[4][KI], pf[4][PI];                                                                                         \
+        _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                               \
+            _Pragma("unroll") for (int j = 0; j < KI; ++j) {                                                             \
+                const int b_ = wk * KI + j;                                                                              \
+                wf[s4][j] = rd_row<T>(lds[BUF][PI + (b_ >> 1)], fo, b_ & 1, s4);                                         \
+            }                                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < PI; ++i) {                                                             \
+                const int b_ = wp * PI + i;                                                                              \
+                pf[s4][i] = rd_row<T>(lds[BUF][b_ >> 1], fo, b_ & 1, s4);                                                \
+            }                                                                                                            \
         }                                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < PI; ++i) {                                                                 \
-            const int b_ = wp * PI + i;                                                                                  \
-            pf[i] = rd_row<T>(lds[BUF][b_ >> 1], fo, b_ & 1, s4);                                                        \
-        }                                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < KI; ++j)                                                                   \
-            _Pragma("unroll") for (int i = 0; i < PI; ++i) acc[j][i] = TR::mfma32(wf[j], pf[i], acc[j][i]);              \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < KI; ++j)                                                               \
+                _Pragma("unroll") for (int i = 0; i < PI; ++i) acc[j][i] = TR::mfma32(wf[s4][j], pf[s4][i], acc[j][i]);  \
     }
 
     u32x4 R0[2 * NT], R1[2 * NT];
-    GD_CONV_LOAD(R0, s_lo);
-    if (ns > 1) GD_CONV_LOAD(R1, s_lo + 1);
+    GD_CONV_LOAD(R0);
+    if (ns > 1) GD_CONV_LOAD(R1);
     GD_CONV_STORE(R0, 0);
-    if (ns > 2) GD_CONV_LOAD(R0, s_lo + 2);
+    if (ns > 2) GD_CONV_LOAD(R0);
     __syncthreads();
     int it = 0;
+    // steady state: both loads unconditional (a conditional load makes the compiler wait vmcnt(0) before the LDS stores, i.e. for the
+    // loads it has just issued); the last <= 4 steps run in the guarded copy below
+#pragma unroll 1
+    for (; it + 4 < ns; it += 2) {
+        GD_CONV_COMPUTE(0);
+        GD_CONV_STORE(R1, 1);
+        __syncthreads();
+        GD_CONV_LOAD(R1);
+        GD_CONV_COMPUTE(1);
+        GD_CONV_STORE(R0, 0);
+        __syncthreads();
+        GD_CONV_LOAD(R0);
+    }
 #pragma unroll 1
     for (; it + 2 <= ns; it += 2) {
         GD_CONV_COMPUTE(0);
         GD_CONV_STORE(R1, 1);
         __syncthreads();
-        if (it + 3 < ns) GD_CONV_LOAD(R1, s_lo + it + 3);
+        if (it + 3 < ns) GD_CONV_LOAD(R1);
         GD_CONV_COMPUTE(1);
         if (it + 2 < ns) GD_CONV_STORE(R0, 0);
         __syncthreads();
-        if (it + 4 < ns) GD_CONV_LOAD(R0, s_lo + it + 4);
+        if (it + 4 < ns) GD_CONV_LOAD(R0);
     }
     if (it < ns) { GD_CONV_COMPUTE(0); }
 #undef GD_CONV_LOAD
+#undef GD_CONV_SET_TAP
 #undef GD_CONV_STORE
 #undef GD_CONV_COMPUTE
 
@@ -274,6 +320,18 @@ extern "C" int gd_conv3x3(const void* in, const void* w, const void* bias, void*
     a.spc = (a.steps + sp - 1) / sp;
     a.ksplit = (a.steps + a.spc - 1) / a.spc;                  // no empty split
     a.nwg = a.tiles_p * a.tiles_k * a.ksplit;
+    {
+        // Which operand an XCD's L2 (4 MB, not shared between the 8 XCDs) should see only a slice of.  An XCD runs a contiguous chunk of
+        // the 1-D grid (xcd_remap); with the pixel tile as the slowest index it covers a few pixel tiles x ALL (channel tile, split)
+        // pairs, i.e. every XCD streams the whole weight tensor (22-59 MB at 32^2 / 16^2: measured 130 MB of L2 misses for a 34 MB
+        // problem); with the pixel tile fastest it covers all pixels x a slice of the weights.  Take the order that fetches less.
+        const double I = (double)n * Hi * Wi * C * 2, W = (double)K * 9 * C * 2;
+        const double chunk = a.nwg / 8.0, cols = (double)a.tiles_k * a.ksplit, rows = a.tiles_p;
+        const double r0 = fmin(rows, ceil(chunk / cols) + 1), w0 = fmin(1.0, chunk / cols);
+        const double c1 = fmin(cols, ceil(chunk / rows) + 1), i1 = fmin(1.0, chunk / rows);
+        const double t0 = I * r0 / rows + W * w0, t1 = I * i1 + W * c1 / cols;
+        a.order = t1 < t0 ? 1 : 0;
+    }
     if (a.ksplit > 1) {
         const size_t need = (size_t)a.ksplit * a.P * K * sizeof(float);
         GD_REQUIRE(workspace && workspace_bytes >= need, GD_EWORKSPACE, "gd_conv3x3: workspace %zu B < %zu B", workspace_bytes, need);

@@ -4,7 +4,7 @@
 // the largest single share of an edit (31 % of the kernel time; MIOpen's kernels for these shapes issue the 32x32x8 matrix instruction
 // and leave 100-160 of 256 CUs idle at batch 1-3).
 //
-//   out[p, k] = bias[k] + sum_{ky, kx, c} in[img, y*stride + ky - 1, x*stride + kx - 1, c] * w[k, ky, kx, c]
+//   out[p, k] = bias[k] + residual[p, k] + sum_{ky, kx, c} in[img, y*stride + ky - 1, x*stride + kx - 1, c] * w[k, ky, kx, c]
 //
 // GEMM view: the reduction index (tap, c) is contiguous in BOTH operands — w is [K, 3, 3, C] ("KYXC", what a channels_last
 // torch weight holds) and an input pixel's C channels are contiguous — so a reduction step of 64 channels of one tap is a 64-row x 128-B
@@ -20,7 +20,7 @@
 #include "attn_common.hpp"
 
 struct ConvArgs {
-    const void* in; const void* w; const void* bias; void* out; float* ws;
+    const void* in; const void* w; const void* bias; const void* res; void* out; float* ws;
     int n, Hi, Wi, C, K, Ho, Wo, stride, up;
     int P;                       // n * Ho * Wo output pixels
     int Hv, Wv;                  // extent of the (virtual) input grid the taps index: 2 Hi x 2 Wi when upsampling
@@ -201,15 +201,22 @@ k_conv3x3(const ConvArgs a) {
                     for (int e = 0; e < 4; ++e) v[e] = acc[j][ii][4 * g + e];
                     *(f32x4*)(a.ws + ((size_t)sp * a.P + p) * a.K + ch) = v;
                 } else {
-                    typename TR::vec4 v;
+                    f32x4 f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = acc[j][ii][4 * g + e];
                     if (a.bias) {
                         const typename TR::vec4 b = *(const typename TR::vec4*)((const T*)a.bias + ch);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = TR::from_f32(acc[j][ii][4 * g + e] + TR::to_f32(b[e]));
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = TR::from_f32(acc[j][ii][4 * g + e]);
+                        for (int e = 0; e < 4; ++e) f[e] += TR::to_f32(b[e]);
                     }
+                    if (a.res) {
+                        const typename TR::vec4 r = *(const typename TR::vec4*)((const T*)a.res + (size_t)p * a.K + ch);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] += TR::to_f32(r[e]);
+                    }
+                    typename TR::vec4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = TR::from_f32(f[e]);
                     *(typename TR::vec4*)((T*)a.out + (size_t)p * a.K + ch) = v;
                 }
             }
@@ -231,15 +238,19 @@ __global__ void k_conv_fold(const ConvArgs a) {
         for (int e = 0; e < 4; ++e) s[e] += t[e];
     }
     const int ch = (int)((i4 * 4) % a.K);
-    typename TR::vec4 v;
     if (a.bias) {
         const typename TR::vec4 b = *(const typename TR::vec4*)((const T*)a.bias + ch);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = TR::from_f32(s[e] + TR::to_f32(b[e]));
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = TR::from_f32(s[e]);
+        for (int e = 0; e < 4; ++e) s[e] += TR::to_f32(b[e]);
     }
+    if (a.res) {
+        const typename TR::vec4 r = *(const typename TR::vec4*)((const T*)a.res + i4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += TR::to_f32(r[e]);
+    }
+    typename TR::vec4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = TR::from_f32(s[e]);
     *(typename TR::vec4*)((T*)a.out + i4 * 4) = v;
 }
 
@@ -293,7 +304,7 @@ extern "C" size_t gd_conv3x3_workspace_bytes(int n, int Ho, int Wo, int C, int K
     return sp > 1 ? (size_t)sp * P * K * sizeof(float) : 0;
 }
 
-extern "C" int gd_conv3x3(const void* in, const void* w, const void* bias, void* out, int n, int Hi, int Wi, int C, int K, int stride,
+extern "C" int gd_conv3x3(const void* in, const void* w, const void* bias, const void* residual, void* out, int n, int Hi, int Wi, int C, int K, int stride,
                           int upsample, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
     GD_REQUIRE(in && w && out, GD_EINVAL, "gd_conv3x3: null pointer");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_conv3x3: dtype must be f16/bf16");
@@ -305,7 +316,7 @@ extern "C" int gd_conv3x3(const void* in, const void* w, const void* bias, void*
                "gd_conv3x3: operand larger than 2 GiB");
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = in; a.w = w; a.bias = bias; a.out = out;
+    a.in = in; a.w = w; a.bias = bias; a.res = residual; a.out = out;
     a.n = n; a.Hi = Hi; a.Wi = Wi; a.C = C; a.K = K; a.stride = stride; a.up = upsample;
     a.Hv = upsample ? 2 * Hi : Hi; a.Wv = upsample ? 2 * Wi : Wi;
     a.Ho = upsample ? 2 * Hi : (Hi - 1) / stride + 1;          // padding 1, kernel 3

@@ -562,9 +562,10 @@ def conv3x3_supported(x, w, stride=1) -> bool:
             and w.is_contiguous(memory_format=torch.channels_last))
 
 
-def conv3x3(x, w, bias=None, stride: int = 1, upsample: bool = False):
+def conv3x3(x, w, bias=None, stride: int = 1, upsample: bool = False, res=None):
     """3x3 convolution, padding 1 (F.conv2d(x, w, bias, stride, 1); with ``upsample`` over F.interpolate(x, 2.0, 'nearest') without
-    building it).  x [n, C, H, W] and the result [n, K, Ho, Wo] are channels_last (NHWC memory)."""
+    building it) [+ res, added before the result is rounded].  x [n, C, H, W], res and the result [n, K, Ho, Wo] are channels_last
+    (NHWC memory)."""
     lib = _lib.load()
     if not conv3x3_supported(x, w, stride):
         raise _lib.GeodiffError("conv3x3: needs 16-bit channels_last x [n,C,H,W] / w [K,C,3,3] with C % 64 == 0, K % 8 == 0")
@@ -578,9 +579,11 @@ def conv3x3(x, w, bias=None, stride: int = 1, upsample: bool = False):
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if bias is not None:
         _need(bias, "bias", x.dtype)
+    if res is not None and (tuple(res.shape) != (n, K, Ho, Wo) or res.dtype != x.dtype or not res.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.GeodiffError("conv3x3: res must be a channels_last tensor of the output's shape and dtype")
     out = torch.empty((n, K, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     nb = int(lib.gd_conv3x3_workspace_bytes(n, Ho, Wo, C, K))
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
-    check(lib.gd_conv3x3(x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), n, H, W, C, K, stride, int(bool(upsample)),
+    check(lib.gd_conv3x3(x.data_ptr(), w.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, H, W, C, K, stride, int(bool(upsample)),
                          _p(ws), nb, _DT[x.dtype], _stream()), "gd_conv3x3")
     return out

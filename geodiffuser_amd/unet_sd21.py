@@ -92,36 +92,41 @@ def _weight_bwd(w):
 
 
 class _Conv3x3Fn(torch.autograd.Function):
-    """Stride-1 3x3 convolution with a frozen weight: the gradient w.r.t. the input is the same kernel on the flipped weight."""
+    """Stride-1 3x3 convolution (+ residual) with a frozen weight: the gradient w.r.t. the input is the same kernel on the flipped
+    weight, the residual's gradient is the incoming one."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, res):
         from . import ops
         ctx.save_for_backward(weight)
-        return ops.conv3x3(x, weight, bias)
+        ctx.x_grad = x.requires_grad
+        return ops.conv3x3(x, weight, bias, res=res)
 
     @staticmethod
     def backward(ctx, g):
         from . import ops
         (weight,) = ctx.saved_tensors
-        return ops.conv3x3(g.contiguous(memory_format=torch.channels_last), _weight_bwd(weight)), None, None
+        g = g.contiguous(memory_format=torch.channels_last)
+        gx = ops.conv3x3(g, _weight_bwd(weight)) if ctx.x_grad else None
+        return gx, None, None, (g if ctx.needs_input_grad[3] else None)
 
 
-def conv3x3(x, weight, bias=None, stride=1, upsample=False):
-    """F.conv2d(x [upsampled 2x nearest], weight, bias, stride, padding=1) — on gd_conv3x3 when the call qualifies (16-bit channels_last
-    GPU tensors, C % 64 == 0, K % 8 == 0, frozen weights), on the library otherwise (conv_in / conv_out, fp32 models, CPU)."""
+def conv3x3(x, weight, bias=None, stride=1, upsample=False, res=None):
+    """F.conv2d(x [upsampled 2x nearest], weight, bias, stride, padding=1) [+ res] — on gd_conv3x3 when the call qualifies (16-bit
+    channels_last GPU tensors, C % 64 == 0, K % 8 == 0, frozen weights), on the library otherwise (conv_in / conv_out, fp32, CPU)."""
     if CONV3X3 and x.is_cuda and not weight.requires_grad and (bias is None or not bias.requires_grad):
         from . import ops
-        if ops.conv3x3_supported(x, weight, stride):
-            if torch.is_grad_enabled() and x.requires_grad:
+        if ops.conv3x3_supported(x, weight, stride) and (res is None or res.is_contiguous(memory_format=torch.channels_last)):
+            if torch.is_grad_enabled() and (x.requires_grad or (res is not None and res.requires_grad)):
                 # the backward-data kernel needs C' = K % 64 == 0; strided / upsampled calls keep autograd's library backward
                 if stride == 1 and not upsample and weight.shape[0] % 64 == 0:
-                    return _Conv3x3Fn.apply(x, weight, bias)
+                    return _Conv3x3Fn.apply(x, weight, bias, res)
             else:
-                return ops.conv3x3(x, weight, bias, stride=stride, upsample=upsample)
+                return ops.conv3x3(x, weight, bias, stride=stride, upsample=upsample, res=res)
     if upsample:
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-    return F.conv2d(x, weight, bias, stride=stride, padding=1)
+    y = F.conv2d(x, weight, bias, stride=stride, padding=1)
+    return y if res is None else y + res
 
 
 class UNetOutput(dict):
@@ -282,9 +287,11 @@ class ResnetBlock2D(nn.Module):
         from . import ops
         h = conv3x3(self.norm1(x, silu=True), self.conv1.weight)
         h = group_norm_fused(h, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, True, add_bc=tb)
-        h = conv3x3(h, self.conv2.weight)
         if self.conv_shortcut is not None:
             x = F.conv2d(x, self.conv_shortcut.weight, None)
+        if CONV3X3 and ops.conv3x3_supported(h, self.conv2.weight):           # bias + residual in the convolution's epilogue
+            return conv3x3(h, self.conv2.weight, self._out_bias(), res=x)
+        h = conv3x3(h, self.conv2.weight)
         if torch.is_grad_enabled() and (h.requires_grad or x.requires_grad):
             return _BiasResidualFn.apply(h, self._out_bias(), x)
         return ops.bias_residual(h, self._out_bias(), x)

@@ -340,7 +340,7 @@ int gd_add_layer_norm(const void* a, const void* b, const void* gamma, const voi
  * UNet harness: the 3x3 convolutions of the UNet the reference drives (diffusers' UNet2DConditionModel -> torch.nn.functional.conv2d;
  * GeoDiffuser/utils/diffusion.py:87-143 builds it, U/editor.py:248,305 call it) as an implicit GEMM on the matrix cores.
  * in [n, Hi, Wi, C] and out [n, Ho, Wo, K] are NHWC (torch channels_last), w [K, 3, 3, C] (a channels_last conv weight), bias [K] or
- * NULL, all 16-bit of `dtype`; padding 1; stride 1 or 2 (Ho = (Hi-1)/stride + 1); upsample = 1: the convolution runs over the
+ * NULL, residual [n, Ho, Wo, K] or NULL (added in f32 before the one rounding: the ResnetBlock's `x + h`), all 16-bit of `dtype`; padding 1; stride 1 or 2 (Ho = (Hi-1)/stride + 1); upsample = 1: the convolution runs over the
  * nearest-neighbour 2x upsampling of `in` (Ho = 2 Hi) without materialising it (diffusers Upsample2D).  C % 64 == 0, K % 8 == 0
  * (GD_EUNSUPPORTED otherwise: the caller keeps its library convolution for conv_in / conv_out).  Accumulation in f32 over
  * (ky, kx, c) in that order, one rounding at the end; launches that cannot fill the chip split the reduction and fold the f32
@@ -348,7 +348,7 @@ int gd_add_layer_norm(const void* a, const void* b, const void* gamma, const voi
  * gd_conv3x3_set_config(PI, KI, ksplit) forces the tile shape (64 PI pixels x 64 KI channels) / split for tuning; PI <= 0: heuristic.
  * ---------------------------------------------------------------------------------------------- */
 size_t gd_conv3x3_workspace_bytes(int n, int Ho, int Wo, int C, int K);
-int gd_conv3x3(const void* in, const void* w, const void* bias, void* out, int n, int Hi, int Wi, int C, int K, int stride,
+int gd_conv3x3(const void* in, const void* w, const void* bias, const void* residual, void* out, int n, int Hi, int Wi, int C, int K, int stride,
                int upsample, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 int gd_conv3x3_set_config(int pi, int ki, int ksplit);
 

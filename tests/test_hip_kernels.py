@@ -1075,6 +1075,16 @@ def test_conv3x3_matches_fp32_convolution(ops, dtype, n, C, H, W, K, stride, up,
         assert o.shape == r.shape and o.is_contiguous(memory_format=torch.channels_last)
         assert rel_err(o.float(), r) < tol(dtype)
         assert torch.equal(o, o2), "split reductions must fold in a fixed order"
+    # residual added in the epilogue (before the one rounding)
+    res = torch.randn_like(r).to(dtype).contiguous(memory_format=torch.channels_last)
+    if cfg:
+        lib.gd_conv3x3_set_config(*cfg)
+    try:
+        o = ops.conv3x3(x, w, b, stride=stride, upsample=bool(up), res=res)
+    finally:
+        lib.gd_conv3x3_set_config(0, 0, 0)
+    rr = _conv_ref(x, w, b, stride, up) + res.float()
+    assert rel_err(o.float(), rr) < tol(dtype)
 
 
 def test_conv3x3_rejects_what_it_cannot_do(ops):
@@ -1109,6 +1119,12 @@ def test_unet_conv3x3_autograd_matches_library(dtype):
     (gr,) = torch.autograd.grad(yr, xr, gy.float())
     assert rel_err(y.float(), yr) < tol(dtype)
     assert rel_err(gx.float(), gr) < tol(dtype)
+    # with a residual that also needs its gradient (the ResnetBlock's x + h)
+    rs = torch.randn_like(y).requires_grad_(True)
+    y4 = U.conv3x3(xg, w, b, res=rs)
+    gx4, gr4 = torch.autograd.grad(y4, (xg, rs), gy)
+    assert rel_err(y4.float(), yr + rs.float()) < tol(dtype)
+    assert torch.equal(gx4, gx) and torch.equal(gr4, gy)
     # strided call under autograd: library backward, same values
     y2 = U.conv3x3(xg, w, b, stride=2)
     assert "Conv3x3Fn" not in type(y2.grad_fn).__name__

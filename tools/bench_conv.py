@@ -59,6 +59,7 @@ SHAPES = [(320, 64, 320), (640, 64, 320), (960, 64, 320), (320, 32, 640), (640, 
 EXTRA = [(320, 64, 320, 2, 0), (640, 32, 640, 2, 0), (1280, 16, 1280, 2, 0), (1280, 8, 1280, 1, 1), (1280, 16, 1280, 1, 1), (640, 32, 640, 1, 1)]
 print("== timing, us per call from a hipGraph (library = F.conv2d -> MIOpen) ==", flush=True)
 tot_lib = tot_own = 0.0
+ALL = []
 for n in (1, 3):
     for (C, H, K, stride, up) in [(c, h, k, 1, 0) for (c, h, k) in SHAPES] + EXTRA:
         x, w, b = mk(n, C, H, K)
@@ -78,6 +79,7 @@ for n in (1, 3):
                     t = graph_time(lambda: ops.conv3x3(x, w, None, stride=stride, upsample=bool(up)), reps=10, replays=3)
                     rows.append((t, pi, ki, sp, tiles * sp))
             lib.gd_conv3x3_set_config(0, 0, 0)
+            ALL.append(dict(n=n, C=C, H=H, K=K, stride=stride, up=up, P=P, steps=steps, lib=t_lib, rows=[list(r) for r in rows]))
             rows.sort()
             t_h = graph_time(lambda: ops.conv3x3(x, w, None, stride=stride, upsample=bool(up)))
             top = "  ".join(f"{pi}x{ki}/{sp}:{t:.1f}" for (t, pi, ki, sp, _) in rows[:4])
@@ -89,3 +91,7 @@ for n in (1, 3):
             tot_own += t_own
         tot_lib += t_lib
 print(f"sum over shapes: library {tot_lib:.0f} us, own {tot_own:.0f} us", flush=True)
+if SWEEP:
+    import json
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(ALL, open(os.path.join(ROOT, "gpurun_out", "conv_sweep.json"), "w"))

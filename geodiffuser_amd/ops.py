@@ -559,7 +559,7 @@ def conv3x3_supported(x, w, stride=1) -> bool:
     return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and w.dtype == x.dtype and x.dim() == 4 and w.dim() == 4
             and tuple(w.shape[2:]) == (3, 3) and w.shape[1] == x.shape[1] and x.shape[1] % 64 == 0 and w.shape[0] % 8 == 0
             and stride in (1, 2) and x.is_contiguous(memory_format=torch.channels_last)
-            and w.is_contiguous(memory_format=torch.channels_last))
+            and w.is_contiguous(memory_format=torch.channels_last) and x.numel() * 2 < 0x7FFFFFFF and w.numel() * 2 < 0x7FFFFFFF)
 
 
 def conv3x3(x, w, bias=None, stride: int = 1, upsample: bool = False, res=None):

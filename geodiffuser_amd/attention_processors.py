@@ -381,14 +381,14 @@ class _EditLayer(torch.autograd.Function):
             ctrl.attn_store(ops.attn_probs(q_edit, K, lse_e, None, scale)[:, :, :M].float(), is_cross=is_cross,
                             place_in_unet=ctrl.__dict__.get("_place_in_unet", "up"))
 
-        terms = torch.zeros(5, dtype=torch.float32, device=dev)            # sim, movement, removal, smoothness, amodal
-        loss = torch.zeros((), dtype=torch.float32, device=dev)
+        terms = ops.zeros_f32(5, dev)                                      # sim, movement, removal, smoothness, amodal
+        loss = ops.zeros_f32(1, dev).view(())
         Pe = Pb = aux = tgt = None
         coefs = rm_coef = None
         if want_losses:
             kind = "cross" if is_cross else "self"
             R = c["rows"].numel()
-            rm = torch.zeros(1, dtype=torch.float32, device=dev)
+            rm = ops.zeros_f32(1, dev)
             if R > 0:
                 Pb = ops.attn_probs(q_base, k_base, lse_van[b0 * f:b1 * f], None, scale)     # base_att (:307-317)
                 Pe = ops.attn_probs(q_edit, K, lse_e, c["rows"], scale, n_valid=c.get("n_rows"))   # replace_att[:, inpaint rows]

@@ -18,6 +18,8 @@ from typing import Callable, Dict, Hashable, Optional, Tuple
 
 import torch
 
+from . import ops
+
 ENABLED = os.environ.get("GD_GRAPHS", "1") == "1"
 OPT_PASS_ENABLED = os.environ.get("GD_OPT_GRAPH", "1") == "1"
 
@@ -60,8 +62,10 @@ class GraphedUNet:
             e.t = torch.tensor([tval], device=x.device, dtype=torch.long)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            ops.zero_pool_reset()
             with torch.cuda.graph(g):
                 e.out = self.unet(e.x, e.t, encoder_hidden_states=e.ctx)["sample"]
+            ops.zero_pool_reset()
             e.graph = g
             e.graph.replay()
             return e.out, False                                # Python side effects DID run (during capture)
@@ -148,8 +152,10 @@ class GraphedOptPass:
                   "t": torch.tensor([int(t)], device=dev, dtype=torch.long)}
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            ops.zero_pool_reset()
             with torch.cuda.graph(g):
                 st["g_lat"], st["g_ctx"] = self._eager(controller, st["lat"], st["ctx"], st["t"], skip_scheduler=True)
+            ops.zero_pool_reset()
             st["loss"] = controller.loss
             st["log"] = {k: (dict(v) if isinstance(v, dict) else v) for k, v in controller.loss_log_dict.items()}
             st["graph"] = g

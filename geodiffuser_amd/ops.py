@@ -24,6 +24,59 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _ZeroPool:
+    """The few-float f32 accumulators of the loss kernels (5 terms, one scalar ...) come out of one pre-zeroed chunk instead of one
+    ``torch.zeros`` fill launch each (~160 per optimisation pass).  A slice is handed out once and never reused; a chunk never spans a
+    hipGraph capture boundary — the key holds the runtime's capture id, and graphs.py also calls ``zero_pool_reset`` around its captures —
+    because a slice zeroed by a fill OUTSIDE a graph would not be re-zeroed by the graph's replays."""
+    CHUNK = 2048
+
+    def __init__(self):
+        self.buf, self.pos, self.key, self.gen = None, 0, None, 0
+
+    _hip = None
+
+    @classmethod
+    def _capture_id(cls) -> int:
+        """0 outside a capture, otherwise the runtime's id of the capture sequence the current stream is recording."""
+        if not torch.cuda.is_current_stream_capturing():
+            return 0
+        if cls._hip is None:
+            cls._hip = ctypes.CDLL("libamdhip64.so")
+        status, cid = ctypes.c_int(0), ctypes.c_ulonglong(0)
+        rc = cls._hip.hipStreamGetCaptureInfo(_stream(), ctypes.byref(status), ctypes.byref(cid))
+        return int(cid.value) + 1 if rc == 0 else -1 - cls._bump()
+
+    _n = 0
+
+    @classmethod
+    def _bump(cls) -> int:                                # capture id unavailable: never share a chunk inside a capture
+        cls._n += 1
+        return cls._n
+
+    def take(self, n: int, device) -> torch.Tensor:
+        key = (torch.device(device), self._capture_id(), self.gen)
+        if self.buf is None or self.key != key or self.pos + n > self.CHUNK:
+            self.buf = torch.zeros(self.CHUNK, dtype=torch.float32, device=device)
+            self.pos, self.key = 0, key
+        v = self.buf[self.pos:self.pos + n]
+        self.pos += (n + 3) // 4 * 4                      # keep every slice 16-byte aligned
+        return v
+
+
+_ZEROS = _ZeroPool()
+
+
+def zeros_f32(n: int, device) -> torch.Tensor:
+    """n zeroed floats (a slice of the current pre-zeroed chunk)."""
+    return _ZEROS.take(n, device)
+
+
+def zero_pool_reset() -> None:
+    """Called around every hipGraph capture (graphs.py): the next request starts a fresh chunk."""
+    _ZEROS.gen += 1
+
+
 def _need(t: torch.Tensor, name: str, dtype=None):
     if not t.is_cuda:
         raise _lib.GeodiffError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback), got {t.device}")
@@ -291,7 +344,7 @@ def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int, n_valid=None):
     check(lib.gd_removal_corr_max(_p(Pe), _p(Pb), _p(m_inp), _p(m_wo), _p(n_valid), H, R, N, Mpad, _p(best), dt, _stream()), "gd_removal_corr_max")
     p_in = torch.empty(H, R, dtype=torch.float32, device=dev); p_wo = torch.empty_like(p_in); wgt = torch.empty_like(p_in)
     j_in = torch.empty(H, R, dtype=torch.int32, device=dev); j_wo = torch.empty_like(j_in)
-    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    loss = zeros_f32(1, dev)
     check(lib.gd_removal_loss_reduce(_p(best), _p(rows), _p(n_valid), H, R, S, _p(p_in), _p(j_in), _p(p_wo), _p(j_wo), _p(wgt), _p(loss), _stream()),
           "gd_removal_loss_reduce")
     return dict(p_in=p_in, j_in=j_in, p_wo=p_wo, j_wo=j_wo, wgt=wgt), loss
@@ -343,7 +396,7 @@ def edit_losses_fwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int):
     dt = _dt16(eo, "eo")
     _need(eo, "eo"); _need(ro, "ro", eo.dtype)
     H, N, D = eo.shape
-    sums = torch.zeros(5, dtype=torch.float32, device=eo.device)
+    sums = zeros_f32(5, eo.device)
     ws = torch.empty(lib.gd_edit_losses_fwd_workspace_bytes(H, S, D) // 4, dtype=torch.float32, device=eo.device)
     check(lib.gd_edit_losses_fwd(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), H, S, D, _p(sums), _p(ws), dt,
                                  _stream()), "gd_edit_losses_fwd")
@@ -445,7 +498,7 @@ def masked_latent_update(x, g, m, step: float):
 def sumsq(x):
     lib = _lib.load()
     _need(x, "x", torch.float32)
-    acc = torch.zeros(1, dtype=torch.float32, device=x.device)
+    acc = zeros_f32(1, x.device)
     check(lib.gd_sumsq(_p(x), x.numel(), _p(acc), _stream()), "gd_sumsq")
     return acc
 

@@ -1133,3 +1133,29 @@ def test_unet_conv3x3_autograd_matches_library(dtype):
         y3 = U.conv3x3(x, w, b, upsample=True)
         r3 = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
     assert rel_err(y3.float(), r3) < tol(dtype)
+
+
+def test_zero_pool_slices_are_rezeroed_by_graph_replays(ops):
+    """The loss kernels' small accumulators are slices of a pre-zeroed chunk (ops.zeros_f32).  Inside a captured graph the chunk's fill
+    must be part of THAT graph: replays give the same sums, and two captures back to back do not share a chunk."""
+    x = torch.randn(4096, device=DEV)
+    want = float((x.double() ** 2).sum())
+    a = ops.zeros_f32(5, DEV); b = ops.zeros_f32(1, DEV)
+    assert a.data_ptr() != b.data_ptr() and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+    assert float(a.abs().sum()) == 0.0 and float(b.abs().sum()) == 0.0
+    eager = float(ops.sumsq(x))
+    assert abs(eager - want) < 1e-3 * want
+    torch.cuda.synchronize()
+    graphs, accs = [], []
+    for _ in range(2):                                       # no eager request between the two captures
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            acc = ops.sumsq(x)
+        graphs.append(g); accs.append(acc)
+    for _ in range(3):
+        for g in graphs:
+            g.replay()
+    torch.cuda.synchronize()
+    assert float(accs[0]) == eager and float(accs[1]) == eager
+    assert accs[0].data_ptr() != accs[1].data_ptr()
+    assert float(ops.sumsq(x)) == eager                      # and eager requests after the captures start a fresh chunk

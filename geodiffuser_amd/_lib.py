@@ -75,6 +75,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gd_blend_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gd_group_norm_nhwc_scratch_floats": (c_int64, [c_int, c_int, c_int]),
+    "gd_group_norm_set_single_launch": (c_int, [c_int]),
     "gd_group_norm_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
                                    c_int, c_void_p]),
     "gd_group_norm_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,

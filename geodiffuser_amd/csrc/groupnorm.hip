@@ -188,6 +188,123 @@ k_gn_apply(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, co
     *(V8*)(y + off) = o;
 }
 
+// ---- single-launch variant for maps whose (batch entry, group) slice fits one workgroup's LDS -------------------------------
+// One workgroup of 1024 threads per (group, batch entry): the slice (HW pixels x C/G channels, <= 40 KB) is read ONCE, rounded
+// (x + add) values are parked in LDS while the moments are summed, then normalised from LDS.  One launch instead of two and no
+// partial-moment round trip: at the UNet's sizes both kernels of the two-launch form sit on the launch floor (5-7 us each), so this
+// is what a norm costs less (tools/bench_gn.py).  Addressing: a pixel's group segment is C/G * 2 bytes (20 ... 160 B, 4-byte aligned),
+// handled in 2-channel (4-byte) units; LP = the power of two >= units per pixel lanes walk one pixel, so a thread's unit index j —
+// and with it its add / gamma / beta values — is loop-invariant and no division is needed.  Reductions in a fixed order (wave
+// shuffles, then one thread over the 16 wave sums): bit-reproducible.  The slab-partial scratch of the two-launch form is filled
+// compatibly (totals in slab 0, zeros elsewhere) for the backward kernels.
+#define GN1_THREADS 1024
+#define GN1_MAX_LDS (128 * 1024)
+
+template <typename T, bool SILU>
+__global__ void __launch_bounds__(GN1_THREADS)
+k_gn_fused(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, const T* __restrict__ gamma, const T* __restrict__ beta,
+           int HW, int C, int G, int LP, float eps, float* __restrict__ partial, int nslab, T* __restrict__ y) {
+    using TR = elem_traits<T>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t gn1_lds[];        // [HW][U] units of two 16-bit values
+    __shared__ float s_w[2][GN1_THREADS / 64];
+    __shared__ float s_mr[2];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / G, U = cpg >> 1;
+    const int j = tid & (LP - 1), slot = tid / LP, nslot = GN1_THREADS / LP;
+    const bool act = j < U;
+    const size_t base = (size_t)b * HW * C + (size_t)g * cpg + 2 * (act ? j : 0);
+    float ad0 = 0.f, ad1 = 0.f;
+    if (add_bc && act) {
+        const uint32_t aw = *(const uint32_t*)(add_bc + (size_t)b * add_ld + g * cpg + 2 * j);
+        T a2[2];
+        __builtin_memcpy(a2, &aw, 4);
+        ad0 = TR::to_f32(a2[0]); ad1 = TR::to_f32(a2[1]);
+    }
+    float sum = 0.f, sq = 0.f;
+    if (act) {
+        int p = slot;
+        for (; p + 3 * nslot < HW; p += 4 * nslot) {                        // four pixels in flight per thread
+            uint32_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = *(const uint32_t*)(x + base + (size_t)(p + u * nslot) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                T v2[2];
+                __builtin_memcpy(v2, &w[u], 4);
+                if (add_bc) {           // x + add is rounded to the storage type first, as the unfused `h + temb[:, :, None, None]` does
+                    v2[0] = TR::from_f32(TR::to_f32(v2[0]) + ad0); v2[1] = TR::from_f32(TR::to_f32(v2[1]) + ad1);
+                    __builtin_memcpy(&w[u], v2, 4);
+                }
+                const float f0 = TR::to_f32(v2[0]), f1 = TR::to_f32(v2[1]);
+                sum += f0 + f1;
+                sq = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, sq));
+                gn1_lds[(size_t)(p + u * nslot) * U + j] = w[u];
+            }
+        }
+        for (; p < HW; p += nslot) {
+            uint32_t w = *(const uint32_t*)(x + base + (size_t)p * C);
+            T v2[2];
+            __builtin_memcpy(v2, &w, 4);
+            if (add_bc) {
+                v2[0] = TR::from_f32(TR::to_f32(v2[0]) + ad0); v2[1] = TR::from_f32(TR::to_f32(v2[1]) + ad1);
+                __builtin_memcpy(&w, v2, 4);
+            }
+            const float f0 = TR::to_f32(v2[0]), f1 = TR::to_f32(v2[1]);
+            sum += f0 + f1;
+            sq = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, sq));
+            gn1_lds[(size_t)p * U + j] = w;
+        }
+    }
+    sum = wave_sum(sum); sq = wave_sum(sq);
+    if ((tid & 63) == 0) { s_w[0][tid >> 6] = sum; s_w[1][tid >> 6] = sq; }
+    __syncthreads();
+    if (tid == 0) {
+        float ts = 0.f, tq = 0.f;
+        for (int w = 0; w < GN1_THREADS / 64; ++w) { ts += s_w[0][w]; tq += s_w[1][w]; }
+        const float inv_n = 1.0f / ((float)HW * (float)cpg);
+        const float m = ts * inv_n;
+        s_mr[0] = m;
+        s_mr[1] = rsqrtf(fmaxf(tq * inv_n - m * m, 0.f) + eps);
+        partial[((size_t)b * nslab) * G * 2 + g * 2] = ts;                   // what k_gn_stats would have left, folded: slab 0 = totals
+        partial[((size_t)b * nslab) * G * 2 + g * 2 + 1] = tq;
+    } else if (tid < nslab) {
+        partial[((size_t)b * nslab + tid) * G * 2 + g * 2] = 0.f;
+        partial[((size_t)b * nslab + tid) * G * 2 + g * 2 + 1] = 0.f;
+    }
+    __syncthreads();
+    if (!act) return;
+    const float mean = s_mr[0], rstd = s_mr[1];
+    float ga0, ga1, be0, be1;
+    {
+        T t2[2];
+        const uint32_t gw = *(const uint32_t*)(gamma + g * cpg + 2 * j), bw = *(const uint32_t*)(beta + g * cpg + 2 * j);
+        __builtin_memcpy(t2, &gw, 4); ga0 = TR::to_f32(t2[0]); ga1 = TR::to_f32(t2[1]);
+        __builtin_memcpy(t2, &bw, 4); be0 = TR::to_f32(t2[0]); be1 = TR::to_f32(t2[1]);
+    }
+    for (int p = slot; p < HW; p += nslot) {
+        const uint32_t w = gn1_lds[(size_t)p * U + j];
+        T v2[2];
+        __builtin_memcpy(v2, &w, 4);
+        // same association as k_gn_apply: ((f - mean) * rstd) * gamma + beta
+        float t0 = (TR::to_f32(v2[0]) - mean) * rstd * ga0 + be0, t1 = (TR::to_f32(v2[1]) - mean) * rstd * ga1 + be1;
+        if (SILU) { t0 = t0 / (1.0f + __expf(-t0)); t1 = t1 / (1.0f + __expf(-t1)); }
+        v2[0] = TR::from_f32(t0); v2[1] = TR::from_f32(t1);
+        uint32_t o;
+        __builtin_memcpy(&o, v2, 4);
+        *(uint32_t*)(y + base + (size_t)p * C) = o;
+    }
+}
+
+static int g_gn_single = 1;                 // gd_group_norm_set_single_launch(0): always the two-launch form (benchmarks / tests)
+extern "C" int gd_group_norm_set_single_launch(int on) { g_gn_single = on ? 1 : 0; return GD_OK; }
+
+static bool gn_single_ok(int HW, int C, int G) {
+    const int cpg = C / G;
+    // measured (tools/bench_gn.py, batch 1 and 3): 8^2 and 16^2 maps 7.5-13 -> 4-10 us, 32^2 a tie around 40 KB slices, 64^2 x 320
+    // (80 KB slices on 32-96 workgroups) 12 -> 21 us: one launch up to 40 KB per (batch entry, group)
+    return g_gn_single && (cpg & 1) == 0 && cpg <= 128 && (size_t)HW * cpg * 2 <= 40 * 1024;
+}
+
 extern "C" int64_t gd_group_norm_nhwc_scratch_floats(int B, int HW, int G) {
     if (B <= 0 || HW <= 0 || G <= 0) return 0;
     const int pix = gn_pix_per_slab(HW);
@@ -206,6 +323,29 @@ extern "C" int gd_group_norm_nhwc(const void* x, const void* add_bc, int add_ld,
     hipStream_t st = as_stream(stream);
     const int pix = gn_pix_per_slab(HW);
     const int nslab = (HW + pix - 1) / pix;
+    if (gn_single_ok(HW, C, G)) {
+        const int U = (C / G) >> 1;
+        int LP = 1;
+        while (LP < U) LP <<= 1;
+        const size_t lds = (size_t)HW * U * 4;
+        dim3 grid(G, B);
+        static bool attr_set = false;             // all four instantiations at once (the first call must not fall inside a capture)
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)k_gn_fused<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GN1_MAX_LDS);
+            hipFuncSetAttribute((const void*)k_gn_fused<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GN1_MAX_LDS);
+            hipFuncSetAttribute((const void*)k_gn_fused<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GN1_MAX_LDS);
+            hipFuncSetAttribute((const void*)k_gn_fused<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GN1_MAX_LDS);
+            attr_set = true;
+        }
+#define GD_GN1(T_, S_)                                                                                                   \
+    k_gn_fused<T_, S_><<<grid, GN1_THREADS, lds, st>>>((const T_*)x, (const T_*)add_bc, add_ld, (const T_*)gamma, (const T_*)beta, HW, C, G, LP, \
+                                                       eps, scratch, nslab, (T_*)y);
+        if (dtype == GD_F16) { if (silu) GD_GN1(f16_t, true) else GD_GN1(f16_t, false) }
+        else { if (silu) GD_GN1(bf16_t, true) else GD_GN1(bf16_t, false) }
+#undef GD_GN1
+        GD_CHECK_LAUNCH("gd_group_norm_nhwc");
+        return GD_OK;
+    }
     dim3 sgrid(nslab, B);
     dim3 agrid((unsigned)(((long long)HW * (C >> 3) + 255) / 256), B);
     if (dtype == GD_F16) {

@@ -316,6 +316,9 @@ int gd_norm_rescale(const float* x, const float* num_sumsq, const float* den_sum
  * (norm of x + add_bc[b,c]: the ResNet block's time-embedding add), gamma/beta [C];
  * scratch: gd_group_norm_nhwc_scratch_floats(B, HW, G) f32 (no need to clear). */
 int64_t gd_group_norm_nhwc_scratch_floats(int B, int HW, int G);
+/* Small maps (HW * C/G * 2 B <= 40 KB per (batch entry, group): the 8^2 / 16^2 levels and the narrow 32^2 norms) take ONE launch; 0 forces the two-launch
+ * form everywhere (benchmarks / tests compare both). */
+int gd_group_norm_set_single_launch(int on);
 int gd_group_norm_nhwc(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
                        int silu, float* scratch, void* y, int dtype, void* stream);
 

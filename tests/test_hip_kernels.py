@@ -1159,3 +1159,38 @@ def test_zero_pool_slices_are_rezeroed_by_graph_replays(ops):
     assert float(accs[0]) == eager and float(accs[1]) == eager
     assert accs[0].data_ptr() != accs[1].data_ptr()
     assert float(ops.sumsq(x)) == eager                      # and eager requests after the captures start a fresh chunk
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,add,silu", [(3, 1280, 16, True, True), (2, 2560, 8, False, True), (1, 320, 32, True, False), (2, 640, 32, False, True)])
+def test_group_norm_single_launch_matches_two_launch_form(ops, dtype, B, C, H, add, silu):
+    """Small maps take one launch (k_gn_fused); the result, and the backward that consumes its scratch, must agree with the two-launch
+    form to rounding (the moments are summed in a different order) and with torch's GroupNorm in fp32."""
+    import torch.nn.functional as F
+    from geodiffuser_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = (torch.randn(B, C, H, H, generator=g) * 1.5 + 0.3).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    ga = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV).to(dtype); be = (0.1 * torch.randn(C, generator=g)).to(DEV).to(dtype)
+    ad = (0.5 * torch.randn(B, C, generator=g)).to(DEV).to(dtype) if add else None
+    dy = torch.randn(B, C, H, H, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for on in (0, 1):
+        lib.gd_group_norm_set_single_launch(on)
+        try:
+            y, scratch = ops.group_norm_nhwc(x, ga, be, 32, 1e-5, silu, add_bc=ad, return_scratch=True)
+            y2 = ops.group_norm_nhwc(x, ga, be, 32, 1e-5, silu, add_bc=ad)
+            dx = ops.group_norm_nhwc_bwd(x, ad, ga, be, dy, 32, 1e-5, silu, scratch)
+        finally:
+            lib.gd_group_norm_set_single_launch(1)
+        assert torch.equal(y, y2)
+        res[on] = (y.float(), dx.float())
+    xf = x.float() if ad is None else (x.float() + ad.float()[:, :, None, None]).to(dtype).float()
+    xr = xf.clone().requires_grad_(True)
+    r = F.group_norm(xr, 32, ga.float(), be.float(), 1e-5)
+    r = F.silu(r) if silu else r
+    (gr,) = torch.autograd.grad(r, xr, dy.float())
+    for on in (0, 1):
+        assert rel_err(res[on][0], r.detach()) < tol(dtype)
+        assert rel_l2(res[on][1], gr) < 3 * tol(dtype)
+    assert rel_err(res[1][0], res[0][0]) < tol(dtype)

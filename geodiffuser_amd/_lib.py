@@ -29,6 +29,7 @@ class GeodiffError(RuntimeError):
 # name -> (restype, argtypes); every symbol of include/geodiff_hip.h must be listed here
 SIGNATURES = {
     "gd_version": (c_int, []),
+    "gd_stream_capture_id": (c_int, [c_void_p, c_void_p]),
     "gd_last_error": (c_char_p, []),
     "gd_error_string": (c_char_p, [c_int]),
     "gd_rasterize_workspace_bytes": (c_size_t, [c_int, c_int, c_float]),

@@ -34,3 +34,16 @@ void gd_zero_async(void* ptr, size_t bytes, hipStream_t st) {
     if (n == 0) return;
     k_zero_u32<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((uint32_t*)ptr, n);
 }
+
+// Id of the capture sequence `stream` is recording (0: not capturing).  Host-side helper for ops.zeros_f32: a pre-zeroed chunk must not
+// be shared between two hipGraph captures (the fill belongs to one graph only).  Lives here so that it asks the HIP runtime this
+// library is bound to — dlopen("libamdhip64.so") from Python can map a SECOND runtime next to the one PyTorch bundles.
+extern "C" int gd_stream_capture_id(void* stream, unsigned long long* id) {
+    GD_REQUIRE(id, GD_EINVAL, "gd_stream_capture_id: null pointer");
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    const hipError_t e = hipStreamGetCaptureInfo((hipStream_t)stream, &status, &cid);
+    GD_REQUIRE(e == hipSuccess, GD_ELAUNCH, "gd_stream_capture_id: %s", hipGetErrorString(e));
+    *id = status == hipStreamCaptureStatusActive ? cid + 1 : 0;
+    return GD_OK;
+}

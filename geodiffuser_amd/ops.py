@@ -34,25 +34,14 @@ class _ZeroPool:
     def __init__(self):
         self.buf, self.pos, self.key, self.gen = None, 0, None, 0
 
-    _hip = None
-
-    @classmethod
-    def _capture_id(cls) -> int:
-        """0 outside a capture, otherwise the runtime's id of the capture sequence the current stream is recording."""
+    @staticmethod
+    def _capture_id() -> int:
+        """0 outside a capture, otherwise 1 + the runtime's id of the capture sequence the current stream is recording."""
         if not torch.cuda.is_current_stream_capturing():
             return 0
-        if cls._hip is None:
-            cls._hip = ctypes.CDLL("libamdhip64.so")
-        status, cid = ctypes.c_int(0), ctypes.c_ulonglong(0)
-        rc = cls._hip.hipStreamGetCaptureInfo(_stream(), ctypes.byref(status), ctypes.byref(cid))
-        return int(cid.value) + 1 if rc == 0 else -1 - cls._bump()
-
-    _n = 0
-
-    @classmethod
-    def _bump(cls) -> int:                                # capture id unavailable: never share a chunk inside a capture
-        cls._n += 1
-        return cls._n
+        cid = ctypes.c_ulonglong(0)
+        check(_lib.load().gd_stream_capture_id(_stream(), ctypes.byref(cid)), "gd_stream_capture_id")
+        return int(cid.value)
 
     def take(self, n: int, device) -> torch.Tensor:
         key = (torch.device(device), self._capture_id(), self.gen)

@@ -374,6 +374,10 @@ int gd_softsplat_fwd(const float* in, const float* flow, int N, int C, int H, in
 int gd_softsplat_bwd(const float* in, const float* flow, const float* outgrad, int N, int C, int H, int W, float* ingrad,
                      float* flowgrad, void* stream);
 
+/* Host helper: *id = 1 + the runtime's id of the capture sequence `stream` is recording, 0 when it is not capturing (callers that hand
+ * out pre-zeroed scratch must not share a chunk between two hipGraph captures). */
+int gd_stream_capture_id(void* stream, unsigned long long* id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -278,6 +278,12 @@ static void conv_plan(int P, int K, int steps, int* pi, int* ki, int* ksplit) {
     int sp = 1;
     *pi = 1; *ki = 1;
     bool found = false;
+    // short reductions (C = 320: 45 steps) whose 64 x 64 tiles already make one to two and a half workgroups per CU: no split, no fold
+    // (sweep: 64^2 x 320 at batch 1 22 vs 24 us, 32^2 320 -> 640 at batch 3 23 vs 26 us)
+    {
+        const long long t11 = (long long)((P + 63) / 64) * ((K + 63) / 64);
+        if (steps <= 45 && t11 >= 240 && t11 <= 640) { *ksplit = 1; return; }
+    }
     for (int c = 0; c < 4 && !found; ++c) {
         const int cp = cand[c][0], ck = cand[c][1];
         if ((ck == 2 && K % 128 != 0) || (cp == 2 && P < 128)) continue;

@@ -83,11 +83,11 @@ for n in (1, 3):
             rows.sort()
             t_h = graph_time(lambda: ops.conv3x3(x, w, None, stride=stride, upsample=bool(up)))
             top = "  ".join(f"{pi}x{ki}/{sp}:{t:.1f}" for (t, pi, ki, sp, _) in rows[:4])
-            print(f"n={n} C={C:4d} H={H:2d} K={K:4d} s={stride} up={up}: lib {t_lib:6.1f}  heur {t_h:6.1f}  best {top}   ({gflop / rows[0][0] / 1e3:.0f} TF/s)", flush=True)
+            print(f"n={n} C={C:4d} H={H:2d} K={K:4d} s={stride} up={up}: lib {t_lib:6.1f}  heur {t_h:6.1f}  best {top}   ({gflop / rows[0][0] * 1e3:.0f} TF/s)", flush=True)
             tot_own += t_h
         else:
             t_own = graph_time(lambda: ops.conv3x3(x, w, None, stride=stride, upsample=bool(up)))
-            print(f"n={n} C={C:4d} H={H:2d} K={K:4d} s={stride} up={up}: lib {t_lib:6.1f}  own {t_own:6.1f}  x{t_lib / t_own:4.2f}  ({gflop / t_own / 1e3:.0f} TF/s)", flush=True)
+            print(f"n={n} C={C:4d} H={H:2d} K={K:4d} s={stride} up={up}: lib {t_lib:6.1f}  own {t_own:6.1f}  x{t_lib / t_own:4.2f}  ({gflop / t_own * 1e3:.0f} TF/s)", flush=True)
             tot_own += t_own
         tot_lib += t_lib
 print(f"sum over shapes: library {tot_lib:.0f} us, own {tot_own:.0f} us", flush=True)

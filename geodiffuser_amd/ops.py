@@ -44,6 +44,8 @@ class _ZeroPool:
         return int(cid.value)
 
     def take(self, n: int, device) -> torch.Tensor:
+        if n > self.CHUNK // 4:                               # not a "few floats" request: its own buffer
+            return torch.zeros(n, dtype=torch.float32, device=device)
         key = (torch.device(device), self._capture_id(), self.gen)
         if self.buf is None or self.key != key or self.pos + n > self.CHUNK:
             self.buf = torch.zeros(self.CHUNK, dtype=torch.float32, device=device)

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import Dict, Optional, Union
 
 import torch
@@ -88,6 +89,8 @@ def _weight_bwd(w):
     c = _WBWD.get(id(w))
     if c is None or c[0] != w._version or c[1] != w.data_ptr():
         wb = w.detach().flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+        if c is None:
+            weakref.finalize(w, _WBWD.pop, id(w), None)          # the entry goes when the weight does
         c = _WBWD[id(w)] = (w._version, w.data_ptr(), wb)
     return c[2]
 

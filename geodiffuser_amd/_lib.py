@@ -88,6 +88,7 @@ SIGNATURES = {
     "gd_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                            c_int, c_void_p]),
     "gd_conv3x3_set_config": (c_int, [c_int, c_int, c_int]),
+    "gd_conv3x3_set_dma": (c_int, [c_int]),
     "gd_softsplat_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gd_softsplat_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gd_hist_match": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -13,11 +13,24 @@
 // with 16 output channels of ITS pixel, stored as 8-byte pieces.
 //
 // Workgroup = 4 waves = (64 PI) pixels x (64 KI) output channels; wave (wp, wk) owns PI x KI accumulator blocks.  Halo / padding /
-// tails are out-of-range buffer-load offsets (the buffer returns zeros).  Global -> register loads run two reduction steps ahead of the
-// matrix work, LDS is double-buffered, one barrier per step.  Launches that cannot fill the chip split the REDUCTION over workgroups
-// (f32 partials, folded in a fixed order by k_conv_fold: deterministic).
+// tails are out-of-range buffer-load offsets (the buffer returns zeros).  Two stagings of the operand tiles (template flag DMA), both
+// two reduction steps ahead of the matrix work and one barrier per step, bit-identical results:
+//   registers : global -> registers -> ds_write_b128 into a double-buffered LDS image (the 128 x 128 tile);
+//   DMA       : buffer_load_dwordx4 ... lds straight into a THREE-stage image (the smaller tiles: no staging registers, no ds_write;
+//               the image's swizzle is applied to the source address).
+// Launches that cannot fill the chip split the REDUCTION over workgroups (f32 partials, folded in a fixed order by k_conv_fold:
+// deterministic).
 #include <math.h>
+#include <stdlib.h>
 #include "attn_common.hpp"
+
+// one direct-to-LDS piece: 64 lanes x 16 B land at lds_dst + 16 * lane (wave-uniform destination, per-lane source offset).  The builtin
+// only exists in the device pass; the host pass needs a body to instantiate the kernel's launch stub.
+__device__ __forceinline__ void conv_dma16(const __amdgpu_buffer_rsrc_t rsrc, char* lds_dst, uint32_t voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+#endif
+}
 
 struct ConvArgs {
     const void* in; const void* w; const void* bias; const void* res; void* out; float* ws;
@@ -29,13 +42,14 @@ struct ConvArgs {
     int order;                   // workgroup order inside an XCD's chunk: 0 = pixel tile slowest, 1 = pixel tile fastest (see gd_conv3x3)
 };
 
-template <typename T, int PI, int KI>
+template <typename T, int PI, int KI, bool DMA>
 __global__ void __launch_bounds__(256, 2)
 k_conv3x3(const ConvArgs a) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
     constexpr int NT = PI + KI;                  // 64-row tiles per stage: PI pixel tiles then KI weight tiles
-    __shared__ __attribute__((aligned(16))) char lds[2][NT][ATT_TILE_BYTES];
+    constexpr int NS = (DMA && NT <= 3) ? 3 : 2;   // LDS stages: direct-to-LDS loads need no registers, so the small tiles run three
+    __shared__ __attribute__((aligned(16))) char lds[NS][NT][ATT_TILE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,7 +73,15 @@ k_conv3x3(const ConvArgs a) {
     const __amdgpu_buffer_rsrc_t wb = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.K * 9 * C * 2), 0x00020000);
 
     // this thread's chunks: rows (tid >> 3) + 32 i of every tile, 16-B chunk tid & 7
-    const int crow = tid >> 3, cch = tid & 7;
+    // register staging: chunk tid & 7 of the row, stored to its swizzled slot.  Direct-to-LDS (DMA): a wave-instruction fills 1 KB = 8 rows
+    // x 8 slots in lane order, so lane i must FETCH the chunk that belongs in slot i & 7 of its row (the swizzle moves to the source
+    // address; rows crow and crow + 32 share it)
+    const int crow = tid >> 3;
+    int cch = tid & 7;
+    if (DMA) {
+        const int x_ = (crow >> 1) & 7;
+        cch ^= (x_ & 2) | ((x_ & 1) << 2) | ((x_ >> 2) & 1);
+    }
     int pbase[2 * PI], vy[2 * PI], vx[2 * PI];
 #pragma unroll
     for (int r = 0; r < 2 * PI; ++r) {
@@ -114,6 +136,30 @@ k_conv3x3(const ConvArgs a) {
             GD_CONV_SET_TAP();                                                                                           \
         }                                                                                                                \
     }
+// the same load stream straight into the LDS image of the stage at DST (buffer_load ... lds): no staging registers, no ds_write
+#define GD_CONV_DMA(DST)                                                                                                 \
+    {                                                                                                                    \
+        char* const d_ = (DST) + wave * 1024;                                                                            \
+        _Pragma("unroll") for (int r = 0; r < 2 * PI; ++r)                                                               \
+            conv_dma16(ib, d_ + (r >> 1) * ATT_TILE_BYTES + (r & 1) * 4096, roff[r], ld_c0b);                            \
+        _Pragma("unroll") for (int r = 0; r < 2 * KI; ++r)                                                               \
+            conv_dma16(wb, d_ + (PI + (r >> 1)) * ATT_TILE_BYTES + (r & 1) * 4096, woff[r], ld_wso);                     \
+        ld_wso += 128;                                                                                                   \
+        ld_c0b += 128;                                                                                                   \
+        if (ld_c0b == 2 * C) {                                                                                           \
+            ld_c0b = 0;                                                                                                  \
+            if (++ld_kx == 3) { ld_kx = 0; ++ld_ky; }                                                                    \
+            GD_CONV_SET_TAP();                                                                                           \
+        }                                                                                                                \
+    }
+// retire this wave's pieces of every step but the newest KEEP ones, finish its own fragment reads, then meet the other waves: after
+// the barrier the retired stage may be read and the stage read last may be overwritten
+#define GD_CONV_DMA_SYNC(KEEP)                                                                                           \
+    {                                                                                                                    \
+        if ((KEEP) == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                     \
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NT) : "memory");                                    \
+        __builtin_amdgcn_s_barrier();                                                                                    \
+    }
 #define GD_CONV_STORE(R, BUF)                                                                                            \
     _Pragma("unroll") for (int r = 0; r < 2 * NT; ++r) *(u32x4*)(lds[BUF][r >> 1] + loff[r & 1]) = R[r]
 
@@ -146,6 +192,53 @@ k_conv3x3(const ConvArgs a) {
                 _Pragma("unroll") for (int i = 0; i < PI; ++i) acc[j][i] = TR::mfma32(wf[s4][j], pf[s4][i], acc[j][i]);  \
     }
 
+#define GD_CONV_COMPUTE_AT(BASE)                                                                                         \
+    {                                                                                                                    \
+        V8 wf[4][KI], pf[4][PI];                                                                                         \
+        _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                               \
+            _Pragma("unroll") for (int j = 0; j < KI; ++j) {                                                             \
+                const int b_ = wk * KI + j;                                                                              \
+                wf[s4][j] = rd_row<T>((BASE) + (PI + (b_ >> 1)) * ATT_TILE_BYTES, fo, b_ & 1, s4);                       \
+            }                                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < PI; ++i) {                                                             \
+                const int b_ = wp * PI + i;                                                                              \
+                pf[s4][i] = rd_row<T>((BASE) + (b_ >> 1) * ATT_TILE_BYTES, fo, b_ & 1, s4);                              \
+            }                                                                                                            \
+        }                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < KI; ++j)                                                               \
+                _Pragma("unroll") for (int i = 0; i < PI; ++i) acc[j][i] = TR::mfma32(wf[s4][j], pf[s4][i], acc[j][i]);  \
+    }
+
+    if (DMA) {
+        // stages rotate: cur is read this step, the step after next is loaded into the stage that was read last step
+        char* cur = lds[0][0];
+        char* nxt = lds[1][0];
+        char* far_ = lds[NS - 1][0];
+        GD_CONV_DMA(cur);
+        if (NS == 3) {
+            if (ns > 1) GD_CONV_DMA(nxt);
+            if (ns > 1) { GD_CONV_DMA_SYNC(1); } else { GD_CONV_DMA_SYNC(0); }
+#pragma unroll 1
+            for (int it = 0; it < ns; ++it) {
+                const bool more = it + 2 < ns;
+                if (more) GD_CONV_DMA(far_);
+                GD_CONV_COMPUTE_AT(cur);
+                if (more) { GD_CONV_DMA_SYNC(1); } else { GD_CONV_DMA_SYNC(0); }
+                char* const t_ = cur; cur = nxt; nxt = far_; far_ = t_;
+            }
+        } else {
+            GD_CONV_DMA_SYNC(0);
+#pragma unroll 1
+            for (int it = 0; it < ns; ++it) {
+                if (it + 1 < ns) GD_CONV_DMA(nxt);
+                GD_CONV_COMPUTE_AT(cur);
+                GD_CONV_DMA_SYNC(0);
+                char* const t_ = cur; cur = nxt; nxt = t_;
+            }
+        }
+    } else {
     u32x4 R0[2 * NT], R1[2 * NT];
     GD_CONV_LOAD(R0);
     if (ns > 1) GD_CONV_LOAD(R1);
@@ -178,7 +271,11 @@ k_conv3x3(const ConvArgs a) {
         if (it + 4 < ns) GD_CONV_LOAD(R0);
     }
     if (it < ns) { GD_CONV_COMPUTE(0); }
+    }
 #undef GD_CONV_LOAD
+#undef GD_CONV_DMA
+#undef GD_CONV_DMA_SYNC
+#undef GD_CONV_COMPUTE_AT
 #undef GD_CONV_SET_TAP
 #undef GD_CONV_STORE
 #undef GD_CONV_COMPUTE
@@ -255,6 +352,8 @@ __global__ void k_conv_fold(const ConvArgs a) {
 }
 
 // configuration of a launch: tile shape (PI, KI) and reduction split.  cfg > 0 forces PI*100 + KI*10... (development): see below.
+static int g_conv_dma = -1;         // direct-to-LDS staging for the tiles that get three LDS stages with it; -1: not read yet (GD_CONV_DMA=0 or gd_conv3x3_set_dma(0): registers everywhere)
+extern "C" int gd_conv3x3_set_dma(int on) { g_conv_dma = on ? 1 : 0; return GD_OK; }
 static int g_conv_force = -1;      // -1: heuristic; otherwise PI * 1000 + KI * 100 + ksplit
 
 extern "C" int gd_conv3x3_set_config(int pi, int ki, int ksplit) {
@@ -272,7 +371,7 @@ static void conv_plan(int P, int K, int steps, int* pi, int* ki, int* ksplit) {
         return;
     }
     // Measured on MI355X over the UNet's shapes at batch 1 and 3 (tools/bench_conv.py --sweep): the best configuration is, almost
-    // everywhere, the LARGEST tile for which tiles x splits reaches ~480 workgroups (two per CU) with at least 15 reduction steps
+    // everywhere, the LARGEST tile for which tiles x splits reaches ~480 workgroups (two per CU) with at least 20 reduction steps
     // left per split; 128-channel tiles need K % 128 == 0 (K = 320 would waste a fifth of them).
     static const int cand[4][2] = {{2, 2}, {1, 2}, {2, 1}, {1, 1}};
     int sp = 1;
@@ -289,7 +388,7 @@ static void conv_plan(int P, int K, int steps, int* pi, int* ki, int* ksplit) {
         if ((ck == 2 && K % 128 != 0) || (cp == 2 && P < 128)) continue;
         const long long tiles = (long long)((P + 64 * cp - 1) / (64 * cp)) * ((K + 64 * ck - 1) / (64 * ck));
         int s2 = tiles >= 384 ? 1 : (int)(512 / tiles);
-        if (s2 > 1 && steps / s2 < 15) continue;
+        if (s2 > 1 && steps / s2 < 20) continue;
         *pi = cp; *ki = ck; sp = s2; found = true;
     }
     if (!found) {                       // tiny launches: 64 x 64 tiles, ~15 steps per split
@@ -355,10 +454,16 @@ extern "C" int gd_conv3x3(const void* in, const void* w, const void* bias, const
         a.ws = (float*)workspace;
     }
     hipStream_t st = as_stream(stream);
-#define GD_CONV(PI_, KI_)                                                              \
-    {                                                                                  \
-        if (dtype == GD_F16) k_conv3x3<f16_t, PI_, KI_><<<a.nwg, 256, 0, st>>>(a);     \
-        else k_conv3x3<bf16_t, PI_, KI_><<<a.nwg, 256, 0, st>>>(a);                    \
+    if (g_conv_dma < 0) { const char* e = getenv("GD_CONV_DMA"); g_conv_dma = (e && e[0] == '0') ? 0 : 1; }
+#define GD_CONV(PI_, KI_)                                                                      \
+    {                                                                                          \
+        if (g_conv_dma && (PI_ + KI_) <= 3) {                                                  \
+            if (dtype == GD_F16) k_conv3x3<f16_t, PI_, KI_, true><<<a.nwg, 256, 0, st>>>(a);   \
+            else k_conv3x3<bf16_t, PI_, KI_, true><<<a.nwg, 256, 0, st>>>(a);                  \
+        } else {                                                                               \
+            if (dtype == GD_F16) k_conv3x3<f16_t, PI_, KI_, false><<<a.nwg, 256, 0, st>>>(a);  \
+            else k_conv3x3<bf16_t, PI_, KI_, false><<<a.nwg, 256, 0, st>>>(a);                 \
+        }                                                                                      \
     }
     if (pi == 2 && ki == 2) GD_CONV(2, 2)
     else if (pi == 2) GD_CONV(2, 1)

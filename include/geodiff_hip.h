@@ -354,6 +354,8 @@ size_t gd_conv3x3_workspace_bytes(int n, int Ho, int Wo, int C, int K);
 int gd_conv3x3(const void* in, const void* w, const void* bias, const void* residual, void* out, int n, int Hi, int Wi, int C, int K, int stride,
                int upsample, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 int gd_conv3x3_set_config(int pi, int ki, int ksplit);
+/* 1: stage the operand tiles with direct-to-LDS loads (buffer_load ... lds) instead of registers + ds_write (same results). */
+int gd_conv3x3_set_dma(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * N2  post-process: masked per-channel histogram matching (GeoDiffuser/utils/image_processing.py:24-77).

@@ -1075,6 +1075,18 @@ def test_conv3x3_matches_fp32_convolution(ops, dtype, n, C, H, W, K, stride, up,
         assert o.shape == r.shape and o.is_contiguous(memory_format=torch.channels_last)
         assert rel_err(o.float(), r) < tol(dtype)
         assert torch.equal(o, o2), "split reductions must fold in a fixed order"
+    # register staging and direct-to-LDS staging (three LDS stages, the default for the small tiles) compute the same sums in the same order
+    outs = []
+    for dma in (0, 1):
+        lib.gd_conv3x3_set_dma(dma)
+        if cfg:
+            lib.gd_conv3x3_set_config(*cfg)
+        try:
+            outs.append(ops.conv3x3(x, w, b, stride=stride, upsample=bool(up)))
+        finally:
+            lib.gd_conv3x3_set_config(0, 0, 0)
+            lib.gd_conv3x3_set_dma(1)
+    assert torch.equal(outs[0], outs[1])
     # residual added in the epilogue (before the one rounding)
     res = torch.randn_like(r).to(dtype).contiguous(memory_format=torch.channels_last)
     if cfg:

@@ -86,11 +86,19 @@ for n in (1, 3):
             print(f"n={n} C={C:4d} H={H:2d} K={K:4d} s={stride} up={up}: lib {t_lib:6.1f}  heur {t_h:6.1f}  best {top}   ({gflop / rows[0][0] * 1e3:.0f} TF/s)", flush=True)
             tot_own += t_h
         else:
+            lib.gd_conv3x3_set_dma(0)
             t_own = graph_time(lambda: ops.conv3x3(x, w, None, stride=stride, upsample=bool(up)))
-            print(f"n={n} C={C:4d} H={H:2d} K={K:4d} s={stride} up={up}: lib {t_lib:6.1f}  own {t_own:6.1f}  x{t_lib / t_own:4.2f}  ({gflop / t_own * 1e3:.0f} TF/s)", flush=True)
+            lib.gd_conv3x3_set_dma(1)
+            o_d = ops.conv3x3(x, w, None, stride=stride, upsample=bool(up))
+            t_dma = graph_time(lambda: ops.conv3x3(x, w, None, stride=stride, upsample=bool(up)))
+            lib.gd_conv3x3_set_dma(0)
+            same = bool(torch.equal(o_d, ops.conv3x3(x, w, None, stride=stride, upsample=bool(up))))
+            lib.gd_conv3x3_set_dma(1)
+            tot_dma = globals().get("tot_dma", 0.0) + t_dma
+            print(f"n={n} C={C:4d} H={H:2d} K={K:4d} s={stride} up={up}: lib {t_lib:6.1f}  own {t_own:6.1f}  x{t_lib / t_own:4.2f}  ({gflop / t_own * 1e3:.0f} TF/s)  dma {t_dma:6.1f} same={same}", flush=True)
             tot_own += t_own
         tot_lib += t_lib
-print(f"sum over shapes: library {tot_lib:.0f} us, own {tot_own:.0f} us", flush=True)
+print(f"sum over shapes: library {tot_lib:.0f} us, own {tot_own:.0f} us, dma {globals().get('tot_dma', 0.0):.0f} us", flush=True)
 if SWEEP:
     import json
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

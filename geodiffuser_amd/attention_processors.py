@@ -312,13 +312,6 @@ _CONST: Dict[tuple, torch.Tensor] = {}
 _WEIGHT_VECTORS: Dict[tuple, list] = {}
 
 
-def _perm5(dev) -> torch.Tensor:
-    k = ("perm5", str(dev))
-    if k not in _CONST:
-        _CONST[k] = torch.tensor([0, 1, 4, 3, 3], dtype=torch.long, device=dev)
-    return _CONST[k]
-
-
 def _zeros5(dev) -> torch.Tensor:
     k = ("zeros5", str(dev))
     if k not in _CONST:
@@ -402,12 +395,9 @@ class _EditLayer(torch.autograd.Function):
             # Everything that depends on the (adaptive) loss weights stays on the device: a captured hipGraph of the
             # optimisation pass then follows the schedule without re-capture, and no host->device copy sits in the layer.
             wv = ctrl.loss_weights_device(kind, dev)                 # [sim, movement, removal, smoothness, amodal]
-            t5 = sums * c["inv5"]
-            l_rm = rm[0] * c["inv_rm"][0]
-            terms = torch.stack([t5[0], t5[1], l_rm, t5[3] + t5[4], t5[2] if use_amodal else t5[1] * 0.0])
-            loss = (terms * wv).sum()
-            coefs = wv.index_select(0, _perm5(dev)) * c["inv5_bwd"]   # d(loss)/d(sum_i): sim, movement, amodal, smooth_h, smooth_w
-            rm_coef = wv[2:3] * c["inv_rm"]
+            # terms = [sim, movement, removal, smoothness_h + smoothness_w, amodal | 0], loss = sum terms * wv,
+            # coefs = d(loss)/d(sum_i) for the backward (sim, movement, amodal, smooth_h, smooth_w), rm_coef = wv[removal] * inv_rm
+            terms, loss, coefs, rm_coef = ops.loss_assemble(sums, rm, c["inv5"], c["inv_rm"], wv, c["inv5_bwd"], use_amodal)
 
         # output (:502-508,617-624 / :831-834,922-925)
         if not remover:

@@ -283,3 +283,40 @@ extern "C" int gd_nn_table(const float* fg, int S, int32_t* nn_idx, float* nn_w,
     GD_CHECK_LAUNCH("gd_nn_table");
     return GD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// R8 — the few-float arithmetic between the loss reductions and the backward of a hooked layer, one launch instead of ~11 scalar ones
+// (normalise the five sums, pick the terms, weight them, and the coefficients d(loss)/d(sum_i) the backward kernels read):
+//   t = sums * inv5;  l_rm = rm * inv_rm
+//   terms = [t0 (sim), t1 (movement), l_rm (removal), t3 + t4 (smoothness), use_amodal ? t2 : t1 * 0]     (U/attention_processors.py:
+//   loss  = sum_i terms_i * wv_i   (ascending i)                                                            231-305, 479-480, 596-597)
+//   coefs = wv[{0, 1, 4, 3, 3}] * inv5_bwd;  rm_coef = wv[2] * inv_rm
+// out[12] = terms[0:5], loss[5], coefs[6:11], rm_coef[11].  All operands stay on the device (the adaptive weights wv change between
+// replays of a captured optimisation pass).
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_loss_assemble(const float* __restrict__ sums, const float* __restrict__ rm, const float* __restrict__ inv5,
+                                const float* __restrict__ inv_rm, const float* __restrict__ wv, const float* __restrict__ inv5_bwd,
+                                int use_amodal, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    float t[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) t[i] = sums[i] * inv5[i];
+    const float l_rm = rm[0] * inv_rm[0];
+    float terms[5] = {t[0], t[1], l_rm, t[3] + t[4], use_amodal ? t[2] : t[1] * 0.0f};
+    float loss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { out[i] = terms[i]; loss += terms[i] * wv[i]; }
+    out[5] = loss;
+    const int perm[5] = {0, 1, 4, 3, 3};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) out[6 + i] = wv[perm[i]] * inv5_bwd[i];
+    out[11] = wv[2] * inv_rm[0];
+}
+
+extern "C" int gd_loss_assemble(const float* sums, const float* rm, const float* inv5, const float* inv_rm, const float* wv,
+                                const float* inv5_bwd, int use_amodal, float* out12, void* stream) {
+    GD_REQUIRE(sums && rm && inv5 && inv_rm && wv && inv5_bwd && out12, GD_EINVAL, "gd_loss_assemble: null pointer");
+    k_loss_assemble<<<1, 64, 0, as_stream(stream)>>>(sums, rm, inv5, inv_rm, wv, inv5_bwd, use_amodal, out12);
+    GD_CHECK_LAUNCH("gd_loss_assemble");
+    return GD_OK;
+}

@@ -382,6 +382,20 @@ def amodal_target(eo, nn_idx, nn_w, fg, S: int):
     return tgt
 
 
+def loss_assemble(sums, rm, inv5, inv_rm, wv, inv5_bwd, use_amodal: bool):
+    """-> (terms [5], loss (), coefs [5], rm_coef [1]): the per-layer scalar arithmetic of the edit losses in one launch
+    (gd_loss_assemble); all operands device f32."""
+    lib = _lib.load()
+    for t, nm, n in ((sums, "sums", 5), (rm, "rm", 1), (inv5, "inv5", 5), (inv_rm, "inv_rm", 1), (wv, "wv", 5), (inv5_bwd, "inv5_bwd", 5)):
+        _need(t, nm, torch.float32)
+        if t.numel() != n:
+            raise _lib.GeodiffError(f"loss_assemble: {nm} must have {n} entries")
+    out = torch.empty(12, dtype=torch.float32, device=sums.device)
+    check(lib.gd_loss_assemble(_p(sums), _p(rm), _p(inv5), _p(inv_rm), _p(wv), _p(inv5_bwd), int(bool(use_amodal)), _p(out), _stream()),
+          "gd_loss_assemble")
+    return out[0:5], out[5], out[6:11], out[11:12]
+
+
 def edit_losses_fwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int):
     lib = _lib.load()
     dt = _dt16(eo, "eo")

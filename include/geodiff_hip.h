@@ -259,6 +259,12 @@ int gd_amodal_target(const void* eo, const int32_t* nn_idx, const float* nn_w, c
  * Bit-reproducible: per-workgroup partials go through `workspace` (gd_edit_losses_fwd_workspace_bytes) and are folded in a
  * fixed order — no floating-point atomics.
  */
+/* The scalar arithmetic between the loss reductions and the backward of a hooked layer in one launch (U/attention_processors.py:231-305,
+ * 479-480,596-597): t = sums * inv5; terms = [t0, t1, rm * inv_rm, t3 + t4, use_amodal ? t2 : t1 * 0]; loss = sum terms_i * wv_i;
+ * coefs = wv[{0,1,4,3,3}] * inv5_bwd (what gd_edit_losses_bwd reads); rm_coef = wv[2] * inv_rm.  out12 = terms[0:5], loss[5], coefs[6:11],
+ * rm_coef[11]; every operand is device f32 (sums / inv5 / wv / inv5_bwd: 5 entries; rm / inv_rm: 1). */
+int gd_loss_assemble(const float* sums, const float* rm, const float* inv5, const float* inv_rm, const float* wv, const float* inv5_bwd,
+                     int use_amodal, float* out12, void* stream);
 size_t gd_edit_losses_fwd_workspace_bytes(int H, int S, int D);
 int gd_edit_losses_fwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
                        const float* w_am, const float* m_amodal, int H, int S, int D, float* sums, float* workspace,

@@ -1206,3 +1206,25 @@ def test_group_norm_single_launch_matches_two_launch_form(ops, dtype, B, C, H, a
         assert rel_err(res[on][0], r.detach()) < tol(dtype)
         assert rel_l2(res[on][1], gr) < 3 * tol(dtype)
     assert rel_err(res[1][0], res[0][0]) < tol(dtype)
+
+
+def test_loss_assemble_matches_the_torch_formulation(ops):
+    """gd_loss_assemble = the scalar arithmetic the hooked layer used to do with ~11 tiny torch kernels (same values, same NaN behaviour)."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for use_amodal in (True, False):
+        for nan in (False, True):
+            sums = torch.rand(5, generator=g).to(DEV) * 100; rm = torch.rand(1, generator=g).to(DEV)
+            if nan:
+                sums[1] = float("nan")
+            inv5 = torch.rand(5, generator=g).to(DEV); inv_rm = torch.rand(1, generator=g).to(DEV)
+            wv = (torch.rand(5, generator=g) * 50).to(DEV); inv5_bwd = torch.rand(5, generator=g).to(DEV)
+            terms, loss, coefs, rm_coef = ops.loss_assemble(sums, rm, inv5, inv_rm, wv, inv5_bwd, use_amodal)
+            t5 = sums * inv5
+            want_terms = torch.stack([t5[0], t5[1], rm[0] * inv_rm[0], t5[3] + t5[4], t5[2] if use_amodal else t5[1] * 0.0])
+            want_coefs = wv[torch.tensor([0, 1, 4, 3, 3], device=DEV)] * inv5_bwd
+            assert torch.equal(terms.isnan(), want_terms.isnan())
+            assert torch.allclose(terms.nan_to_num(), want_terms.nan_to_num(), rtol=1e-6, atol=0)
+            want_loss = (want_terms * wv).sum()
+            assert bool(loss.isnan()) == bool(want_loss.isnan()) and (nan or abs(float(loss) - float(want_loss)) <= 1e-5 * abs(float(want_loss)))
+            assert torch.equal(coefs, want_coefs) and torch.equal(rm_coef, wv[2:3] * inv_rm)
+            assert loss.dim() == 0 and terms.shape == (5,) and coefs.shape == (5,) and rm_coef.shape == (1,)

@@ -38,7 +38,7 @@ def one():
     return g
 for _ in range(3): one()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=True) as prof:
     one(); torch.cuda.synchronize()
 ev = [e for e in prof.key_averages() if e.device_time_total > 0 and e.device_type.name != "CPU"]
 ev.sort(key=lambda e: -e.device_time_total)
@@ -46,3 +46,10 @@ tot = sum(e.device_time_total for e in ev); n = sum(e.count for e in ev)
 print(f"optimisation pass: {n} kernels, {tot / 1e3:.2f} ms of kernel time")
 for e in ev[:60]:
     print(f"{e.count:5d} x {e.device_time_total / e.count:7.1f} us = {e.device_time_total / 1e3:7.3f} ms  {e.key[:120]}")
+
+print("\n== aten::copy_ / contiguous / clone / to by input shape (where do the copy kernels come from) ==")
+ka = prof.key_averages(group_by_input_shape=True)
+rows = [e for e in ka if e.key in ("aten::copy_", "aten::contiguous", "aten::clone", "aten::_to_copy", "aten::cat", "aten::add", "aten::add_", "aten::mul", "aten::zeros", "aten::zero_", "aten::fill_") and e.device_time_total > 0]
+rows.sort(key=lambda e: -e.device_time_total)
+for e in rows[:40]:
+    print(f"{e.count:4d} x {e.device_time_total / max(1, e.count):6.1f} us  {e.key:18s} {str(e.input_shapes)[:110]}")

@@ -485,11 +485,114 @@ k_gn_bwd_apply(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld
     *(V8*)(dx + off) = o;
 }
 
+// single-launch backward for the small maps (same eligibility and addressing as k_gn_fused): one workgroup per (group, batch entry)
+// parks the slice's x (+ add) and dy in LDS while S1 = sum g and S2 = sum g * xh are reduced, then writes dx from LDS.
+template <typename T, bool SILU>
+__global__ void __launch_bounds__(GN1_THREADS)
+k_gn_bwd_fused(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, const T* __restrict__ gamma, const T* __restrict__ beta,
+               const T* __restrict__ dy, const float* __restrict__ fwd_partial, int nslab, int HW, int C, int G, int LP, float eps,
+               T* __restrict__ dx) {
+    using TR = elem_traits<T>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t gn1_lds[];        // [2][HW][U]: x units, then dy units
+    __shared__ float s_w[2][GN1_THREADS / 64];
+    __shared__ float s_c[4];                                                  // mean, rstd, S1 / n, S2 / n
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / G, U = cpg >> 1;
+    const int j = tid & (LP - 1), slot = tid / LP, nslot = GN1_THREADS / LP;
+    const bool act = j < U;
+    const float inv_n = 1.0f / ((float)HW * (float)cpg);
+    // the forward's moments of this (batch entry, group): one thread per slab partial loads (a single thread walking <= 64 slabs paid
+    // 64 dependent-looking loads: 25 us), then thread 0 adds them from LDS in ascending order
+    __shared__ float s_f[2][GN_MAX_SLABS];
+    if (tid < nslab) {
+        s_f[0][tid] = fwd_partial[((size_t)b * nslab + tid) * G * 2 + g * 2];
+        s_f[1][tid] = fwd_partial[((size_t)b * nslab + tid) * G * 2 + g * 2 + 1];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ts = 0.f, tq = 0.f;
+        for (int sl = 0; sl < nslab; ++sl) { ts += s_f[0][sl]; tq += s_f[1][sl]; }
+        const float m = ts * inv_n;
+        s_c[0] = m;
+        s_c[1] = rsqrtf(fmaxf(tq * inv_n - m * m, 0.f) + eps);
+    }
+    __syncthreads();
+    const float mean = s_c[0], rstd = s_c[1];
+    const size_t base = (size_t)b * HW * C + (size_t)g * cpg + 2 * (act ? j : 0);
+    float ad0 = 0.f, ad1 = 0.f, ga0 = 0.f, ga1 = 0.f, be0 = 0.f, be1 = 0.f;
+    if (act) {
+        T t2[2];
+        uint32_t w_;
+        if (add_bc) {
+            w_ = *(const uint32_t*)(add_bc + (size_t)b * add_ld + g * cpg + 2 * j);
+            __builtin_memcpy(t2, &w_, 4); ad0 = TR::to_f32(t2[0]); ad1 = TR::to_f32(t2[1]);
+        }
+        w_ = *(const uint32_t*)(gamma + g * cpg + 2 * j); __builtin_memcpy(t2, &w_, 4); ga0 = TR::to_f32(t2[0]); ga1 = TR::to_f32(t2[1]);
+        w_ = *(const uint32_t*)(beta + g * cpg + 2 * j); __builtin_memcpy(t2, &w_, 4); be0 = TR::to_f32(t2[0]); be1 = TR::to_f32(t2[1]);
+    }
+    uint32_t* const lx = gn1_lds;
+    uint32_t* const ld = gn1_lds + (size_t)HW * U;
+    float s1 = 0.f, s2 = 0.f;
+    if (act) {
+        for (int p = slot; p < HW; p += nslot) {
+            const uint32_t xw = *(const uint32_t*)(x + base + (size_t)p * C), dw = *(const uint32_t*)(dy + base + (size_t)p * C);
+            T x2[2], d2[2];
+            __builtin_memcpy(x2, &xw, 4); __builtin_memcpy(d2, &dw, 4);
+            float xh0, xh1;
+            const float g0 = gn_g<T, SILU>(TR::to_f32(x2[0]), ad0, add_bc != nullptr, mean, rstd, ga0, be0, TR::to_f32(d2[0]), xh0);
+            const float g1 = gn_g<T, SILU>(TR::to_f32(x2[1]), ad1, add_bc != nullptr, mean, rstd, ga1, be1, TR::to_f32(d2[1]), xh1);
+            s1 += g0 + g1;
+            s2 = __builtin_fmaf(g0, xh0, __builtin_fmaf(g1, xh1, s2));
+            lx[(size_t)p * U + j] = xw;
+            ld[(size_t)p * U + j] = dw;
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((tid & 63) == 0) { s_w[0][tid >> 6] = s1; s_w[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int w = 0; w < GN1_THREADS / 64; ++w) { t1 += s_w[0][w]; t2 += s_w[1][w]; }
+        s_c[2] = t1 * inv_n;
+        s_c[3] = t2 * inv_n;
+    }
+    __syncthreads();
+    if (!act) return;
+    const float m1 = s_c[2], m2 = s_c[3];
+    for (int p = slot; p < HW; p += nslot) {
+        const uint32_t xw = lx[(size_t)p * U + j], dw = ld[(size_t)p * U + j];
+        T x2[2], d2[2], o2[2];
+        __builtin_memcpy(x2, &xw, 4); __builtin_memcpy(d2, &dw, 4);
+        float xh0, xh1;
+        const float g0 = gn_g<T, SILU>(TR::to_f32(x2[0]), ad0, add_bc != nullptr, mean, rstd, ga0, be0, TR::to_f32(d2[0]), xh0);
+        const float g1 = gn_g<T, SILU>(TR::to_f32(x2[1]), ad1, add_bc != nullptr, mean, rstd, ga1, be1, TR::to_f32(d2[1]), xh1);
+        o2[0] = TR::from_f32(rstd * (g0 - m1 - xh0 * m2));
+        o2[1] = TR::from_f32(rstd * (g1 - m1 - xh1 * m2));
+        uint32_t o;
+        __builtin_memcpy(&o, o2, 4);
+        *(uint32_t*)(dx + base + (size_t)p * C) = o;
+    }
+}
+
 template <typename T, bool SILU>
 static void gn_bwd_launch(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, const void* dy,
                           const float* fwd_scratch, float* scratch, int B, int HW, int C, int G, float eps, void* dx, hipStream_t st) {
     const int pix = gn_pix_per_slab(HW);
     const int nslab = (HW + pix - 1) / pix;
+    if (gn_single_ok(HW, C, G)) {
+        const int U = (C / G) >> 1;
+        int LP = 1;
+        while (LP < U) LP <<= 1;
+        static bool attr_set = false;             // per instantiation; the first call of each happens in an eager pass (graphs.py warms up)
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)k_gn_bwd_fused<T, SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, GN1_MAX_LDS);
+            attr_set = true;
+        }
+        k_gn_bwd_fused<T, SILU><<<dim3(G, B), GN1_THREADS, (size_t)HW * U * 8, st>>>((const T*)x, (const T*)add_bc, add_ld, (const T*)gamma,
+                                                                                   (const T*)beta, (const T*)dy, fwd_scratch, nslab, HW, C,
+                                                                                   G, LP, eps, (T*)dx);
+        return;
+    }
     dim3 sgrid(nslab, B);
     dim3 agrid((unsigned)(((long long)HW * (C >> 3) + 255) / 256), B);
     k_gn_bwd_stats<T, SILU><<<sgrid, 256, 0, st>>>((const T*)x, (const T*)add_bc, add_ld, (const T*)gamma, (const T*)beta, (const T*)dy,

@@ -82,6 +82,47 @@ extern "C" int gd_geglu(const void* x, int64_t rows, int C, void* y, int dtype, 
     return GD_OK;
 }
 
+// backward of y = h * gelu(gate) w.r.t. x = [h | gate] (the optimisation pass differentiates through the feed-forward layers): one launch
+// instead of autograd's mul / gelu_backward / mul / cat.  Rounding points as autograd has them: gelu(gate) and dy * h are 16-bit tensors there.
+//   dh = dy * gelu(gate);  dgate = (dy * h) * gelu'(gate),  gelu'(g) = 0.5 (1 + erf(g / sqrt 2)) + g exp(-g^2 / 2) / sqrt(2 pi)
+template <typename T>
+__global__ void k_geglu_bwd(const T* __restrict__ x, const T* __restrict__ dy, long long nvec, int cv, T* __restrict__ dx) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    const long long row = i / cv;
+    const int k = (int)(i - row * cv);
+    const T* xr = x + row * (long long)cv * 16;
+    const V8 h = *(const V8*)(xr + k * 8), g = *(const V8*)(xr + (cv + k) * 8), d = *(const V8*)(dy + i * 8);
+    V8 oh, og;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float gf = TR::to_f32(g[j]), df = TR::to_f32(d[j]);
+        const float cdf = 0.5f * (1.0f + erff(gf * 0.70710678118654752440f));
+        const float ge = TR::to_f32(TR::from_f32(gf * cdf));
+        oh[j] = TR::from_f32(df * ge);
+        const float dge = TR::to_f32(TR::from_f32(df * TR::to_f32(h[j])));
+        og[j] = TR::from_f32(dge * (cdf + gf * 0.39894228040143267794f * __expf(-0.5f * gf * gf)));
+    }
+    T* dr = dx + row * (long long)cv * 16;
+    *(V8*)(dr + k * 8) = oh;
+    *(V8*)(dr + (cv + k) * 8) = og;
+}
+
+extern "C" int gd_geglu_bwd(const void* x, const void* dy, int64_t rows, int C, void* dx, int dtype, void* stream) {
+    GD_REQUIRE(x && dy && dx, GD_EINVAL, "gd_geglu_bwd: null pointer");
+    GD_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0, GD_EINVAL, "gd_geglu_bwd: need C %% 8 == 0 (C=%d)", C);
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_geglu_bwd: dtype must be f16/bf16");
+    const long long nvec = (long long)rows * (C >> 3);
+    const int blocks = (int)((nvec + 255) / 256);
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16) k_geglu_bwd<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)x, (const f16_t*)dy, nvec, C >> 3, (f16_t*)dx);
+    else k_geglu_bwd<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, nvec, C >> 3, (bf16_t*)dx);
+    GD_CHECK_LAUNCH("gd_geglu_bwd");
+    return GD_OK;
+}
+
 // one wave per row; C <= 8 * 64 * LN_MAXV
 #define LN_MAXV 4
 template <typename T>

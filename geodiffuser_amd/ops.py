@@ -594,6 +594,18 @@ def geglu(x):
     return y
 
 
+def geglu_bwd(x, dy):
+    """Gradient of ``geglu`` w.r.t. x [..., 2C] for dy [..., C]."""
+    lib = _lib.load()
+    rows, C2 = _rows_c(x, "geglu_bwd x")
+    _need(dy, "dy", x.dtype)
+    if x.dim() == 4 or C2 % 16 or dy.shape != x.shape[:-1] + (C2 // 2,):
+        raise _lib.GeodiffError("geglu_bwd: expected x [..., 2C] (C % 8 == 0) and dy [..., C]")
+    dx = torch.empty_like(x)
+    check(lib.gd_geglu_bwd(_p(x), _p(dy), rows, C2 // 2, _p(dx), _DT[x.dtype], _stream()), "gd_geglu_bwd")
+    return dx
+
+
 def add_layer_norm(a, b, gamma, beta, eps: float):
     """-> (s, y): s = a + b (a itself when b is None), y = LayerNorm(s)."""
     lib = _lib.load()

@@ -56,6 +56,22 @@ class _GroupNormFn(torch.autograd.Function):
         return ops.group_norm_nhwc_bwd(x, ctx.add_bc, weight, bias, dy, groups, eps, silu, scratch), None, None, None, None, None, None
 
 
+class _GegluFn(torch.autograd.Function):
+    """x[..., :C] * gelu(x[..., C:]) with a one-launch HIP backward (the optimisation pass differentiates through the feed-forward layers)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import ops
+        ctx.save_for_backward(x)
+        return ops.geglu(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        (x,) = ctx.saved_tensors
+        return ops.geglu_bwd(x, dy.contiguous())
+
+
 class _BiasResidualFn(torch.autograd.Function):
     """y = x + bias[c] + res with a frozen bias: both gradients are the incoming gradient (no kernel)."""
 
@@ -219,9 +235,12 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        if _DBG["GD_FUSE_GEGLU"] and _fast(x) and self.proj.out_features % 16 == 0:
-            from . import ops
-            return ops.geglu(self.proj(x))
+        if _DBG["GD_FUSE_GEGLU"] and self.proj.out_features % 16 == 0:
+            if _fast(x):
+                from . import ops
+                return ops.geglu(self.proj(x))
+            if _fast(x, grad_ok=True) and x.requires_grad and not self.proj.weight.requires_grad:
+                return _GegluFn.apply(self.proj(x).contiguous())
         x, gate = self.proj(x).chunk(2, dim=-1)
         return x * F.gelu(gate)
 

@@ -339,6 +339,9 @@ int gd_bias_residual(const void* x, const void* bias, const void* res, int64_t r
 
 /* y [rows, C] = x[:, :C] * gelu(x[:, C:]) with x [rows, 2C] (GEGLU, exact erf GELU). */
 int gd_geglu(const void* x, int64_t rows, int C, void* y, int dtype, void* stream);
+/* dx [rows, 2C] of the above for dy [rows, C]: dx[:, :C] = dy * gelu(gate), dx[:, C:] = (dy * h) * gelu'(gate) (16-bit rounding where
+ * autograd's unfused chain rounds). */
+int gd_geglu_bwd(const void* x, const void* dy, int64_t rows, int C, void* dx, int dtype, void* stream);
 
 /* s = a + b (16-bit, written to sum_out unless NULL; b may be NULL: s = a);  y = LayerNorm(s) * gamma + beta over the C channels of
  * each row; C <= 2048. */

@@ -1228,3 +1228,33 @@ def test_loss_assemble_matches_the_torch_formulation(ops):
             assert bool(loss.isnan()) == bool(want_loss.isnan()) and (nan or abs(float(loss) - float(want_loss)) <= 1e-5 * abs(float(want_loss)))
             assert torch.equal(coefs, want_coefs) and torch.equal(rm_coef, wv[2:3] * inv_rm)
             assert loss.dim() == 0 and terms.shape == (5,) and coefs.shape == (5,) and rm_coef.shape == (1,)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_geglu_backward_matches_autograd(ops, dtype):
+    """gd_geglu_bwd against autograd of the unfused chain in fp32, and the harness module's autograd path (frozen projection)."""
+    import torch.nn.functional as F
+    from geodiffuser_amd import unet_sd21 as U
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for rows, C in ((3 * 1024, 640), (77, 1280), (5, 2560)):
+        x = (torch.randn(1, rows, 2 * C, generator=g) * 1.5).to(DEV).to(dtype)
+        dy = torch.randn(1, rows, C, generator=g).to(DEV).to(dtype)
+        dx = ops.geglu_bwd(x, dy)
+        xr = x.float().requires_grad_(True)
+        h, gate = xr.chunk(2, dim=-1)
+        (gr,) = torch.autograd.grad(h * F.gelu(gate), xr, dy.float())
+        assert rel_err(dx.float(), gr) < tol(dtype)
+    m = U.GEGLU(128, 256).to(DEV, dtype)
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    xin = torch.randn(2, 50, 128, generator=g).to(DEV).to(dtype).requires_grad_(True)
+    y = m(xin)
+    assert "GegluFn" in type(y.grad_fn).__name__
+    gy = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, xin, gy)
+    xr = xin.detach().float().requires_grad_(True)
+    pr = F.linear(xr, m.proj.weight.float(), m.proj.bias.float())
+    h, gate = pr.chunk(2, dim=-1)
+    yr = h * F.gelu(gate)
+    (gr,) = torch.autograd.grad(yr, xr, gy.float())
+    assert rel_err(y.float(), yr.detach()) < tol(dtype) and rel_l2(gx.float(), gr) < 2 * tol(dtype)

@@ -85,6 +85,7 @@ SIGNATURES = {
     "gd_bias_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "gd_geglu": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "gd_geglu_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
+    "gd_layer_norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_int, c_void_p]),
     "gd_add_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "gd_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "gd_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,

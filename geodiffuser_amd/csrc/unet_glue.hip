@@ -185,6 +185,91 @@ k_add_layer_norm(const T* __restrict__ a, const T* __restrict__ b, const T* __re
     }
 }
 
+// backward of y = LayerNorm(s) * gamma + beta w.r.t. s for frozen gamma / beta, plus the gradient that reaches s directly (s is also
+// the residual stream): ds = rstd * (g - mean(g) - xh * mean(g * xh)) + gs,  g = gy * gamma,  xh = (s - mean) * rstd.  One wave per row,
+// mean / rstd recomputed from s (nothing saved by the forward but s itself).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_layer_norm_bwd(const T* __restrict__ s_in, const T* __restrict__ gamma, const T* __restrict__ gy, const T* __restrict__ gs,
+                 long long rows, int C, float eps, T* __restrict__ ds) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int cv = C >> 3;
+    float v[LN_MAXV][8], g[LN_MAXV][8];
+    float sm = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        const int k = lane + 64 * t;
+        if (k < cv) {
+            const V8 x = *(const V8*)(s_in + row * C + k * 8);
+            const V8 d = *(const V8*)(gy + row * C + k * 8);
+            const V8 ga = *(const V8*)(gamma + k * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[t][j] = TR::to_f32(x[j]);
+                g[t][j] = TR::to_f32(d[j]) * TR::to_f32(ga[j]);
+                sm += v[t][j];
+            }
+        }
+    }
+    const float mean = wave_sum(sm) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t)
+        if (lane + 64 * t < cv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[t][j] - mean; q = __builtin_fmaf(d, d, q); }
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t)
+        if (lane + 64 * t < cv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[t][j] = (v[t][j] - mean) * rstd;                     // xh
+                a1 += g[t][j];
+                a2 = __builtin_fmaf(g[t][j], v[t][j], a2);
+            }
+        }
+    const float m1 = wave_sum(a1) / (float)C, m2 = wave_sum(a2) / (float)C;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        const int k = lane + 64 * t;
+        if (k < cv) {
+            V8 o;
+            if (gs) {
+                const V8 u = *(const V8*)(gs + row * C + k * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = TR::from_f32(rstd * (g[t][j] - m1 - v[t][j] * m2) + TR::to_f32(u[j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = TR::from_f32(rstd * (g[t][j] - m1 - v[t][j] * m2));
+            }
+            *(V8*)(ds + row * C + k * 8) = o;
+        }
+    }
+}
+
+extern "C" int gd_layer_norm_bwd(const void* s, const void* gamma, const void* gy, const void* gs, int64_t rows, int C, float eps, void* ds,
+                                 int dtype, void* stream) {
+    GD_REQUIRE(s && gamma && gy && ds, GD_EINVAL, "gd_layer_norm_bwd: null pointer");
+    GD_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0 && C <= 8 * 64 * LN_MAXV, GD_EINVAL, "gd_layer_norm_bwd: need C %% 8 == 0 and C <= %d (C=%d)",
+               8 * 64 * LN_MAXV, C);
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_layer_norm_bwd: dtype must be f16/bf16");
+    const int blocks = (int)((rows + 3) / 4);
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16)
+        k_layer_norm_bwd<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)s, (const f16_t*)gamma, (const f16_t*)gy, (const f16_t*)gs, rows, C, eps, (f16_t*)ds);
+    else
+        k_layer_norm_bwd<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)s, (const bf16_t*)gamma, (const bf16_t*)gy, (const bf16_t*)gs, rows, C, eps, (bf16_t*)ds);
+    GD_CHECK_LAUNCH("gd_layer_norm_bwd");
+    return GD_OK;
+}
+
 extern "C" int gd_add_layer_norm(const void* a, const void* b, const void* gamma, const void* beta, int64_t rows, int C, float eps,
                                  void* sum_out, void* y, int dtype, void* stream) {
     GD_REQUIRE(a && gamma && beta && y, GD_EINVAL, "gd_add_layer_norm: null pointer");

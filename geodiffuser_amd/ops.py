@@ -594,6 +594,18 @@ def geglu(x):
     return y
 
 
+def layer_norm_bwd(s, gamma, gy, gs, eps: float):
+    """ds = dLayerNorm(gy | s) (+ gs): gradient of ``add_layer_norm`` w.r.t. its sum s (frozen gamma / beta)."""
+    lib = _lib.load()
+    rows, C = _rows_c(s, "layer_norm_bwd s")
+    _need(gamma, "gamma", s.dtype); _need(gy, "gy", s.dtype)
+    if gy.shape != s.shape or (gs is not None and (gs.shape != s.shape or gs.dtype != s.dtype or not gs.is_contiguous())):
+        raise _lib.GeodiffError("layer_norm_bwd: gy / gs must match s")
+    ds = torch.empty_like(s)
+    check(lib.gd_layer_norm_bwd(_p(s), _p(gamma), _p(gy), _p(gs), rows, C, eps, _p(ds), _DT[s.dtype], _stream()), "gd_layer_norm_bwd")
+    return ds
+
+
 def geglu_bwd(x, dy):
     """Gradient of ``geglu`` w.r.t. x [..., 2C] for dy [..., C]."""
     lib = _lib.load()

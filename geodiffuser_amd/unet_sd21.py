@@ -56,6 +56,47 @@ class _GroupNormFn(torch.autograd.Function):
         return ops.group_norm_nhwc_bwd(x, ctx.add_bc, weight, bias, dy, groups, eps, silu, scratch), None, None, None, None, None, None
 
 
+class _AddLayerNormFn(torch.autograd.Function):
+    """(s, y) = (a + b, LayerNorm(a + b)) with frozen gamma / beta: one HIP launch forward, one backward (the gradient that reaches the
+    residual stream s directly is added inside it); a and b both receive that gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps):
+        from . import ops
+        s, y = ops.add_layer_norm(a, b, gamma, beta, eps)
+        ctx.save_for_backward(s, gamma)
+        ctx.eps = eps
+        return s, y
+
+    @staticmethod
+    def backward(ctx, gs, gy):
+        from . import ops
+        s, gamma = ctx.saved_tensors
+        if gy is None:
+            ds = gs
+        else:
+            ds = ops.layer_norm_bwd(s, gamma, gy.contiguous(), None if gs is None else gs.contiguous(), ctx.eps)
+        return ds, ds, None, None, None
+
+
+class _LayerNormFn(torch.autograd.Function):
+    """LayerNorm(x) with frozen gamma / beta on the same kernels (the first norm of a transformer block: nothing is added)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        from . import ops
+        _, y = ops.add_layer_norm(x, None, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x, gamma = ctx.saved_tensors
+        return ops.layer_norm_bwd(x, gamma, gy.contiguous(), None, ctx.eps), None, None, None
+
+
 class _GegluFn(torch.autograd.Function):
     """x[..., :C] * gelu(x[..., C:]) with a one-launch HIP backward (the optimisation pass differentiates through the feed-forward layers)."""
 
@@ -273,6 +314,15 @@ class BasicTransformerBlock(nn.Module):
             x, h = ops.add_layer_norm(a.contiguous(), x, self.norm2.weight, self.norm2.bias, self.norm2.eps)   # x = a + x; h = LN(x)
             a = self.attn2(h, encoder_hidden_states=ctx)
             x, h = ops.add_layer_norm(a.contiguous(), x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+            return self.ff(h) + x
+        if (_DBG["GD_FUSE_TF"] and _fast(x, grad_ok=True) and x.requires_grad and x.is_contiguous() and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048
+                and not any(p.requires_grad for n_ in (self.norm1, self.norm2, self.norm3) for p in n_.parameters())):
+            # optimisation pass: the same fused add + LayerNorm with a one-launch backward
+            h = _LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            a = self.attn1(h)
+            x, h = _AddLayerNormFn.apply(a.contiguous(), x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            a = self.attn2(h, encoder_hidden_states=ctx)
+            x, h = _AddLayerNormFn.apply(a.contiguous(), x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
             return self.ff(h) + x
         x = self.attn1(self.norm1(x)) + x
         x = self.attn2(self.norm2(x), encoder_hidden_states=ctx) + x

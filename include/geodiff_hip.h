@@ -343,6 +343,10 @@ int gd_geglu(const void* x, int64_t rows, int C, void* y, int dtype, void* strea
  * autograd's unfused chain rounds). */
 int gd_geglu_bwd(const void* x, const void* dy, int64_t rows, int C, void* dx, int dtype, void* stream);
 
+/* Gradient of the above w.r.t. s for frozen gamma / beta: ds = dLayerNorm(gy | s) + gs (gs [rows, C] or NULL: the gradient that reaches
+ * the residual stream s directly); mean / rstd are recomputed from s.  a and b of the forward both receive ds. */
+int gd_layer_norm_bwd(const void* s, const void* gamma, const void* gy, const void* gs, int64_t rows, int C, float eps, void* ds,
+                      int dtype, void* stream);
 /* s = a + b (16-bit, written to sum_out unless NULL; b may be NULL: s = a);  y = LayerNorm(s) * gamma + beta over the C channels of
  * each row; C <= 2048. */
 int gd_add_layer_norm(const void* a, const void* b, const void* gamma, const void* beta, int64_t rows, int C, float eps,

@@ -1258,3 +1258,52 @@ def test_geglu_backward_matches_autograd(ops, dtype):
     yr = h * F.gelu(gate)
     (gr,) = torch.autograd.grad(yr, xr, gy.float())
     assert rel_err(y.float(), yr.detach()) < tol(dtype) and rel_l2(gx.float(), gr) < 2 * tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_layer_norm_backward_and_transformer_block_autograd(ops, dtype):
+    """gd_layer_norm_bwd against autograd of F.layer_norm in fp32 (with and without a direct gradient on the sum), and the harness'
+    transformer block under autograd (fused add + LayerNorm functions) against its unfused module chain."""
+    import torch.nn.functional as F
+    from geodiffuser_amd import unet_sd21 as U
+    g = torch.Generator(device="cpu").manual_seed(6)
+    for rows, C in ((2 * 1024, 640), (77, 320), (9, 2048)):
+        s = (torch.randn(1, rows, C, generator=g) * 1.3 + 0.2).to(DEV).to(dtype)
+        ga = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV).to(dtype); be = (0.1 * torch.randn(C, generator=g)).to(DEV).to(dtype)
+        gy = torch.randn(1, rows, C, generator=g).to(DEV).to(dtype); gs = torch.randn(1, rows, C, generator=g).to(DEV).to(dtype)
+        sr = s.float().requires_grad_(True)
+        (gr,) = torch.autograd.grad(F.layer_norm(sr, (C,), ga.float(), be.float(), 1e-5), sr, gy.float())
+        assert rel_err(ops.layer_norm_bwd(s, ga, gy, None, 1e-5).float(), gr) < tol(dtype)
+        assert rel_err(ops.layer_norm_bwd(s, ga, gy, gs, 1e-5).float(), gr + gs.float()) < tol(dtype)
+    torch.manual_seed(2)
+    blk = U.BasicTransformerBlock(256, 4, 64, 128).to(DEV, dtype).eval()
+    for p_ in blk.parameters():
+        p_.requires_grad_(False)
+
+    class TorchAttention:
+        def __call__(self, attn, hidden_states, encoder_hidden_states=None, **kw):
+            c_ = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+            b, n, _ = hidden_states.shape
+            sp = lambda t: t.reshape(b, t.shape[1], attn.heads, -1).transpose(1, 2)
+            o = F.scaled_dot_product_attention(sp(attn.to_q(hidden_states)), sp(attn.to_k(c_)), sp(attn.to_v(c_)))
+            return attn.to_out[0](o.transpose(1, 2).reshape(b, n, -1))
+
+    for a_ in (blk.attn1, blk.attn2):
+        a_.processor = TorchAttention()
+    x0 = torch.randn(2, 64, 256, generator=g).to(DEV).to(dtype); c0 = torch.randn(2, 77, 128, generator=g).to(DEV).to(dtype)
+    w = torch.randn(2, 64, 256, generator=g).to(DEV)
+
+    def run(fused):
+        prev = U.FUSED
+        U.FUSED = fused
+        try:
+            x = x0.clone().requires_grad_(True)
+            with torch.enable_grad():
+                y = blk(x, c0)
+                (gx,) = torch.autograd.grad((y.float() * w).sum(), x)
+            return y.float().detach(), gx.float()
+        finally:
+            U.FUSED = prev
+
+    (y0, g0), (y1, g1) = run(False), run(True)
+    assert rel_err(y1, y0) < 4 * tol(dtype) and rel_l2(g1, g0) < 4 * tol(dtype)

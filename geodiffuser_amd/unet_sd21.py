@@ -310,7 +310,7 @@ class BasicTransformerBlock(nn.Module):
     def forward(self, x, ctx):
         if _DBG["GD_FUSE_TF"] and _fast(x) and x.is_contiguous() and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048:
             from . import ops
-            a = self.attn1(self.norm1(x))
+            a = self.attn1(ops.add_layer_norm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)[1])
             x, h = ops.add_layer_norm(a.contiguous(), x, self.norm2.weight, self.norm2.bias, self.norm2.eps)   # x = a + x; h = LN(x)
             a = self.attn2(h, encoder_hidden_states=ctx)
             x, h = ops.add_layer_norm(a.contiguous(), x, self.norm3.weight, self.norm3.bias, self.norm3.eps)

@@ -339,6 +339,31 @@ def cpu_baseline_configs0(cores, sample_steps=4):
                         f"{c['steps']} inversion) = {total:.0f} s per 256^2 / 20-step edit"))
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv, device_count=None, run=None) -> int:
+    """``bench.py --gpus N`` with no torchrun environment: run ``python -m torch.distributed.run --nproc-per-node N bench.py <argv>`` as a
+    CHILD process (this process has not initialised the GPU: ``device_count`` does not, and a process that has must never exec), relay
+    its output — rank 0 prints the JSON line — and return its exit code.  Fails loudly when fewer than N devices are visible.  The
+    path shards by independent edit (the reference is single-GPU, /root/reference/README.md:88): one rank per GPU, a free
+    rendezvous port on 127.0.0.1.  ``device_count`` / ``run`` are injection points of the CPU test."""
+    import subprocess
+    have = torch.cuda.device_count() if device_count is None else device_count
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible on this node", file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return (run or subprocess.call)(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -353,6 +378,9 @@ def main():
     ap.add_argument("--model", default="sd21", choices=["sd21", "sdxl"],
                     help="sd21 = BASELINE configs[1] (the benchmark); sdxl = SDXL-base-shaped UNet, use with --size 1024 (configs[4] shape, bf16 path)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (before anything touches the GPU)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     # Let MIOpen time its convolution solvers per shape during the warm-up edit instead of taking the heuristic pick (which
     # favours split-K igemm kernels with an fp32 workspace + cast kernels here): -7 % per edit, ~90 s more warm-up on a fresh box.
@@ -364,7 +392,7 @@ def main():
     miopen_db = miopen_cache.configure()
     from geodiffuser_amd import dist as gdist
     rank, world, local = gdist.init()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
@@ -395,6 +423,7 @@ def main():
         torch.cuda.synchronize()
         warm_s.append(time.perf_counter() - tw)
     torch.cuda.synchronize()
+    db_ok = miopen_cache.check_db_used()          # warns when the committed find-db is keyed to another MIOpen build
     gdist.barrier()
     timer.enabled = rank == 0
     mark = os.environ.get("GD_BENCH_MARK") == "1"   # profiling aid: a uniquely named kernel brackets the timed region in a trace
@@ -434,7 +463,7 @@ def main():
                        "tiny_debug_model": bool(args.tiny),
                        # multi-GPU reporting: seconds of the timed region on every rank (value uses their max) and of each rank's
                        # FIRST warm-up edit (solver search unless the find-db has the shapes, graph captures, allocator growth)
-                       "per_rank_s": per_rank, "first_warmup_edit_s": first_edit, "miopen_db": os.path.relpath(miopen_db, ROOT)},
+                       "per_rank_s": per_rank, "first_warmup_edit_s": first_edit, "miopen_db": os.path.relpath(miopen_cache._DIR, ROOT), "miopen_db_matched": db_ok},
         }
         if roof:
             line["roofline"] = {"kernel": f"k_attn_fwd_mp (attention forward, N = M = {timer.n} self-attention launches)", "bound": "mfma", "achieved": roof["achieved"] / 1e12,

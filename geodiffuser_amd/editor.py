@@ -46,6 +46,8 @@ TOKENIZER = None
 UNET_NAME = None
 PROGRESS_BAR = None
 TIE_IDENTICAL_ROWS = os.environ.get("GD_TIE_ROWS", "1") == "1"   # first optimisation pass of an edit: see attention_processors.rows_identical
+HONOUR_SPLAT_ARGS = os.environ.get("GD_HONOUR_SPLAT_ARGS", "0") == "1"   # see _perform_geometric_edit: the reference ignores them (F3)
+SPLATTER = warp_utils.RasterizePointsXYsBlending()      # editor.py:50 — the reference's dead object, kept for attribute compatibility
 SKIP_UNCOND_REF = True      # drop the CFG pass's unused `uncond_ref` batch row (identical edit output)
 
 
@@ -86,7 +88,6 @@ def _resize_mask(m, s):
     return F.interpolate(m, size=(s, s), mode="bilinear", align_corners=False, antialias=False)
 
 
-@torch.no_grad()
 def _coords_dtype(like: torch.Tensor):
     """Dtype the warp coordinates are rounded through where the reference writes ``.type_as(<a model tensor>)`` (U/editor.py:148,389): fp16
     on its GPU path.  A bf16 model must NOT round pixel coordinates through bf16 (8 mantissa bits = 2 pixels at 512^2 — found by the
@@ -94,6 +95,7 @@ def _coords_dtype(like: torch.Tensor):
     return torch.float16 if like.dtype == torch.bfloat16 else like.dtype
 
 
+@torch.no_grad()
 def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_steps: int = 20, guidance_scale: Optional[float] = 7.5,
                           generator=None, latent=None, uncond_embeddings=None, start_time=50, return_type="image",
                           transform_coordinates=None, mask_obj=None, optimize_steps=0.2, latent_replace=0.2, lr=0.0,
@@ -139,6 +141,8 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
     skip_ref = ddim_latents is not None and batch_size == 2 and SKIP_UNCOND_REF
 
     def cfg_pass(lat, ctx, tt):
+        # the reference decorates this driver with @torch.no_grad() (editor.py:64); the graph / token-major fast paths depend on it
+        assert not torch.is_grad_enabled(), "text2image_ldm_stable: the CFG pass must run without autograd"
         if skip_ref:
             set_attn_processor_for_edit(model, coords_base=(1, 2), coords_edit=(2, 3), use_cfg=True, n_batch=3)
             return diffusion_step(model, controller, lat, ctx, tt, guidance_scale, transform_coords=transform_coordinates,
@@ -290,11 +294,15 @@ def _perform_geometric_edit(image, depth, image_mask, transform_in, prompt, ldm_
     max_opt = max(self_replace_steps, cross_replace_steps["default_"])
     if optimize_steps > max_opt:
         optimize_steps = max_opt
-    # the reference writes these onto editor.SPLATTER, which nothing reads (F3); honour the caller on the live object
+    # editor.py:487-490 writes these onto editor.SPLATTER — an object of its own that nothing reads (the warps run on
+    # warp_utils.SPLATTER, which keeps radius 1.3 / tau 1.0 / K 15 unless a warp_grid_edit call passed explicit values).  A drop-in does
+    # the same: the arguments are IGNORED by default; HONOUR_SPLAT_ARGS (GD_HONOUR_SPLAT_ARGS=1) applies them to the live splatter.
+    SPLATTER.radius, SPLATTER.tau, SPLATTER.points_per_pixel = splatting_radius, splatting_tau, splatting_points_per_pixel
     warp_utils.SPLATTER.clear_cache()
-    warp_utils.SPLATTER.radius = splatting_radius
-    warp_utils.SPLATTER.tau = splatting_tau
-    warp_utils.SPLATTER.points_per_pixel = splatting_points_per_pixel
+    if HONOUR_SPLAT_ARGS:
+        warp_utils.SPLATTER.radius = splatting_radius
+        warp_utils.SPLATTER.tau = splatting_tau
+        warp_utils.SPLATTER.points_per_pixel = splatting_points_per_pixel
     PROGRESS_BAR = progress
     GUIDANCE_SCALE, SKIP_OPTIM_STEPS, NUM_DDIM_STEPS = guidance_scale, skip_optim_steps, num_ddim_steps
     if edit_type not in ("geometry_editor", "geometry_remover"):

@@ -14,18 +14,11 @@ def _miopen_for_tests():
     search (geodiffuser_amd/miopen_cache.py) — on a fresh box the first convolution of every new shape otherwise costs seconds, minutes
     over the full-width tests.  Must happen before the first convolution; harmless without a GPU."""
     try:
-        import shutil
-        import tempfile
         import torch
         if not torch.cuda.is_available() or os.environ.get("MIOPEN_USER_DB_PATH"):
             return
-        src = os.path.join(ROOT, "geodiffuser_amd", "miopen_db")
-        dst = tempfile.mkdtemp(prefix="gd_miopen_db_tests_")
-        if os.path.isdir(src):
-            shutil.copytree(src, dst, dirs_exist_ok=True)
-        os.environ["GD_MIOPEN_DB"] = dst
         from geodiffuser_amd import miopen_cache
-        miopen_cache.configure()
+        miopen_cache.configure()            # scratch copy of the committed seed, removed at exit
     except Exception:  # noqa: BLE001 - an optimisation of the test run only
         pass
 

@@ -4,6 +4,7 @@
 #   gpurun --timeout 1500 -- 'tools/record_miopen_db.sh'
 cd "$(dirname "$0")/.."
 export GD_MIOPEN_DB=$PWD/gpurun_out/miopen_db
+export GD_MIOPEN_DB_RECORD=1      # work IN that directory (the default is a scratch copy of the seed, removed at exit)
 rm -rf "$GD_MIOPEN_DB"; mkdir -p "$GD_MIOPEN_DB"
 cp -r geodiffuser_amd/miopen_db/. "$GD_MIOPEN_DB"/ 2>/dev/null
 for run in cold warm; do

@@ -40,6 +40,9 @@ SIGNATURES = {
                                    c_void_p, c_int, c_void_p]),
     "gd_mesh_coverage": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gd_attn_fwd": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "gd_attn_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gd_attn_fwd_ws": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_int, c_void_p]),
+    "gd_attn_fwd_set_even_split": (c_int, [c_int]),
     "gd_attn_fwd_plan": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "gd_attn_fwd_set_config": (c_int, [c_int, c_int]),
     "gd_attn_fwd_splitkv": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_int, c_void_p]),

@@ -121,7 +121,23 @@ struct FwdArgs {
     int nsplit, tps, tot_bh;
     float* ws_o;                    // [nsplit, tot_bh, N, 64] f32
     float* ws_ml;                   // [nsplit, tot_bh, N, 2]  f32 (reference max, row sum)
+    // even split of the key tiles over the workgroups (attn_fwd_mp.hip, SK): the launch's units (head x 128-query tile) x key tiles are
+    // one linear range; workgroup w handles tiles [w*sk_tpw, (w+1)*sk_tpw) whatever unit borders fall inside, so every workgroup has the
+    // same work (20 heads at 64^2: 640 units on 512 resident workgroups ran 1.57 rounds instead of 1.25).  A unit cut over several
+    // workgroups is merged by the workgroup that finishes last: un-normalised (O, reference, row sum) through sk_ws, arrival counter per
+    // unit in sk_cnt (zero before the first launch; the merging workgroup leaves it zero).
+    int sk_tpw, sk_total;
+    int sk_force;                   // tuning hook: split every launch that can be split (default: where the last round is badly filled)
+    int sk_mode;                    // hand-off of the parts: 0 = agent-scope release / acquire fences around the ticket, 1 = device-scope stores and loads only
+    f32x4* sk_ws;                   // [2 * nwg] slots of GD_SK_SLOT_F4 float4
+    int* sk_cnt;                    // [units]
 };
+#define GD_SK_SLOT_F4 (4 * 9 * 64)  // 4 waves x (8 chunks of O + 1 of (reference, row sum)) x 64 lanes
+#define GD_SK_SLOTS 512             // resident workgroups of 4 waves at two waves per SIMD on 256 CUs
+// workspace layout: [2 * GD_SK_SLOTS part slots][arrival counter per unit] — the counters sit at the same offset for every launch shape,
+// so a launch can only ever find the zeros its predecessors left there
+#define GD_SK_SLOT_BYTES ((size_t)2 * GD_SK_SLOTS * GD_SK_SLOT_F4 * sizeof(f32x4))
+size_t gd_attn_sk_workspace_bytes(int tot_bh, int N, int M);
 
 // Per-lane LDS byte offsets of the fragment reads, computed once (the swizzle term does not depend on the k-step /
 // key block, which therefore become immediates): krd[s] for the row fragments, vrd[dblk][hh] for the transposed ones.

@@ -335,7 +335,7 @@ static int env_qb = -2, env_ks = 0;
 extern "C" int gd_attn_fwd_set_config(int qb, int ks) {
     if (qb > 0) {
         const int cfg = qb * 10 + ks;
-        GD_REQUIRE(cfg == 41 || cfg == 22 || cfg == 42 || cfg == 24, GD_EINVAL, "gd_attn_fwd_set_config: no kernel for QB=%d KS=%d", qb, ks);
+        GD_REQUIRE(cfg == 41 || cfg == 22 || cfg == 42 || cfg == 24 || cfg == 81, GD_EINVAL, "gd_attn_fwd_set_config: no kernel for QB=%d KS=%d", qb, ks);
     }
     env_qb = qb < 0 ? -1 : qb;
     env_ks = qb > 0 ? ks : 0;
@@ -355,6 +355,7 @@ static void mp_config(int tot_bh, int N, int M, int* qb, int* ks) {
     const int T = M / ATT_BN;
     if (M % ATT_BN != 0 || env_qb == 0) return;
     if (env_qb > 0) {
+        if (env_qb == 8) { if (T % 4 == 0) { *qb = 8; *ks = 1; } return; }
         if (T % (2 * env_ks) == 0) { *qb = env_qb; *ks = env_ks; }
         return;
     }
@@ -363,12 +364,33 @@ static void mp_config(int tot_bh, int N, int M, int* qb, int* ks) {
     // 5 heads (640 blocks) 43 -> 34 us with two key ranges per workgroup, 10 heads (1280 blocks) 59 us unsplit vs 69 split, 32^2 with
     // 30 heads (960 blocks) 14.5 -> 13.3 us split; from 1280 blocks up the unsplit 128-query workgroup wins.
     const long long blocks = (long long)((N + 31) / 32) * tot_bh;
+    // From 160 units of 256 queries up (10 heads at 64^2) the 64-query-per-wave kernel wins (k_attn_fwd_w64, bf16 only — the launcher
+    // falls back to 4 x 1 for fp16): tools/bench_sk.py, 64^2: 15 heads 66.5 -> 59.1 us, 20 heads 102.3 -> 86.2 us (even split),
+    // 32 heads 135.3 -> 122.0 us; 96^2: 20 heads 427 -> 377 us; 32^2 x 10 heads (40 units) 12.1 -> 17.5 us: stays below.
+    if (T % 4 == 0 && blocks >= 1280 && M >= 1024) { *qb = 8; *ks = 1; return; }
     if (blocks < 1280 && T % 4 == 0) { *qb = 4; *ks = 2; return; }
     *qb = 4; *ks = 1;
 }
 
 extern "C" int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int dtype, void* stream) {
     return attn_fwd_launch(segs, nseg, N, M, D, scale, 1, nullptr, 0, dtype, stream);
+}
+
+// Even split (attn_fwd_mp.hip, SK): 1 = where it pays (default; GD_ATTN_EVEN_SPLIT=0 in the environment turns it off), 0 = never
+static int env_sk = -1, env_sk_mode = 1, env_sk_force = 0;
+extern "C" int gd_attn_fwd_set_even_split(int on) {
+    // 0 = never, 1 = where it pays (default), 2 = every launch that can be split; development: 10 = as 2 with release / acquire fences
+    // around the ticket (k_attn_fwd_mp only), 11 = as 2 with device-scope stores / loads only (what 1 and 2 use), 12 = no merge (timing)
+    env_sk = on ? 1 : 0;
+    env_sk_force = on >= 2;
+    env_sk_mode = on >= 10 ? on - 10 : 1;
+    return GD_OK;
+}
+extern "C" size_t gd_attn_fwd_workspace_bytes(int tot_bh, int N, int M) { return gd_attn_sk_workspace_bytes(tot_bh, N, M); }
+
+extern "C" int gd_attn_fwd_ws(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, void* workspace,
+                              size_t workspace_bytes, int dtype, void* stream) {
+    return attn_fwd_launch(segs, nseg, N, M, D, scale, -1, workspace, workspace_bytes, dtype, stream);
 }
 
 extern "C" int gd_attn_fwd_splitkv(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
@@ -381,7 +403,7 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
     GD_REQUIRE(segs && nseg >= 1 && nseg <= GD_ATTN_MAX_SEGS, GD_EINVAL, "gd_attn_fwd: nseg=%d (1..%d)", nseg, GD_ATTN_MAX_SEGS);
     GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED,
                "gd_attn_fwd: head dim %d unsupported (64, 128, 192; zero-pad 40 / 80 / 160 and pass the true scale)", D);
-    GD_REQUIRE(D == ATT_D || nsplit == 1, GD_EUNSUPPORTED, "gd_attn_fwd_splitkv: head dim %d unsupported (only 64)", D);
+    GD_REQUIRE(D == ATT_D || nsplit == 1 || nsplit == -1, GD_EUNSUPPORTED, "gd_attn_fwd_splitkv: head dim %d unsupported (only 64)", D);
     GD_REQUIRE(N > 0 && M > 0, GD_EINVAL, "gd_attn_fwd: bad sizes N=%d M=%d", N, M);
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_fwd: dtype must be f16/bf16");
     FwdArgs a;
@@ -395,8 +417,27 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
         tot += segs[i].bh;
         a.bh_end[i] = tot;
     }
+    // nsplit == -1: gd_attn_fwd_ws — the workspace is the even split's (arrival counters, zero before the first launch, + part slots)
+    bool sk_ws_ok = false;
+    if (nsplit == -1) {
+        nsplit = 1;
+        if (env_sk < 0) { const char* e = getenv("GD_ATTN_EVEN_SPLIT"); const int v = e ? atoi(e) : 1; env_sk = v ? 1 : 0; env_sk_force = v >= 2; }
+        if (workspace && env_sk) {
+            const size_t need = gd_attn_sk_workspace_bytes(tot, N, M);
+            GD_REQUIRE(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0, GD_EINVAL,
+                       "gd_attn_fwd_ws: workspace %zu B < %zu B (gd_attn_fwd_workspace_bytes) or not 256-byte aligned", workspace_bytes, need);
+            sk_ws_ok = true;
+        }
+        workspace = sk_ws_ok ? workspace : nullptr;
+    }
     a.nseg = nseg; a.N = N; a.M = M;
     a.tiles = (N + ATT_BM - 1) / ATT_BM;
+    if (sk_ws_ok) {
+        a.sk_ws = (f32x4*)workspace;
+        a.sk_cnt = (int*)((char*)workspace + GD_SK_SLOT_BYTES);
+        a.sk_mode = env_sk_mode;
+        a.sk_force = env_sk_force;
+    }
     a.scale = scale;
     a.c = scale * 1.4426950408889634f;
     a.q_prescaled = segs[0].q_scaled != 0;

@@ -154,6 +154,21 @@ SPLIT_KV = os.environ.get("GD_ATTN_SPLIT_KV", "1") == "1"
 _PLAN_CACHE = {}
 
 
+_SK_WS = {}          # device index -> zero-initialised workspace of the even split (persistent: captured graphs hold its address)
+
+
+def _attn_ws(lib, dev: torch.device, tot_bh: int, N: int, M: int):
+    """Workspace of gd_attn_fwd_ws: arrival counters (zero before the first launch, every launch leaves them zero) + part slots.  One
+    buffer per device, grown on demand — all launches of a process run on one stream at a time (the library's contract)."""
+    need = int(lib.gd_attn_fwd_workspace_bytes(tot_bh, N, M))
+    ws = _SK_WS.get(dev.index)
+    if ws is None or ws.numel() < need:
+        if ws is not None and torch.cuda.is_current_stream_capturing():
+            raise _lib.GeodiffError("attn_fwd: the even-split workspace must not grow inside a graph capture (run one eager pass first)")
+        ws = _SK_WS[dev.index] = torch.zeros(max(need, 40 << 20), dtype=torch.uint8, device=dev)
+    return ws
+
+
 def _attn_plan(lib, tot_bh: int, N: int, M: int):
     key = (tot_bh, N, M)
     p = _PLAN_CACHE.get(key)
@@ -217,6 +232,9 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
     if nsplit > 1:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q0.device)
         check(lib.gd_attn_fwd_splitkv(arr, n, N, M, D, scale, nsplit, _p(ws), ws_bytes, dt, _stream()), "gd_attn_fwd_splitkv")
+    elif D == 64 and M % 256 == 0 and M >= 1024:
+        ws = _attn_ws(lib, q0.device, tot_bh, N, M)
+        check(lib.gd_attn_fwd_ws(arr, n, N, M, D, scale, _p(ws), ws.numel(), dt, _stream()), "gd_attn_fwd_ws")
     else:
         check(lib.gd_attn_fwd(arr, n, N, M, D, scale, dt, _stream()), "gd_attn_fwd")
 

@@ -123,6 +123,21 @@ typedef struct {
  * (vanilla rows, edit_out with warped queries, replace_out) that share N, M, D.  D must be 64. */
 int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int dtype, void* stream);
 
+/* gd_attn_fwd with the EVEN SPLIT of the key tiles over the resident workgroups (replaces the same reference lines as gd_attn_fwd:
+ * U/attention_sharing.py:30-47 + torch.bmm at U/attention_processors.py:428,433,549,557,644,647).  A 64^2 launch of 20 heads is 640
+ * units (head x 128-query tile) for 512 resident workgroups: 1.57 rounds; 5 heads fill 160 of 256 CUs.  With a workspace the launch's
+ * units x key tiles are dealt out as one linear range, the same number of key tiles to every workgroup; a unit that ends up in several
+ * workgroups is merged (un-normalised O, reference, row sum in f32, fixed part order: bit-reproducible) by the workgroup that finishes
+ * last.  workspace: gd_attn_fwd_workspace_bytes(sum of segment bh, N, M) bytes, 256-byte aligned, ZERO before its first use (arrival
+ * counters; every launch leaves them zero), private to one stream at a time.  workspace == NULL, head dims other than 64, key counts
+ * that are not a multiple of 256 and launches too short to split behave exactly like gd_attn_fwd.
+ * gd_attn_fwd_set_even_split(0 = never, 1 = where the last round of workgroups would be badly filled (default), 2 = every launch that
+ * can be split): tuning hook (benchmarks, tests; environment: GD_ATTN_EVEN_SPLIT). */
+size_t gd_attn_fwd_workspace_bytes(int tot_bh, int N, int M);
+int gd_attn_fwd_ws(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, void* workspace, size_t workspace_bytes,
+                   int dtype, void* stream);
+int gd_attn_fwd_set_even_split(int on);
+
 /* Split-KV variant for launches that would leave most of the 256 CUs idle (e.g. the batch-1 inversion pass: 5 heads x 32 query
  * tiles = 160 workgroups): the keys are cut into nsplit ranges handled by separate workgroups, whose un-normalised partial results
  * (O, reference max, row sum; f32) go through `workspace` and are merged by a second small kernel.  Same result as gd_attn_fwd up to
@@ -132,7 +147,7 @@ int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_bytes);
 
 /* Tuning hook (benchmarks / tests): which software-pipelined kernel gd_attn_fwd uses on launches with full key tiles
  * (M % 128 == 0): a workgroup of QB query blocks (32 rows each) x KS key ranges merged through LDS; (4,1), (2,2), (4,2), (2,4)
- * exist.  qb < 0: automatic (default; also GD_ATTN_CFG="QBxKS" in the environment), qb == 0: always the plain kernel. */
+ * exist, and (8,1) = the 64-queries-per-wave kernel (256-query workgroups, one wave per SIMD, direct-to-LDS staging; bf16, M % 256 == 0).  qb < 0: automatic (default; also GD_ATTN_CFG="QBxKS" in the environment), qb == 0: always the plain kernel. */
 int gd_attn_fwd_set_config(int qb, int ks);
 int gd_attn_fwd_splitkv(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
                         size_t workspace_bytes, int dtype, void* stream);

@@ -232,10 +232,10 @@ def test_attention_forward_pipelined_configs(ops, dtype, BH, N, M):
     rso, rsl, _ = _ref_attn(qs.cpu(), k.cpu(), v.cpu(), 0.6931471805599453)
     ran = 0
     try:
-        for (qb, ks) in ((4, 1), (2, 2), (4, 2), (2, 4)):
-            if (M // 64) % (2 * ks) != 0:
+        for (qb, ks) in ((4, 1), (2, 2), (4, 2), (2, 4), (8, 1)):
+            if (M // 64) % (2 * ks) != 0 or (qb == 8 and M % 256 != 0):
                 continue
-            lib.gd_attn_fwd_set_config(qb, ks)
+            lib.gd_attn_fwd_set_config(qb, ks)          # (8, 1) = the 64-query-per-wave kernel (bf16; fp16 falls back to 4 x 1)
             out = torch.zeros_like(q); lse = torch.zeros(BH, N, device=DEV)
             ops.attn_fwd([(q, k, v, out, lse)], 0.125, nsplit=1)
             out2 = torch.zeros_like(q); lse2 = torch.zeros(BH, N, device=DEV)
@@ -249,6 +249,102 @@ def test_attention_forward_pipelined_configs(ops, dtype, BH, N, M):
     finally:
         lib.gd_attn_fwd_set_config(-1, 0)
     assert ran >= 1
+
+
+@pytest.mark.parametrize("cfg", [(4, 1), (8, 1)])
+@pytest.mark.parametrize("BH,N,M", [(5, 4096, 4096), (20, 4096, 4096), (13, 2304, 2304), (7, 1000, 4096)])
+def test_attention_forward_even_split(ops, cfg, BH, N, M):
+    """gd_attn_fwd_ws: the launch's key tiles dealt out evenly over the workgroups, units that end up in several workgroups merged by the
+    last to arrive (attn_fwd_mp.hip SK).  Against the fp32 formulation (with rows that force the reference-value fallback: scores
+    climbing by ~100 nats, a 6x outlier key), against the unsplit launch of the same kernel, and bit-reproducible run to run (the
+    merge folds the parts in part order whoever arrives last).  Both kernels: 128-query workgroups (4, 1) and the 64-query-per-wave
+    kernel (8, 1)."""
+    from geodiffuser_amd import _lib
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    torch.manual_seed(BH + M)
+    q = (torch.randn(BH, N, 64, device=DEV) * 1.5).to(dtype); k = (torch.randn(BH, M, 64, device=DEV) * 1.5).to(dtype)
+    v = torch.randn(BH, M, 64, device=DEV).to(dtype)
+    k[0, :, 0] += torch.linspace(-40, 40, M, device=DEV).to(dtype); q[0, :, 0] = 8.0
+    k[1, M // 2, :] *= 6.0
+    rows = torch.arange(3, N, 61)
+    ro, rl, _ = _ref_attn(q[:, rows].cpu(), k.cpu(), v.cpu(), 0.125)
+    try:
+        lib.gd_attn_fwd_set_config(*cfg)
+        res = []
+        for split in (0, 2, 2):
+            lib.gd_attn_fwd_set_even_split(split)
+            out = torch.zeros_like(q); lse = torch.zeros(BH, N, device=DEV)
+            ops.attn_fwd([(q, k, v, out, lse)], 0.125, nsplit=1)
+            torch.cuda.synchronize()
+            res.append((out, lse))
+    finally:
+        lib.gd_attn_fwd_set_config(-1, 0); lib.gd_attn_fwd_set_even_split(1)
+    (o0, l0), (o1, l1), (o2, l2) = res
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)                     # reproducible
+    for o, l in ((o0, l0), (o1, l1)):
+        assert rel_err(o[:, rows].float().cpu(), ro) < tol(dtype)
+        assert float((l[:, rows].cpu().double() - rl).abs().max()) < 2e-4 * max(1.0, float(rl.abs().max()))
+    assert rel_err(o1.float().cpu(), o0.float().cpu()) < tol(dtype)        # every row, against the unsplit launch
+
+
+@pytest.mark.parametrize("cfg", [(4, 1), (8, 1)])
+def test_attention_even_split_segments_warp_and_handoff(ops, cfg):
+    """The even split under the launch forms of an edit (four token-major segments that share K / V, a fused query warp on one of them)
+    equals the unsplit launch; then a hand-off stress: launches with ALTERNATING inputs (a stale part left by the previous launch would
+    be wrong data, not the same data) while a second stream keeps the chip unevenly busy."""
+    from geodiffuser_amd import _lib
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, N, heads, K = 4, 4096, 5, 15
+    C = 64 * heads
+    q = torch.randn(B, N, C, device=DEV, generator=g).to(dtype); k = torch.randn(B, N, C, device=DEV, generator=g).to(dtype)
+    v = torch.randn(B, N, C, device=DEV, generator=g).to(dtype)
+    idx = torch.randint(-1, N, (N, K), device=DEV, dtype=torch.int32); w = torch.rand(N, K, device=DEV) * 0.3
+    m = torch.tensor([0.0, 0.25, 0.5, 1.0], device=DEV)[torch.randint(0, 4, (N,), device=DEV)].contiguous()
+    try:
+        lib.gd_attn_fwd_set_config(*cfg)
+        outs = []
+        for split in (0, 2):
+            lib.gd_attn_fwd_set_even_split(split)
+            o = [torch.zeros_like(q[:1]) for _ in range(4)]
+            ls = [torch.zeros(heads, N, device=DEV) for _ in range(4)]
+            ops.attn_fwd([(q[0:1], k[0:1], v[0:1], o[0], ls[0]), (q[1:2], k[1:2], v[1:2], o[1], None),
+                          (q[2:3], k[2:3], v[2:3], o[2], ls[2], (idx, w, m)), (q[1:2], k[2:3], v[2:3], o[3], None)], 0.125, heads=heads, nsplit=1)
+            torch.cuda.synchronize()
+            outs.append((o, ls))
+        for a, b in zip(outs[0][0], outs[1][0]):
+            assert float((a.float() - b.float()).abs().max()) < 2e-2
+        for i in (0, 2):
+            assert float((outs[0][1][i] - outs[1][1][i]).abs().max()) < 1e-4
+        # hand-off stress
+        sets = []
+        for seed, BH in ((10, 5), (11, 5), (12, 20), (13, 20)):
+            gg = torch.Generator(device=DEV).manual_seed(seed)
+            sets.append(tuple((torch.randn(BH, N, 64, device=DEV, generator=gg) * s_).to(dtype) for s_ in (1.5, 1.5, 1.0)))
+        lib.gd_attn_fwd_set_even_split(0)
+        want = []
+        for (qq, kk, vv) in sets:
+            o = torch.zeros_like(qq); ops.attn_fwd([(qq, kk, vv, o, None)], 0.125, nsplit=1); want.append(o)
+        lib.gd_attn_fwd_set_even_split(2)
+        side = torch.cuda.Stream()
+        junk = torch.randn(32 << 20, device=DEV)
+        bad = 0
+        for it in range(120):
+            if it % 3 == 0:
+                with torch.cuda.stream(side):
+                    junk[: (1 + it % 7) << 21].mul_(1.0001)
+            i = (it * 7 + it // 5) % 4
+            qq, kk, vv = sets[i]
+            o = torch.full_like(qq, float("nan"))
+            ops.attn_fwd([(qq, kk, vv, o, None)], 0.125, nsplit=1)
+            d = float((o.float() - want[i].float()).abs().max())
+            bad += not (d < 2e-2)
+        torch.cuda.synchronize()
+        assert bad == 0
+    finally:
+        lib.gd_attn_fwd_set_config(-1, 0); lib.gd_attn_fwd_set_even_split(1)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -270,8 +366,8 @@ def test_fused_query_warp_is_bit_identical_to_two_launches(ops, dtype, f, N, M, 
     m = torch.tensor([0.0, 0.25, 0.5, 1.0], device=DEV)[torch.randint(0, 4, (N,), device=DEV)].contiguous()
     qw = ops.splat_composite(q, idx, w, m, GD_TOKEN_MAJOR)
     try:
-        for (qb, ks) in ((-1, 0), (0, 0), (4, 1), (4, 2), (2, 4)):
-            if qb > 0 and (M % 64 or (M // 64) % (2 * ks) != 0):
+        for (qb, ks) in ((-1, 0), (0, 0), (4, 1), (4, 2), (2, 4), (8, 1)):
+            if qb > 0 and (M % 64 or (M // 64) % (2 * ks) != 0 or (qb == 8 and M % 256 != 0)):
                 continue
             lib.gd_attn_fwd_set_config(qb, ks)
             o1 = torch.zeros_like(q); o2 = torch.zeros_like(q)

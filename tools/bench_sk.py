@@ -1,0 +1,124 @@
+"""Even split of the key tiles over the workgroups (gd_attn_fwd_ws, attn_fwd_mp.hip SK): correctness against the unsplit kernel and an
+fp32 formulation, bit-reproducibility, a hand-off stress (alternating inputs so that a stale part from the previous launch is WRONG data,
+with a second stream keeping the chip unevenly busy), then interleaved timing with the split on / off (development aid)."""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from geodiffuser_amd import ops, _lib
+lib = _lib.load()
+dt = torch.bfloat16 if "--fp16" not in sys.argv else torch.float16
+W64 = "--w64" in sys.argv            # force the 64-query-per-wave kernel (configuration 8x1) in the correctness sections
+if W64: lib.gd_attn_fwd_set_config(8, 1)
+C2 = 0.125 * 1.4426950408889634
+
+def ref(q, k, v, scale):
+    s = torch.einsum("bnd,bmd->bnm", q.float(), k.float()) * scale
+    lse = torch.logsumexp(s, -1)
+    return torch.einsum("bnm,bmd->bnd", torch.softmax(s, -1), v.float()), lse
+
+def mk(BH, N, M, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = (torch.randn(BH, N, 64, device="cuda", generator=g) * 1.5).to(dt); k = (torch.randn(BH, M, 64, device="cuda", generator=g) * 1.5).to(dt)
+    v = torch.randn(BH, M, 64, device="cuda", generator=g).to(dt)
+    return q, k, v
+
+def run(q, k, v, sk, q_scaled=False, lse=True):
+    lib.gd_attn_fwd_set_even_split(2 if sk else 0)
+    out = torch.zeros_like(q); l = torch.zeros(q.shape[0], q.shape[1], device="cuda") if lse else None
+    ops.attn_fwd([(q, k, v, out, l)], 0.125, nsplit=1, q_scaled=q_scaled)
+    return out, l
+
+print("== correctness: even split vs unsplit kernel vs fp32 ==", flush=True)
+bad = 0
+for (BH, N, M) in ((5, 4096, 4096), (3, 4096, 4096), (20, 4096, 4096), (7, 1000, 4096), (15, 4096, 1024), (2, 4096, 2048), (13, 2304, 2304)):
+    q, k, v = mk(BH, N, M, 1)
+    k[0, :, 0] += torch.linspace(-40, 40, M, device="cuda").to(dt); q[0, :, 0] = 8.0          # scores climbing by ~100 nats over the keys
+    if BH > 1: k[1, M // 2, :] *= 6.0
+    r, rl = ref(q, k, v, 0.125)
+    for qs in (False, True):
+        qq = (q.float() * C2).to(dt) if qs else q
+        if qs: r, rl = ref(qq, k, v, 0.6931471805599453)
+        o0, l0 = run(qq, k, v, False, qs); o1, l1 = run(qq, k, v, True, qs); o2, l2 = run(qq, k, v, True, qs)
+        torch.cuda.synchronize()
+        e0 = float((o0.float() - r).abs().max() / r.abs().max()); e1 = float((o1.float() - r).abs().max() / r.abs().max())
+        d = float((o1.float() - o0.float()).abs().max() / r.abs().max()); el = float((l1 - rl).abs().max())
+        ok = e1 < 8e-3 and el < 2e-3 and torch.equal(o1, o2) and torch.equal(l1, l2)
+        bad += not ok
+        print(f"BH={BH} N={N} M={M} q_scaled={qs}: unsplit {e0:.2e} split {e1:.2e} split-vs-unsplit {d:.2e} lse {el:.2e} reproducible {torch.equal(o1, o2)}  {'OK' if ok else 'FAIL'}", flush=True)
+
+print("== segments / token-major / fused warp with the split (vs unsplit, same kernel otherwise) ==", flush=True)
+for (B, N, heads) in ((3, 4096, 5), (4, 4096, 5)):
+    K = 15; C = 64 * heads
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randn(B, N, C, device="cuda", generator=g).to(dt); k = torch.randn(B, N, C, device="cuda", generator=g).to(dt); v = torch.randn(B, N, C, device="cuda", generator=g).to(dt)
+    idx = torch.randint(-1, N, (N, K), device="cuda", dtype=torch.int32); w = torch.rand(N, K, device="cuda") * 0.3
+    m = torch.tensor([0.0, 0.25, 0.5, 1.0], device="cuda")[torch.randint(0, 4, (N,), device="cuda")].contiguous()
+    outs = []
+    for sk in (0, 2):
+        lib.gd_attn_fwd_set_even_split(sk)
+        o = [torch.zeros_like(q[:1]) for _ in range(4)]
+        ls = [torch.zeros(heads, N, device="cuda") for _ in range(4)]
+        segs = [(q[0:1], k[0:1], v[0:1], o[0], ls[0]), (q[1:2], k[1:2], v[1:2], o[1], None),
+                (q[2:3], k[2:3], v[2:3], o[2], ls[2], (idx, w, m)), (q[1:2], k[2:3], v[2:3], o[3], None)]
+        ops.attn_fwd(segs[:B], 0.125, heads=heads, nsplit=1)
+        torch.cuda.synchronize()
+        outs.append((o, ls))
+    dmax = max(float((a.float() - b.float()).abs().max()) for a, b in zip(outs[0][0][:B], outs[1][0][:B]))
+    lmax = max(float((a - b).abs().max()) for a, b in zip(outs[0][1][:B], outs[1][1][:B]))
+    ok = dmax < 2e-2 and lmax < 1e-3
+    bad += not ok
+    print(f"B={B} heads={heads} token-major, {B} segments, warp on segment 2: max |split - unsplit| {dmax:.2e}, lse {lmax:.2e}  {'OK' if ok else 'FAIL'}", flush=True)
+
+print("== hand-off stress: alternating inputs, uneven background load on a second stream ==", flush=True)
+sets = [mk(5, 4096, 4096, 10), mk(5, 4096, 4096, 11), mk(20, 4096, 4096, 12), mk(20, 4096, 4096, 13)]
+lib.gd_attn_fwd_set_even_split(0)
+want = []
+for (q, k, v) in sets:
+    o = torch.zeros_like(q); ops.attn_fwd([(q, k, v, o, None)], 0.125, nsplit=1); want.append(o)
+torch.cuda.synchronize()
+side = torch.cuda.Stream()
+junk = torch.randn(64 << 20, device="cuda")
+for mode in (10, 11):
+  lib.gd_attn_fwd_set_even_split(mode)
+  worst = 0.0; nbad = 0
+  for it in range(300):
+      if it % 3 == 0:
+          with torch.cuda.stream(side):
+              junk[: (1 + it % 7) << 22].mul_(1.0001)                     # uneven streaming load beside the attention launch
+      i = (it * 7 + it // 5) % 4
+      q, k, v = sets[i]
+      o = torch.empty_like(q).fill_(float("nan"))
+      ops.attn_fwd([(q, k, v, o, None)], 0.125, nsplit=1)
+      d = float((o.float() - want[i].float()).abs().max())
+      if not (d < 2e-2): nbad += 1
+      worst = max(worst, d if d == d else 1e9)
+  torch.cuda.synchronize()
+  bad += nbad
+  print(f"mode {mode}: 300 launches: worst |split - unsplit| {worst:.2e}, launches off {nbad}  {'OK' if nbad == 0 else 'FAIL'}", flush=True)
+
+def t(fn, n=30):
+    for _ in range(3): fn()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+print("== timing (us, median of 5 interleaved rounds): product default | 4x1 unsplit (round 2) | 4x1 even split | 64-query kernel unsplit | 64-query kernel even split ==", flush=True)
+VARS = (("auto", -1, 0, 1), ("r02", 4, 1, 0), ("4x1 split", 4, 1, 2), ("w64", 8, 1, 0), ("w64 split", 8, 1, 2))
+for (BH, N) in ((5, 4096), (10, 4096), (15, 4096), (20, 4096), (25, 4096), (30, 4096), (32, 4096), (40, 4096), (5, 9216), (20, 9216), (10, 1024), (40, 1024)):
+    q, k, v = mk(BH, N, N, 3)
+    qs = (q.float() * C2).to(dt); o = torch.empty_like(q)
+    res = {}
+    for rnd in range(6):
+        for (nm, qb, ks, sk) in VARS:
+            lib.gd_attn_fwd_set_config(qb, ks); lib.gd_attn_fwd_set_even_split(sk)
+            for pre in (0, 1):
+                us = t(lambda: ops.attn_fwd([(qs if pre else q, k, v, o, None)], 0.125, nsplit=1, q_scaled=bool(pre)))
+                if rnd: res.setdefault((nm, pre), []).append(us)
+    f = 4.0 * BH * N * N * 64
+    med = {kk: sorted(vv)[len(vv) // 2] for kk, vv in res.items()}
+    best = min(med[(nm, 1)] for (nm, _, _, _) in VARS)
+    print(f"BH={BH:3d} N={N}: exact " + " | ".join(f"{med[(nm,0)]:6.1f}" for (nm, _, _, _) in VARS) + "   q_scaled " + " | ".join(f"{med[(nm,1)]:6.1f}" for (nm, _, _, _) in VARS)
+          + f"   (best {f/best/2.5e9:.3f} of peak, default {f/med[('auto',1)]/2.5e9:.3f}, round 2 {f/med[('r02',1)]/2.5e9:.3f})", flush=True)
+lib.gd_attn_fwd_set_config(-1, 0); lib.gd_attn_fwd_set_even_split(1)
+print("FAILURES:", bad)

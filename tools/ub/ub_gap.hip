@@ -54,6 +54,23 @@ __global__ void __launch_bounds__(256, 2) k(float* out, long long* cyc, int iter
                 if (MODE == 6) { asm volatile("" :: "v"(L)); }
                 if (MODE == 7) { ps0 += 0.f; }
             }
+            if (MODE == 9) {          // pre-scaled queries: MFMA + 2 x (exp, add) + cvt, each result used at once
+                if (g & 1) acc1 = mf(a, b, acc1); else acc0 = mf(a, b, acc0);
+                const float q0 = __builtin_amdgcn_exp2f(X[2 * g]);
+                const float q1 = __builtin_amdgcn_exp2f(X[2 * g + 1]);
+                P[g & 3] = pack2(q0, q1); ps0 += q0; ps1 += q1;
+            }
+            if (MODE == 10) {         // the same, the pack / adds of a gap consume the PREVIOUS gap's exponentials
+                if (g & 1) acc1 = mf(a, b, acc1); else acc0 = mf(a, b, acc0);
+                P[g & 3] = pack2(p0, p1); ps0 += p0; ps1 += p1;
+                p0 = __builtin_amdgcn_exp2f(X[2 * g]); p1 = __builtin_amdgcn_exp2f(X[2 * g + 1]);
+            }
+            if (MODE == 11) {         // exponentials first, then the MFMA, then the previous gap's pack / adds
+                p0 = __builtin_amdgcn_exp2f(X[2 * g]); p1 = __builtin_amdgcn_exp2f(X[2 * g + 1]);
+                if (g & 1) acc1 = mf(a, b, acc1); else acc0 = mf(a, b, acc0);
+                P[g & 3] = pack2(x0, x1); ps0 += x0; ps1 += x1;
+                x0 = p0; x1 = p1;
+            }
             if (MODE == 8) {          // MFMA + 7 independent plain VALU (no transcendental)
                 if (g & 1) acc1 = mf(a, b, acc1); else acc0 = mf(a, b, acc0);
                 x0 = __builtin_fmaf(X[2 * g], c, x0); x1 = __builtin_fmaf(X[2 * g + 1], c, x1);
@@ -100,6 +117,9 @@ int main() {
         run<4>("VALU only: 2x(fma,exp,add)+cvt dependent", blocks);
         run<5>("VALU only: pipelined across gaps", blocks);
         run<6>("MFMA + pipelined + ds_read_b128", blocks);
+        run<9>("pre-scaled: MFMA + 2x(exp,add)+cvt dependent", blocks);
+        run<10>("pre-scaled: pack/add one gap behind the exps", blocks);
+        run<11>("pre-scaled: exps, MFMA, previous pack/adds", blocks);
     }
     return 0;
 }

@@ -790,7 +790,7 @@ k_attn_fwd_w64(const FwdArgs a) {
     // if that ever exceeded 2^60 (scores > 40 nats above the first tile's maximum: never seen outside the adversarial tests) the whole
     // workgroup repeats the segment with the EXACT row maxima from a scores-only pre-pass.  Exact for every input either way.
 #pragma unroll 1
-  for (int attempt = 0;; ++attempt) {
+  for (int attempt = (GD_MP_DBG & 16) ? 1 : 0;; ++attempt) {          // debug bit 4: always take the exact row maxima
     if (tid == 0) w_abort = 0;
     float mxe[2] = {-INFINITY, -INFINITY};
     if (attempt) {
@@ -1056,6 +1056,7 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
 }
 
 int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st) {
+    if (qb == 8 && dtype != GD_BF16) { qb = 4; ks = 1; }     // the 64-query kernel is bf16 only (see k_attn_fwd_w64)
     a.tiles = (a.N + 32 * qb - 1) / (32 * qb);
     int tot = 0;
     for (int i = 0; i < a.nseg; ++i) tot = a.bh_end[i];
@@ -1089,8 +1090,7 @@ int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st) 
     static int env_pre = -1;
     if (env_pre < 0) { const char* e = getenv("GD_ATTN_PRESCALE"); env_pre = e ? atoi(e) : 0; }
     const int pre = (a.q_prescaled || env_pre) ? 1 : 0;
-    if (qb == 8 && dtype == GD_BF16) return w64_launch(a, tot, pre, dtype, st, a.sk_mode >= 1 && a.sk_force);
-    if (qb == 8) { qb = 4; ks = 1; }
+    if (qb == 8) return w64_launch(a, tot, pre, dtype, st, a.sk_mode >= 1 && a.sk_force);
     if (sk_plan(a, tot, qb, ks)) {
 #define GD_SK_LAUNCH(T_, PRE_) k_attn_fwd_mp<T_, 4, 1, 2, PRE_, true><<<a.nwg, 256, 0, st>>>(a)
         if (dtype == GD_F16) { if (pre) GD_SK_LAUNCH(f16_t, true); else GD_SK_LAUNCH(f16_t, false); }

@@ -285,7 +285,7 @@ def test_attention_forward_even_split(ops, cfg, BH, N, M):
     for o, l in ((o0, l0), (o1, l1)):
         assert rel_err(o[:, rows].float().cpu(), ro) < tol(dtype)
         assert float((l[:, rows].cpu().double() - rl).abs().max()) < 2e-4 * max(1.0, float(rl.abs().max()))
-    assert rel_err(o1.float().cpu(), o0.float().cpu()) < tol(dtype)        # every row, against the unsplit launch
+    assert rel_err(o1.float().cpu(), o0.float().cpu()) < 2 * tol(dtype)    # every row, against the unsplit launch (two roundings apart)
 
 
 @pytest.mark.parametrize("cfg", [(4, 1), (8, 1)])

@@ -569,13 +569,23 @@ template <> struct score_mfma<bf16_t> {
     static __device__ __forceinline__ void acc(f32x16& d, const bf16x8 a, const bf16x8 b) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
     }
+    static __device__ __forceinline__ void acc_pad(f32x16& d, const bf16x8 a, const bf16x8 b) {
+        asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
+    }
 };
+// (acc_pad: for the code outside the loop, where the compiler may have just copied a fragment into a[...] with v_accvgpr_write — an
+// MFMA must not read such a register in the next wait states, and the hazard recogniser does not pad in front of asm.  Seen as NaNs in
+// query block B only: its fragment was written immediately before the instruction.  In the loop the fragments are resident in a[...]
+// (the instruction-mix check of tools/loopstat shows no v_accvgpr traffic) and K fragments arrive by ds_read, which s_waitcnt covers.)
 template <> struct score_mfma<f16_t> {
     static __device__ __forceinline__ void head(f32x16& d, const f16x8 a, const f16x8 b, const f32x16& c) {
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
     }
     static __device__ __forceinline__ void acc(f32x16& d, const f16x8 a, const f16x8 b) {
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
+    }
+    static __device__ __forceinline__ void acc_pad(f32x16& d, const f16x8 a, const f16x8 b) {
+        asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
     }
 };
 
@@ -766,10 +776,19 @@ k_attn_fwd_w64(const FwdArgs a) {
         w64_dma(RS, (DSTTILE) + wave * 2048, st.voff[0], (TILE_IDX) * tB);                          \
         w64_dma(RS, (DSTTILE) + wave * 2048 + 1024, st.voff[1], (TILE_IDX) * tB);                   \
     }
+    // first tiles on their way before the query loads (with warp tables: dependent round trips, slow in the launch's opening burst) start
+    W64_ISSUE_TILE(st.kb, 0, ldsB[0])
+    W64_ISSUE_TILE(st.kb, 1, ldsA[0]) W64_ISSUE_TILE(st.kb, 2, ldsA[1]) W64_ISSUE_TILE(st.vb, 0, ldsA[2]) W64_ISSUE_TILE(st.vb, 1, ldsA[3])
     const int qrowA = tile * 256 + wave * 64 + (lane & 31), qrowB = qrowA + 32;
     V8 qf[2][4];
-    load_q_frags<T>(sg, qp, rs, qrowA < N ? qrowA : N - 1, h, qf[0]);
-    load_q_frags<T>(sg, qp, rs, qrowB < N ? qrowB : N - 1, h, qf[1]);
+    if (sg.warp_idx) {               // warped, blended queries of both blocks built together (composite_chunks2: fewer dependent round trips)
+        const int coff[4] = {8 * h, 16 + 8 * h, 32 + 8 * h, 48 + 8 * h};
+        const int pix[2] = {qrowA < N ? qrowA : N - 1, qrowB < N ? qrowB : N - 1};
+        composite_chunks2<T, 4>(qp, (size_t)rs, coff, sg.warp_idx, sg.warp_w, sg.warp_m, pix, sg.warp_K, qf);
+    } else {
+        load_q_frags<T>(sg, qp, rs, qrowA < N ? qrowA : N - 1, h, qf[0]);
+        load_q_frags<T>(sg, qp, rs, qrowB < N ? qrowB : N - 1, h, qf[1]);
+    }
     if (PRE && !a.q_prescaled) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -783,6 +802,10 @@ k_attn_fwd_w64(const FwdArgs a) {
     f32x16 o[2][2], X0[2], X1[2], Y0[2], Y1[2], negmu[2];
     float m2[2], l_run[2];
     u32x4 pb0[2], pb1[2];
+    // wait states around the asm score MFMAs outside the loop.  The X tiles are OPERANDS of the pad: an asm with only a memory clobber
+    // does not stop the compiler from moving the vector instructions that write / read X across it (seen: row maxima read before the
+    // MFMAs had landed — a timing-dependent reference value, outputs one ulp apart run to run)
+#define W64_PAD(NOPS) asm volatile(NOPS : "+v"(X0[0]), "+v"(X0[1]), "+v"(X1[0]), "+v"(X1[1]));
     // Reference value of the softmax.  There is no per-step maximum and — unlike k_attn_fwd_mp — no in-loop rescue (its in-place updates of
     // seven tiles per query block, inlined at 16 check points, made the register allocator park the bias tiles in a[...] and copy them
     // back for every score MFMA).  bf16 probabilities and f32 sums are exact in RELATIVE terms for any reference as long as nothing
@@ -803,14 +826,14 @@ k_attn_fwd_w64(const FwdArgs a) {
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { X0[b][i] = 0.f; X1[b][i] = 0.f; }
-            asm volatile("s_nop 7" ::: "memory");
+            W64_PAD("s_nop 7")
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const V8 f0 = rd_row<T>(ldsB[0], fo, 0, s4), f1 = rd_row<T>(ldsB[0], fo, 1, s4);
-                score_mfma<T>::acc(X0[0], f0, qf[0][s4]); score_mfma<T>::acc(X0[1], f0, qf[1][s4]);
-                score_mfma<T>::acc(X1[0], f1, qf[0][s4]); score_mfma<T>::acc(X1[1], f1, qf[1][s4]);
+                score_mfma<T>::acc_pad(X0[0], f0, qf[0][s4]); score_mfma<T>::acc_pad(X0[1], f0, qf[1][s4]);
+                score_mfma<T>::acc_pad(X1[0], f1, qf[0][s4]); score_mfma<T>::acc_pad(X1[1], f1, qf[1][s4]);
             }
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            W64_PAD("s_nop 15\n\ts_nop 15")
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -818,8 +841,10 @@ k_attn_fwd_w64(const FwdArgs a) {
             __syncthreads();
         }
     }
-    W64_ISSUE_TILE(st.kb, 0, ldsB[0])
-    W64_ISSUE_TILE(st.kb, 1, ldsA[0]) W64_ISSUE_TILE(st.kb, 2, ldsA[1]) W64_ISSUE_TILE(st.vb, 0, ldsA[2]) W64_ISSUE_TILE(st.vb, 1, ldsA[3])
+    if (attempt) {                    // (attempt 0: issued before the query loads)
+        W64_ISSUE_TILE(st.kb, 0, ldsB[0])
+        W64_ISSUE_TILE(st.kb, 1, ldsA[0]) W64_ISSUE_TILE(st.kb, 2, ldsA[1]) W64_ISSUE_TILE(st.vb, 0, ldsA[2]) W64_ISSUE_TILE(st.vb, 1, ldsA[3])
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -828,17 +853,17 @@ k_attn_fwd_w64(const FwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { o[b][0][i] = 0.f; o[b][1][i] = 0.f; X0[b][i] = 0.f; X1[b][i] = 0.f; Y0[b][i] = 0.f; Y1[b][i] = 0.f; }
     }
-    asm volatile("s_nop 7" ::: "memory");
+    W64_PAD("s_nop 7")
     {
         const char* k0 = ldsB[0];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const V8 f0 = rd_row<T>(k0, fo, 0, s4), f1 = rd_row<T>(k0, fo, 1, s4);
-            score_mfma<T>::acc(X0[0], f0, qf[0][s4]); score_mfma<T>::acc(X0[1], f0, qf[1][s4]);
-            score_mfma<T>::acc(X1[0], f1, qf[0][s4]); score_mfma<T>::acc(X1[1], f1, qf[1][s4]);
+            score_mfma<T>::acc_pad(X0[0], f0, qf[0][s4]); score_mfma<T>::acc_pad(X0[1], f0, qf[1][s4]);
+            score_mfma<T>::acc_pad(X1[0], f1, qf[0][s4]); score_mfma<T>::acc_pad(X1[1], f1, qf[1][s4]);
         }
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the asm MFMAs above have landed before vector instructions read X
+    W64_PAD("s_nop 15\n\ts_nop 15")                          // the asm MFMAs above have landed before vector instructions read X
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         float mx = mxe[b];
@@ -999,6 +1024,7 @@ k_attn_fwd_w64(const FwdArgs a) {
     }
   } while (SK && lin < lin_end);
 #undef W64_ISSUE_TILE
+#undef W64_PAD
 }
 
 size_t gd_attn_sk_workspace_bytes(int tot_bh, int N, int M) {

@@ -84,6 +84,28 @@ def test_g5_interpolate_and_smooth():
     assert np.array_equal(dist[0, 517].numpy(), g["dist_row517"])
 
 
+def test_deterministic_nearest4_rule_keeps_the_reference_distances():
+    """ref_cpu.nearest4_by_index (test aid: ascending (background, exact integer squared distance, index)) picks, for every pixel, four
+    pixels at exactly the inverse distances the reference's torch.topk keeps (pinned by G5 above) — it only resolves WHICH of several
+    equidistant pixels is taken — and the distance-decay weights are identical."""
+    for S in (32, 64):
+        mask = cases.ellipse_mask()
+        m_s = (O.reshape_attention_mask(torch.from_numpy(mask)[None, None], S) > 0.5) * 1.0
+        fg = m_s[0, 0].reshape(-1)[None, None, :, None]
+        dist = O.coord_distance(S)
+        d_new = dist * 512 / 2.0 + 100000 * (1.0 - (fg[:1, :1, :, 0] > 0.5) * 1.0)
+        inv = 1.0 / (d_new + 1e-4)
+        top = torch.topk(inv, k=4, dim=-1, largest=True, sorted=False).values[0].sort(-1).values
+        idx = O.nearest4_by_index(fg[0, 0, :, 0], S)
+        got = torch.gather(inv[0], 1, idx).sort(-1).values
+        assert rel_err(got, top) < 1e-6
+        assert bool((fg[0, 0, :, 0][idx] > 0.5).all())                       # the ellipse has >= 4 foreground pixels: never a background pick
+        feats = torch.from_numpy(cases.make_qkv(5, 1, 2, S * S, S * S, 8)[2])[None]
+        _, w_a = O.interpolate_from_mask(feats, fg, dist, ties="topk")
+        _, w_b = O.interpolate_from_mask(feats, fg, dist, ties="index")
+        assert torch.equal(w_a, w_b)
+
+
 def _run_oracle_case(case):
     q, k, v, mask, coords = case_inputs(case)
     cls = O.GeometryEditOracle if case["kind"] == "edit" else O.GeometryRemoverOracle

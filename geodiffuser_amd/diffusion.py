@@ -28,15 +28,27 @@ def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None):
             or not getattr(controller, "persistent_tables", False):
         return model.unet(x, t, encoder_hidden_states=ctx)["sample"]
     seen = model.__dict__.setdefault("_cfg_layers", {})
-    lk = tuple(x.shape[2:])
+    # the hooked (resolution, heads, head dim) set is a property of (latent size, hooked-module census): a model whose processors were
+    # re-registered with other hooks / heads learns it again
+    lk = tuple(x.shape[2:]) + (len(getattr(model.unet, "attn_processors", ())), type(controller).__name__)
     layers = seen.get(lk)
+
+    def learnt():
+        return sorted((S, c["f"], c["D"]) for S, c in controller.masks_cache_dict.items() if "f" in c)
+
     if layers is None:                                    # first hooked no-grad pass at this latent size: eager, learn the layers
         out = model.unet(x, t, encoder_hidden_states=ctx)["sample"]
-        seen[lk] = sorted((S, c["f"], c["D"]) for S, c in controller.masks_cache_dict.items() if "f" in c)
+        seen[lk] = learnt()
         return out
     if not controller.tables_built(layers):
         q_like = torch.empty(1, device=x.device, dtype=model.unet.dtype)
         controller.prebuild_tables(layers, q_like, transform_coords)
+    if learnt() != layers:
+        # the controller holds a table the learnt list does not know (the first pass did not reach every hooked resolution, or the hooks
+        # changed on this model object): a capture would build it lazily, with host syncs, inside torch.cuda.graph — run eagerly and relearn
+        out = model.unet(x, t, encoder_hidden_states=ctx)["sample"]
+        seen[lk] = learnt()
+        return out
     runner = model.__dict__.get("_graphed")
     if runner is None:
         runner = model.__dict__["_graphed"] = graphs.GraphedUNet(model.unet)

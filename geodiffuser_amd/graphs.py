@@ -84,9 +84,13 @@ _SEEN_LAYERS: Dict[tuple, tuple] = {}   # (id(unet), latent shape) -> (weakref, 
 
 
 def reset_opt_graphs():
+    """Drop the captured optimisation-pass graphs and what only they keep alive: the backward-data copies of the 3x3 convolution
+    weights (~1 GB for SD2.1; both are rebuilt on the next optimisation pass)."""
     for e in _OPT_GRAPHS.values():
         e["graph"].reset()
     _OPT_GRAPHS.clear()
+    from .unet_sd21 import release_backward_weights
+    release_backward_weights()
 
 
 class GraphedOptPass:

@@ -146,7 +146,19 @@ class NullInversion:
         ``epsilon + 2e-5 i``.  The UNet passes run with the vanilla processor; their attention goes through gd_attn_fwd and the full
         backward (dQ, dK, dV: gd_attn_bwd / gd_attn_bwd_dkv).  Off in every reference driver ("not required for GeoDiffuser",
         inversion.py:269), on by default in ``perform_geometric_edit``'s signature (editor.py:437)."""
-        self.model.unet.set_attn_processor(VanillaAttentionProcessor())
+        unet = self.model.unet
+        # the reference leaves the processors alone (its vanilla path is diffusers' default); here the vanilla processor is attached for
+        # the optimisation and whatever the caller had registered — and the parameters' requires_grad flags — come back afterwards
+        saved_procs, saved_rg = dict(unet.attn_processors), [p.requires_grad for p in unet.parameters()]
+        unet.set_attn_processor(VanillaAttentionProcessor())
+        try:
+            return self._null_optimization(latents, num_inner_steps, epsilon)
+        finally:
+            unet.set_attn_processor(saved_procs)
+            for p, rg in zip(unet.parameters(), saved_rg):
+                p.requires_grad = rg
+
+    def _null_optimization(self, latents, num_inner_steps, epsilon):
         uncond_embeddings, cond_embeddings = self.context.chunk(2)
         uncond_embeddings_list = []
         latent_cur = latents[-1]

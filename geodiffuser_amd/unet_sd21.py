@@ -137,7 +137,17 @@ def group_norm_fused(x, weight, bias, groups, eps, silu, add_bc=None):
 # 3x3 convolutions on the hand-written implicit-GEMM kernel (conv3x3.hip) instead of the library call; GD_CONV3X3=0 = F.conv2d (MIOpen).
 CONV3X3 = os.environ.get("GD_CONV3X3", "1") == "1"
 CONV1X1 = os.environ.get("GD_CONV1X1", "1") == "1"      # 1x1 shortcut convolutions as F.linear on channels_last views
-_WBWD = {}          # id(weight) -> (version, data_ptr, weight of the backward-data convolution)
+# id(weight) -> (version, data_ptr, weight of the backward-data convolution).  One flipped / transposed copy per frozen 3x3 weight that
+# an optimisation pass has differentiated through: about the 3x3 weight set again (~1 GB for SD2.1 in 16 bits, ~3 GB for SDXL), built on
+# the first optimisation pass, kept across edits (a rebuild costs ~20 ms), dropped with its weight, by ``release_backward_weights()``
+# (called from graphs.reset_opt_graphs()) or never built at all with GD_CONV3X3=0.
+_WBWD = {}
+
+
+def release_backward_weights():
+    """Free the backward-data copies of the 3x3 convolution weights (they are rebuilt on the next optimisation pass)."""
+    _WBWD.clear()
+
 
 
 def _weight_bwd(w):

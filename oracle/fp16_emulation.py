@@ -141,7 +141,9 @@ def main():
         print("v-prediction remover loop: ideal 16-bit storage vs fp32 (oracle loop):", out["vpred_remover_loop"])
         json.dump(out, open(path, "w"), indent=1)
         return
-    for flag, fixture, cfg in (("--g21-only", "G21_loop_cfg0_full", cases.LOOP_CFG0), ("--g22-only", "G22_loop_cfg1_full", cases.LOOP_CFG1),
+    for flag, fixture, cfg in (("--g18-only", "G18_loop", cases.LOOP), ("--g19-only", "G19_loop_remover", cases.LOOP),
+                               ("--g20-only", "G20_loop_cfg0", cases.LOOP_CFG0),
+                               ("--g21-only", "G21_loop_cfg0_full", cases.LOOP_CFG0), ("--g22-only", "G22_loop_cfg1_full", cases.LOOP_CFG1),
                                ("--g23-only", "G23_loop_sd14", cases.LOOP), ("--g26-only", "G26_loop_remover_full", cases.LOOP),
                                ("--g27-only", "G27_loop_sdxl", cases.LOOP_SDXL)):
         if flag in sys.argv:                       # the full-width loops (fixtures G21 / G22): add / refresh that entry only
@@ -153,11 +155,17 @@ def main():
             e = out.get(fixture, {})
             for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
                 if ("--" + dn) in sys.argv or not any(a in sys.argv for a in ("--fp16", "--bf16")):
-                    lat, _, ce, _ = gen_golden.run_reference_loop(R, "geometry_remover" if "remover" in fixture else "geometry_editor", cfg,
-                                                                  prepare=emulate_16bit(dt), tiny=fixture.startswith(("G23", "G27")), sdxl=fixture.startswith("G27"),
-                                                                  sd14=fixture.startswith("G23"))
+                    lat, log, ce, _ = gen_golden.run_reference_loop(R, "geometry_remover" if "remover" in fixture else "geometry_editor", cfg,
+                                                                    prepare=emulate_16bit(dt), tiny=fixture.startswith(("G18", "G19", "G20", "G23", "G27")),
+                                                                    sdxl=fixture.startswith("G27"), sd14=fixture.startswith("G23"))
                     e["emulated_" + dn] = rel_l2(lat[-1:], ref[-1:])
                     e["emulated_" + dn + "_first_update"] = rel_l2(ce._recorded_updates[0], up32)
+                    # loss terms of the LAST optimisation pass (after the loop has amplified the storage rounding): |emulated - fp32| / |fp32|
+                    # per term — the yardstick of the device path's last-pass check (tests/test_end_to_end.py)
+                    last = int(g["steps"][-1])
+                    e["emulated_" + dn + "_last_terms"] = {
+                        f"{kind}/{k}": abs(float(v) - float(g[f"log_{last}_{kind}_{k}"])) / (abs(float(g[f"log_{last}_{kind}_{k}"])) + 1e-12)
+                        for kind in ("self", "cross") for k, v in log[last][kind].items()}
                     print(fixture, dn, e, flush=True)
                     out[fixture] = e
                     json.dump(out, open(path, "w"), indent=1)

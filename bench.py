@@ -54,8 +54,10 @@ class AttnTimer:
     def _cfg(self, segs, scale, heads, q_scaled=False):
         q0 = segs[0][0]
         # per segment: q shape, k shape, lse wanted, slot count K of a fused query warp (0 = plain queries)
+        # (+ the padded length of a query row list: the warped segment computed only inside the soft edit mask, gd_attn_seg_t.q_rows)
         return (tuple((tuple(s[0].shape), tuple(s[1].shape), s[4] is not None,
-                       int(s[5][0].shape[-1]) if len(s) > 5 and s[5] is not None else 0) for s in segs),
+                       int(s[5][0].shape[-1]) if len(s) > 5 and s[5] is not None else 0,
+                       int(s[6][0].numel()) if len(s) > 6 and s[6] is not None else 0) for s in segs),
                 float(scale), heads, q0.dtype, bool(q_scaled))
 
     def _entry(self, cfg):
@@ -63,7 +65,10 @@ class AttnTimer:
         if e is None:
             shapes, _, heads, _, _ = cfg
             bh = sum(sh[0][0] for sh in shapes) * (heads if heads else 1)
-            e = self.cfgs[cfg] = dict(count=0, ev=[], flops=4.0 * bh * self.n * self.n * 64, heads=bh)
+            # algorithmic work of the launch = what the reference computes for it: every row of every segment (4 BH N M 64).  A segment
+            # with a query row list EXECUTES only its (padded) list: reported beside it as flops_exec
+            ex = sum(sh[0][0] * (heads if heads else 1) * (sh[4] if sh[4] else self.n) for sh in shapes)
+            e = self.cfgs[cfg] = dict(count=0, ev=[], flops=4.0 * bh * self.n * self.n * 64, heads=bh, flops_exec=4.0 * ex * self.n * 64)
         return e
 
     def _timed(self, cfg, segs, scale, heads, q_scaled, key="ev"):
@@ -119,7 +124,7 @@ class AttnTimer:
                 continue
             shapes, scale, heads, dt, q_scaled = cfg
             segs = []
-            for qs, ks, want_lse, warp_k in shapes:
+            for qs, ks, want_lse, warp_k, rows_len in shapes:
                 # unit-variance q / k (scaled scores ~ N(0, 1) nats, as at a freshly initialised layer); queries that arrive
                 # pre-scaled carry scale*log2(e) like the projection's output
                 q = torch.randn(qs, device="cuda")
@@ -137,6 +142,11 @@ class AttnTimer:
                     yy, xx = torch.meshgrid(torch.arange(side, device="cuda"), torch.arange(side, device="cuda"), indexing="ij")
                     m = ((((xx - 0.56 * side) / (0.17 * side)) ** 2 + ((yy - 0.47 * side) / (0.14 * side)) ** 2) <= 1.0).float().reshape(-1)   # compact object mask (~8 % of the map)
                     seg = seg + ((idx.contiguous(), w.contiguous(), m.contiguous()),)
+                    if rows_len:                           # the rows inside the mask, padded to the launch's list length
+                        rows = torch.nonzero(m > 0).reshape(-1).to(torch.int32)[:rows_len]
+                        n_dev = torch.tensor([rows.numel()], dtype=torch.int32, device="cuda")
+                        rows = torch.cat([rows, torch.zeros(rows_len - rows.numel(), dtype=torch.int32, device="cuda")]).contiguous()
+                        seg = (q, k, v, torch.empty(qs[0], rows_len, qs[2], dtype=dt, device="cuda"), None, seg[5], (rows, n_dev))
                 segs.append(seg)
             for _ in range(30):                            # warm: clocks ramp down while the host builds the tensors above
                 self._orig(segs, scale, heads, q_scaled=q_scaled)
@@ -158,7 +168,8 @@ class AttnTimer:
                 else:
                     us = 1e3 * sum(a.elapsed_time(b) for a, b in e["ev"]) / len(e["ev"])
                 row = dict(heads=e["heads"], token_major=bool(cfg[2]), q_scaled=bool(cfg[4]),
-                           fused_warp=any(sh[3] for sh in cfg[0]), launches=e["count"], avg_us=us, tflops=e["flops"] / us * 1e-6)
+                           fused_warp=any(sh[3] for sh in cfg[0]), warp_row_list=max(sh[4] for sh in cfg[0]), launches=e["count"], avg_us=us,
+                           tflops=e["flops"] / us * 1e-6, tflops_executed=e["flops_exec"] / us * 1e-6)
                 if e["ev"]:
                     row["eager_avg_us"] = 1e3 * sum(a.elapsed_time(b) for a, b in e["ev"]) / len(e["ev"])
                 rows.append(row)
@@ -167,6 +178,7 @@ class AttnTimer:
         n = sum(r["launches"] for r in rows)
         t_us = sum(r["launches"] * r["avg_us"] for r in rows)
         fl = sum(r["launches"] * r["tflops"] * r["avg_us"] * 1e6 for r in rows)
+        fl_ex = sum(r["launches"] * r["tflops_executed"] * r["avg_us"] * 1e6 for r in rows)
         # HBM traffic of the most frequent launch shape, from the committed PMC run of the same kernel (profiles/)
         traffic = None
         try:
@@ -185,7 +197,8 @@ class AttnTimer:
                 traffic = int(sum(c * t for c, t in tw) / sum(c for c, _ in tw))
         except Exception:  # noqa: BLE001
             pass
-        return dict(launches=n, avg_us=t_us / n, flops_per_launch=fl / n, achieved=fl / (t_us * 1e-6), traffic=traffic, configs=rows)
+        return dict(launches=n, avg_us=t_us / n, flops_per_launch=fl / n, achieved=fl / (t_us * 1e-6), achieved_executed=fl_ex / (t_us * 1e-6),
+                    traffic=traffic, configs=rows)
 
 
 def cpu_baseline(budget_s=45.0):
@@ -469,6 +482,10 @@ def main():
             line["roofline"] = {"kernel": f"k_attn_fwd_mp (attention forward, N = M = {timer.n} self-attention launches)", "bound": "mfma", "achieved": roof["achieved"] / 1e12,
                                 "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s", "frac": roof["achieved"] / PEAK_MFMA_16BIT,
                                 "traffic": roof["traffic"], "launches": roof["launches"], "avg_launch_us": roof["avg_us"],
+                                # `achieved` counts the ALGORITHMIC FLOPs of a launch (every row of every segment, as the reference
+                                # computes them); the warped segment executes only the rows inside the soft edit mask (the others equal
+                                # the reference rows): the rate over the FLOPs actually executed
+                                "achieved_executed": roof["achieved_executed"] / 1e12, "frac_executed": roof["achieved_executed"] / PEAK_MFMA_16BIT,
                                 "configs": roof["configs"],
                                 "flops_per_launch": roof["flops_per_launch"]}
         if not args.no_cpu_baseline and world == 1:

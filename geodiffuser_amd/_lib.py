@@ -19,7 +19,8 @@ GD_ATTN_MAX_SEGS = 4
 class GdAttnSeg(Structure):
     _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("lse", c_void_p),
                 ("bh", c_int32), ("heads", c_int32),
-                ("warp_idx", c_void_p), ("warp_w", c_void_p), ("warp_m", c_void_p), ("warp_K", c_int32), ("q_scaled", c_int32)]
+                ("warp_idx", c_void_p), ("warp_w", c_void_p), ("warp_m", c_void_p), ("warp_K", c_int32), ("q_scaled", c_int32),
+                ("q_rows", c_void_p), ("q_rows_n", c_void_p), ("q_rows_len", c_int32)]
 
 
 class GeodiffError(RuntimeError):
@@ -40,6 +41,7 @@ SIGNATURES = {
                                    c_void_p, c_int, c_void_p]),
     "gd_mesh_coverage": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gd_attn_fwd": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "gd_rows_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gd_attn_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gd_attn_fwd_ws": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_int, c_void_p]),
     "gd_attn_fwd_set_even_split": (c_int, [c_int]),
@@ -125,8 +127,8 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
             raise GeodiffError(f"libgeodiff_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.gd_version() != 2:
-        raise GeodiffError(f"ABI version mismatch: library {lib.gd_version()} != binding 2")
+    if lib.gd_version() != 3:
+        raise GeodiffError(f"ABI version mismatch: library {lib.gd_version()} != binding 3")
     _lib = lib
     return lib
 

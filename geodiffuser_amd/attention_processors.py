@@ -173,6 +173,12 @@ BATCHED_QKV = os.environ.get("GD_BATCHED_QKV", "1") == "1"   # no-grad passes: q
 SCALED_Q = os.environ.get("GD_SCALED_Q", "1") == "1"      # token-major passes: scale*log2(e) folded into the query projection
 LOG2E = 1.4426950408889634
 FUSED_WARP = os.environ.get("GD_FUSED_WARP", "1") == "1"   # build the warped queries inside the attention launch
+# The edit attention with warped queries (q*(1-m) + m*splat(q), U/attention_processors.py:424-428,544-549) is computed only for the rows
+# where the soft edit mask m is non-zero (~10 % of a 64^2 map): for m == 0 the warped query IS the reference query, so that row of
+# edit_out equals the reference row's attention output, which the same launch computes anyway.  gd_attn_seg_t.q_rows + gd_rows_merge.
+# Self-attention layers from 64^2 tokens up (below, the saved work is smaller than the merge launch).
+WARP_ROWS = os.environ.get("GD_WARP_ROWS", "1") == "1"
+WARP_ROWS_MIN_TOKENS = 64 ** 2
 
 
 def _tok_ok(attn, hidden_states) -> bool:
@@ -353,7 +359,12 @@ class _EditLayer(torch.autograd.Function):
             # q_warp = q_base*(1-m) + m*splat(q_base) (:424,544), built in the attention kernel's prologue from the splat tables
             # (the fused attention-warp launch; bit-identical to the separate gd_splat_composite launch, GD_FUSED_WARP=0)
             edit_out = torch.empty(f, N, D, dtype=dt, device=dev)
-            if FUSED_WARP:
+            edit_act = None
+            if FUSED_WARP and WARP_ROWS and (not is_cross) and D == 64 and "edit_rows" in c and k_base.shape[1] % 256 == 0:
+                # only the rows inside the soft edit mask; the others are the reference rows' outputs (rows_merge below)
+                edit_act = torch.empty(f, c["edit_rows"].numel(), D, dtype=dt, device=dev)
+                segs.append((q_base, k_base, v_base, edit_act, None, (c["idx"], c["w"], c["m_edit"]), (c["edit_rows"], c["n_edit_rows"])))
+            elif FUSED_WARP:
                 segs.append((q_base, k_base, v_base, edit_out, None, (c["idx"], c["w"], c["m_edit"])))       # :427-428,548-549
             else:
                 q_warp = ops.splat_composite(q_base, c["idx"], c["w"], c["m_edit"], GD_TOKEN_MAJOR)
@@ -367,6 +378,8 @@ class _EditLayer(torch.autograd.Function):
                 segs.append((q_edit, k_edit, v_edit, ident_out, None))
         segs.append((q_edit, K, v_base, replace_out, lse_e))                # :433,557 / :791,883
         ops.attn_fwd(segs, scale)
+        if (not remover) and edit_act is not None:
+            ops.rows_merge(out_full[b0 * f:b1 * f], edit_act, c["edit_pos"], out=edit_out)
         if remover:
             edit_out = out_full[b0 * f:b1 * f].clone() if want_losses else out_full[b0 * f:b1 * f]
         if store:
@@ -570,6 +583,19 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             c["m_amodal"] = _flat(amodal)
             idx_, w_ = warp_utils.SPLATTER.tables(t_q[0].reshape(-1, 3))
             c["idx"], c["w"] = _persist(pt, ("idx", S), idx_), _persist(pt, ("w", S), w_)
+            if N >= WARP_ROWS_MIN_TOKENS:
+                # rows whose warped query differs from the reference query (m_edit > 0), as a list padded to a bucketed length (launch
+                # dimensions repeat from edit to edit: hipGraph reuse), its length on the device, and the inverse map row -> list slot
+                er = torch.nonzero(c["m_edit"] > 0).reshape(-1).to(torch.int32)
+                bucket = N // 16
+                R_e = int(er.numel())                                      # (host sync: once per resolution per edit, like the mask sums)
+                R_pad = max(bucket, -(-R_e // bucket) * bucket)
+                pos = torch.full((N,), -1, dtype=torch.int32, device=dev)
+                pos[er.long()] = torch.arange(R_e, dtype=torch.int32, device=dev)
+                er = torch.cat([er, torch.zeros(R_pad - R_e, dtype=torch.int32, device=dev)]).contiguous()
+                c["edit_rows"] = _persist(pt, ("edit_rows", S, R_pad), er)
+                c["n_edit_rows"] = _persist(pt, ("n_edit_rows", S), torch.tensor([R_e], dtype=torch.int32, device=dev))
+                c["edit_pos"] = _persist(pt, ("edit_pos", S), pos)
         else:
             self.image_mask = self.image_mask.to(dev).float().detach()         # :758,852
             mask_warp = binarize_tensor(self.image_mask)[:, None]
@@ -631,7 +657,8 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         slot count K of the splat tables — i.e. every launch dimension / buffer shape that comes from the per-resolution tables
         (``_persist`` keys its buffers on shape: a different K lives in different buffers, so it must be a different graph)."""
         return tuple(sorted((S, c["rows"].numel() if S * S >= 32 ** 2 else 0, c["f"],            # losses exist only at N >= 32^2
-                             int(c["idx"].shape[-1]) if "idx" in c else 0)
+                             int(c["idx"].shape[-1]) if "idx" in c else 0,
+                             int(c["edit_rows"].numel()) if "edit_rows" in c else 0)
                             for S, c in self.masks_cache_dict.items() if "f" in c))
 
     def tables_built(self, layers) -> bool:
@@ -690,13 +717,16 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         q_edit, k_edit, v_edit = q[e0:e1], k[e0:e1], v[e0:e1]
         segs = [(q[:cb], k[:cb], v[:cb], out_full[:cb], None)]
         replace_out = out_full[cb:]
-        edit_out = ident_out = None
+        edit_out = ident_out = edit_act = None
         if not remover:
             K = k_edit if is_cross else k_base
             if blend:
                 edit_out = torch.empty_like(q_edit)
                 replace_out = torch.empty_like(q_edit)
-                if FUSED_WARP:                                  # warped queries built in the attention kernel's prologue
+                if FUSED_WARP and WARP_ROWS and (not is_cross) and "edit_rows" in c and k_base.shape[1] % 256 == 0:
+                    edit_act = torch.empty(1, c["edit_rows"].numel(), q.shape[2], dtype=q.dtype, device=q.device)
+                    segs.append((q_base, k_base, v_base, edit_act, None, (c["idx"], c["w"], c["m_edit"]), (c["edit_rows"], c["n_edit_rows"])))
+                elif FUSED_WARP:                                # warped queries built in the attention kernel's prologue
                     segs.append((q_base, k_base, v_base, edit_out, None, (c["idx"], c["w"], c["m_edit"])))
                 else:
                     q_warp = ops.splat_composite(q_base, c["idx"], c["w"], c["m_edit"], GD_TOKEN_MAJOR)   # all heads in one row
@@ -709,6 +739,8 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
                 segs.append((q_edit, k_edit, v_edit, ident_out, None))
         segs.append((q_edit, K, v_base, replace_out, None))
         ops.attn_fwd(segs, scale, heads=heads, q_scaled=self.q_scaled_tok)
+        if edit_act is not None:                                # rows outside the soft edit mask: the reference row's output
+            ops.rows_merge(out_full[b0:b1], edit_act, c["edit_pos"], out=edit_out)
         if edit_out is not None:
             ops.blend_tokens(edit_out, replace_out, c["m_edit"], out=out_full[cb:])
         elif ident_out is not None:

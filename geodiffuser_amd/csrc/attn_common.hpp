@@ -116,6 +116,8 @@ struct FwdArgs {
     // of different segments are interleaved (n_order == 0: segment after segment, via bh_end)
     int n_order;
     unsigned short order[GD_ATTN_MAX_ORDER];
+    // segment with a query row list (gd_attn_seg_t::q_rows; -1: none): its units (tiles_c per head) follow the units of all other segments
+    int cseg, tiles_c, units_full;
     // split-KV (launches that would leave most CUs idle): split sp handles key tiles [sp*tps, (sp+1)*tps) and leaves an
     // un-normalised partial (O, m, l) in the workspace; k_attn_combine merges them
     int nsplit, tps, tot_bh;

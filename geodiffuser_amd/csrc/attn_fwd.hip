@@ -302,7 +302,7 @@ __global__ void k_attn_combine(const FwdArgs a) {
     if (sg.lse && dq == 0) sg.lse[(size_t)bh * a.N + row] = mref * a.scale + __logf(L);
 }
 
-static void mp_config(int tot_bh, int N, int M, int* qb, int* ks, int q_prescaled = 1);
+static void mp_config(long long blocks, int N, int M, int* qb, int* ks, int q_prescaled = 1);
 
 // Split-KV plan: how many key splits make a launch of tot_bh heads fill the chip (1 = none), and the workspace they need.
 extern "C" int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_bytes) {
@@ -310,7 +310,7 @@ extern "C" int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_byte
     if (tot_bh <= 0 || N <= 0 || M <= 0) return 1;
     {
         int qb = 0, ks = 0;
-        mp_config(tot_bh, N, M, &qb, &ks);
+        mp_config((long long)((N + 31) / 32) * tot_bh, N, M, &qb, &ks);
         if (qb > 0) return 1;          // the pipelined kernel splits keys inside the workgroup (no workspace)
     }
     const int tiles = (N + ATT_BM - 1) / ATT_BM, t_all = (M + ATT_BN - 1) / ATT_BN;
@@ -342,7 +342,7 @@ extern "C" int gd_attn_fwd_set_config(int qb, int ks) {
     return GD_OK;
 }
 
-static void mp_config(int tot_bh, int N, int M, int* qb, int* ks, int q_prescaled) {
+static void mp_config(long long blocks, int N, int M, int* qb, int* ks, int q_prescaled) {
     if (env_qb == -2) {
         const char* e = getenv("GD_ATTN_CFG");
         int q = -1, k = 0;
@@ -363,7 +363,6 @@ static void mp_config(int tot_bh, int N, int M, int* qb, int* ks, int q_prescale
     // wave-sized query blocks against the chip's 1024 SIMDs x 2 resident waves.  Measured on MI355X (tools/bench_mp.py, bf16, 64^2):
     // 5 heads (640 blocks) 43 -> 34 us with two key ranges per workgroup, 10 heads (1280 blocks) 59 us unsplit vs 69 split, 32^2 with
     // 30 heads (960 blocks) 14.5 -> 13.3 us split; from 1280 blocks up the unsplit 128-query workgroup wins.
-    const long long blocks = (long long)((N + 31) / 32) * tot_bh;
     // From 160 units of 256 queries up (10 heads at 64^2) the 64-query-per-wave kernel wins (k_attn_fwd_w64, bf16 only — the launcher
     // falls back to 4 x 1 for fp16): tools/bench_sk.py, 64^2: 15 heads 66.5 -> 59.1 us, 20 heads 102.3 -> 86.2 us (even split),
     // 32 heads 135.3 -> 122.0 us; 96^2: 20 heads 427 -> 377 us; 32^2 x 10 heads (40 units) 12.1 -> 17.5 us: stays below.
@@ -414,6 +413,7 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_fwd: dtype must be f16/bf16");
     FwdArgs a;
     memset(&a, 0, sizeof(a));
+    a.cseg = -1;
     int tot = 0;
     for (int i = 0; i < nseg; ++i) {
         GD_REQUIRE(segs[i].q && segs[i].k && segs[i].v && segs[i].out && segs[i].bh > 0, GD_EINVAL,
@@ -422,6 +422,11 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
         a.seg[i] = segs[i];
         tot += segs[i].bh;
         a.bh_end[i] = tot;
+        if (segs[i].q_rows) {
+            GD_REQUIRE(a.cseg < 0, GD_EUNSUPPORTED, "gd_attn_fwd: at most one segment of a launch may carry a query row list");
+            GD_REQUIRE(segs[i].q_rows_n && segs[i].q_rows_len > 0, GD_EINVAL, "gd_attn_fwd: segment %d: q_rows without q_rows_n / q_rows_len", i);
+            a.cseg = i;
+        }
     }
     // nsplit == -1: gd_attn_fwd_ws — the workspace is the even split's (arrival counters, zero before the first launch, + part slots)
     bool sk_ws_ok = false;
@@ -465,9 +470,13 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
     hipStream_t st = as_stream(stream);
     if (nsplit == 1 && D == ATT_D) {
         int qb = 0, ks = 0;
-        mp_config(tot, N, M, &qb, &ks, a.q_prescaled);
+        // 32-query blocks of the launch (a row-list segment counts its list, not N)
+        long long blocks = (long long)((N + 31) / 32) * tot;
+        if (a.cseg >= 0) blocks -= (long long)((N + 31) / 32 - (segs[a.cseg].q_rows_len + 31) / 32) * segs[a.cseg].bh;
+        mp_config(blocks, N, M, &qb, &ks, a.q_prescaled);
         if (qb > 0) return gd_attn_fwd_mp_launch(a, qb, ks, dtype, st);       // software-pipelined kernels (attn_fwd_mp.hip)
     }
+    GD_REQUIRE(a.cseg < 0, GD_EUNSUPPORTED, "gd_attn_fwd: a query row list needs head dim 64 and full key tiles (M=%d, D=%d)", M, D);
     a.nwg = a.tiles * tot * nsplit;
     if (D == 128) {
         if (dtype == GD_F16) k_attn_fwd<f16_t, 2><<<a.nwg, 256, 0, st>>>(a);

@@ -226,30 +226,42 @@ k_attn_fwd_mp(const FwdArgs a) {
     } else {
         t_first = ks * Tg;
     }
-    const int gbh = unit / a.tiles, tile = unit - gbh * a.tiles;
-    int sidx = 0, bh;
-    if (a.n_order > 0) {                                   // interleaved head order (see gd_attn_fwd_mp_launch)
-        const int code = a.order[gbh];
-        sidx = code >> 12;
-        bh = code & 4095;
+    int sidx = 0, bh, tile;
+    const bool compact = a.cseg >= 0 && unit >= a.units_full;      // the segment with a query row list: units after everyone else's
+    if (compact) {
+        const int uc = unit - a.units_full;
+        bh = uc / a.tiles_c;
+        tile = uc - bh * a.tiles_c;
+        sidx = a.cseg;
     } else {
+        const int gbh = unit / a.tiles;
+        tile = unit - gbh * a.tiles;
+        if (a.n_order > 0) {                               // interleaved head order (see gd_attn_fwd_mp_launch)
+            const int code = a.order[gbh];
+            sidx = code >> 12;
+            bh = code & 4095;
+        } else {
 #pragma unroll
-        for (int i = 0; i < GD_ATTN_MAX_SEGS - 1; ++i)
-            if (i < a.nseg - 1 && gbh >= a.bh_end[i]) sidx = i + 1;
-        bh = gbh - (sidx ? a.bh_end[sidx - 1] : 0);
+            for (int i = 0; i < GD_ATTN_MAX_SEGS - 1; ++i)
+                if (i < a.nseg - 1 && gbh >= a.bh_end[i]) sidx = i + 1;
+            bh = gbh - (sidx ? a.bh_end[sidx - 1] : 0);
+        }
     }
     const gd_attn_seg_t sg = a.seg[sidx];
     const int N = a.N, M = a.M;
+    const int Nq = compact ? sg.q_rows_len : N;            // rows of this segment's query list / of its dense output
     // row stride / base offsets: head-major [bh, N, 64] or token-major [B, N, heads*64]
     const int rs = sg.heads > 0 ? sg.heads * ATT_D : ATT_D;
-    size_t qoff, koff;
+    size_t qoff, koff, ooff;
     if (sg.heads > 0) {
         const int b = bh / sg.heads, hh = bh - b * sg.heads;
         qoff = (size_t)b * N * rs + (size_t)hh * ATT_D;
         koff = (size_t)b * M * rs + (size_t)hh * ATT_D;
+        ooff = (size_t)b * Nq * rs + (size_t)hh * ATT_D;
     } else {
         qoff = (size_t)bh * N * ATT_D;
         koff = (size_t)bh * M * ATT_D;
+        ooff = (size_t)bh * Nq * ATT_D;
     }
     const T* __restrict__ qp = (const T*)sg.q + qoff;
     // wave-uniform buffer descriptors (scalar registers) over this key range's K / V rows: buffer_load takes the per-thread part as a
@@ -288,8 +300,9 @@ k_attn_fwd_mp(const FwdArgs a) {
         k0_at = L0;
     }
 
-    const int qrow = tile * BMQ + qb * 32 + (lane & 31);
-    const int qld = qrow < N ? qrow : N - 1;
+    const int qrow = tile * BMQ + qb * 32 + (lane & 31);   // row of the output (= of the row list, for a compact segment)
+    const int qok = qrow < (compact ? sg.q_rows_n[0] : N);
+    const int qld = compact ? sg.q_rows[qrow < Nq ? qrow : Nq - 1] : (qrow < N ? qrow : N - 1);       // row of q it is computed from
     V8 qf[4];
     load_q_frags<T>(sg, qp, rs, qld, h, qf);
     if (PRE && !a.q_prescaled) {         // Q' = 16-bit(c Q): the softmax scale and log2(e) folded into the queries here
@@ -505,8 +518,8 @@ k_attn_fwd_mp(const FwdArgs a) {
     if (write_out) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
-        if (qrow < N) {
-            T* __restrict__ op = (T*)sg.out + qoff + (size_t)qrow * rs;
+        if (qok) {
+            T* __restrict__ op = (T*)sg.out + ooff + (size_t)qrow * rs;
 #pragma unroll
             for (int dblk = 0; dblk < 2; ++dblk)
 #pragma unroll
@@ -517,7 +530,7 @@ k_attn_fwd_mp(const FwdArgs a) {
                     *(typename TR::vec4*)(op + dblk * 32 + 8 * g + 4 * h) = w;
                 }
             // natural-log sum-exp of the scaled scores: m2 is in the log2 domain
-            if (sg.lse && h == 0) sg.lse[(size_t)bh * N + qrow] = m2 * 0.6931471805599453f + __logf(l_tot);
+            if (sg.lse && h == 0) sg.lse[(size_t)bh * Nq + qrow] = m2 * 0.6931471805599453f + __logf(l_tot);
         }
     }
     if (SK) {
@@ -732,29 +745,41 @@ k_attn_fwd_w64(const FwdArgs a) {
         t_first = lin - unit * TU;
         Tg = TU - t_first < lin_end - lin ? TU - t_first : lin_end - lin;
     }
-    const int gbh = unit / a.tiles, tile = unit - gbh * a.tiles;
-    int sidx = 0, bh;
-    if (a.n_order > 0) {
-        const int code = a.order[gbh];
-        sidx = code >> 12;
-        bh = code & 4095;
+    int sidx = 0, bh, tile;
+    const bool compact = a.cseg >= 0 && unit >= a.units_full;      // the segment with a query row list (see k_attn_fwd_mp)
+    if (compact) {
+        const int uc = unit - a.units_full;
+        bh = uc / a.tiles_c;
+        tile = uc - bh * a.tiles_c;
+        sidx = a.cseg;
     } else {
+        const int gbh = unit / a.tiles;
+        tile = unit - gbh * a.tiles;
+        if (a.n_order > 0) {
+            const int code = a.order[gbh];
+            sidx = code >> 12;
+            bh = code & 4095;
+        } else {
 #pragma unroll
-        for (int i = 0; i < GD_ATTN_MAX_SEGS - 1; ++i)
-            if (i < a.nseg - 1 && gbh >= a.bh_end[i]) sidx = i + 1;
-        bh = gbh - (sidx ? a.bh_end[sidx - 1] : 0);
+            for (int i = 0; i < GD_ATTN_MAX_SEGS - 1; ++i)
+                if (i < a.nseg - 1 && gbh >= a.bh_end[i]) sidx = i + 1;
+            bh = gbh - (sidx ? a.bh_end[sidx - 1] : 0);
+        }
     }
     const gd_attn_seg_t sg = a.seg[sidx];
     const int N = a.N, M = a.M;
+    const int Nq = compact ? sg.q_rows_len : N;
     const int rs = sg.heads > 0 ? sg.heads * ATT_D : ATT_D;
-    size_t qoff, koff;
+    size_t qoff, koff, ooff;
     if (sg.heads > 0) {
         const int b = bh / sg.heads, hh = bh - b * sg.heads;
         qoff = (size_t)b * N * rs + (size_t)hh * ATT_D;
         koff = (size_t)b * M * rs + (size_t)hh * ATT_D;
+        ooff = (size_t)b * Nq * rs + (size_t)hh * ATT_D;
     } else {
         qoff = (size_t)bh * N * ATT_D;
         koff = (size_t)bh * M * ATT_D;
+        ooff = (size_t)bh * Nq * ATT_D;
     }
     const T* __restrict__ qp = (const T*)sg.q + qoff;
     W64Stage st;
@@ -779,15 +804,17 @@ k_attn_fwd_w64(const FwdArgs a) {
     // first tiles on their way before the query loads (with warp tables: dependent round trips, slow in the launch's opening burst) start
     W64_ISSUE_TILE(st.kb, 0, ldsB[0])
     W64_ISSUE_TILE(st.kb, 1, ldsA[0]) W64_ISSUE_TILE(st.kb, 2, ldsA[1]) W64_ISSUE_TILE(st.vb, 0, ldsA[2]) W64_ISSUE_TILE(st.vb, 1, ldsA[3])
-    const int qrowA = tile * 256 + wave * 64 + (lane & 31), qrowB = qrowA + 32;
+    const int qrowA = tile * 256 + wave * 64 + (lane & 31), qrowB = qrowA + 32;      // rows of the output (= of the row list, if any)
+    const int nq_ok = compact ? sg.q_rows_n[0] : N;
+    const int pix[2] = {compact ? sg.q_rows[qrowA < Nq ? qrowA : Nq - 1] : (qrowA < N ? qrowA : N - 1),
+                        compact ? sg.q_rows[qrowB < Nq ? qrowB : Nq - 1] : (qrowB < N ? qrowB : N - 1)};   // rows of q they are computed from
     V8 qf[2][4];
     if (sg.warp_idx) {               // warped, blended queries of both blocks built together (composite_chunks2: fewer dependent round trips)
         const int coff[4] = {8 * h, 16 + 8 * h, 32 + 8 * h, 48 + 8 * h};
-        const int pix[2] = {qrowA < N ? qrowA : N - 1, qrowB < N ? qrowB : N - 1};
         composite_chunks2<T, 4>(qp, (size_t)rs, coff, sg.warp_idx, sg.warp_w, sg.warp_m, pix, sg.warp_K, qf);
     } else {
-        load_q_frags<T>(sg, qp, rs, qrowA < N ? qrowA : N - 1, h, qf[0]);
-        load_q_frags<T>(sg, qp, rs, qrowB < N ? qrowB : N - 1, h, qf[1]);
+        load_q_frags<T>(sg, qp, rs, pix[0], h, qf[0]);
+        load_q_frags<T>(sg, qp, rs, pix[1], h, qf[1]);
     }
     if (PRE && !a.q_prescaled) {
 #pragma unroll
@@ -1003,8 +1030,8 @@ k_attn_fwd_w64(const FwdArgs a) {
             const int qrow = b ? qrowB : qrowA;
             const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
             const float inv = 1.0f / l_tot;
-            if (qrow < N) {
-                T* __restrict__ op = (T*)sg.out + qoff + (size_t)qrow * rs;
+            if (qrow < nq_ok) {
+                T* __restrict__ op = (T*)sg.out + ooff + (size_t)qrow * rs;
 #pragma unroll
                 for (int dblk = 0; dblk < 2; ++dblk)
 #pragma unroll
@@ -1014,7 +1041,7 @@ k_attn_fwd_w64(const FwdArgs a) {
                         for (int j = 0; j < 4; ++j) w[j] = TR::from_f32(o[b][dblk][4 * g + j] * inv);
                         *(typename TR::vec4*)(op + dblk * 32 + 8 * g + 4 * h) = w;
                     }
-                if (sg.lse && h == 0) sg.lse[(size_t)bh * N + qrow] = m2[b] * 0.6931471805599453f + __logf(l_tot);
+                if (sg.lse && h == 0) sg.lse[(size_t)bh * Nq + qrow] = m2[b] * 0.6931471805599453f + __logf(l_tot);
             }
         }
     }
@@ -1032,12 +1059,25 @@ size_t gd_attn_sk_workspace_bytes(int tot_bh, int N, int M) {
     return GD_SK_SLOT_BYTES + units * sizeof(int);
 }
 
+// units of a launch: `unit_rows` queries of one head; a segment with a query row list has its own (shorter) row count
+static int set_units(FwdArgs& a, int tot, int unit_rows) {
+    a.tiles = (a.N + unit_rows - 1) / unit_rows;
+    a.tiles_c = 0;
+    int bh_c = 0;
+    if (a.cseg >= 0) {
+        a.tiles_c = (a.seg[a.cseg].q_rows_len + unit_rows - 1) / unit_rows;
+        bh_c = a.seg[a.cseg].bh;
+    }
+    a.units_full = a.tiles * (tot - bh_c);
+    return a.units_full + a.tiles_c * bh_c;
+}
+
 // sk_ws != NULL (set by the caller from its workspace): deal the key tiles out evenly where that pays
 static bool sk_plan(FwdArgs& a, int tot, int qb, int ks) {
     const int TU = a.M / ATT_BN;
     // measured equal to the in-workgroup key ranges at 5 heads (31.9 vs 32.2 us) and behind k_attn_fwd_w64 from 10 heads up: only on request
     if (!a.sk_ws || !a.sk_force || qb != 4 || TU % 4 != 0 || TU < 16) return false;
-    const long long total = (long long)a.tiles * tot * TU;
+    const long long total = (long long)a.nwg * TU;
     int tpw = (int)((total + GD_SK_SLOTS - 1) / GD_SK_SLOTS);
     tpw = (tpw + 3) & ~3;
     if (tpw < 16 || total > 0x7FFFFFFF) return false;                      // short runs: prologue / merge would dominate
@@ -1051,8 +1091,7 @@ static bool sk_plan(FwdArgs& a, int tot, int qb, int ks) {
 static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bool sk_force) {
     const int TU = a.M / ATT_BN;
     GD_REQUIRE(a.M % (4 * ATT_BN) == 0, GD_EINVAL, "gd_attn_fwd: the 64-query kernel needs a multiple of four full key tiles (M=%d)", a.M);
-    a.tiles = (a.N + 255) / 256;
-    a.nwg = a.tiles * tot;
+    a.nwg = set_units(a, tot, 256);
     bool sk = false;
     // Even split where the last round of 256 workgroups would be badly filled: 20 heads = 320 units = 1.25 rounds (109.9 -> 86.2 us),
     // 15 heads = 240 units = 0.94 (59.1 unsplit, 70.0 split: the hand-off is not free), 30 heads = 1.875 (117.1 unsplit, 126.2 split)
@@ -1083,22 +1122,23 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
 
 int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st) {
     if (qb == 8 && dtype != GD_BF16) { qb = 4; ks = 1; }     // the 64-query kernel is bf16 only (see k_attn_fwd_w64)
-    a.tiles = (a.N + 32 * qb - 1) / (32 * qb);
     int tot = 0;
     for (int i = 0; i < a.nseg; ++i) tot = a.bh_end[i];
-    a.nwg = a.tiles * tot;
+    a.nwg = set_units(a, tot, 32 * qb);
     // Head order of the grid.  The 1-D grid is cut into 8 contiguous chunks, one per XCD (xcd_remap), and an XCD runs its chunk in
     // ascending order.  Segment after segment, the heads whose workgroups build warped queries in their prologue (~8 us of dependent
     // gathers) all land on two XCDs, which then finish last (measured: +17 us on a 106 us launch).  Interleaving the segments by
     // relative position spreads them over the XCDs, puts a warped head before the plain heads of its neighbourhood, and places the
     // edit_out / replace_out heads that share k_base / v_base on the same XCD's L2.
     a.n_order = 0;
+    GD_REQUIRE(a.cseg < 0 || a.nseg == 1 || tot <= GD_ATTN_MAX_ORDER, GD_EUNSUPPORTED,
+               "gd_attn_fwd: a query row list needs <= %d heads per launch (%d)", GD_ATTN_MAX_ORDER, tot);
     if (a.nseg > 1 && tot <= GD_ATTN_MAX_ORDER) {
         float key[GD_ATTN_MAX_ORDER];
         int n = 0, start = 0;
         for (int sgi = 0; sgi < a.nseg; ++sgi) {
             const int cnt = a.bh_end[sgi] - start;
-            for (int i = 0; i < cnt; ++i) {
+            for (int i = 0; i < cnt && sgi != a.cseg; ++i) {                // (the row-list segment's units come after the others')
                 key[n] = ((float)i + (a.seg[sgi].warp_idx ? 0.25f : 0.5f)) / (float)cnt + 1e-4f * (float)sgi;
                 a.order[n++] = (unsigned short)((sgi << 12) | i);
             }

@@ -237,6 +237,31 @@ extern "C" int gd_blend_tokens(const void* a, const void* b, const float* m, int
     return GD_OK;
 }
 
+// ---- full edit-attention output from the reference rows + the rows a q_rows segment computed (gd_attn_seg_t::q_rows) ----
+template <typename T>
+__global__ void k_rows_merge(const u32x4* __restrict__ base, const u32x4* __restrict__ act, const int32_t* __restrict__ pos, int H, int N,
+                             int R, int D8, u32x4* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;                   // one 16-byte chunk of 8 elements
+    if (gid >= (long long)H * N * D8) return;
+    const int c = (int)(gid % D8);
+    const long long hn = gid / D8;
+    const int n = (int)(hn % N), h = (int)(hn / N);
+    const int p = pos[n];
+    out[gid] = p >= 0 ? act[((long long)h * R + p) * D8 + c] : base[gid];
+}
+
+extern "C" int gd_rows_merge(const void* base, const void* act, const int32_t* pos, int H, int N, int R, int D, void* out, int dtype,
+                             void* stream) {
+    GD_REQUIRE(base && act && pos && out, GD_EINVAL, "gd_rows_merge: null pointer");
+    GD_REQUIRE(H > 0 && N > 0 && R > 0 && D > 0 && D % 8 == 0, GD_EINVAL, "gd_rows_merge: bad sizes (D must be a multiple of 8)");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_rows_merge: dtype must be f16/bf16");
+    const long long total = (long long)H * N * (D / 8);
+    k_rows_merge<f16_t><<<(int)((total + 255) / 256), 256, 0, as_stream(stream)>>>((const u32x4*)base, (const u32x4*)act, pos, H, N, R, D / 8,
+                                                                                  (u32x4*)out);
+    GD_CHECK_LAUNCH("gd_rows_merge");
+    return GD_OK;
+}
+
 // ---- 4-nearest-foreground table ----------------------------------------------------------------------------
 // The mask-only part of interpolate_from_mask (GeoDiffuser/utils/attention_sharing.py:81-83,103): for every pixel the
 // k = 4 columns with the largest 1/(dist*256 + 1e5*background + 1e-4).  torch.topk leaves the choice among equal

@@ -199,17 +199,24 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
     for i, seg in enumerate(segs):
         q, k, v, o, lse = seg[:5]
         warp = seg[5] if len(seg) > 5 else None
+        qrows = seg[6] if len(seg) > 6 else None          # (rows i32 [R], n_valid i32 [1] on the device): see gd_attn_seg_t.q_rows
         for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "out")):
             _need(t, nm, q0.dtype)
+        No = N if qrows is None else int(qrows[0].numel())
         if heads:
-            ok = q.shape[1:] == (N, heads * D) and k.shape[1:] == (M, heads * D) and v.shape == k.shape and o.shape == q.shape \
-                and k.shape[0] == q.shape[0]
+            ok = q.shape[1:] == (N, heads * D) and k.shape[1:] == (M, heads * D) and v.shape == k.shape and k.shape[0] == q.shape[0] \
+                and tuple(o.shape) == (q.shape[0], No, heads * D)
         else:
-            ok = q.shape[1:] == (N, D) and k.shape[1:] == (M, D) and v.shape == k.shape and o.shape == q.shape and k.shape[0] == q.shape[0]
+            ok = q.shape[1:] == (N, D) and k.shape[1:] == (M, D) and v.shape == k.shape and k.shape[0] == q.shape[0] \
+                and tuple(o.shape) == (q.shape[0], No, D)
         if not ok:
             raise _lib.GeodiffError("attn_fwd: segment shapes disagree")
         if lse is not None:
             _need(lse, "lse", torch.float32)
+        rl = rn = 0
+        if qrows is not None:
+            _need(qrows[0], "q_rows", torch.int32); _need(qrows[1], "q_rows_n", torch.int32)
+            rl, rn = qrows[0].data_ptr(), qrows[1].data_ptr()
         bh = q.shape[0] * (heads if heads else 1)
         tot_bh += bh
         widx = ww = wm = 0
@@ -224,7 +231,7 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
                 _need(t_m, "warp m", torch.float32)
             widx, ww, wm = t_idx.data_ptr(), t_w.data_ptr(), 0 if t_m is None else t_m.data_ptr()
         arr[i] = GdAttnSeg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 0 if lse is None else lse.data_ptr(), bh, heads,
-                           widx, ww, wm, wK, int(bool(q_scaled)))
+                           widx, ww, wm, wK, int(bool(q_scaled)), rl, rn, 0 if qrows is None else No)
     if nsplit is None:
         nsplit, ws_bytes = _attn_plan(lib, tot_bh, N, M) if SPLIT_KV else (1, 0)
     else:
@@ -237,6 +244,21 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
         check(lib.gd_attn_fwd_ws(arr, n, N, M, D, scale, _p(ws), ws.numel(), dt, _stream()), "gd_attn_fwd_ws")
     else:
         check(lib.gd_attn_fwd(arr, n, N, M, D, scale, dt, _stream()), "gd_attn_fwd")
+
+
+def rows_merge(base: torch.Tensor, act: torch.Tensor, pos: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[h, n] = act[h, pos[n]] where pos[n] >= 0, else base[h, n]  (base / out [H, N, D], act [H, R, D] 16-bit, pos [N] i32)."""
+    lib = _lib.load()
+    dt = _dt16(base, "base")
+    _need(base, "base"); _need(act, "act", base.dtype); _need(pos, "pos", torch.int32)
+    H, N, D = base.shape
+    if act.shape[0] != H or act.shape[2] != D or pos.numel() != N:
+        raise _lib.GeodiffError("rows_merge: shapes disagree")
+    if out is None:
+        out = torch.empty_like(base)
+    _need(out, "out", base.dtype)
+    check(lib.gd_rows_merge(_p(base), _p(act), _p(pos), H, N, act.shape[1], D, _p(out), dt, _stream()), "gd_rows_merge")
+    return out
 
 
 def fp8_quantize(q, k, v, scale: float, heads: int = 0):

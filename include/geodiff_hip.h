@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 2
+#define GD_ABI_VERSION 3
 
 enum { GD_F16 = 0, GD_BF16 = 1, GD_F32 = 2 };
 enum { GD_TOKEN_MAJOR = 0 /* [B, P, C] */, GD_CHANNEL_MAJOR = 1 /* [B, C, P] */ };
@@ -115,6 +115,15 @@ typedef struct {
      * per probability instead of two on the vector-issue-bound D = 64 path) and `scale` is ignored.  All segments of a launch must
      * agree.  lse stays the natural-log sum-exp of the scaled scores. */
     int32_t q_scaled;
+    /* Query ROW LIST (at most one segment of a launch; NULL: all N rows).  The segment attends only with rows q_rows[0 .. *q_rows_n) of q
+     * (taken from the full [.., N, ..] tensor; the warp tables, if any, are indexed by the same row ids) and writes a DENSE result:
+     * out [bh, q_rows_len, D] / [B, q_rows_len, heads*D], lse [bh, q_rows_len]; list slots >= *q_rows_n are padding (computed on row
+     * q_rows[i] but not stored; the list is padded so that launch dimensions repeat from edit to edit).  Use: the edit attention
+     * with warped queries (U/attention_processors.py:424-428,544-549) differs from the reference row's attention only where the soft edit
+     * mask is non-zero (q*(1-m) + m*splat(q) == q for m == 0) — ~10 % of the rows; gd_rows_merge puts the two together. */
+    const int32_t* q_rows;     /* [q_rows_len] i32 row ids, or NULL */
+    const int32_t* q_rows_n;   /* DEVICE int32[1]: number of wanted list entries */
+    int32_t q_rows_len;
 } gd_attn_seg_t;
 
 #define GD_ATTN_MAX_SEGS 4
@@ -122,6 +131,10 @@ typedef struct {
 /* out = softmax(scale * q k^T) v for up to GD_ATTN_MAX_SEGS independent segments in ONE launch
  * (vanilla rows, edit_out with warped queries, replace_out) that share N, M, D.  D must be 64. */
 int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int dtype, void* stream);
+
+/* out[h, n, :] = pos[n] >= 0 ? act[h, pos[n], :] : base[h, n, :]   (16-bit; base / out [H, N, D], act [H, R, D], pos [N] i32):
+ * the full edit-attention output from the reference rows and the dense rows a q_rows segment computed (see gd_attn_seg_t.q_rows). */
+int gd_rows_merge(const void* base, const void* act, const int32_t* pos, int H, int N, int R, int D, void* out, int dtype, void* stream);
 
 /* gd_attn_fwd with the EVEN SPLIT of the key tiles over the resident workgroups (replaces the same reference lines as gd_attn_fwd:
  * U/attention_sharing.py:30-47 + torch.bmm at U/attention_processors.py:428,433,549,557,644,647).  A 64^2 launch of 20 heads is 640

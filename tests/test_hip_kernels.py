@@ -381,6 +381,62 @@ def test_fused_query_warp_is_bit_identical_to_two_launches(ops, dtype, f, N, M, 
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("heads", [0, 5])
+@pytest.mark.parametrize("cfg", [(-1, 0), (4, 1), (8, 1)])
+def test_query_row_list_segment_equals_the_full_launch(ops, dtype, heads, cfg):
+    """gd_attn_seg_t.q_rows: the warped-query segment computed only for the rows inside the soft edit mask, dense output, then
+    gd_rows_merge with the reference rows' output.  Against the full launch of the same segment: rows inside the mask bit-identical,
+    rows outside equal to the reference segment's rows (for m == 0 the warped query IS the reference query) — in every kernel that
+    serves such a launch, head-major and token-major, with the even split on and off, with a padded list."""
+    from geodiffuser_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(3 + heads)
+    N, K, f = 4096, 15, 5
+    C = 64 * (heads if heads else 1)
+    B = 1 if heads else f
+    q = torch.randn(2 * B, N, C, device=DEV).to(dtype); k = torch.randn(2 * B, N, C, device=DEV).to(dtype); v = torch.randn(2 * B, N, C, device=DEV).to(dtype)
+    idx = torch.randint(-1, N, (N, K), device=DEV, dtype=torch.int32); idx[:, 6:] = -1
+    w = torch.rand(N, K, device=DEV) * 0.3
+    m = torch.zeros(N, device=DEV)
+    inside = torch.zeros(64, 64, dtype=torch.bool, device=DEV); inside[20:41, 17:40] = True
+    m[inside.reshape(-1)] = torch.tensor([0.25, 0.5, 1.0], device=DEV)[torch.randint(0, 3, (int(inside.sum()),), device=DEV)]
+    rows = torch.nonzero(m > 0).reshape(-1).to(torch.int32)
+    R = rows.numel()
+    R_pad = -(-R // 256) * 256 + 256                              # a padded list: slots >= n are never stored
+    rows_p = torch.cat([rows, torch.zeros(R_pad - R, dtype=torch.int32, device=DEV)]).contiguous()
+    n_dev = torch.tensor([R], dtype=torch.int32, device=DEV)
+    pos = torch.full((N,), -1, dtype=torch.int32, device=DEV); pos[rows.long()] = torch.arange(R, dtype=torch.int32, device=DEV)
+    qb_, kb_, vb_ = q[:B], k[:B], v[:B]
+    try:
+        lib.gd_attn_fwd_set_config(*cfg)
+        for split in (0, 2):
+            lib.gd_attn_fwd_set_even_split(split)
+            o_ref = torch.zeros_like(qb_); o_full = torch.zeros_like(qb_); o_other = torch.zeros_like(qb_)
+            ops.attn_fwd([(qb_, kb_, vb_, o_ref, None), (qb_, kb_, vb_, o_full, None, (idx, w, m)), (q[B:], kb_, vb_, o_other, None)], 0.125,
+                         heads=heads, nsplit=1)
+            o_ref2 = torch.zeros_like(qb_); o_other2 = torch.zeros_like(qb_)
+            act = torch.full((B, R_pad, C), float("nan"), dtype=dtype, device=DEV)
+            ops.attn_fwd([(qb_, kb_, vb_, o_ref2, None), (qb_, kb_, vb_, act, None, (idx, w, m), (rows_p, n_dev)),
+                          (q[B:], kb_, vb_, o_other2, None)], 0.125, heads=heads, nsplit=1)
+            merged = ops.rows_merge(o_ref2, act, pos)
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(act[:, R:].float()).all())                         # padding slots untouched
+            tol_ = 0 if split == 0 else 2 * tol(dtype)                                 # the split moves unit borders: f32 merge order
+            for a_, b_ in ((o_ref2, o_ref), (o_other2, o_other), (merged[:, rows.long()], o_full[:, rows.long()])):
+                if split == 0:
+                    assert torch.equal(a_, b_), (cfg, split)
+                else:
+                    assert rel_err(a_.float().cpu(), b_.float().cpu()) < tol_, (cfg, split)
+            outside = (m == 0)
+            assert torch.equal(merged[:, outside], o_ref2[:, outside])
+            # ... and the full launch's rows outside the mask are the reference rows as well (same kernel, same query)
+            if split == 0:
+                assert torch.equal(o_full[:, outside], o_ref[:, outside])
+    finally:
+        lib.gd_attn_fwd_set_config(-1, 0); lib.gd_attn_fwd_set_even_split(1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("BH,N,M,nsplit", [(5, 4096, 4096, 4), (2, 1024, 1024, 2), (3, 512, 1100, 3), (1, 256, 4096 + 37, 8), (2, 100, 640, 2)])
 def test_attention_forward_split_kv(ops, dtype, BH, N, M, nsplit):
     """Split-KV launches (keys cut into nsplit ranges, partials merged by k_attn_combine) equal the single-pass kernel up to f32

@@ -74,33 +74,55 @@ __global__ void k_count_fill(const float* __restrict__ pts, int P, int S, float 
     }
 }
 
-// exclusive scan of count[0..n) into offset[0..n], offset[n] = total.  One workgroup of 1024 threads.
-__global__ void k_scan(const int* __restrict__ count, int* __restrict__ offset, int n) {
-    __shared__ int wave_tot[16];
-    __shared__ int carry_s;
+// exclusive scan of count[0..n) into offset[0..n], offset[n] = total, in two launches over blocks of SCAN_BLOCK elements (one workgroup
+// of 1024 threads looping over the array took 281 us at 512^2: 256 iterations x 3 barriers):
+//   k_scan_local: every workgroup scans its own block (16 consecutive elements per thread, wave scan of the thread sums) and leaves the
+//                 block's total in bsum[block];
+//   k_scan_add:   adds the sum of the preceding blocks' totals (<= a few hundred values, summed by one wave) to the block's offsets.
+#define SCAN_BLOCK 4096
+__global__ void __launch_bounds__(256) k_scan_local(const int* __restrict__ count, int* __restrict__ offset, int* __restrict__ bsum, int n) {
+    __shared__ int wave_tot[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        const int v = (i < n) ? count[i] : 0;
-        int x = v;
+    const int i0 = blockIdx.x * SCAN_BLOCK + tid * 16;
+    int v[16];
+    int tsum = 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(x, o, 64);
-            if (lane >= o) x += y;
-        }
-        if (lane == 63) wave_tot[wid] = x;
-        __syncthreads();
-        int wpre = 0;
-        for (int w = 0; w < wid; ++w) wpre += wave_tot[w];
-        const int carry = carry_s;
-        if (i < n) offset[i] = carry + wpre + x - v;
-        __syncthreads();
-        if (tid == 1023) carry_s = carry + wpre + x;
-        __syncthreads();
+    for (int e = 0; e < 16; ++e) { v[e] = (i0 + e < n) ? count[i0 + e] : 0; tsum += v[e]; }
+    int x = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
     }
-    if (tid == 0) offset[n] = carry_s;
+    if (lane == 63) wave_tot[wid] = x;
+    __syncthreads();
+    int pre = x - tsum;
+    for (int w = 0; w < wid; ++w) pre += wave_tot[w];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (i0 + e < n) offset[i0 + e] = pre;
+        pre += v[e];
+    }
+    if (tid == 255) bsum[blockIdx.x] = pre;
+}
+
+__global__ void __launch_bounds__(256) k_scan_add(int* __restrict__ offset, const int* __restrict__ bsum, int n, int nblocks) {
+    __shared__ int carry_s;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        int c = 0;
+        for (int b2 = tid; b2 < (int)blockIdx.x; b2 += 64) c += bsum[b2];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (tid == 0) carry_s = c;
+    }
+    __syncthreads();
+    const int carry = carry_s;
+    const int i0 = blockIdx.x * SCAN_BLOCK + tid * 16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        if (i0 + e < n) offset[i0 + e] += carry;
+    if ((int)blockIdx.x == nblocks - 1 && tid == 0) offset[n] = carry + bsum[blockIdx.x];
 }
 
 __device__ void sort_indices(int* a, int n) {
@@ -197,7 +219,8 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t gd_rasterize_workspace_bytes(int P, int S, float radius_ndc) {
     if (P <= 0 || S <= 0) return 0;
     const size_t npix = (size_t)S * S;
-    return align256((npix + 1) * 4) * 3 + align256((size_t)P * hits_per_point_bound(S, radius_ndc) * 4) + 256;
+    const size_t nblocks = (npix + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    return align256((npix + 1) * 4) * 3 + align256(nblocks * 4) + align256((size_t)P * hits_per_point_bound(S, radius_ndc) * 4) + 256;
 }
 
 extern "C" int gd_rasterize_points(const float* pts, int P, int S, float radius_ndc, int K,
@@ -214,13 +237,16 @@ extern "C" int gd_rasterize_points(const float* pts, int P, int S, float radius_
     int* count = (int*)w;            w += align256((npix + 1) * 4);
     int* offset = (int*)w;           w += align256((npix + 1) * 4);
     int* cursor = (int*)w;           w += align256((npix + 1) * 4);
+    const int nblocks = (int)((npix + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    int* bsum = (int*)w;             w += align256((size_t)nblocks * 4);
     int* cand = (int*)w;
     const float r2 = radius_ndc * radius_ndc;
     gd_zero_async(count, (npix + 1) * 4, st);
     gd_zero_async(cursor, (npix + 1) * 4, st);
     const int tp = 256;
     k_count_fill<false><<<(P + tp - 1) / tp, tp, 0, st>>>(pts, P, S, radius_ndc, r2, count, nullptr, nullptr, nullptr);
-    k_scan<<<1, 1024, 0, st>>>(count, offset, (int)npix);
+    k_scan_local<<<nblocks, 256, 0, st>>>(count, offset, bsum, (int)npix);
+    k_scan_add<<<nblocks, 256, 0, st>>>(offset, bsum, (int)npix, nblocks);
     k_count_fill<true><<<(P + tp - 1) / tp, tp, 0, st>>>(pts, P, S, radius_ndc, r2, nullptr, offset, cursor, cand);
     k_select<<<((int)npix + SEL_THREADS - 1) / SEL_THREADS, SEL_THREADS, 0, st>>>(pts, S, K, r2, offset, cand, idx, zbuf, dist2);
     GD_CHECK_LAUNCH("gd_rasterize_points");

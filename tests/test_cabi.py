@@ -63,3 +63,41 @@ def test_missing_library_fails_loudly(tmp_path):
             _lib.load(str(tmp_path / "nope.so"))
     finally:
         _lib._lib = saved
+
+
+def test_w64_main_loop_has_no_register_file_copies(tmp_path):
+    """k_attn_fwd_w64 mixes MFMA builtins (accumulators in a[...]) with inline-asm score MFMAs (D / C in v[...], fragments in a[...]);
+    its correctness argument (DESIGN 4a') needs the loop to run WITHOUT v_accvgpr_* copies next to the asm MFMAs (the hazard recogniser
+    does not pad in front of asm) and its speed needs it too (a first build had 352 copies per 64 MFMAs).  Compile to assembly and check
+    the main loop of every instantiation: 128 MFMAs, no v_accvgpr_*, no scratch."""
+    import re
+    import shutil
+    import subprocess
+    from collections import Counter
+    from geodiffuser_amd import build
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "mp.s"
+    src = os.path.join(build.CSRC, "attn_fwd_mp.hip")
+    subprocess.run([hipcc, *build.FLAGS, *build.EXTRA_FLAGS["attn_fwd_mp.hip"], "-Wno-pass-failed", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=600)
+    text = out.read_text().split("\n")
+    starts = [i for i, ln in enumerate(text) if re.match(r"^_Z14k_attn_fwd_w64\w+:", ln)]
+    assert len(starts) >= 4
+    for st in starts:
+        end = next(i for i in range(st, len(text)) if text[i].startswith(".Lfunc_end"))
+        body = text[st:end]
+        labels = {m.group(1): i for i, ln in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", ln))}
+        found = False
+        for i, ln in enumerate(body):
+            m = re.search(r"s_(?:cbranch_\w+|branch) (\.LBB\d+_\d+)", ln)
+            if m and labels.get(m.group(1), 1 << 30) < i:
+                ops_ = Counter(x.split()[0] for x in (y.strip() for y in body[labels[m.group(1)]:i]) if x and x[0] not in ";.")
+                if sum(v for k, v in ops_.items() if k.startswith("v_mfma")) == 128:
+                    found = True
+                    assert not any(k.startswith("v_accvgpr") for k in ops_), (text[st], {k: v for k, v in ops_.items() if k.startswith("v_accvgpr")})
+                    break
+        assert found, text[st]
+    for m in re.finditer(r"\.amdhsa_kernel (_Z14k_attn_fwd_w64\w+).*?; ScratchSize: (\d+)", "\n".join(text), re.S):
+        assert int(m.group(2)) == 0, (m.group(1), m.group(2))

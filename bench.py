@@ -35,7 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_MFMA_16BIT = 2.5e15     # dense bf16/fp16 MFMA peak of MI355X, /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_TABLE = "r02_attn_traffic.json"   # PMC-measured HBM bytes per launch of the attention kernel, by head count (profiles/)
+TRAFFIC_TABLE = "r03_attn_traffic.json"   # PMC-measured HBM bytes per launch of the attention kernel, by head count (profiles/)
 
 
 class AttnTimer:
@@ -185,8 +185,8 @@ class AttnTimer:
             tab = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_TABLE)))["bytes_per_launch"]
             common = max(rows, key=lambda r: r["launches"])["heads"]
             traffic = tab.get(str(common))
-            if traffic is None:                       # measured at 10 / 15 / 20 heads; linear in the head count (Q, K, V, O once each)
-                traffic = int(tab["10"] + (tab["20"] - tab["10"]) * (common - 10) / 10.0)
+            if traffic is None:                       # measured at 5 / 15 / 20 (CFG form) / 32 heads; linear in the head count (Q, K, V, O once each)
+                traffic = int(tab["15"] + (tab["32"] - tab["15"]) * (common - 15) / 17.0)
         except Exception:  # noqa: BLE001
             pass
         rows.sort(key=lambda r: -r["launches"])

@@ -163,8 +163,9 @@ def _attn_ws(lib, dev: torch.device, tot_bh: int, N: int, M: int):
     need = int(lib.gd_attn_fwd_workspace_bytes(tot_bh, N, M))
     ws = _SK_WS.get(dev.index)
     if ws is None or ws.numel() < need:
-        if ws is not None and torch.cuda.is_current_stream_capturing():
-            raise _lib.GeodiffError("attn_fwd: the even-split workspace must not grow inside a graph capture (run one eager pass first)")
+        if torch.cuda.is_current_stream_capturing():
+            # (a buffer allocated during a capture lives in that graph's private pool and would be zero-filled again by every replay)
+            raise _lib.GeodiffError("attn_fwd: the even-split workspace must exist before a graph capture (run one eager pass first)")
         ws = _SK_WS[dev.index] = torch.zeros(max(need, 40 << 20), dtype=torch.uint8, device=dev)
     return ws
 

@@ -1,14 +1,32 @@
-"""Launch the 64^2 forward attention a few times (for rocprofv3 --pmc runs)."""
+"""Launch the 64^2 forward attention a few times (for rocprofv3 --pmc runs).  BH = heads (plain head-major launch); FORM=cfg: the CFG
+pass's launch of an edit instead (4 token-major segments x 5 heads that share K / V, fused query warp + row list on one of them)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from geodiffuser_amd import ops
 BH, N, M = int(os.environ.get("BH", "32")), 4096, 4096
 torch.manual_seed(0)
-q = (torch.randn(BH, N, 64, device="cuda") * 1.2).bfloat16(); k = (torch.randn(BH, M, 64, device="cuda") * 1.2).bfloat16(); v = torch.randn(BH, M, 64, device="cuda").bfloat16()
-out = torch.empty_like(q); lse = torch.empty(BH, N, device="cuda")
 QS = os.environ.get("QS", "0") == "1"
-if QS:
-    q = (q.float() * (0.125 * 1.4426950408889634)).bfloat16()
-for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
-    ops.attn_fwd([(q, k, v, out, lse if not QS else None)], 0.125, q_scaled=QS)
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+if os.environ.get("FORM") == "cfg":
+    heads, K, C = 5, 15, 320
+    q = (torch.randn(3, N, C, device="cuda") * 0.2).bfloat16(); k = torch.randn(3, N, C, device="cuda").bfloat16(); v = torch.randn(3, N, C, device="cuda").bfloat16()
+    yy, xx = torch.meshgrid(torch.arange(64), torch.arange(64), indexing="ij")
+    m = (((yy - 33) ** 2 + (xx - 33) ** 2) < 13 ** 2).float().reshape(-1).cuda()
+    idx = torch.full((N, K), -1, dtype=torch.int32, device="cuda"); w = torch.zeros(N, K, device="cuda")
+    for j in range(4):
+        idx[:, j] = torch.where(m > 0, (torch.arange(N, device="cuda") + 64 * 3 + 5 + j) % N, torch.full((N,), -1, device="cuda")).int(); w[:, j] = 0.25
+    rows = torch.nonzero(m > 0).reshape(-1).int(); R = rows.numel(); Rp = -(-R // 256) * 256
+    rows_p = torch.cat([rows, torch.zeros(Rp - R, dtype=torch.int32, device="cuda")]).contiguous(); n_dev = torch.tensor([R], dtype=torch.int32, device="cuda")
+    o = [torch.empty_like(q[:1]) for _ in range(3)]; act = torch.empty(1, Rp, C, device="cuda", dtype=torch.bfloat16)
+    segs = [(q[0:1], k[0:1], v[0:1], o[0], None), (q[1:2], k[1:2], v[1:2], o[1], None),
+            (q[1:2], k[1:2], v[1:2], act, None, (idx, w, m), (rows_p, n_dev)), (q[2:3], k[1:2], v[1:2], o[2], None)]
+    for _ in range(reps):
+        ops.attn_fwd(segs, 0.125, heads=heads, nsplit=1, q_scaled=True)
+else:
+    q = (torch.randn(BH, N, 64, device="cuda") * 1.2).bfloat16(); k = (torch.randn(BH, M, 64, device="cuda") * 1.2).bfloat16(); v = torch.randn(BH, M, 64, device="cuda").bfloat16()
+    out = torch.empty_like(q); lse = torch.empty(BH, N, device="cuda")
+    if QS:
+        q = (q.float() * (0.125 * 1.4426950408889634)).bfloat16()
+    for _ in range(reps):
+        ops.attn_fwd([(q, k, v, out, lse if not QS else None)], 0.125, q_scaled=QS)
 torch.cuda.synchronize()

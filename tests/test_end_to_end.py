@@ -709,7 +709,7 @@ def test_sdxl_full_width_edit_1024_with_fp8_vanilla_passes(monkeypatch):
     """BASELINE configs[4] at its stated workload: the FULL-width SDXL-base-shaped UNet (2.57 B parameters, 10 / 20 heads) at 1024 x 1024
     with the fp8 attention mode ON for the vanilla no-grad self-attention passes, while every hooked edit layer (warped queries, losses,
     gradients) stays on the 16-bit kernels.  Short (3 DDIM steps); checked: which kernels served which calls, finiteness, the
-    reference row (the inversion trajectory's start — independent of the fp8 mode) bit-identical to a 16-bit run of the same edit, and
+    reference row (the inversion trajectory's start — independent of the fp8 mode) equal to a 16-bit run's to rounding level, and
     the edit row within the fp8 mode's contract (a few per cent on a UNet pass, amplified by the loop: same order as a 16-bit repeat)."""
     from geodiffuser_amd import attention_sharing, editor, ops
     from geodiffuser_amd.diffusion import load_model
@@ -746,7 +746,9 @@ def test_sdxl_full_width_edit_1024_with_fp8_vanilla_passes(monkeypatch):
         assert (calls["fp8"] > 0) == fp8
         runs[fp8] = lat.float().cpu()
     assert calls["fp8_tokens"] <= {64 * 64, 32 * 32}                 # SDXL's self-attention levels at 1024^2
-    assert torch.equal(runs[True][0], runs[False][0])                 # reference row: the trajectory's start
+    # reference row: the trajectory's start = the VAE encoding of the image, untouched by the attention mode (the library convolutions of
+    # the full-width VAE are not bit-reproducible run to run: compared to rounding level)
+    assert rel_l2(runs[True][0], runs[False][0]) < 2e-3
     e = rel_l2(runs[True][1], runs[False][1])
     print(f"[configs4] full-width SDXL 1024^2, 3 steps: edit latent fp8-vanilla vs 16-bit rel_l2 {e:.3f}")
     assert 0.0 < e < 1.0

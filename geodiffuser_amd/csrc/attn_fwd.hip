@@ -381,13 +381,10 @@ static void mp_config(long long blocks, int N, int M, int* qb, int* ks, int q_pr
     // From 160 units of 256 queries up (10 heads at 64^2) the 64-query-per-wave kernel wins (k_attn_fwd_w64, bf16 only — the launcher
     // falls back to 4 x 1 for fp16): tools/bench_sk.py, 64^2: 15 heads 66.5 -> 59.1 us, 20 heads 102.3 -> 86.2 us (even split),
     // 32 heads 135.3 -> 122.0 us; 96^2: 20 heads 427 -> 377 us; 32^2 x 10 heads (40 units) 12.1 -> 17.5 us: stays below.
-    // Only for launches whose queries arrive pre-scaled, i.e. the no-grad passes (inversion, CFG).  The optimisation pass (exact scale,
-    // losses and gradients hang off the outputs) stays on k_attn_fwd_mp: its reference value lands exactly on a row maximum, so the
-    // probability of a DOMINANT key is exactly 1.0 in 16 bits, while k_attn_fwd_w64's reference is just the first tile's maximum and a
-    // dominant probability carries the storage type's rounding (2^-9 relative in bf16): on peaked rows its output error is 1.1-1.7x
-    // (controller case edit_self_opt_32_f20: 5.1e-3 against 3.1e-3, which moves that case's L1 'sim' term by 1.6 %).  GD_ATTN_CFG=8x1
-    // / gd_attn_fwd_set_config(8, 1) force it everywhere.
-    if (T % 4 == 0 && blocks >= 1280 && M >= 1024 && q_prescaled) { *qb = 8; *ks = 1; return; }
+    // Both variants: pre-scaled queries (no-grad passes; reference = first tile's maximum, retry with exact maxima on overflow) and exact
+    // scale (optimisation pass; in-loop rescue like k_attn_fwd_mp's, so a dominant probability is exactly 1.0 after a rescue — the
+    // property the optimisation pass's parity tolerances were calibrated on).
+    if (T % 4 == 0 && blocks >= 1280 && M >= 1024) { *qb = 8; *ks = 1; return; }
     if (blocks < 1280 && T % 4 == 0) { *qb = 4; *ks = 2; return; }
     *qb = 4; *ks = 1;
 }

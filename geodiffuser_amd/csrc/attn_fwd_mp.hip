@@ -579,6 +579,15 @@ template <> struct score_mfma<bf16_t> {
     static __device__ __forceinline__ void head(f32x16& d, const bf16x8 a, const bf16x8 b, const f32x16& c) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
     }
+    // exact-scale variant: no bias tile (C = the inline constant 0), and the query fragments live in v[...] — the registers the bias
+    // tiles occupy in the pre-scaled variant; with an "a" operand the compiler kept them in v[...] anyway and copied them into a[...]
+    // in front of every use (96 v_accvgpr_write per 128 MFMAs, each one the hazard described above)
+    static __device__ __forceinline__ void head_zero(f32x16& d, const bf16x8 a, const bf16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(d) : "a"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void acc_vb(f32x16& d, const bf16x8 a, const bf16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b));
+    }
     static __device__ __forceinline__ void acc(f32x16& d, const bf16x8 a, const bf16x8 b) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
     }
@@ -594,6 +603,15 @@ template <> struct score_mfma<f16_t> {
     static __device__ __forceinline__ void head(f32x16& d, const f16x8 a, const f16x8 b, const f32x16& c) {
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
     }
+    // exact-scale variant: no bias tile (C = the inline constant 0), and the query fragments live in v[...] — the registers the bias
+    // tiles occupy in the pre-scaled variant; with an "a" operand the compiler kept them in v[...] anyway and copied them into a[...]
+    // in front of every use (96 v_accvgpr_write per 128 MFMAs, each one the hazard described above)
+    static __device__ __forceinline__ void head_zero(f32x16& d, const f16x8 a, const f16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(d) : "a"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void acc_vb(f32x16& d, const f16x8 a, const f16x8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b));
+    }
     static __device__ __forceinline__ void acc(f32x16& d, const f16x8 a, const f16x8 b) {
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
     }
@@ -602,6 +620,9 @@ template <> struct score_mfma<f16_t> {
     }
 };
 
+// Two scores -> two probabilities.  Plain fp32 VALU on purpose: the packed forms (v_pk_fma_f32 for the exact-scale variant's
+// scale-and-shift, v_pk_add_f32 for the row sums) halve the issue slots but run on the pipe the MFMAs use — measured with them the
+// 15-head exact-scale launch went 69 -> 86 us and the 20-head pre-scaled one 98 -> 133 us (profiles/r03_packed_fp32.log).
 #define W64_EG2(SRC, i, DST, j, QI)                                                                              \
     {                                                                                                            \
         const float p0_ = __builtin_amdgcn_exp2f(PRE ? SRC[i] : __builtin_fmaf(SRC[i], c, -m2[QI]));             \
@@ -610,11 +631,49 @@ template <> struct score_mfma<f16_t> {
         ps0 += p0_;                                                                                              \
         ps1 += p1_;                                                                                              \
     }
-// end of a half step: row sums, and the running maximum of the half-step sums (checked once per segment, see k_attn_fwd_w64)
-#define W64_CHECK(QI)                                                                                            \
+// Cold path of the exact-scale variant (!PRE: the optimisation pass): a half step's probability sum left [0, 2^14] — raise the reference
+// by the half's maximum exponent, rescale O and l, recompute the half's probabilities, exactly like softmax_rescue of k_attn_fwd_mp.
+// With raw scores in the tiles (p = exp2(c S - mu), mu a scalar) nothing but O, l and mu changes: no score or bias tile is touched, which
+// is what made the in-place rescue unaffordable for the pre-scaled variant (see the kernel's header).  It also keeps the property the
+// parity tests of the optimisation pass were calibrated on: after a rescue the reference sits exactly on a row maximum, so a DOMINANT
+// probability is exactly 1.0 in 16 bits.
+template <typename T>
+__device__ __forceinline__ void w64_rescue(const f32x16& H, f32x16 (&o)[2], float& m2, float& l_run, const float c, u32x4& pf0, u32x4& pf1,
+                                           float& ps) {
+    float mx = H[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, H[i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(__builtin_fmaf(mx, c, -m2), 0.f);
+    float alpha = __builtin_amdgcn_exp2f(-mx);
+    l_run *= alpha;
+    m2 += mx;
+    GD_TILE_OP("v_mul_f32", o[0], alpha)
+    GD_TILE_OP("v_mul_f32", o[1], alpha)
+    ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(H[i], c, -m2));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(H[i + 1], c, -m2));
+        const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(H[8 + i], c, -m2));
+        const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(H[8 + i + 1], c, -m2));
+        pf0[i >> 1] = pack2<T>(p0, p1);
+        pf1[i >> 1] = pack2<T>(p2, p3);
+        ps += (p0 + p1) + (p2 + p3);
+    }
+}
+
+// end of a half step: row sums; pre-scaled variant: the running maximum of the half-step sums (checked once per segment, see
+// k_attn_fwd_w64); exact-scale variant: the in-loop rescue above
+#define W64_CHECK(H, QI, PF0, PF1)                                                                               \
     {                                                                                                            \
-        const float ps = ps0 + ps1;                                                                              \
-        chk = fmaxf(chk, ps);                                                                                    \
+        float ps = ps0 + ps1;                                                                                    \
+        if (!PRE) {                                                                                              \
+            if (!(GD_MP_DBG & 4) && __builtin_expect(__builtin_amdgcn_ballot_w64(!(ps <= P_SUM_LIMIT)) != 0, 0)) \
+                w64_rescue<T>(H, o[QI], m2[QI], l_run[QI], c, PF0, PF1, ps);                                     \
+        } else {                                                                                                 \
+            chk = fmaxf(chk, ps);                                                                                \
+        }                                                                                                        \
         l_run[QI] += ps;                                                                                         \
         ps0 = 0.f; ps1 = 0.f;                                                                                    \
     }
@@ -651,31 +710,31 @@ __device__ __forceinline__ void w64_iter(const char* lk, const char* lv, const F
     if (!LAST) kf[3] = ((GD_MP_DBG & 8) ? qf[0][3] : rd_row<T>(lk, fo, 0, 3));
     o[0][1] = TR::mfma32(vc[3], as_frag<T>(pb1[0]), o[0][1]); W64_EG2(X0[0], 12, pa1[0], 4, 0); GD_SB();
     o[1][1] = TR::mfma32(vc[3], as_frag<T>(pb1[1]), o[1][1]); W64_EG2(X0[0], 14, pa1[0], 6, 0); GD_SB();
-    W64_CHECK(0)
+    W64_CHECK(X0[0], 0, pa0[0], pa1[0])
     GD_SB();
     // ---- gaps 9-16: scores of tile t+1, keys 0..31 | probabilities of block B, keys 0..31 | V(t) keys 0..31 ----
     if (DMA && !(GD_MP_DBG & 1)) w64_dma(sg.kb, sg.kdst + 1024, sg.voff[1], sg.ksoff);
     va[0] = ((GD_MP_DBG & 8) ? qf[1][0] : rd_tr<T>(lv, fo, 0, 0));
-    if (!LAST) score_mfma<T>::head(Y0[0], kf[0], qf[0][0], negmu[0]);
+    if (!LAST) { if (PRE) score_mfma<T>::head(Y0[0], kf[0], qf[0][0], negmu[0]); else score_mfma<T>::head_zero(Y0[0], kf[0], qf[0][0]); }
     W64_EG2(X0[1], 0, pa0[1], 0, 1); GD_SB();
-    if (!LAST) score_mfma<T>::head(Y0[1], kf[0], qf[1][0], negmu[1]);
+    if (!LAST) { if (PRE) score_mfma<T>::head(Y0[1], kf[0], qf[1][0], negmu[1]); else score_mfma<T>::head_zero(Y0[1], kf[0], qf[1][0]); }
     W64_EG2(X0[1], 2, pa0[1], 2, 1); GD_SB();
     va[1] = ((GD_MP_DBG & 8) ? qf[1][0] : rd_tr<T>(lv, fo, 1, 0));
-    if (!LAST) score_mfma<T>::acc(Y0[0], kf[1], qf[0][1]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[0], kf[1], qf[0][1]); else score_mfma<T>::acc_vb(Y0[0], kf[1], qf[0][1]); }
     W64_EG2(X0[1], 4, pa0[1], 4, 1); GD_SB();
-    if (!LAST) score_mfma<T>::acc(Y0[1], kf[1], qf[1][1]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[1], kf[1], qf[1][1]); else score_mfma<T>::acc_vb(Y0[1], kf[1], qf[1][1]); }
     W64_EG2(X0[1], 6, pa0[1], 6, 1); GD_SB();
     va[2] = ((GD_MP_DBG & 8) ? qf[1][1] : rd_tr<T>(lv, fo, 0, 1));
-    if (!LAST) score_mfma<T>::acc(Y0[0], kf[2], qf[0][2]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[0], kf[2], qf[0][2]); else score_mfma<T>::acc_vb(Y0[0], kf[2], qf[0][2]); }
     W64_EG2(X0[1], 8, pa1[1], 0, 1); GD_SB();
-    if (!LAST) score_mfma<T>::acc(Y0[1], kf[2], qf[1][2]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[1], kf[2], qf[1][2]); else score_mfma<T>::acc_vb(Y0[1], kf[2], qf[1][2]); }
     W64_EG2(X0[1], 10, pa1[1], 2, 1); GD_SB();
     va[3] = ((GD_MP_DBG & 8) ? qf[1][1] : rd_tr<T>(lv, fo, 1, 1));
-    if (!LAST) score_mfma<T>::acc(Y0[0], kf[3], qf[0][3]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[0], kf[3], qf[0][3]); else score_mfma<T>::acc_vb(Y0[0], kf[3], qf[0][3]); }
     W64_EG2(X0[1], 12, pa1[1], 4, 1); GD_SB();
-    if (!LAST) score_mfma<T>::acc(Y0[1], kf[3], qf[1][3]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[1], kf[3], qf[1][3]); else score_mfma<T>::acc_vb(Y0[1], kf[3], qf[1][3]); }
     W64_EG2(X0[1], 14, pa1[1], 6, 1); GD_SB();
-    W64_CHECK(1)
+    W64_CHECK(X0[1], 1, pa0[1], pa1[1])
     GD_SB();
     // ---- gaps 17-24: first half of tile t into O | probabilities of block A, keys 32..63 | K(t+1) rows 32..63 ----
     if (DMA && !(GD_MP_DBG & 1)) w64_dma(sg.vb, sg.vdst, sg.voff[0], sg.vsoff);
@@ -691,31 +750,31 @@ __device__ __forceinline__ void w64_iter(const char* lk, const char* lv, const F
     if (!LAST) kf[3] = ((GD_MP_DBG & 8) ? qf[0][3] : rd_row<T>(lk, fo, 1, 3));
     o[0][1] = TR::mfma32(va[3], as_frag<T>(pa1[0]), o[0][1]); W64_EG2(X1[0], 12, pb1[0], 4, 0); GD_SB();
     o[1][1] = TR::mfma32(va[3], as_frag<T>(pa1[1]), o[1][1]); W64_EG2(X1[0], 14, pb1[0], 6, 0); GD_SB();
-    W64_CHECK(0)
+    W64_CHECK(X1[0], 0, pb0[0], pb1[0])
     GD_SB();
     // ---- gaps 25-32: scores of tile t+1, keys 32..63 | probabilities of block B, keys 32..63 | V(t) keys 32..63 ----
     if (DMA && !(GD_MP_DBG & 1)) w64_dma(sg.vb, sg.vdst + 1024, sg.voff[1], sg.vsoff);
     vc[0] = ((GD_MP_DBG & 8) ? qf[1][2] : rd_tr<T>(lv, fo, 0, 2));
-    if (!LAST) score_mfma<T>::head(Y1[0], kf[0], qf[0][0], negmu[0]);
+    if (!LAST) { if (PRE) score_mfma<T>::head(Y1[0], kf[0], qf[0][0], negmu[0]); else score_mfma<T>::head_zero(Y1[0], kf[0], qf[0][0]); }
     W64_EG2(X1[1], 0, pb0[1], 0, 1); GD_SB();
-    if (!LAST) score_mfma<T>::head(Y1[1], kf[0], qf[1][0], negmu[1]);
+    if (!LAST) { if (PRE) score_mfma<T>::head(Y1[1], kf[0], qf[1][0], negmu[1]); else score_mfma<T>::head_zero(Y1[1], kf[0], qf[1][0]); }
     W64_EG2(X1[1], 2, pb0[1], 2, 1); GD_SB();
     vc[1] = ((GD_MP_DBG & 8) ? qf[1][2] : rd_tr<T>(lv, fo, 1, 2));
-    if (!LAST) score_mfma<T>::acc(Y1[0], kf[1], qf[0][1]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[0], kf[1], qf[0][1]); else score_mfma<T>::acc_vb(Y1[0], kf[1], qf[0][1]); }
     W64_EG2(X1[1], 4, pb0[1], 4, 1); GD_SB();
-    if (!LAST) score_mfma<T>::acc(Y1[1], kf[1], qf[1][1]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[1], kf[1], qf[1][1]); else score_mfma<T>::acc_vb(Y1[1], kf[1], qf[1][1]); }
     W64_EG2(X1[1], 6, pb0[1], 6, 1); GD_SB();
     vc[2] = ((GD_MP_DBG & 8) ? qf[1][3] : rd_tr<T>(lv, fo, 0, 3));
-    if (!LAST) score_mfma<T>::acc(Y1[0], kf[2], qf[0][2]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[0], kf[2], qf[0][2]); else score_mfma<T>::acc_vb(Y1[0], kf[2], qf[0][2]); }
     W64_EG2(X1[1], 8, pb1[1], 0, 1); GD_SB();
-    if (!LAST) score_mfma<T>::acc(Y1[1], kf[2], qf[1][2]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[1], kf[2], qf[1][2]); else score_mfma<T>::acc_vb(Y1[1], kf[2], qf[1][2]); }
     W64_EG2(X1[1], 10, pb1[1], 2, 1); GD_SB();
     vc[3] = ((GD_MP_DBG & 8) ? qf[1][3] : rd_tr<T>(lv, fo, 1, 3));
-    if (!LAST) score_mfma<T>::acc(Y1[0], kf[3], qf[0][3]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[0], kf[3], qf[0][3]); else score_mfma<T>::acc_vb(Y1[0], kf[3], qf[0][3]); }
     W64_EG2(X1[1], 12, pb1[1], 4, 1); GD_SB();
-    if (!LAST) score_mfma<T>::acc(Y1[1], kf[3], qf[1][3]);
+    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[1], kf[3], qf[1][3]); else score_mfma<T>::acc_vb(Y1[1], kf[3], qf[1][3]); }
     W64_EG2(X1[1], 14, pb1[1], 6, 1); GD_SB();
-    W64_CHECK(1)
+    W64_CHECK(X1[1], 1, pb0[1], pb1[1])
 }
 
 template <typename T, bool PRE, bool SK>
@@ -1093,10 +1152,13 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
     GD_REQUIRE(a.M % (4 * ATT_BN) == 0, GD_EINVAL, "gd_attn_fwd: the 64-query kernel needs a multiple of four full key tiles (M=%d)", a.M);
     a.nwg = set_units(a, tot, 256);
     bool sk = false;
-    // Even split where the last round of 256 workgroups would be badly filled: 20 heads = 320 units = 1.25 rounds (109.9 -> 86.2 us),
-    // 15 heads = 240 units = 0.94 (59.1 unsplit, 70.0 split: the hand-off is not free), 30 heads = 1.875 (117.1 unsplit, 126.2 split)
-    const int last_round = a.nwg % 256;
-    if (a.sk_ws && TU >= 16 && (sk_force || (last_round != 0 && last_round < 205))) {
+    // Even split where it beats whole units.  Cost model in key tiles per workgroup: unsplit = rounds of 256 workgroups x TU; split =
+    // the equal share + ~24 tiles' worth of hand-off (a second prologue, the partial tiles through the workspace, ticket, merge: 17 us on
+    // the pre-scaled variant, more on the exact-scale one).  Measured: 20 heads = 320 units, 128 vs 80 + 24 (109.9 -> 86.2 us); 15 heads
+    // = 240 units, 64 vs 60 + 24 (59.1 unsplit, 70.0 split); 30 heads, 128 vs 120 + 24 (117.1 / 126.2); the optimisation pass's 165
+    // units (two dense segments + the edit rows), 64 vs 42 + 24 (70.0 unsplit, 73.4 split: tools/bench_opt15.py).
+    const long long tiles_unsplit = (long long)((a.nwg + 255) / 256) * TU, tiles_split = ((long long)a.nwg * TU + 255) / 256 + 24;
+    if (a.sk_ws && TU >= 16 && (sk_force || tiles_split < tiles_unsplit)) {
         const long long total = (long long)a.nwg * TU;
         int tpw = (int)((total + 255) / 256);
         tpw = (tpw + 3) & ~3;

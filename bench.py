@@ -119,6 +119,7 @@ class AttnTimer:
         """Re-issue every configuration that ran in the timed region, back to back (outside the timed region).  Event brackets
         around isolated eager launches also contain the launch latency of an idle queue (+20-40 us); the back-to-back samples agree
         with rocprofv3's kernel durations and are the ones reported, the in-region eager samples are kept as ``eager_avg_us``."""
+        built = []
         for cfg, e in self.cfgs.items():
             if e["count"] == 0:
                 continue
@@ -148,15 +149,27 @@ class AttnTimer:
                         rows = torch.cat([rows, torch.zeros(rows_len - rows.numel(), dtype=torch.int32, device="cuda")]).contiguous()
                         seg = (q, k, v, torch.empty(qs[0], rows_len, qs[2], dtype=dt, device="cuda"), None, seg[5], (rows, n_dev))
                 segs.append(seg)
-            for _ in range(30):                            # warm: clocks ramp down while the host builds the tensors above
+            built.append((e, segs, scale, heads, q_scaled))
+        # Interleaved rounds over all configurations: a configuration timed right after the host built its tensors meets a chip whose
+        # clocks have dropped (seen: the same launch 8-12 us apart depending on its place in the order), so every configuration is
+        # warmed, then timed in `rounds` slices spread over the whole replay.  One event bracket around each slice of back-to-back
+        # launches: the queue stays full, so host dispatch time is not measured.
+        rounds = 5
+        per = max(1, reps // rounds)
+        for e, segs, scale, heads, q_scaled in built:
+            for _ in range(30):
                 self._orig(segs, scale, heads, q_scaled=q_scaled)
-            # one event bracket around `reps` back-to-back launches: the queue stays full, so host dispatch time is not measured
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                self._orig(segs, scale, heads, q_scaled=q_scaled)
-            e1.record()
-            e["rep"] = (e0, e1, reps)
+            e["rep"] = []
+        for _ in range(rounds):
+            for e, segs, scale, heads, q_scaled in built:
+                for _ in range(10):
+                    self._orig(segs, scale, heads, q_scaled=q_scaled)
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(per):
+                    self._orig(segs, scale, heads, q_scaled=q_scaled)
+                e1.record()
+                e["rep"].append((e0, e1, per))
         torch.cuda.synchronize()
 
     def summary(self):
@@ -164,7 +177,7 @@ class AttnTimer:
         for cfg, e in self.cfgs.items():
             if e["count"] and (e.get("rep") or e["ev"]):
                 if e.get("rep"):
-                    us = 1e3 * e["rep"][0].elapsed_time(e["rep"][1]) / e["rep"][2]
+                    us = 1e3 * sum(a.elapsed_time(b) for a, b, _ in e["rep"]) / sum(n for _, _, n in e["rep"])
                 else:
                     us = 1e3 * sum(a.elapsed_time(b) for a, b in e["ev"]) / len(e["ev"])
                 row = dict(heads=e["heads"], token_major=bool(cfg[2]), q_scaled=bool(cfg[4]),

@@ -75,8 +75,9 @@ def set_attn_processor_for_edit(model, perform_edit=True, coords_base=(2, 3), co
         proc.controller.n_batch = n_batch
 
 
-def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_major=False):
-    """Shared front half of both processors (attention_processors.py:85-120 / :165-203)."""
+def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_major=False, scaled_q_head_major=False):
+    """Shared front half of both processors (attention_processors.py:85-120 / :165-203).  ``scaled_q_head_major``: the caller's
+    head-major consumer (_EditLayer: the optimisation pass) takes pre-scaled queries too."""
     args = () if USE_PEFT_BACKEND else (scale,)
     if getattr(attn, "spatial_norm", None) is not None:
         hidden_states = attn.spatial_norm(hidden_states, temb)
@@ -94,10 +95,14 @@ def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_
         fused = _batched_qkv(attn, hidden_states, encoder_hidden_states)
         if fused is not None:
             return fused[:4] + (shape4,) + fused[5:]
-    if token_major and SCALED_Q and not lin_args and type(attn.to_q) is torch.nn.Linear and attn.to_q.bias is None:
+    if ((token_major and SCALED_Q) or (scaled_q_head_major and SCALED_Q_OPT)) and not lin_args and type(attn.to_q) is torch.nn.Linear \
+            and attn.to_q.bias is None:
         # q' = 16-bit(scale*log2(e) * (x W^T)): the softmax scale and the base change applied as the GEMM's alpha in its fp32
         # epilogue, BEFORE the one rounding to 16 bits (no extra rounding, unlike scaling a rounded q).  The attention kernels
-        # then compute p = exp2(q'.k - mu) with one vector instruction per probability (gd_attn_seg_t::q_scaled).
+        # then compute p = exp2(q'.k - mu) with one vector instruction per probability (gd_attn_seg_t::q_scaled).  addmm is
+        # differentiable, so the optimisation pass takes the same route: its backward kernels then see q' with scale = ln 2
+        # (s = ln2 * q'.k), i.e. the probabilities they recompute are EXACTLY the forward's — with unscaled queries the forward's
+        # and the backward's scores differ by the rounding of scale*log2(e) inside the kernel.
         w = attn.to_q.weight
         x2 = hidden_states.reshape(-1, hidden_states.shape[-1])
         query = torch.addmm(w[:, 0], x2, w.t(), beta=0.0, alpha=float(attn.scale) * LOG2E).view(*hidden_states.shape[:-1], w.shape[0])
@@ -119,7 +124,7 @@ def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_
     query = attn.head_to_batch_dim(query).contiguous()
     key = attn.head_to_batch_dim(key).contiguous()
     value = attn.head_to_batch_dim(value).contiguous()
-    return query, key, value, is_cross, shape4, lin_args, False
+    return query, key, value, is_cross, shape4, lin_args, q_scaled
 
 
 def _stacked_weights(attn, names, alpha0):
@@ -171,6 +176,8 @@ def _batched_qkv(attn, hidden_states, encoder_hidden_states):
 TOKEN_MAJOR = os.environ.get("GD_TOKEN_MAJOR", "1") == "1"
 BATCHED_QKV = os.environ.get("GD_BATCHED_QKV", "1") == "1"   # no-grad passes: q / k / v projections of one input as one batched GEMM
 SCALED_Q = os.environ.get("GD_SCALED_Q", "1") == "1"      # token-major passes: scale*log2(e) folded into the query projection
+SCALED_Q_OPT = os.environ.get("GD_SCALED_Q_OPT", "1") == "1"   # the same for the optimisation pass's hooked (head-major) layers
+LN2 = 0.6931471805599453
 LOG2E = 1.4426950408889634
 FUSED_WARP = os.environ.get("GD_FUSED_WARP", "1") == "1"   # build the warped queries inside the attention launch
 # The edit attention with warped queries (q*(1-m) + m*splat(q), U/attention_processors.py:424-428,544-549) is computed only for the rows
@@ -232,17 +239,22 @@ class EditProcessor:
         # losses (use_cfg False) and stored maps stay on the head-major path
         tok = _tok_ok(attn, hidden_states) and (not self.perform_edit or (
             getattr(ctrl, "supports_token_major", False) and ctrl.use_cfg and not getattr(ctrl, "store_attention_maps", False)))
-        q, k, v, is_cross, shape4, lin_args, qs = _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, tok)
+        q, k, v, is_cross, shape4, lin_args, qs = _project_qkv(
+            attn, hidden_states, encoder_hidden_states, temb, scale, tok,
+            scaled_q_head_major=self.perform_edit and not tok and getattr(ctrl, "supports_scaled_q_head_major", False))
         if self.perform_edit:
             if tok:
                 ctrl.heads_tok = attn.heads
                 ctrl.q_scaled_tok = qs
+            else:
+                ctrl.q_scaled_hm = qs
             try:
                 out = ctrl(q, k, v, is_cross=is_cross, place_in_unet=self.place_in_unet,
                            transform_coords=self.transform_coords, scale=attn.scale, mask=None)
             finally:
                 ctrl.heads_tok = 0
                 ctrl.q_scaled_tok = False
+                ctrl.q_scaled_hm = False
         else:
             out = attention_tok(q, k, v, attn.scale, attn.heads, q_scaled=qs) if tok else attention(q, k, v, attn.scale)
         return _finish(attn, out, residual, shape4, lin_args, tok)
@@ -333,7 +345,9 @@ class _EditLayer(torch.autograd.Function):
     replace_{self,cross}_attention inlined).  Returns (out [(cb+1)*f, N, D], layer_loss [] f32, terms [5] f32)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, ctrl, is_cross, scale, c):
+    def forward(ctx, q, k, v, ctrl, is_cross, scale, c, q_pre=False):
+        # q_pre: the queries carry scale*log2(e) and ``scale`` is ln 2 (controller forward); only the forward kernel needs telling
+        # (gd_attn_seg_t::q_scaled: it skips the multiply) — every other kernel computes exp(scale * q.k - lse) as it stands
         f = c["f"]
         remover = ctrl._is_remover
         (b0, b1), (e0, e1) = ctrl.coords_base, ctrl.coords_edit
@@ -377,7 +391,7 @@ class _EditLayer(torch.autograd.Function):
                 ident_out = torch.empty(f, N, D, dtype=dt, device=dev)
                 segs.append((q_edit, k_edit, v_edit, ident_out, None))
         segs.append((q_edit, K, v_base, replace_out, lse_e))                # :433,557 / :791,883
-        ops.attn_fwd(segs, scale)
+        ops.attn_fwd(segs, scale, q_scaled=q_pre)
         if (not remover) and edit_act is not None:
             ops.rows_merge(out_full[b0 * f:b1 * f], edit_act, c["edit_pos"], out=edit_out)
         if remover:
@@ -466,7 +480,7 @@ class _EditLayer(torch.autograd.Function):
         if dk32 is not None:
             grad_k = torch.zeros(m["k_shape"], dtype=dt, device=dev)
             grad_k[m["e0"] * f:m["e1"] * f] = dk32.to(dt)
-        return grad_q, grad_k, None, None, None, None, None
+        return grad_q, grad_k, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -686,6 +700,8 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
     supports_token_major = True
     heads_tok = 0
     q_scaled_tok = False
+    q_scaled_hm = False
+    supports_scaled_q_head_major = True
     # Set by the driver for an optimisation pass whose reference and edit samples are the SAME sample in every layer (the first pass of
     # a removal edit: both rows start from x_T with the same text, and the remover's output for the edit row equals the vanilla
     # output, so the rows never diverge).  In exact arithmetic their q / k / v are then equal, the attention outputs
@@ -759,6 +775,9 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             return self._forward_tok(q, k, v, is_cross, transform_coords, float(scale), heads)
         f = q.shape[0] // nb
         self._place_in_unet = place_in_unet
+        q_pre = bool(self.q_scaled_hm)
+        if q_pre:                        # q carries scale*log2(e) (_project_qkv): s = ln2 * q'.k for everything that takes a scale
+            scale = LN2
         if not active:
             return attention(q, k, v, scale)                                   # :646-647
         if is_cross:
@@ -770,7 +789,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             q, k, v = (self._tie_rows(t, f) for t in (q, k, v))
         if D % 64:      # SD1.x heads (40 / 80 / 160): zero columns up to the kernels' 64 / 128 / 192; the loss normalisers keep the true D
             q, k, v = pad_head_dim(q), pad_head_dim(k), pad_head_dim(v)
-        out, loss, terms = _EditLayer.apply(q.contiguous(), k.contiguous(), v.contiguous(), self, is_cross, float(scale), c)
+        out, loss, terms = _EditLayer.apply(q.contiguous(), k.contiguous(), v.contiguous(), self, is_cross, float(scale), c, q_pre)
         out = out[..., :D]
         if (q.shape[1] >= 32 ** 2) and (not self.use_cfg):
             kind = "cross" if is_cross else "self"

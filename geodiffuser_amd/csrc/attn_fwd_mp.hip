@@ -216,8 +216,15 @@ k_attn_fwd_mp(const FwdArgs a) {
     int lin = SK ? wg * a.sk_tpw : 0;                                      // SK: this workgroup's run of the launch's linear tile range
     const int lin_end = SK ? (lin + a.sk_tpw < a.sk_total ? lin + a.sk_tpw : a.sk_total) : 0;
     const int lin_first = lin;
+#if GD_MP_DBG & 32
+    int dbg_seg = 0;
+#define MP_STAMP(E) { if (tid == 0 && a.sk_ws) ((unsigned long long*)((char*)a.sk_ws + GD_SK_SLOT_BYTES + (1u << 20)))[(wg * 4 + dbg_seg) * 8 + (E)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define MP_STAMP(E) {}
+#endif
 #pragma unroll 1
   do {
+    MP_STAMP(0)
     int unit = wg, t_first = 0, Tg = TU / KS;                              // key tiles [t_first, t_first + Tg) of this segment
     if (SK) {
         unit = lin / TU;
@@ -342,6 +349,7 @@ k_attn_fwd_mp(const FwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) vc[j][i] = TR::from_f32(0.f);
     __syncthreads();                  // every wave has read K(0) before the loop's first stores reuse its tile
+    MP_STAMP(1)
 
 #define GD_GLD_L(BASE, TILE, R) if (!(GD_MP_DBG & 1)) { GD_GLD(BASE, TILE, R); }
 #define GD_LST_L(DST, R) if (!(GD_MP_DBG & 1)) { GD_LST(DST, R); }
@@ -400,6 +408,7 @@ k_attn_fwd_mp(const FwdArgs a) {
 #undef GD_SYNC_L
 #undef GD_GLD
 #undef GD_LST
+    MP_STAMP(2)
     // second half of the last tile
     o[0] = TR::mfma32(vc[0], as_frag<T>(pb0), o[0]);
     o[1] = TR::mfma32(vc[1], as_frag<T>(pb0), o[1]);
@@ -434,6 +443,7 @@ k_attn_fwd_mp(const FwdArgs a) {
         }
     }
 
+    MP_STAMP(3)
     bool write_out = true;
     if (SK && Tg != TU) {
         // This segment holds only part of its unit's keys.  Park the un-normalised (O, reference, row sum) of the 128 queries in this
@@ -515,6 +525,7 @@ k_attn_fwd_mp(const FwdArgs a) {
         }
     }
 
+    MP_STAMP(4)
     if (write_out) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
@@ -533,11 +544,16 @@ k_attn_fwd_mp(const FwdArgs a) {
             if (sg.lse && h == 0) sg.lse[(size_t)bh * Nq + qrow] = m2 * 0.6931471805599453f + __logf(l_tot);
         }
     }
+    MP_STAMP(5)
+#if GD_MP_DBG & 32
+    ++dbg_seg;
+#endif
     if (SK) {
         lin += Tg;
         if (lin < lin_end) __syncthreads();           // the next segment's first stores reuse the tile rings
     }
   } while (SK && lin < lin_end);
+#undef MP_STAMP
 }
 
 // =================================================================================================================================
@@ -792,12 +808,20 @@ k_attn_fwd_w64(const FwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = xcd_remap(blockIdx.x, a.nwg);
     const int TU = a.M / ATT_BN;
+    // debug bit 32 (timing builds, tools/w64_phases.py): 100 MHz timestamps of the phases of every segment, 1 MB behind the part slots of the workspace
+#if GD_MP_DBG & 32
+    int dbg_seg = 0;
+#define W64_STAMP(E) { if (tid == 0 && a.sk_ws) ((unsigned long long*)((char*)a.sk_ws + GD_SK_SLOT_BYTES + (1u << 20)))[(wg * 4 + dbg_seg) * 8 + (E)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define W64_STAMP(E) {}
+#endif
     int lin = SK ? wg * a.sk_tpw : 0;
     const int lin_end = SK ? (lin + a.sk_tpw < a.sk_total ? lin + a.sk_tpw : a.sk_total) : 0;
     const int lin_first = lin;
     const FragOffs fo = make_frag_offs(lane);
 #pragma unroll 1
   do {
+    W64_STAMP(0)
     int unit = wg, t_first = 0, Tg = TU;
     if (SK) {
         unit = lin / TU;
@@ -860,9 +884,10 @@ k_attn_fwd_w64(const FwdArgs a) {
         w64_dma(RS, (DSTTILE) + wave * 2048, st.voff[0], (TILE_IDX) * tB);                          \
         w64_dma(RS, (DSTTILE) + wave * 2048 + 1024, st.voff[1], (TILE_IDX) * tB);                   \
     }
-    // first tiles on their way before the query loads (with warp tables: dependent round trips, slow in the launch's opening burst) start
+    // K(0) on its way before the query loads (with warp tables: dependent round trips, slow in the launch's opening burst) start; the
+    // other four tiles of the pipeline's fill behind them: the reference value (first tile's scores) needs K(0) and the queries only,
+    // and memory operations complete in order — `vmcnt(8)` below = everything but the last eight pieces has landed
     W64_ISSUE_TILE(st.kb, 0, ldsB[0])
-    W64_ISSUE_TILE(st.kb, 1, ldsA[0]) W64_ISSUE_TILE(st.kb, 2, ldsA[1]) W64_ISSUE_TILE(st.vb, 0, ldsA[2]) W64_ISSUE_TILE(st.vb, 1, ldsA[3])
     const int qrowA = tile * 256 + wave * 64 + (lane & 31), qrowB = qrowA + 32;      // rows of the output (= of the row list, if any)
     const int nq_ok = compact ? sg.q_rows_n[0] : N;
     const int pix[2] = {compact ? sg.q_rows[qrowA < Nq ? qrowA : Nq - 1] : (qrowA < N ? qrowA : N - 1),
@@ -875,6 +900,7 @@ k_attn_fwd_w64(const FwdArgs a) {
         load_q_frags<T>(sg, qp, rs, pix[0], h, qf[0]);
         load_q_frags<T>(sg, qp, rs, pix[1], h, qf[1]);
     }
+    W64_ISSUE_TILE(st.kb, 1, ldsA[0]) W64_ISSUE_TILE(st.kb, 2, ldsA[1]) W64_ISSUE_TILE(st.vb, 0, ldsA[2]) W64_ISSUE_TILE(st.vb, 1, ldsA[3])
     if (PRE && !a.q_prescaled) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -931,7 +957,7 @@ k_attn_fwd_w64(const FwdArgs a) {
         W64_ISSUE_TILE(st.kb, 0, ldsB[0])
         W64_ISSUE_TILE(st.kb, 1, ldsA[0]) W64_ISSUE_TILE(st.kb, 2, ldsA[1]) W64_ISSUE_TILE(st.vb, 0, ldsA[2]) W64_ISSUE_TILE(st.vb, 1, ldsA[3])
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // K(0) (and, by the compiler's own count, the queries where they are used)
     __syncthreads();
 
 #pragma unroll
@@ -976,7 +1002,9 @@ k_attn_fwd_w64(const FwdArgs a) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) vc[j][i] = TR::from_f32(0.f);
-    __syncthreads();                  // every wave has read K(0) before the next pair's pieces land on its tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the rest of the fill
+    __syncthreads();                  // (and every wave has read K(0) before the next pair's pieces land on its tile)
+    W64_STAMP(1)
 
 #define W64_ITER(LAST_, DMA_, LK, LV, SA0, SA1, SB0, SB1) \
     w64_iter<T, LAST_, PRE, DMA_>(LK, LV, fo, qf, SA0, SA1, SB0, SB1, negmu, o, m2, l_run, c, pb0, pb1, vc, st, chk)
@@ -1007,6 +1035,7 @@ k_attn_fwd_w64(const FwdArgs a) {
         o[b][0] = TR::mfma32(vc[2], as_frag<T>(pb1[b]), o[b][0]);
         o[b][1] = TR::mfma32(vc[3], as_frag<T>(pb1[b]), o[b][1]);
     }
+    W64_STAMP(2)
     if (attempt) break;
     if (__builtin_amdgcn_ballot_w64(!(chk <= W64_SUM_LIMIT)) != 0 && lane == 0) w_abort = 1;
     __syncthreads();
@@ -1038,6 +1067,7 @@ k_attn_fwd_w64(const FwdArgs a) {
             sk_last = last;
         }
         __syncthreads();
+        W64_STAMP(3)
         write_out = sk_last != 0;
         if (write_out) {
 #pragma unroll 1
@@ -1083,27 +1113,44 @@ k_attn_fwd_w64(const FwdArgs a) {
         }
     }
 
+    W64_STAMP(4)
     if (write_out) {
+        // Through LDS, one 32-query block at a time, so that the global stores are whole 128-byte rows: in the accumulator layout a lane
+        // holds 4 columns of one row — written from there, every store instruction is 64 separate 8-byte pieces and the output phase took
+        // 3.2 us of a 70 us launch (tools/w64_phases.py); 8 lanes x 16 bytes per row it takes well under 1 us.  Set A's tiles are free
+        // here (last read one barrier ago; a split workgroup's next segment starts behind the barrier at the end of this one).  Row
+        // pitch 144 B: the 8-byte writes and the 16-byte reads are both bank-conflict free.
+        char* const stg = ldsA[0] + wave * (32 * 144);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int qrow = b ? qrowB : qrowA;
             const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
             const float inv = 1.0f / l_tot;
-            if (qrow < nq_ok) {
-                T* __restrict__ op = (T*)sg.out + ooff + (size_t)qrow * rs;
 #pragma unroll
-                for (int dblk = 0; dblk < 2; ++dblk)
+            for (int dblk = 0; dblk < 2; ++dblk)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        typename TR::vec4 w;
+                for (int g = 0; g < 4; ++g) {
+                    typename TR::vec4 w;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) w[j] = TR::from_f32(o[b][dblk][4 * g + j] * inv);
-                        *(typename TR::vec4*)(op + dblk * 32 + 8 * g + 4 * h) = w;
-                    }
-                if (sg.lse && h == 0) sg.lse[(size_t)bh * Nq + qrow] = m2[b] * 0.6931471805599453f + __logf(l_tot);
+                    for (int j = 0; j < 4; ++j) w[j] = TR::from_f32(o[b][dblk][4 * g + j] * inv);
+                    *(typename TR::vec4*)(stg + (lane & 31) * 144 + (dblk * 32 + 8 * g + 4 * h) * (int)sizeof(T)) = w;
+                }
+            if (sg.lse && h == 0 && qrow < nq_ok) sg.lse[(size_t)bh * Nq + qrow] = m2[b] * 0.6931471805599453f + __logf(l_tot);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own writes, other lanes' rows: in order, no barrier
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (lane >> 3);
+                const int row = tile * 256 + wave * 64 + b * 32 + r;
+                const u32x4 val = *(const u32x4*)(stg + r * 144 + (lane & 7) * 16);
+                if (row < nq_ok) *(u32x4*)((char*)((T*)sg.out + ooff + (size_t)row * rs) + (lane & 7) * 16) = val;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // block A's rows are in registers before block B overwrites them
         }
     }
+    W64_STAMP(5)
+#if GD_MP_DBG & 32
+    ++dbg_seg;
+#endif
     if (SK) {
         lin += Tg;
         if (lin < lin_end) __syncthreads();
@@ -1111,6 +1158,7 @@ k_attn_fwd_w64(const FwdArgs a) {
   } while (SK && lin < lin_end);
 #undef W64_ISSUE_TILE
 #undef W64_PAD
+#undef W64_STAMP
 }
 
 size_t gd_attn_sk_workspace_bytes(int tot_bh, int N, int M) {

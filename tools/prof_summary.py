@@ -5,7 +5,18 @@
 """
 import collections
 import csv
+import re
 import sys
+
+
+def base_name(n):
+    """rocprofv3 prints some rows demangled (`void k_x<...>(Args)`) and some mangled (`_Z3k_xI...`): one key for both."""
+    m = re.match(r"_Z(\d+)", n)
+    if m:
+        k = int(m.group(1))
+        return n[m.end():m.end() + k]
+    m = re.match(r"(?:void\s+)?([A-Za-z_][\w:]*)\s*[<(]", n)
+    return m.group(1) if m else n
 
 
 def main():
@@ -25,30 +36,35 @@ def main():
         region = "whole trace (no markers)"
     t_first, t_last = rows[0][0], max(r[1] for r in rows)
     span = (t_last - t_first) * 1e-6
-    agg = collections.defaultdict(lambda: [0, 0.0, 1e30, 0.0])
-    busy, cur_end = 0.0, t_first
+    agg = collections.defaultdict(lambda: [0, 0.0, 1e30, 0.0])          # per printed name (template variants apart)
+    fam = collections.defaultdict(lambda: [0, 0.0, 1e30, 0.0])          # own kernels per base name (k_x / gd_x), both spellings merged
+    busy, cur_end, prev_name = 0.0, t_first, "(region start)"
     gaps = collections.Counter()
-    by_grid = collections.defaultdict(lambda: [0, 0.0])
-    big = [0, 0.0]                      # 64^2 self-attention launches: >= 320 workgroups AND >= 35 us (77-key cross attention at 64^2 has
-    #                                     the same workgroup count but runs ~8 us, 32^2 self-attention with 40 heads ~29 us)
+    top_gaps = []
+    self64 = collections.defaultdict(lambda: [0, 0.0])                  # 64^2 self-attention launches by (kernel, workgroups)
     for s, e, n, wgs in rows:
-        if "k_attn_fwd" in n:
-            g = by_grid[wgs]
-            g[0] += 1; g[1] += (e - s) * 1e-3
-            # r02: the pipelined kernels serve every self-attention launch; 64^2 launches run >= 28 us (5 heads), 32^2 ones <= 22 us
-            if ("k_attn_fwd_mp" in n and (e - s) >= 26000) or ("k_attn_fwd_mp" not in n and wgs >= 320 and (e - s) >= 35000):
-                big[0] += 1; big[1] += (e - s) * 1e-3
-        a = agg[n]
+        b = base_name(n)
         d = (e - s) * 1e-3
-        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+        # 64^2 self-attention (N = M = 4096): every k_attn_fwd_w64 launch; k_attn_fwd_mp launches of >= 26 us (its 32^2 launches run <= 22 us,
+        # the 77-key cross-attention launches go to k_attn_fwd)
+        if b == "k_attn_fwd_w64" or (b == "k_attn_fwd_mp" and d >= 26.0):
+            g = self64[(b, wgs)]
+            g[0] += 1; g[1] += d
+        for tab, key in ((agg, n), (fam, b)):
+            a = tab[key]
+            a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
         if s > cur_end:
             g = (s - cur_end) * 1e-3
             gaps["<5us" if g < 5 else "5-20us" if g < 20 else "20-100us" if g < 100 else "0.1-1ms" if g < 1000 else ">1ms"] += g
+            if g >= 300:
+                top_gaps.append((g, (cur_end - t_first) * 1e-6, prev_name, b))
             busy += (e - s) * 1e-6
             cur_end = e
+            prev_name = b
         elif e > cur_end:
             busy += (e - cur_end) * 1e-6
             cur_end = e
+            prev_name = b
     tot = sum(a[1] for a in agg.values()) * 1e-3
     items = sorted(agg.items(), key=lambda kv: -kv[1][1])
     with open(out_csv, "w") as fh:
@@ -56,29 +72,34 @@ def main():
         w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "MinUs", "MaxUs", "Percentage"])
         for n, a in items:
             w.writerow([n, a[0], f"{a[1]:.1f}", f"{a[1] / a[0]:.2f}", f"{a[2]:.2f}", f"{a[3]:.2f}", f"{100 * a[1] * 1e-3 / tot:.2f}"])
-    own = [(n, a) for n, a in items if n.startswith("_Z") and ("k_" in n[:8] or "gd_" in n[:10])]
+    own = sorted(((n, a) for n, a in fam.items() if n.startswith("k_") or n.startswith("gd_")), key=lambda kv: -kv[1][1])
     with open(out_md, "w") as fh:
         fh.write(f"# {title}\n\nRegion: {region}.\n\n")
         fh.write(f"* span {span:.1f} ms, GPU busy {busy:.1f} ms ({100 * busy / span:.1f} %), sum of kernel durations {tot:.1f} ms over "
                  f"{len(rows)} launches\n")
         fh.write("* idle time by gap length (us): " + ", ".join(f"{k}: {v * 1e-3:.1f} ms" for k, v in sorted(gaps.items())) + "\n\n")
-        fh.write("| kernel | calls | total ms | avg us | % of kernel time |\n|---|---|---|---|---|\n")
+        fh.write("| kernel (as rocprofv3 prints it: demangled and mangled rows of one kernel are separate lines here, merged in the next table) "
+                 "| calls | total ms | avg us | % of kernel time |\n|---|---|---|---|---|\n")
         for n, a in items[:32]:
             fh.write(f"| `{n[:72]}` | {a[0]} | {a[1] * 1e-3:.1f} | {a[1] / a[0]:.1f} | {100 * a[1] * 1e-3 / tot:.2f} |\n")
-        fh.write("\n## own HIP kernels (libgeodiff_hip.so)\n\n| kernel | calls | total ms | avg us | min us | max us |\n|---|---|---|---|---|---|\n")
+        fh.write("\n## own HIP kernels (libgeodiff_hip.so), all template variants of a kernel together\n\n"
+                 "| kernel | calls | total ms | avg us | min us | max us |\n|---|---|---|---|---|---|\n")
         for n, a in own:
-            fh.write(f"| `{n[:72]}` | {a[0]} | {a[1] * 1e-3:.1f} | {a[1] / a[0]:.1f} | {a[2]:.1f} | {a[3]:.1f} |\n")
+            fh.write(f"| `{n}` | {a[0]} | {a[1] * 1e-3:.1f} | {a[1] / a[0]:.1f} | {a[2]:.1f} | {a[3]:.1f} |\n")
         fh.write(f"\nown kernels total {sum(a[1] for _, a in own) * 1e-3:.1f} ms of {tot:.1f} ms\n")
-        if by_grid:
-            fh.write("\n## k_attn_fwd by launch size (workgroups = 128-query tiles x heads x key splits)\n\n"
-                     "bench.py's `roofline` is computed from the 64^2 SELF-attention launches (N = M = 4096): 32 query tiles x 5-20 heads x 1-4 key "
-                     "splits = 320-640 workgroups.  64^2 CROSS attention (77 keys) has the same workgroup counts but runs ~8 us, so the classes "
-                     "below mix the two (and the 320 class also holds the 40-head 32^2 launches, ~29 us); the launches of those classes that take >= 35 us are the 64^2 self-attention ones:\n\n"
-                     f"* **64^2 self-attention launches: {big[0]}, total {big[1] * 1e-3:.1f} ms, average {big[1] / max(1, big[0]):.1f} us** "
-                     "(bench.py's `avg_launch_us` additionally contains the ~6 us split-KV merge kernel of the inversion-pass launches)\n\n"
-                     "| workgroups | launches | total ms | avg us |\n|---|---|---|---|\n")
-            for wgs, (cnt, us) in sorted(by_grid.items(), key=lambda kv: -kv[1][1])[:16]:
-                fh.write(f"| {wgs} | {cnt} | {us * 1e-3:.1f} | {us / cnt:.1f} |\n")
+        if self64:
+            cnt = sum(v[0] for v in self64.values()); us = sum(v[1] for v in self64.values())
+            fh.write("\n## 64^2 self-attention launches (N = M = 4096: the launches bench.py's `roofline` is computed from)\n\n"
+                     "Every `k_attn_fwd_w64` launch and the `k_attn_fwd_mp` launches of >= 26 us (5-head inversion passes; its 32^2 launches run "
+                     "<= 22 us).  Workgroups: w64 = 256-query units (or their even split), mp = 128-query units x key ranges.\n\n"
+                     f"* **{cnt} launches, total {us * 1e-3:.1f} ms, average {us / max(1, cnt):.1f} us** — compare bench.py's `roofline.avg_launch_us`\n\n"
+                     "| kernel | workgroups | launches | total ms | avg us |\n|---|---|---|---|---|\n")
+            for (b, wgs), (c, u) in sorted(self64.items(), key=lambda kv: -kv[1][1]):
+                fh.write(f"| `{b}` | {wgs} | {c} | {u * 1e-3:.1f} | {u / c:.1f} |\n")
+        if top_gaps:
+            fh.write("\n## idle gaps >= 0.3 ms (host work between launches)\n\n| at ms | gap ms | after kernel | before kernel |\n|---|---|---|---|\n")
+            for g, at, pn, nn in sorted(top_gaps, key=lambda x: x[1])[:80]:
+                fh.write(f"| {at:.1f} | {g * 1e-3:.2f} | `{pn[:48]}` | `{nn[:48]}` |\n")
 
 
 if __name__ == "__main__":

@@ -346,8 +346,13 @@ class _EditLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, ctrl, is_cross, scale, c, q_pre=False):
-        # q_pre: the queries carry scale*log2(e) and ``scale`` is ln 2 (controller forward); only the forward kernel needs telling
-        # (gd_attn_seg_t::q_scaled: it skips the multiply) — every other kernel computes exp(scale * q.k - lse) as it stands
+        # q_pre: the queries carry scale*log2(e) and ``scale`` is ln 2 (controller forward): every kernel computes
+        # exp(scale * q.k - lse) as it stands.  The forward is NOT told (gd_attn_seg_t::q_scaled stays 0, its multiplier becomes
+        # ln2 * log2(e) = 1): the pre-scaled variant of the 64-query kernel takes the first key tile's maximum as the softmax reference
+        # and never moves it, the exact-scale variant rescues onto a row maximum like k_attn_fwd_mp — after which a DOMINANT probability
+        # is exactly 1.0 in 16 bits, as in any online softmax.  The no-grad passes do without that (outputs within the storage
+        # rounding either way); the L1 loss terms between two nearly equal attention outputs measure exactly that rounding (the
+        # `sim` term of an SDXL-shaped bf16 case moved by 1.6 %), so the optimisation pass pays the 9 us per 64^2 launch.
         f = c["f"]
         remover = ctrl._is_remover
         (b0, b1), (e0, e1) = ctrl.coords_base, ctrl.coords_edit
@@ -391,7 +396,7 @@ class _EditLayer(torch.autograd.Function):
                 ident_out = torch.empty(f, N, D, dtype=dt, device=dev)
                 segs.append((q_edit, k_edit, v_edit, ident_out, None))
         segs.append((q_edit, K, v_base, replace_out, lse_e))                # :433,557 / :791,883
-        ops.attn_fwd(segs, scale, q_scaled=q_pre)
+        ops.attn_fwd(segs, scale)
         if (not remover) and edit_act is not None:
             ops.rows_merge(out_full[b0 * f:b1 * f], edit_act, c["edit_pos"], out=edit_out)
         if remover:

@@ -149,8 +149,12 @@ def _make_regrad(case, q, k, v, mask, coords, scale, gout, nn_ties="topk"):
 # bf16 out <= 3.7e-3, loss <= 9.6e-5, dq L2 <= 1.8e-2, dq max <= 1.1e-2.
 # ``tie``: how close (relative) two correlation candidates of the removal loss's arg-max may be for either to count as the maximiser — the
 # precision of the stored probabilities (16 bits: 11 / 8 mantissa bits).
+# ``loss_removal`` (bf16): the removal term is a mean over rows of MAXIMA of correlations of two stored 16-bit probability maps; a maximum
+# picks up the maps' rounding one-sidedly, so its error depends on the instance: 1.3e-4 on edit_cross_opt_32 with unscaled queries,
+# 1.2e-3 on the same case with pre-scaled ones (other roundings of q, identical kernels: tools/dbg_pre2.py shows equal lse / map errors
+# for both scale conventions) — bounded by 2^-9 (one bf16 rounding step, relative).
 TOLS = {torch.float16: dict(out=1e-3, loss=5e-4, gl2=8e-3, gmax=2.5e-2, tie=2e-3),
-        torch.bfloat16: dict(out=8e-3, loss=1e-3, gl2=4e-2, gmax=5e-2, tie=1.6e-2)}
+        torch.bfloat16: dict(out=8e-3, loss=1e-3, gl2=4e-2, gmax=5e-2, tie=1.6e-2, loss_removal=2e-3)}
 TOLS_GOLDEN = dict(out=1e-3, loss=5e-3, gl2=1.5e-2, gmax=0.1)      # fixtures: fp32 inputs on the reference side, fp16-rounded here
 
 
@@ -176,7 +180,7 @@ def _check_losses_and_grads(case, ch, co, res, loss_ref, log_ref, dq_ref, dk_ref
         assert abs(res["loss"] - loss_expected) <= TOL_GRAD * max(1.0, abs(loss_expected))
         for key, val in ch.loss_log_dict[kind].items():
             ref = rm_expected if key == "removal" else float(log_ref[key]) * fac_d
-            assert abs(float(val) - ref) <= TOL_GRAD * max(abs(ref), 0.05), key
+            assert abs(float(val) - ref) <= tols.get("loss_" + key, TOL_GRAD) * max(abs(ref), 0.05), key
     lim_l2, lim_max = tols["gl2"], tols["gmax"]
     if not same:                  # a different (equally maximal) arg-max moves its rows' gradient: compare at the device's indices
         assert regrad is not None, "arg-max differs from the fixture's and no oracle re-evaluation was supplied"
@@ -224,17 +228,29 @@ ORACLE_CASES = {
 }
 
 
-def _oracle_case(case, dtype):
+def _oracle_case(case, dtype, prescaled=False):
+    """``prescaled``: the device gets q' = 16-bit(scale*log2(e) * q) with ``q_scaled_hm`` set, as EditProcessor hands the optimisation
+    pass's queries over (attention_processors._project_qkv); the oracle gets the SAME numbers un-scaled in fp32 (q' / c) and its usual
+    scale, so the comparison measures the kernels, not the extra rounding; d/dq = c * d/dq'."""
     q, k, v, mask, coords = case_inputs(case)
     q, k, v = (t.to(dtype).float() for t in (q, k, v))
     tols = TOLS[dtype]
     f, D = case["f"], case["D"]
     scale = D ** -0.5
+    cfac = scale * 1.4426950408889634
+    q_dev = q
+    if prescaled:
+        q_dev = (q * cfac).to(dtype).float()
+        q = q_dev / cfac
     co, qo, ko, out_ref = _oracle_run(case, q, k, v, mask, coords, scale, None, nn_ties="index")
     gout = case_gout(case, out_ref.shape)
     ch = _make_hip_controller(case, mask)
     _prebuild_tables(ch, case, q, coords, dtype, inject_topk=False)
-    res = _run_hip(ch, case, q, k, v, coords, scale, gout, dtype)
+    if prescaled:
+        ch.q_scaled_hm = True
+    res = _run_hip(ch, case, q_dev, k, v, coords, scale, gout, dtype)
+    if prescaled and "dq" in res:
+        res["dq"] = res["dq"] * cfac
     assert res["out"].shape == out_ref.shape
     assert rel_err(res["out"], out_ref.detach()) < tols["out"]
     assert (ch.cur_att_layer, ch.cur_step) == (co.cur_att_layer, co.cur_step)
@@ -258,6 +274,15 @@ def test_controller_vs_oracle_d64(name, dtype):
     Both sides start from the SAME 16-bit-representable q/k/v (rounded through ``dtype`` once), so the comparison measures the
     kernels' arithmetic and their 16-bit intermediates, not the input rounding."""
     _oracle_case(ORACLE_CASES[name], dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("name", [n for n, c in ORACLE_CASES.items() if not c["cfg"]] + ["edit_self_opt_32_f20", "edit_cross_opt_64_f10"])
+def test_controller_prescaled_queries_vs_oracle(name, dtype):
+    """The optimisation pass as the driver runs it since round 3: queries that carry scale*log2(e) from the projection GEMM, ln 2 as the
+    scale of every kernel that recomputes probabilities (forward's pre-scaled variant, gd_attn_probs, backward, removal backward).
+    Outputs, loss terms and gradients against the oracle at the same bounds as the unscaled path."""
+    _oracle_case(ORACLE_CASES.get(name) or SDXL_CASES[name], dtype, prescaled=True)
 
 
 # The SD1.x head dims (BASELINE configs[2]: CompVis/stable-diffusion-v1-4, 8 heads over 320 / 640 / 1280 channels): the controller

@@ -385,6 +385,10 @@ static void mp_config(long long blocks, int N, int M, int* qb, int* ks, int q_pr
     // scale (optimisation pass; in-loop rescue like k_attn_fwd_mp's, so a dominant probability is exactly 1.0 after a rescue — the
     // property the optimisation pass's parity tolerances were calibrated on).
     if (T % 4 == 0 && blocks >= 1280 && M >= 1024) { *qb = 8; *ks = 1; return; }
+    // 64-128 units against 48+ key tiles (the 5-head inversion launch at 64^2: 80 units): the same kernel with every unit cut into
+    // 2-4 runs of key tiles, one per workgroup (needs the even split's workspace: without it the launcher falls back to 4 x 2 below):
+    // 30.3 us against 34.5 us for two key ranges inside 160 workgroups (tools/bench_sk.py)
+    if (T % 4 == 0 && T >= 48 && blocks >= 512 && blocks <= 1024) { *qb = 8; *ks = 1; return; }
     if (blocks < 1280 && T % 4 == 0) { *qb = 4; *ks = 2; return; }
     *qb = 4; *ks = 1;
 }

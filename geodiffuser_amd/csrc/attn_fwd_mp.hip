@@ -815,15 +815,25 @@ k_attn_fwd_w64(const FwdArgs a) {
 #else
 #define W64_STAMP(E) {}
 #endif
-    int lin = SK ? wg * a.sk_tpw : 0;
-    const int lin_end = SK ? (lin + a.sk_tpw < a.sk_total ? lin + a.sk_tpw : a.sk_total) : 0;
+    // SK, two ways of dealing the key tiles out: one linear range (a workgroup walks one or more segments, see k_attn_fwd_mp), or — few
+    // units — every unit in P = sk_parts equal runs, one per workgroup (workgroup = unit * P + part: one segment, one prologue)
+    const int P = SK ? a.sk_parts : 0;
+    int lin = SK ? (P ? 0 : wg * a.sk_tpw) : 0;
+    const int lin_end = SK ? (P ? 1 : (lin + a.sk_tpw < a.sk_total ? lin + a.sk_tpw : a.sk_total)) : 0;
     const int lin_first = lin;
     const FragOffs fo = make_frag_offs(lane);
 #pragma unroll 1
   do {
     W64_STAMP(0)
     int unit = wg, t_first = 0, Tg = TU;
-    if (SK) {
+    if (SK && P) {
+        // parts 1 .. P-1 hold sk_tpw tiles each, part 0 the rest (>= sk_tpw): the holder of the unit's FIRST part finishes last, finds
+        // the other parts in place and merges without storing its own (see the hand-off below)
+        unit = wg / P;
+        const int part = wg - unit * P, first_len = TU - (P - 1) * a.sk_tpw;
+        t_first = part ? first_len + (part - 1) * a.sk_tpw : 0;
+        Tg = part ? a.sk_tpw : first_len;
+    } else if (SK) {
         unit = lin / TU;
         t_first = lin - unit * TU;
         Tg = TU - t_first < lin_end - lin ? TU - t_first : lin_end - lin;
@@ -1045,38 +1055,58 @@ k_attn_fwd_w64(const FwdArgs a) {
 
     bool write_out = true;
     if (SK && Tg != TU) {
-        // part of a unit: see k_attn_fwd_mp (same hand-off; a slot holds 4 waves x 2 query blocks x 9 chunks)
-        const int w_first = (unit * TU) / a.sk_tpw, w_last = ((unit + 1) * TU - 1) / a.sk_tpw;
-        f32x4* const slot = a.sk_ws + (size_t)(2 * wg + (lin != lin_first ? 1 : 0)) * (2 * GD_SK_SLOT_F4) + (size_t)wave * 18 * 64 + lane;
+        // Part of a unit (slots, counters, write-through stores as in k_attn_fwd_mp; a slot holds 4 waves x 2 query blocks x 9 chunks).
+        // Two things differ from that kernel's hand-off (tools/w64_phases.py: store + ticket 3.3 us, merge 3.5-5.5 us per unit):
+        //  * the workgroup that holds a unit's FIRST part first LOOKS at the unit's counter: if every other part is already there it
+        //    is the merger and never stores its own part — its O tiles are the start of the accumulation anyway (with the linear range
+        //    the workgroup that finishes a unit last holds its head, and that one is on the launch's critical path).  Any other
+        //    merger reads all parts back, its own included: the fold runs in part order whoever merges, so the result does not depend
+        //    on the arrival order;
+        //  * both query blocks of a part are fetched in one round trip.
+        const int w_first = P ? unit * P : (unit * TU) / a.sk_tpw, w_last = P ? unit * P + P - 1 : ((unit + 1) * TU - 1) / a.sk_tpw;
+        const int others = w_last - w_first;
+#define W64_SLOT(W2) (a.sk_ws + (size_t)(2 * (W2) + ((!P && (W2) * a.sk_tpw < unit * TU) ? 1 : 0)) * (2 * GD_SK_SLOT_F4) + (size_t)wave * 18 * 64 + lane)
+        bool merger = false, published = false;
+        if (wg == w_first) {
+            if (tid == 0) sk_last = a.sk_mode != 2 && __hip_atomic_fetch_add(a.sk_cnt + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == others;
+            __syncthreads();
+            merger = sk_last != 0;
+            __syncthreads();                                   // everyone has read the flag before the ticket below rewrites it
+        }
+        if (!merger) {
+            f32x4* const slot = W64_SLOT(wg);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < 2; ++b) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const f32x4 v = {o[b][j >> 2][4 * (j & 3)], o[b][j >> 2][4 * (j & 3) + 1], o[b][j >> 2][4 * (j & 3) + 2], o[b][j >> 2][4 * (j & 3) + 3]};
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(slot + (b * 9 + j) * 64), "v"(v) : "memory");
+                for (int j = 0; j < 8; ++j) {
+                    const f32x4 v = {o[b][j >> 2][4 * (j & 3)], o[b][j >> 2][4 * (j & 3) + 1], o[b][j >> 2][4 * (j & 3) + 2], o[b][j >> 2][4 * (j & 3) + 3]};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(slot + (b * 9 + j) * 64), "v"(v) : "memory");
+                }
+                const f32x4 v = {m2[b], l_run[b], 0.f, 0.f};
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(slot + (b * 9 + 8) * 64), "v"(v) : "memory");
             }
-            const f32x4 v = {m2[b], l_run[b], 0.f, 0.f};
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(slot + (b * 9 + 8) * 64), "v"(v) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const int ticket = a.sk_mode == 2 ? -1 : __hip_atomic_fetch_add(a.sk_cnt + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sk_last = ticket == others;
+            }
+            __syncthreads();
+            merger = sk_last != 0;
+            published = true;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            const int ticket = __hip_atomic_fetch_add(a.sk_cnt + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = ticket == w_last - w_first;
-            if (last) __hip_atomic_store(a.sk_cnt + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sk_last = last;
-        }
-        __syncthreads();
         W64_STAMP(3)
-        write_out = sk_last != 0;
-        if (write_out) {
+        write_out = merger;
+        if (merger) {
+            if (tid == 0) __hip_atomic_store(a.sk_cnt + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero for the next launch
 #pragma unroll 1
-            for (int w2 = w_first; w2 <= w_last; ++w2) {
-                const f32x4* const sl0 = a.sk_ws + (size_t)(2 * w2 + (w2 * a.sk_tpw < unit * TU ? 1 : 0)) * (2 * GD_SK_SLOT_F4) + (size_t)wave * 18 * 64 + lane;
+            for (int w2 = published ? w_first : w_first + 1; w2 <= w_last; ++w2) {
+                const f32x4* const sl = W64_SLOT(w2);
+                f32x4 pv[2][9];
+                // device-scope loads of both query blocks, then one wait; the registers they write are operands of the wait (nothing
+                // that reads them may be scheduled in front of it)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const f32x4* const sl = sl0 + b * 9 * 64;
-                    f32x4 pv[9];
+                for (int b = 0; b < 2; ++b)
                     asm volatile("global_load_dwordx4 %0, %9, off sc0 sc1\n\t"
                                  "global_load_dwordx4 %1, %9, off offset:1024 sc0 sc1\n\t"
                                  "global_load_dwordx4 %2, %9, off offset:2048 sc0 sc1\n\t"
@@ -1085,32 +1115,40 @@ k_attn_fwd_w64(const FwdArgs a) {
                                  "global_load_dwordx4 %5, %10, off offset:1024 sc0 sc1\n\t"
                                  "global_load_dwordx4 %6, %10, off offset:2048 sc0 sc1\n\t"
                                  "global_load_dwordx4 %7, %10, off offset:3072 sc0 sc1\n\t"
-                                 "global_load_dwordx4 %8, %11, off sc0 sc1\n\t"
-                                 "s_waitcnt vmcnt(0)"
-                                 : "=&v"(pv[0]), "=&v"(pv[1]), "=&v"(pv[2]), "=&v"(pv[3]), "=&v"(pv[4]), "=&v"(pv[5]), "=&v"(pv[6]),
-                                   "=&v"(pv[7]), "=&v"(pv[8])
-                                 : "v"(sl), "v"(sl + 4 * 64), "v"(sl + 8 * 64)
+                                 "global_load_dwordx4 %8, %11, off sc0 sc1"
+                                 : "=&v"(pv[b][0]), "=&v"(pv[b][1]), "=&v"(pv[b][2]), "=&v"(pv[b][3]), "=&v"(pv[b][4]), "=&v"(pv[b][5]),
+                                   "=&v"(pv[b][6]), "=&v"(pv[b][7]), "=&v"(pv[b][8])
+                                 : "v"(sl + b * 9 * 64), "v"(sl + b * 9 * 64 + 4 * 64), "v"(sl + b * 9 * 64 + 8 * 64)
                                  : "memory");
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(pv[0][0]), "+v"(pv[0][1]), "+v"(pv[0][2]), "+v"(pv[0][3]), "+v"(pv[0][4]), "+v"(pv[0][5]), "+v"(pv[0][6]),
+                               "+v"(pv[0][7]), "+v"(pv[0][8]), "+v"(pv[1][0]), "+v"(pv[1][1]), "+v"(pv[1][2]), "+v"(pv[1][3]), "+v"(pv[1][4]),
+                               "+v"(pv[1][5]), "+v"(pv[1][6]), "+v"(pv[1][7]), "+v"(pv[1][8])
+                             :
+                             : "memory");
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
                     if (w2 == w_first) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) o[b][j >> 2][4 * (j & 3) + i] = pv[j][i];
-                        m2[b] = pv[8][0]; l_run[b] = pv[8][1];
+                            for (int i = 0; i < 4; ++i) o[b][j >> 2][4 * (j & 3) + i] = pv[b][j][i];
+                        m2[b] = pv[b][8][0]; l_run[b] = pv[b][8][1];
                     } else {
-                        const float mk = pv[8][0], mn = fmaxf(m2[b], mk);
+                        const float mk = pv[b][8][0], mn = fmaxf(m2[b], mk);
                         const float a0 = __builtin_amdgcn_exp2f(m2[b] - mn), a1 = __builtin_amdgcn_exp2f(mk - mn);
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                o[b][j >> 2][4 * (j & 3) + i] = __builtin_fmaf(o[b][j >> 2][4 * (j & 3) + i], a0, pv[j][i] * a1);
-                        l_run[b] = __builtin_fmaf(l_run[b], a0, pv[8][1] * a1);
+                                o[b][j >> 2][4 * (j & 3) + i] = __builtin_fmaf(o[b][j >> 2][4 * (j & 3) + i], a0, pv[b][j][i] * a1);
+                        l_run[b] = __builtin_fmaf(l_run[b], a0, pv[b][8][1] * a1);
                         m2[b] = mn;
                     }
                 }
             }
         }
+#undef W64_SLOT
     }
 
     W64_STAMP(4)
@@ -1152,7 +1190,7 @@ k_attn_fwd_w64(const FwdArgs a) {
     ++dbg_seg;
 #endif
     if (SK) {
-        lin += Tg;
+        lin = P ? lin_end : lin + Tg;
         if (lin < lin_end) __syncthreads();
     }
   } while (SK && lin < lin_end);
@@ -1206,7 +1244,22 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
     // = 240 units, 64 vs 60 + 24 (59.1 unsplit, 70.0 split); 30 heads, 128 vs 120 + 24 (117.1 / 126.2); the optimisation pass's 165
     // units (two dense segments + the edit rows), 64 vs 42 + 24 (70.0 unsplit, 73.4 split: tools/bench_opt15.py).
     const long long tiles_unsplit = (long long)((a.nwg + 255) / 256) * TU, tiles_split = ((long long)a.nwg * TU + 255) / 256 + 24;
-    if (a.sk_ws && TU >= 16 && (sk_force || tiles_split < tiles_unsplit)) {
+    // Few units (at most half the CUs: the 5-head inversion launch = 80 units): every unit in P equal runs, one per workgroup — one
+    // prologue per workgroup and at most P - 1 parts to fetch for the merger (tools/w64_phases.py: with the linear range a quarter of the
+    // workgroups walk two segments and a unit has up to five parts)
+    if (a.sk_ws && a.sk_mode >= 1 && a.nwg <= 128 && TU >= 48) {
+        int P = 256 / a.nwg;
+        if (P > 4) P = 4;
+        const int tpp = (TU / P) & ~3;                 // parts 1 .. P-1; part 0 takes the rest (64 tiles in 3 parts: 24 + 20 + 20)
+        if (P >= 2 && tpp >= 16) {
+            a.sk_parts = P;
+            a.sk_tpw = tpp;
+            a.sk_total = a.nwg * TU;
+            a.nwg *= P;
+            sk = true;
+        }
+    }
+    if (!sk && a.sk_ws && TU >= 16 && (sk_force || tiles_split < tiles_unsplit)) {
         const long long total = (long long)a.nwg * TU;
         int tpw = (int)((total + 255) / 256);
         tpw = (tpw + 3) & ~3;
@@ -1231,9 +1284,17 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
 }
 
 int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st) {
-    if (qb == 8 && dtype != GD_BF16) { qb = 4; ks = 1; }     // the 64-query kernel is bf16 only (see k_attn_fwd_w64)
     int tot = 0;
     for (int i = 0; i < a.nseg; ++i) tot = a.bh_end[i];
+    {
+        // the 64-query kernel is bf16 only (see k_attn_fwd_w64), and below 160 units it needs the even split's workspace (unit parts)
+        const long long blocks = (long long)((a.N + 31) / 32) * tot;
+        const int T = a.M / ATT_BN;
+        if (qb == 8 && (dtype != GD_BF16 || (blocks < 1280 && !(a.sk_ws && a.sk_mode >= 1)))) {
+            qb = 4;
+            ks = (blocks < 1280 && T % 4 == 0) ? 2 : 1;
+        }
+    }
     a.nwg = set_units(a, tot, 32 * qb);
     // Head order of the grid.  The 1-D grid is cut into 8 contiguous chunks, one per XCD (xcd_remap), and an XCD runs its chunk in
     // ascending order.  Segment after segment, the heads whose workgroups build warped queries in their prologue (~8 us of dependent

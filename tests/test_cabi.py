@@ -101,3 +101,25 @@ def test_w64_main_loop_has_no_register_file_copies(tmp_path):
         assert found, text[st]
     for m in re.finditer(r"\.amdhsa_kernel (_Z14k_attn_fwd_w64\w+).*?; ScratchSize: (\d+)", "\n".join(text), re.S):
         assert int(m.group(2)) == 0, (m.group(1), m.group(2))
+    # Outside the loop too (prologue, peeled last iterations): no asm-form MFMA (D in v[...]) may read a fragment register that a
+    # v_accvgpr_write filled fewer than 4 wait states earlier — the compiler pads its own MFMAs, not the ones inside asm.  (A build whose
+    # epilogue needed more registers moved the query fragments to v[...] in the peeled iterations and copied them back right in front of
+    # each use: wrong, irreproducible outputs on the device.)
+    for st in starts:
+        end = next(i for i in range(st, len(text)) if text[i].startswith(".Lfunc_end"))
+        ins = [y for y in (x.strip() for x in text[st:end]) if y and y[0] not in ";." and not y.endswith(":")]
+        n_asm = 0
+        for k, ln in enumerate(ins):
+            if not re.match(r"v_mfma\S+ v\[", ln):
+                continue
+            n_asm += 1
+            srcs = [(int(a), int(b)) for a, b in re.findall(r"a\[(\d+):(\d+)\]", ln)]
+            ws = 0
+            for prev in reversed(ins[max(0, k - 12):k]):
+                m = re.match(r"v_accvgpr_write_b32 a(\d+)", prev)
+                if m and any(lo <= int(m.group(1)) <= hi for lo, hi in srcs):
+                    assert ws >= 4, (text[st], ln, prev, ws)
+                    break
+                m = re.match(r"s_nop (\d+)", prev)
+                ws += int(m.group(1)) + 1 if m else 1
+        assert n_asm >= 128, (text[st], n_asm)

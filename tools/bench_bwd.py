@@ -1,6 +1,7 @@
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-from geodiffuser_amd import ops
+from geodiffuser_amd import ops, _lib
+_lib.load(os.environ.get("GD_LIB", _lib.LIB_PATH))      # GD_LIB: an A/B build of the library
 dev = "cuda"; dt = torch.bfloat16
 def bench(fn, n=20):
     for _ in range(3): fn()

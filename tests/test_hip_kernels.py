@@ -252,7 +252,7 @@ def test_attention_forward_pipelined_configs(ops, dtype, BH, N, M):
 
 
 @pytest.mark.parametrize("cfg", [(4, 1), (8, 1)])
-@pytest.mark.parametrize("BH,N,M", [(5, 4096, 4096), (20, 4096, 4096), (13, 2304, 2304), (7, 1000, 4096)])
+@pytest.mark.parametrize("BH,N,M", [(5, 4096, 4096), (20, 4096, 4096), (13, 2304, 2304), (7, 1000, 4096), (6, 4096, 4096), (2, 9216, 9216)])
 def test_attention_forward_even_split(ops, cfg, BH, N, M):
     """gd_attn_fwd_ws: the launch's key tiles dealt out evenly over the workgroups, units that end up in several workgroups merged by the
     last to arrive (attn_fwd_mp.hip SK).  Against the fp32 formulation (with rows that force the reference-value fallback: scores
@@ -286,6 +286,44 @@ def test_attention_forward_even_split(ops, cfg, BH, N, M):
         assert rel_err(o[:, rows].float().cpu(), ro) < tol(dtype)
         assert float((l[:, rows].cpu().double() - rl).abs().max()) < 2e-4 * max(1.0, float(rl.abs().max()))
     assert rel_err(o1.float().cpu(), o0.float().cpu()) < 2 * tol(dtype)    # every row, against the unsplit launch (two roundings apart)
+
+
+def test_attention_unit_parts_with_segments_warp_and_row_list(ops):
+    """The 64-query kernel's unit parts (launches of at most 128 units: every unit cut into 2-4 runs of key tiles, one per workgroup; the
+    holder of a unit's first part merges without storing its own) under the launch forms of an edit: token-major segments, LSE outputs,
+    a fused query warp with a query row list (its own, shorter unit count) — against the unsplit launch, twice (reproducible)."""
+    from geodiffuser_amd import _lib
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(9)
+    B, N, heads, K = 2, 4096, 3, 15
+    C = 64 * heads
+    q = (torch.randn(B, N, C, device=DEV, generator=g) * 0.25).to(dtype)            # pre-scaled queries: scores ~ N(0, 2) in log2 units
+    k = torch.randn(B, N, C, device=DEV, generator=g).to(dtype); v = torch.randn(B, N, C, device=DEV, generator=g).to(dtype)
+    idx = torch.randint(-1, N, (N, K), device=DEV, dtype=torch.int32); w = torch.rand(N, K, device=DEV) * 0.3
+    m = torch.zeros(N, device=DEV); m[torch.randperm(N, device=DEV, generator=g)[:300]] = 1.0
+    rows = torch.nonzero(m > 0).flatten().int()
+    nv = torch.tensor([rows.numel()], dtype=torch.int32, device=DEV)
+    rows = torch.cat([rows, torch.zeros(512 - rows.numel(), dtype=torch.int32, device=DEV)]).contiguous()
+    try:
+        lib.gd_attn_fwd_set_config(8, 1)
+        outs = []
+        for split in (0, 1, 1):                        # 0: no workspace -> unsplit units; 1: the default (parts: 48 + 48 + 6 units <= 128)
+            lib.gd_attn_fwd_set_even_split(split)
+            o = [torch.zeros_like(q[:1]) for _ in range(2)]; act = torch.zeros(1, 512, C, device=DEV, dtype=dtype)
+            ls = [torch.zeros(heads, N, device=DEV) for _ in range(2)]
+            ops.attn_fwd([(q[0:1], k[0:1], v[0:1], o[0], ls[0]), (q[1:2], k[0:1], v[0:1], o[1], ls[1]),
+                          (q[0:1], k[0:1], v[0:1], act, None, (idx, w, m), (rows, nv))], 0.125, heads=heads, q_scaled=True)
+            torch.cuda.synchronize()
+            outs.append((o[0], o[1], act[:, :int(nv)], ls[0], ls[1]))
+    finally:
+        lib.gd_attn_fwd_set_config(-1, 0); lib.gd_attn_fwd_set_even_split(1)
+    for a, b in zip(outs[1], outs[2]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert float((a.float() - b.float()).abs().max()) < 1e-2 and float(b.float().abs().max()) > 0.1
+    for a, b in zip(outs[0][3:], outs[1][3:]):
+        assert float((a - b).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("cfg", [(4, 1), (8, 1)])

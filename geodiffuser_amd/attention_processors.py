@@ -168,11 +168,16 @@ def _batched_qkv(attn, hidden_states, encoder_hidden_states):
     if w2.shape[1] != e2.shape[1]:
         return None
     q = torch.mm(x2, wq[0]).view(*hidden_states.shape[:-1], wq.shape[2])
-    kv = torch.bmm(e2.unsqueeze(0).expand(2, -1, -1), w2)
+    # K / V of the text rows: the same for every pass over one context.  A captured pass (graphs.GraphedUNet) reads them from
+    # persistent buffers that the runner re-fills only when the context changes (16 small GEMMs less per pass)
+    kv = KV_PROVIDER.get(id(attn)) if KV_PROVIDER is not None else None
+    if kv is None or kv.shape[1] != e2.shape[0] or kv.dtype != e2.dtype:
+        kv = torch.bmm(e2.unsqueeze(0).expand(2, -1, -1), w2)
     shp = (*encoder_hidden_states.shape[:-1], w2.shape[2])
     return q, kv[0].view(shp), kv[1].view(shp), True, None, (), True
 
 
+KV_PROVIDER = None           # {id(cross-attention module): [2, B*77, C] k / v of the current context}, set by graphs.GraphedUNet around a capture
 TOKEN_MAJOR = os.environ.get("GD_TOKEN_MAJOR", "1") == "1"
 BATCHED_QKV = os.environ.get("GD_BATCHED_QKV", "1") == "1"   # no-grad passes: q / k / v projections of one input as one batched GEMM
 SCALED_Q = os.environ.get("GD_SCALED_Q", "1") == "1"      # token-major passes: scale*log2(e) folded into the query projection

@@ -15,7 +15,7 @@ from .pipeline import build_random_sd21
 from .scheduler import DDIMScheduler
 
 
-def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None):
+def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None, ctx_src=None):
     """UNet call of a no-grad pass, through a captured hipGraph when the controller's launch sequence is static.
 
     A replay runs no Python, and the captured kernels read the controller's per-resolution tables (masks, splat idx / w, inpaint
@@ -52,7 +52,7 @@ def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None):
     runner = model.__dict__.get("_graphed")
     if runner is None:
         runner = model.__dict__["_graphed"] = graphs.GraphedUNet(model.unet)
-    out, replayed = runner((tag,) + key_fn() + (controller.table_signature(),), x, t, ctx)
+    out, replayed = runner((tag,) + key_fn() + (controller.table_signature(),), x, t, ctx, ctx_src=ctx_src)
     if replayed:
         controller.after_graph_replay()
     return out
@@ -78,13 +78,13 @@ def diffusion_step(model, controller, latents, context, t, guidance_scale, low_r
         # is not (vanilla attention, per-sample norms => no influence on other rows).  Batch [uncond_edit, cond_ref, cond_edit].
         latents_input = torch.cat([latents[1:2], latents[0:1], latents[1:2]])
         ctx3 = torch.cat([context[1:2], context[2:3], context[3:4]])
-        noise_pred = _unet_nograd(model, controller, latents_input, t, ctx3, "cfg3", transform_coords)
+        noise_pred = _unet_nograd(model, controller, latents_input, t, ctx3, "cfg3", transform_coords, ctx_src=context)
         edit_out = _sched_step(model.scheduler, noise_pred[0:1], t, latents[1:2], noise_pred[2:3], guidance_scale)
         latents_out = torch.cat([latents[0:1].to(edit_out.dtype), edit_out])
         noise_pred_out = None
     elif use_cfg:
         latents_input = torch.cat([latents] * 2)
-        noise_pred = _unet_nograd(model, controller, latents_input, t, context, "cfg4", transform_coords)
+        noise_pred = _unet_nograd(model, controller, latents_input, t, context, "cfg4", transform_coords, ctx_src=context)
         noise_pred_uncond, noise_prediction_text = noise_pred.chunk(2)
         if return_noise:
             noise_pred_out = noise_pred_uncond + guidance_scale * (noise_prediction_text - noise_pred_uncond)

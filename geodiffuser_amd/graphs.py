@@ -22,14 +22,18 @@ from . import ops
 
 ENABLED = os.environ.get("GD_GRAPHS", "1") == "1"
 OPT_PASS_ENABLED = os.environ.get("GD_OPT_GRAPH", "1") == "1"
+KV_CACHE = os.environ.get("GD_KV_CACHE", "1") == "1"     # captured no-grad passes: text-row K / V projections outside the graph, per context
 
 
 class _Entry:
-    __slots__ = ("seen", "graph", "x", "t", "ctx", "out")
+    __slots__ = ("seen", "graph", "x", "t", "ctx", "out", "kv", "kv_src", "kv_ver")
 
     def __init__(self):
         self.seen = 0
         self.graph = None
+        self.kv = None
+        self.kv_src = None
+        self.kv_ver = -1
 
 
 class GraphedUNet:
@@ -41,11 +45,45 @@ class GraphedUNet:
         self.replays = 0
 
     def reset(self):
+        """Drop every captured pass — explicitly and with the device idle: a graph left to the garbage collector may be destroyed in the
+        middle of another stream capture, which aborts the process."""
+        torch.cuda.synchronize()
+        for e in self.entries.values():
+            if e.graph is not None:
+                e.graph.reset()
         self.entries.clear()
+        torch.cuda.synchronize()
+
+    def _cross_modules(self):
+        mods = self.__dict__.get("_cross")
+        if mods is None:
+            mods = self.__dict__["_cross"] = [m for m in self.unet.modules() if getattr(m, "is_cross_attention", False) and hasattr(m, "to_k")]
+        return mods
+
+    def _refresh_kv(self, e):
+        """K / V of the context rows for every cross-attention layer, into the entry's persistent buffers (allocated on the first call,
+        OUTSIDE any capture).  The text rows enter the UNet only through these projections (unet_sd21: ``ctx`` feeds ``attn2`` alone), and
+        one context serves 50 inversion passes / the CFG passes after the optimisation window: 16 batched GEMMs per pass that a replay
+        does not have to repeat.  Same arithmetic as attention_processors._batched_qkv (one batched GEMM per layer, stacked weights)."""
+        from .attention_processors import _stacked_weights
+        ctxd = e.ctx.to(self.unet.dtype)
+        e2 = ctxd.reshape(-1, ctxd.shape[-1])
+        for m in self._cross_modules():
+            w2 = _stacked_weights(m, ("to_k", "to_v"), 1.0)
+            if w2 is None or w2.shape[1] != e2.shape[1]:
+                continue
+            buf = e.kv.get(id(m))
+            if buf is None:
+                e.kv[id(m)] = torch.bmm(e2.unsqueeze(0).expand(2, -1, -1), w2)
+            else:
+                torch.bmm(e2.unsqueeze(0).expand(2, -1, -1), w2, out=buf)
 
     @torch.no_grad()
-    def __call__(self, key: Hashable, x: torch.Tensor, t, ctx: torch.Tensor) -> Tuple[torch.Tensor, bool]:
-        """-> (noise_pred, replayed).  ``replayed`` tells the caller that no Python side effect ran."""
+    def __call__(self, key: Hashable, x: torch.Tensor, t, ctx: torch.Tensor, ctx_src: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, bool]:
+        """-> (noise_pred, replayed).  ``replayed`` tells the caller that no Python side effect ran.
+        ``ctx_src``: the tensor ``ctx`` is a pure function of (the caller's context tensor itself, or the one it was sliced / concatenated
+        from).  While the SAME tensor object at the SAME ``_version`` comes back, the cached K / V of the text rows stay valid; a strong
+        reference is held, so another tensor cannot take its identity.  None: re-compute on every call."""
         if not ENABLED or torch.is_grad_enabled():
             return self.unet(x, t, encoder_hidden_states=ctx)["sample"], False
         key = (key, tuple(x.shape), x.dtype, tuple(ctx.shape), ctx.dtype)
@@ -60,17 +98,29 @@ class GraphedUNet:
             e.x = x.clone()
             e.ctx = ctx.clone()
             e.t = torch.tensor([tval], device=x.device, dtype=torch.long)
+            if KV_CACHE:
+                e.kv = {}
+                self._refresh_kv(e)
+                e.kv_src, e.kv_ver = ctx_src, (ctx_src._version if ctx_src is not None else -1)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             ops.zero_pool_reset()
-            with torch.cuda.graph(g):
-                e.out = self.unet(e.x, e.t, encoder_hidden_states=e.ctx)["sample"]
+            from . import attention_processors as _ap
+            _ap.KV_PROVIDER = e.kv
+            try:
+                with torch.cuda.graph(g):
+                    e.out = self.unet(e.x, e.t, encoder_hidden_states=e.ctx)["sample"]
+            finally:
+                _ap.KV_PROVIDER = None
             ops.zero_pool_reset()
             e.graph = g
             e.graph.replay()
             return e.out, False                                # Python side effects DID run (during capture)
         e.x.copy_(x)
         e.ctx.copy_(ctx)
+        if e.kv and (ctx_src is None or ctx_src is not e.kv_src or ctx_src._version != e.kv_ver):
+            self._refresh_kv(e)
+            e.kv_src, e.kv_ver = ctx_src, (ctx_src._version if ctx_src is not None else -1)
         e.t.fill_(tval)
         e.graph.replay()
         self.replays += 1

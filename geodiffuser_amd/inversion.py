@@ -83,7 +83,7 @@ class NullInversion:
                 runner = self.model.__dict__.get("_graphed")
                 if runner is None:
                     runner = self.model.__dict__["_graphed"] = graphs.GraphedUNet(self.model.unet)
-                noise_pred, _ = runner(("inversion",), latent_model_input, t, context_in)
+                noise_pred, _ = runner(("inversion",), latent_model_input, t, context_in, ctx_src=context_in)
             else:
                 noise_pred = self.model.unet(latent_model_input, t, encoder_hidden_states=context_in, return_dict=False)[0]
             if single:

@@ -572,8 +572,14 @@ k_attn_fwd_mp(const FwdArgs a) {
 //     gaps  9-16   S'_A, S'_B(t+1)[keys  0..31] = K(t+1) Q'^T | exp2 of S'_B(t)[keys  0..31]   | read V(t)[keys  0..31] (transposed)
 //     gaps 17-24   O_A, O_B += V(t)[keys  0..31] P(t)         | exp2 of S'_A(t)[keys 32..63]   | read K(t+1)[rows 32..63]
 //     gaps 25-32   S'_A, S'_B(t+1)[keys 32..63]               | exp2 of S'_B(t)[keys 32..63]   | read V(t)[keys 32..63]
-// one direct-to-LDS piece (1 KB) per 8 gaps.  Softmax (reference value, cold rescue path, exact l / lse), segments, token-major rows,
-// fused query warp, even split (SK) exactly as k_attn_fwd_mp; units are 256 queries.
+// one direct-to-LDS piece (1 KB) per 8 gaps.  Segments, token-major rows, fused query warp, query row lists as in k_attn_fwd_mp;
+// units are 256 queries.  What differs:
+//   * softmax reference: PRE (queries carry scale*log2 e): the first key tile's row maximum, fixed; a segment whose half-step sums ever
+//     exceed 2^60 is repeated with exact row maxima (see the attempt loop).  !PRE (exact scale: the optimisation pass): raw scores in
+//     the tiles and k_attn_fwd_mp's in-loop rescue, which only touches O, l and the reference (w64_rescue);
+//   * SK: the linear range of k_attn_fwd_mp, or — launches of at most 128 units — every unit in 2-4 parts, one per workgroup
+//     (FwdArgs::sk_parts); hand-off: the holder of a unit's first part merges without storing its own (see the epilogue);
+//   * the output goes through LDS so that the global stores are whole rows.
 // =================================================================================================================================
 
 #define W64_SUM_LIMIT 1.152921504606847e18f       // 2^60

@@ -139,12 +139,13 @@ int gd_rows_merge(const void* base, const void* act, const int32_t* pos, int H, 
 /* gd_attn_fwd with the EVEN SPLIT of the key tiles over the resident workgroups (replaces the same reference lines as gd_attn_fwd:
  * U/attention_sharing.py:30-47 + torch.bmm at U/attention_processors.py:428,433,549,557,644,647).  A 64^2 launch of 20 heads is 640
  * units (head x 128-query tile) for 512 resident workgroups: 1.57 rounds; 5 heads fill 160 of 256 CUs.  With a workspace the launch's
- * units x key tiles are dealt out as one linear range, the same number of key tiles to every workgroup; a unit that ends up in several
+ * units x key tiles are dealt out as one linear range, the same number of key tiles to every workgroup (launches of at most 128 units of
+ * 256 queries — the 5-head inversion pass — instead cut every unit into 2-4 parts, one per workgroup); a unit that ends up in several
  * workgroups is merged (un-normalised O, reference, row sum in f32, fixed part order: bit-reproducible) by the workgroup that finishes
  * last.  workspace: gd_attn_fwd_workspace_bytes(sum of segment bh, N, M) bytes, 256-byte aligned, ZERO before its first use (arrival
  * counters; every launch leaves them zero), private to one stream at a time.  workspace == NULL, head dims other than 64, key counts
  * that are not a multiple of 256 and launches too short to split behave exactly like gd_attn_fwd.
- * gd_attn_fwd_set_even_split(0 = never, 1 = where the last round of workgroups would be badly filled (default), 2 = every launch that
+ * gd_attn_fwd_set_even_split(0 = never, 1 = where the launcher's cost model says it pays (default), 2 = every launch that
  * can be split): tuning hook (benchmarks, tests; environment: GD_ATTN_EVEN_SPLIT). */
 size_t gd_attn_fwd_workspace_bytes(int tot_bh, int N, int M);
 int gd_attn_fwd_ws(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, void* workspace, size_t workspace_bytes,

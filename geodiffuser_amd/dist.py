@@ -25,7 +25,11 @@ def init(backend: str = None) -> tuple:
     rank, world, local = env_rank_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            # every rank must name the SAME port, so a rank cannot pick (or retry) one on its own: the launcher does
+            # (torchrun --master-port, `bench.py --gpus N` takes a free one).  A silent default collides with whatever else runs on the node.
+            raise RuntimeError("geodiffuser_amd.dist.init: WORLD_SIZE > 1 but MASTER_PORT is not set — start the ranks through "
+                               "torchrun / `bench.py --gpus N` (they pass a port to every rank)")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -286,3 +286,11 @@ def test_miopen_cache_works_on_a_scratch_copy(tmp_path, monkeypatch):
         monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
         monkeypatch.delenv("MIOPEN_CUSTOM_CACHE_DIR", raising=False)
         importlib.reload(mc)
+
+
+def test_dist_init_needs_a_port_from_the_launcher(monkeypatch):
+    """More than one rank without MASTER_PORT: a loud error, not a silent 29500 (the ranks cannot agree on a port among themselves)."""
+    from geodiffuser_amd import dist
+    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "0"); monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        dist.init("gloo")

@@ -131,6 +131,8 @@ class AttnTimer:
                 q = torch.randn(qs, device="cuda")
                 if q_scaled:
                     q = q * (scale * 1.4426950408889634)
+                elif abs(scale - 0.125) > 1e-9:            # the optimisation pass: queries pre-scaled by the projection, scale = ln 2 (head dim 64)
+                    q = q * (0.125 / scale)                # same distribution of the scores: N(0, 1) nats
                 q = q.to(dt); k = torch.randn(ks, device="cuda").to(dt); v = torch.randn(ks, device="cuda").to(dt)
                 lse = torch.empty(qs[0] * (heads if heads else 1), qs[1], device="cuda") if want_lse else None
                 seg = (q, k, v, torch.empty_like(q), lse)

@@ -129,7 +129,8 @@ struct FwdArgs {
     // workgroups is merged by the workgroup that finishes last: un-normalised (O, reference, row sum) through sk_ws, arrival counter per
     // unit in sk_cnt (zero before the first launch; the merging workgroup leaves it zero).
     int sk_tpw, sk_total;
-    int sk_parts;                   // k_attn_fwd_w64, few units: > 0 = every unit cut into sk_parts runs of sk_tpw key tiles, one per workgroup
+    int sk_parts;                   // k_attn_fwd_w64: > 0 = the units from sk_unit0 on are cut into sk_parts runs of key tiles, one per workgroup
+    int sk_unit0;                   //   (0: every unit — few units; units_full: only the segment with a query row list), the units below it stay whole
     int sk_force;                   // tuning hook: split every launch that can be split (default: where the last round is badly filled)
     int sk_mode;                    // hand-off of the parts: 0 = agent-scope release / acquire fences around the ticket, 1 = device-scope stores and loads only
     f32x4* sk_ws;                   // [2 * nwg] slots of GD_SK_SLOT_F4 float4

@@ -835,10 +835,14 @@ k_attn_fwd_w64(const FwdArgs a) {
     if (SK && P) {
         // parts 1 .. P-1 hold sk_tpw tiles each, part 0 the rest (>= sk_tpw): the holder of the unit's FIRST part finishes last, finds
         // the other parts in place and merges without storing its own (see the hand-off below)
-        unit = wg / P;
-        const int part = wg - unit * P, first_len = TU - (P - 1) * a.sk_tpw;
-        t_first = part ? first_len + (part - 1) * a.sk_tpw : 0;
-        Tg = part ? a.sk_tpw : first_len;
+        // (units below sk_unit0 are not cut: one workgroup, the whole key range, no hand-off)
+        if (wg >= a.sk_unit0) {
+            const int cw = wg - a.sk_unit0;
+            unit = a.sk_unit0 + cw / P;
+            const int part = cw - (unit - a.sk_unit0) * P, first_len = TU - (P - 1) * a.sk_tpw;
+            t_first = part ? first_len + (part - 1) * a.sk_tpw : 0;
+            Tg = part ? a.sk_tpw : first_len;
+        }
     } else if (SK) {
         unit = lin / TU;
         t_first = lin - unit * TU;
@@ -1069,7 +1073,8 @@ k_attn_fwd_w64(const FwdArgs a) {
         //    merger reads all parts back, its own included: the fold runs in part order whoever merges, so the result does not depend
         //    on the arrival order;
         //  * both query blocks of a part are fetched in one round trip.
-        const int w_first = P ? unit * P : (unit * TU) / a.sk_tpw, w_last = P ? unit * P + P - 1 : ((unit + 1) * TU - 1) / a.sk_tpw;
+        const int w_first = P ? a.sk_unit0 + (unit - a.sk_unit0) * P : (unit * TU) / a.sk_tpw;
+        const int w_last = P ? w_first + P - 1 : ((unit + 1) * TU - 1) / a.sk_tpw;
         const int others = w_last - w_first;
 #define W64_SLOT(W2) (a.sk_ws + (size_t)(2 * (W2) + ((!P && (W2) * a.sk_tpw < unit * TU) ? 1 : 0)) * (2 * GD_SK_SLOT_F4) + (size_t)wave * 18 * 64 + lane)
         bool merger = false, published = false;
@@ -1262,6 +1267,24 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
             a.sk_tpw = tpp;
             a.sk_total = a.nwg * TU;
             a.nwg *= P;
+            sk = true;
+        }
+    }
+    // One round of whole units plus a segment with a query row list (the CFG / optimisation pass of an edit: 240 + 5 units): the
+    // workgroups of that segment build warped queries in their prologue (dependent gathers, ~5 us) and then walk the same 64 tiles as
+    // everyone else — they finish last and the launch waits for them.  Where the CUs left over allow it, only THEIR units are cut
+    // into parts (two or three workgroups each, 20-32 tiles): prologue + hand-off then end long before the dense workgroups.
+    if (!sk && a.sk_ws && a.sk_mode >= 1 && a.cseg >= 0 && a.nwg <= 256 && TU >= 48 && !sk_force) {
+        const int cu = a.nwg - a.units_full;                    // units of the row-list segment
+        int P = cu > 0 ? 1 + (256 - a.nwg) / cu : 1;
+        if (P > 3) P = 3;
+        const int tpp = (TU / (P > 1 ? P : 1)) & ~3;
+        if (P >= 2 && tpp >= 16) {
+            a.sk_parts = P;
+            a.sk_unit0 = a.units_full;
+            a.sk_tpw = tpp;
+            a.sk_total = a.nwg * TU;
+            a.nwg = a.units_full + cu * P;
             sk = true;
         }
     }

@@ -288,15 +288,17 @@ def test_attention_forward_even_split(ops, cfg, BH, N, M):
     assert rel_err(o1.float().cpu(), o0.float().cpu()) < 2 * tol(dtype)    # every row, against the unsplit launch (two roundings apart)
 
 
-def test_attention_unit_parts_with_segments_warp_and_row_list(ops):
-    """The 64-query kernel's unit parts (launches of at most 128 units: every unit cut into 2-4 runs of key tiles, one per workgroup; the
-    holder of a unit's first part merges without storing its own) under the launch forms of an edit: token-major segments, LSE outputs,
-    a fused query warp with a query row list (its own, shorter unit count) — against the unsplit launch, twice (reproducible)."""
+@pytest.mark.parametrize("heads", [3, 5])
+def test_attention_unit_parts_with_segments_warp_and_row_list(ops, heads):
+    """The 64-query kernel's unit parts (the holder of a unit's first part merges without storing its own) under the launch forms of an
+    edit: token-major segments, LSE outputs, a fused query warp with a query row list (its own, shorter unit count) — against the
+    unsplit launch, twice (reproducible).  3 heads: 96 + 6 units <= 128: EVERY unit is cut into parts; 5 heads: 160 + 10 units in one
+    round: only the row-list segment's units are (the optimisation pass's launch form)."""
     from geodiffuser_amd import _lib
     lib = _lib.load()
     dtype = torch.bfloat16
     g = torch.Generator(device=DEV).manual_seed(9)
-    B, N, heads, K = 2, 4096, 3, 15
+    B, N, K = 2, 4096, 15
     C = 64 * heads
     q = (torch.randn(B, N, C, device=DEV, generator=g) * 0.25).to(dtype)            # pre-scaled queries: scores ~ N(0, 2) in log2 units
     k = torch.randn(B, N, C, device=DEV, generator=g).to(dtype); v = torch.randn(B, N, C, device=DEV, generator=g).to(dtype)
@@ -308,7 +310,7 @@ def test_attention_unit_parts_with_segments_warp_and_row_list(ops):
     try:
         lib.gd_attn_fwd_set_config(8, 1)
         outs = []
-        for split in (0, 1, 1):                        # 0: no workspace -> unsplit units; 1: the default (parts: 48 + 48 + 6 units <= 128)
+        for split in (0, 1, 1):                        # 0: no workspace -> unsplit units; 1: the default
             lib.gd_attn_fwd_set_even_split(split)
             o = [torch.zeros_like(q[:1]) for _ in range(2)]; act = torch.zeros(1, 512, C, device=DEV, dtype=dtype)
             ls = [torch.zeros(heads, N, device=DEV) for _ in range(2)]

@@ -21,7 +21,7 @@ if os.environ.get("FORM") == "cfg":
     segs = [(q[0:1], k[0:1], v[0:1], o[0], None), (q[1:2], k[1:2], v[1:2], o[1], None),
             (q[1:2], k[1:2], v[1:2], act, None, (idx, w, m), (rows_p, n_dev)), (q[2:3], k[1:2], v[1:2], o[2], None)]
     for _ in range(reps):
-        ops.attn_fwd(segs, 0.125, heads=heads, nsplit=1, q_scaled=True)
+        ops.attn_fwd(segs, 0.125, heads=heads, q_scaled=True)        # the product path: even-split workspace, parts for the row-list units
 else:
     q = (torch.randn(BH, N, 64, device="cuda") * 1.2).bfloat16(); k = (torch.randn(BH, M, 64, device="cuda") * 1.2).bfloat16(); v = torch.randn(BH, M, 64, device="cuda").bfloat16()
     out = torch.empty_like(q); lse = torch.empty(BH, N, device="cuda")

@@ -378,8 +378,8 @@ static void mp_config(long long blocks, int N, int M, int* qb, int* ks, int q_pr
     // wave-sized query blocks against the chip's 1024 SIMDs x 2 resident waves.  Measured on MI355X (tools/bench_mp.py, bf16, 64^2):
     // 5 heads (640 blocks) 43 -> 34 us with two key ranges per workgroup, 10 heads (1280 blocks) 59 us unsplit vs 69 split, 32^2 with
     // 30 heads (960 blocks) 14.5 -> 13.3 us split; from 1280 blocks up the unsplit 128-query workgroup wins.
-    // From 160 units of 256 queries up (10 heads at 64^2) the 64-query-per-wave kernel wins (k_attn_fwd_w64, bf16 only — the launcher
-    // falls back to 4 x 1 for fp16): tools/bench_sk.py, 64^2: 15 heads 66.5 -> 59.1 us, 20 heads 102.3 -> 86.2 us (even split),
+    // From 160 units of 256 queries up (10 heads at 64^2) the 64-query-per-wave kernel wins (k_attn_fwd_w64; fp16 runs its rescue
+    // variant): tools/bench_sk.py, 64^2: 15 heads 66.5 -> 59.1 us, 20 heads 102.3 -> 86.2 us (even split),
     // 32 heads 135.3 -> 122.0 us; 96^2: 20 heads 427 -> 377 us; 32^2 x 10 heads (40 units) 12.1 -> 17.5 us: stays below.
     // Both variants: pre-scaled queries (no-grad passes; reference = first tile's maximum, retry with exact maxima on overflow) and exact
     // scale (optimisation pass; in-loop rescue like k_attn_fwd_mp's, so a dominant probability is exactly 1.0 after a rescue — the

@@ -1305,7 +1305,10 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
         if (pre) { if (sk) GD_W64_LAUNCH(T_, true, true); else GD_W64_LAUNCH(T_, true, false); }   \
         else { if (sk) GD_W64_LAUNCH(T_, false, true); else GD_W64_LAUNCH(T_, false, false); }     \
     }
-    GD_W64_T(bf16_t)                   // bf16 only: fp16 probabilities need the tight range of k_attn_fwd_mp's in-loop rescue
+    // fp16: always the rescue variant — its probabilities stay below the half-step limit of 2^14, inside fp16's range, where the fixed
+    // reference of the pre-scaled variant lets them grow to 2^60 (pre-scaled queries are fine with it: the multiplier is then 1)
+    if (dtype == GD_F16) { if (sk) GD_W64_LAUNCH(f16_t, false, true); else GD_W64_LAUNCH(f16_t, false, false); }
+    else GD_W64_T(bf16_t)
 #undef GD_W64_T
 #undef GD_W64_LAUNCH
     GD_CHECK_LAUNCH("gd_attn_fwd");
@@ -1316,10 +1319,10 @@ int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st) 
     int tot = 0;
     for (int i = 0; i < a.nseg; ++i) tot = a.bh_end[i];
     {
-        // the 64-query kernel is bf16 only (see k_attn_fwd_w64), and below 160 units it needs the even split's workspace (unit parts)
+        // below 160 units the 64-query kernel needs the even split's workspace (unit parts)
         const long long blocks = (long long)((a.N + 31) / 32) * tot;
         const int T = a.M / ATT_BN;
-        if (qb == 8 && (dtype != GD_BF16 || (blocks < 1280 && !(a.sk_ws && a.sk_mode >= 1)))) {
+        if (qb == 8 && blocks < 1280 && !(a.sk_ws && a.sk_mode >= 1)) {
             qb = 4;
             ks = (blocks < 1280 && T % 4 == 0) ? 2 : 1;
         }

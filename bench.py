@@ -494,7 +494,7 @@ def main():
                        "per_rank_s": per_rank, "first_warmup_edit_s": first_edit, "miopen_db": os.path.relpath(miopen_cache._DIR, ROOT), "miopen_db_matched": db_ok},
         }
         if roof:
-            line["roofline"] = {"kernel": f"k_attn_fwd_mp (attention forward, N = M = {timer.n} self-attention launches)", "bound": "mfma", "achieved": roof["achieved"] / 1e12,
+            line["roofline"] = {"kernel": f"k_attn_fwd_w64 / k_attn_fwd_mp (attention forward, N = M = {timer.n} self-attention launches)", "bound": "mfma", "achieved": roof["achieved"] / 1e12,
                                 "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s", "frac": roof["achieved"] / PEAK_MFMA_16BIT,
                                 "traffic": roof["traffic"], "launches": roof["launches"], "avg_launch_us": roof["avg_us"],
                                 # `achieved` counts the ALGORITHMIC FLOPs of a launch (every row of every segment, as the reference

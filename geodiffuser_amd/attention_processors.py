@@ -357,7 +357,7 @@ class _EditLayer(torch.autograd.Function):
         # and never moves it, the exact-scale variant rescues onto a row maximum like k_attn_fwd_mp — after which a DOMINANT probability
         # is exactly 1.0 in 16 bits, as in any online softmax.  The no-grad passes do without that (outputs within the storage
         # rounding either way); the L1 loss terms between two nearly equal attention outputs measure exactly that rounding (the
-        # `sim` term of an SDXL-shaped bf16 case moved by 1.6 %), so the optimisation pass pays the 9 us per 64^2 launch.
+        # `sim` term of an SDXL-shaped bf16 case moved by 1.6 %), so the optimisation pass pays the 6-9 us per 64^2 launch.
         f = c["f"]
         remover = ctrl._is_remover
         (b0, b1), (e0, e1) = ctrl.coords_base, ctrl.coords_edit

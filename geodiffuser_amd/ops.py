@@ -155,6 +155,7 @@ _PLAN_CACHE = {}
 
 
 _SK_WS = {}          # device index -> zero-initialised workspace of the even split (persistent: captured graphs hold its address)
+_SK_WS_RETIRED = []  # buffers replaced by a larger one (never freed: see _attn_ws)
 
 
 def _attn_ws(lib, dev: torch.device, tot_bh: int, N: int, M: int):
@@ -166,6 +167,8 @@ def _attn_ws(lib, dev: torch.device, tot_bh: int, N: int, M: int):
         if torch.cuda.is_current_stream_capturing():
             # (a buffer allocated during a capture lives in that graph's private pool and would be zero-filled again by every replay)
             raise _lib.GeodiffError("attn_fwd: the even-split workspace must exist before a graph capture (run one eager pass first)")
+        if ws is not None:
+            _SK_WS_RETIRED.append(ws)                      # captured passes may still address the smaller buffer: it stays alive
         ws = _SK_WS[dev.index] = torch.zeros(max(need, 40 << 20), dtype=torch.uint8, device=dev)
     return ws
 

@@ -15,4 +15,16 @@ d = json.load(open("gpurun_out/miopen_db_$run.json"))
 print("$run", "first warm-up edit:", d["config"]["first_warmup_edit_s"], "s; timed edit:", d["ms_per_step"], "ms")
 PY
 done
+# the other benchmarked configurations (fp16; 768^2 = BASELINE configs[3]'s size; the SDXL-shaped 1024^2 harness = configs[4]'s shape)
+for extra in "--dtype fp16" "--size 768" "--model sdxl --size 1024"; do
+  tag=$(echo "$extra" | tr -d ' -')
+  for run in cold warm; do
+    python3 bench.py $extra --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/miopen_db_${tag}_$run.json 2> gpurun_out/miopen_db_${tag}_$run.err
+    python3 - <<PY
+import json
+d = json.load(open("gpurun_out/miopen_db_${tag}_$run.json"))
+print("$extra", "$run", "first warm-up edit:", d["config"]["first_warmup_edit_s"], "s; timed edit:", d["ms_per_step"], "ms")
+PY
+  done
+done
 du -sh "$GD_MIOPEN_DB"; find "$GD_MIOPEN_DB" -type f | head -20

@@ -367,6 +367,51 @@ def cpu_baseline_configs0(cores, sample_steps=4):
                         f"{c['steps']} inversion) = {total:.0f} s per 256^2 / 20-step edit"))
 
 
+def dry_run(args) -> int:
+    """``--dry-run``: everything around the edit on CPU / gloo — the rendezvous the launcher set up, the bucketed weight broadcast from
+    rank 0, the barrier + max-over-ranks timing, the per-rank gathers and the rank-0-only JSON line — with the edit itself replaced by a
+    stub (the hot path has no CPU implementation and must not get one).  Used by tests/test_host_logic.py to run `bench.py --gpus 2` for
+    real on a box without GPUs; the printed line says dry_run and carries no metric value."""
+    from geodiffuser_amd import dist as gdist
+    rank, world, local = gdist.init(backend="gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    from geodiffuser_amd.pipeline import build_random_sd21
+    from geodiffuser_amd.synthetic import make_edit
+    # every rank builds ITS OWN weights (seed = rank): after the broadcast they must equal rank 0's
+    pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=True, seed=1234 + rank)
+    nbytes = gdist.broadcast_model([pipe.unet, pipe.vae, pipe.text_encoder], src=0)
+    probe = float(torch.cat([p.detach().reshape(-1)[:16] for p in pipe.unet.parameters()]).double().sum())
+    probes = gdist.gather_over_ranks(probe, device="cpu")
+    inputs = {j: make_edit(j * world + rank, size=64, kind=args.kind) for j in range(args.steps)}
+
+    def stub_edit(j):
+        image, depth, mask, T = inputs[j]
+        return float(mask.sum()) + float(T.sum())
+
+    tw = time.perf_counter()
+    stub_edit(0) if args.steps else None
+    warm = time.perf_counter() - tw
+    gdist.barrier()
+    t0 = time.perf_counter()
+    for j in range(args.steps):
+        stub_edit(j)
+    gdist.barrier()
+    elapsed = time.perf_counter() - t0
+    print(f"[bench rank {rank}/{world}] device cpu (dry run), first warm-up edit {warm:.2f} s, timed region {elapsed:.3f} s for "
+          f"{args.steps} edit(s)", file=sys.stderr, flush=True)
+    per_rank = gdist.gather_over_ranks(elapsed, device="cpu")
+    first = gdist.gather_over_ranks(warm, device="cpu")
+    elapsed = gdist.max_over_ranks(elapsed, device="cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN - no edit executed (launcher / rendezvous / broadcast / reporting check)", "value": None,
+                          "unit": "edits/sec", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": 0, "scaling": "weak",
+                          "config": {"weights_broadcast_bytes": nbytes, "per_rank_s": per_rank, "first_warmup_edit_s": first,
+                                     "weights_equal_after_broadcast": all(abs(p - probes[0]) < 1e-9 for p in probes),
+                                     "edits_by_rank": {str(r): [j * world + r for j in range(args.steps)] for r in range(world)}}}), flush=True)
+    return 0
+
+
 def free_port() -> int:
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -381,7 +426,13 @@ def spawn_ranks(n: int, argv, device_count=None, run=None) -> int:
     path shards by independent edit (the reference is single-GPU, /root/reference/README.md:88): one rank per GPU, a free
     rendezvous port on 127.0.0.1.  ``device_count`` / ``run`` are injection points of the CPU test."""
     import subprocess
-    have = torch.cuda.device_count() if device_count is None else device_count
+    if device_count is None:
+        # (no HIP call in the launcher: visibility masks / the kernel driver's topology; torch's NVML-style count only as the last resort)
+        from geodiffuser_amd.dist import visible_gpu_count
+        device_count = visible_gpu_count()
+        if device_count < 0:
+            device_count = torch.cuda.device_count()
+    have = device_count
     if have < n:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible on this node", file=sys.stderr, flush=True)
         return 2
@@ -403,12 +454,17 @@ def main():
     ap.add_argument("--kind", default="rotate", choices=["rotate", "translate", "mixed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="narrow model (debug only; the result is not a benchmark number)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / broadcast / reporting check WITHOUT a GPU: gloo, narrow model on the CPU, the edit replaced by a "
+                         "stub (there is no CPU path for it).  The line it prints is marked dry_run and is not a measurement")
     ap.add_argument("--model", default="sd21", choices=["sd21", "sdxl"],
                     help="sd21 = BASELINE configs[1] (the benchmark); sdxl = SDXL-base-shaped UNet, use with --size 1024 (configs[4] shape, bf16 path)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (before anything touches the GPU)
-        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:], device_count=args.gpus if args.dry_run else None))
+    if args.dry_run:
+        raise SystemExit(dry_run(args))
 
     # Let MIOpen time its convolution solvers per shape during the warm-up edit instead of taking the heuristic pick (which
     # favours split-K igemm kernels with an fp32 workspace + cast kernels here): -7 % per edit, ~90 s more warm-up on a fresh box.
@@ -436,8 +492,12 @@ def main():
 
     timer = AttnTimer((args.size // (16 if args.model == "sdxl" else 8)) ** 2)      # the largest hooked self-attention layer
     timer.install()
+    # the synthetic inputs of every edit exist before its clock starts (they stand for files already read: image + mask + depth of an
+    # edit are 2.9 MB; their upload and everything else run_geodiffuser does stay inside the timed region)
+    inputs = {j: make_edit(j * world + rank, size=args.size, kind=args.kind) for j in list(range(args.steps)) + [1000 + w for w in range(args.warmup)]}
+
     def one_edit(j):
-        image, depth, mask, T = make_edit(j * world + rank, size=args.size, kind=args.kind)
+        image, depth, mask, T = inputs[j]
         # fresh keyword arguments per edit: like the reference, the controller aliases the caller's loss_weights_dict and the adaptive
         # schedule edits it in place (attention_processors.py:667-668) — a shared dict would leak one edit's weights into the next
         kw = editor_kwargs()
@@ -468,6 +528,9 @@ def main():
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
     timer.enabled = False
+    # one line per rank on stderr: which device it drove and what its first edit cost (first contact with an N-GPU node)
+    print(f"[bench rank {rank}/{world}] device {dev} ({torch.cuda.get_device_name(local)}), first warm-up edit "
+          f"{(warm_s[0] if warm_s else float('nan')):.2f} s, timed region {elapsed:.3f} s for {args.steps} edit(s)", file=sys.stderr, flush=True)
     per_rank = gdist.gather_over_ranks(elapsed, device=dev)
     first_edit = gdist.gather_over_ranks(warm_s[0] if warm_s else 0.0, device=dev)
     elapsed = gdist.max_over_ranks(elapsed, device=dev)
@@ -491,16 +554,20 @@ def main():
                        "tiny_debug_model": bool(args.tiny),
                        # multi-GPU reporting: seconds of the timed region on every rank (value uses their max) and of each rank's
                        # FIRST warm-up edit (solver search unless the find-db has the shapes, graph captures, allocator growth)
-                       "per_rank_s": per_rank, "first_warmup_edit_s": first_edit, "miopen_db": os.path.relpath(miopen_cache._DIR, ROOT), "miopen_db_matched": db_ok},
+                       "per_rank_s": per_rank, "first_warmup_edit_s": first_edit,
+                       # the find-db seed in use (GD_MIOPEN_DB / the committed one) and the directory MIOpen works in (a per-process copy)
+                       "miopen_db": miopen_cache.seed_dir(), "miopen_db_work_dir": miopen_db, "miopen_db_matched": db_ok},
         }
         if roof:
-            line["roofline"] = {"kernel": f"k_attn_fwd_w64 / k_attn_fwd_mp (attention forward, N = M = {timer.n} self-attention launches)", "bound": "mfma", "achieved": roof["achieved"] / 1e12,
-                                "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s", "frac": roof["achieved"] / PEAK_MFMA_16BIT,
+            line["roofline"] = {"kernel": f"k_attn_fwd_w64 / k_attn_fwd_mp (attention forward, N = M = {timer.n} self-attention launches)", "bound": "mfma",
+                                # `achieved` / `frac`: the FLOPs the launches EXECUTE (MFMA utilisation: a segment with a query row list
+                                # computes only its list) over the measured launch time.  `*_algorithmic`: every row of every segment as
+                                # the reference computes them (SURVEY 8d's figure) over the same time — the rows the list skips equal
+                                # the reference rows' outputs, which the same launch computes anyway
+                                "achieved": roof["achieved_executed"] / 1e12,
+                                "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s", "frac": roof["achieved_executed"] / PEAK_MFMA_16BIT,
                                 "traffic": roof["traffic"], "launches": roof["launches"], "avg_launch_us": roof["avg_us"],
-                                # `achieved` counts the ALGORITHMIC FLOPs of a launch (every row of every segment, as the reference
-                                # computes them); the warped segment executes only the rows inside the soft edit mask (the others equal
-                                # the reference rows): the rate over the FLOPs actually executed
-                                "achieved_executed": roof["achieved_executed"] / 1e12, "frac_executed": roof["achieved_executed"] / PEAK_MFMA_16BIT,
+                                "achieved_algorithmic": roof["achieved"] / 1e12, "frac_algorithmic": roof["achieved"] / PEAK_MFMA_16BIT,
                                 "configs": roof["configs"],
                                 "flops_per_launch": roof["flops_per_launch"]}
         if not args.no_cpu_baseline and world == 1:

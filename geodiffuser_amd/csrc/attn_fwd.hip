@@ -400,8 +400,14 @@ extern "C" int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, in
 // Even split (attn_fwd_mp.hip, SK): 1 = where it pays (default; GD_ATTN_EVEN_SPLIT=0 in the environment turns it off), 0 = never
 static int env_sk = -1, env_sk_mode = 1, env_sk_force = 0;
 extern "C" int gd_attn_fwd_set_even_split(int on) {
-    // 0 = never, 1 = where it pays (default), 2 = every launch that can be split; development: 10 = as 2 with release / acquire fences
-    // around the ticket (k_attn_fwd_mp only), 11 = as 2 with device-scope stores / loads only (what 1 and 2 use), 12 = no merge (timing)
+    // 0 = never, 1 = where it pays (default), 2 = every launch that can be split.  Development values, refused unless the process
+    // sets GD_ATTN_DEV_MODES=1 (tools/bench_handoff.py does): 10 = as 2 with release / acquire fences around the ticket (k_attn_fwd_mp
+    // only), 11 = as 2 with device-scope stores / loads only (what 1 and 2 use), 12 = no merge (timing only: WRONG outputs)
+    if (on > 2 || on < 0) {
+        const char* dev = getenv("GD_ATTN_DEV_MODES");
+        GD_REQUIRE(dev && dev[0] == '1' && on >= 10 && on <= 12, GD_EINVAL,
+                   "gd_attn_fwd_set_even_split: mode %d (0, 1, 2; the development modes 10-12 need GD_ATTN_DEV_MODES=1)", on);
+    }
     env_sk = on ? 1 : 0;
     env_sk_force = on >= 2;
     env_sk_mode = on >= 10 ? on - 10 : 1;

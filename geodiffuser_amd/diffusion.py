@@ -28,9 +28,9 @@ def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None, ctx_s
             or not getattr(controller, "persistent_tables", False):
         return model.unet(x, t, encoder_hidden_states=ctx)["sample"]
     seen = model.__dict__.setdefault("_cfg_layers", {})
-    # the hooked (resolution, heads, head dim) set is a property of (latent size, hooked-module census): a model whose processors were
-    # re-registered with other hooks / heads learns it again
-    lk = tuple(x.shape[2:]) + (len(getattr(model.unet, "attn_processors", ())), type(controller).__name__)
+    # the hooked (resolution, heads, head dim) set is learnt per (latent size, controller type); a model whose hooks changed since is
+    # caught by the `learnt() != layers` comparison below (the controller then holds a table the list does not know) and learns it again
+    lk = tuple(x.shape[2:]) + (type(controller).__name__,)
     layers = seen.get(lk)
 
     def learnt():

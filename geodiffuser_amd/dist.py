@@ -39,6 +39,34 @@ def init(backend: str = None) -> tuple:
     return rank, world, local
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process tree may use, WITHOUT touching the HIP runtime (a launcher that only forks rank processes should not
+    initialise the GPU; on ROCm ``torch.cuda.device_count()`` may fall through to ``hipGetDeviceCount``).  The visibility masks win
+    (``HIP_VISIBLE_DEVICES`` / ``CUDA_VISIBLE_DEVICES`` index into what ``ROCR_VISIBLE_DEVICES`` leaves); otherwise the kernel driver's
+    topology: every KFD node with ``simd_count > 0`` is a GPU.  -1 when neither source exists (no amdgpu driver: the caller decides)."""
+    n_mask = None
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            k = len([x for x in v.split(",") if x.strip() not in ("", "-1")])
+            n_mask = k if n_mask is None else min(n_mask, k)
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    n_kfd = None
+    if os.path.isdir(root):
+        n_kfd = 0
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as fh:
+                    props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n_kfd += 1
+            except (OSError, ValueError):
+                continue
+    if n_mask is not None:
+        return n_mask if n_kfd is None else min(n_mask, n_kfd)
+    return -1 if n_kfd is None else n_kfd
+
+
 def shard(items: Sequence[T], rank: int, world: int) -> List[T]:
     """edit j -> rank j mod world."""
     return [x for j, x in enumerate(items) if j % world == rank]

@@ -152,11 +152,14 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
 
     opt_pass = GraphedOptPass(model, transform_coordinates, guidance_scale)
     first_optim_complete = False
+    # :157-160 concatenates the same two tensors at every step; built ONCE here, so the context of a step is the same tensor OBJECT
+    # until an optimisation pass replaces it — which is what the captured passes' text-row K / V cache keys on (graphs.GraphedUNet)
+    context_fixed = torch.cat([uncond_embeddings_, text_embeddings]) if uncond_embeddings_ is not None else None
     for i, t in enumerate(timesteps):
         if uncond_embeddings_ is None:
             context = torch.cat([uncond_embeddings[i].expand(*text_embeddings.shape), text_embeddings])
         else:
-            context = torch.cat([uncond_embeddings_, text_embeddings])
+            context = context_fixed
 
         if not is_geo:
             latents = diffusion_step(model, controller, latents, context, t, guidance_scale, transform_coords=transform_coordinates)

@@ -36,6 +36,14 @@ class _Entry:
         self.kv_ver = -1
 
 
+def _src_version(ctx_src):
+    """(source, version) of a context for the K / V cache; (None, -1) = do not cache (no source named, or an inference-mode tensor: it has no
+    version counter, so an in-place edit could not be seen)."""
+    if ctx_src is None or ctx_src.is_inference():
+        return None, -1
+    return ctx_src, ctx_src._version
+
+
 class GraphedUNet:
     """``runner(key, x, t, ctx) -> noise_pred``; the returned tensor is a static buffer that the next replay overwrites."""
 
@@ -43,6 +51,7 @@ class GraphedUNet:
         self.unet = unet
         self.entries: Dict[Hashable, _Entry] = {}
         self.replays = 0
+        self.kv_refreshes = 0       # replays that had to re-project the text rows' K / V (the context changed)
 
     def reset(self):
         """Drop every captured pass — explicitly and with the device idle: a graph left to the garbage collector may be destroyed in the
@@ -101,7 +110,7 @@ class GraphedUNet:
             if KV_CACHE:
                 e.kv = {}
                 self._refresh_kv(e)
-                e.kv_src, e.kv_ver = ctx_src, (ctx_src._version if ctx_src is not None else -1)
+                e.kv_src, e.kv_ver = _src_version(ctx_src)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             ops.zero_pool_reset()
@@ -118,9 +127,11 @@ class GraphedUNet:
             return e.out, False                                # Python side effects DID run (during capture)
         e.x.copy_(x)
         e.ctx.copy_(ctx)
-        if e.kv and (ctx_src is None or ctx_src is not e.kv_src or ctx_src._version != e.kv_ver):
+        src, ver = _src_version(ctx_src)
+        if e.kv and (src is None or src is not e.kv_src or ver != e.kv_ver):
             self._refresh_kv(e)
-            e.kv_src, e.kv_ver = ctx_src, (ctx_src._version if ctx_src is not None else -1)
+            e.kv_src, e.kv_ver = src, ver
+            self.kv_refreshes += 1
         e.t.fill_(tval)
         e.graph.replay()
         self.replays += 1

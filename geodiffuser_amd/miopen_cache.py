@@ -48,6 +48,7 @@ def configure(path: str = None, per_rank_copy: bool = True) -> str:
         _STATE["scratch"] = True
         atexit.register(_cleanup, use)
     _STATE["dir"] = use
+    _STATE["seed"] = src
     _STATE["seed_names"] = tuple(_db_names(use))
     os.environ["MIOPEN_USER_DB_PATH"] = use
     os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(use, "cache"))
@@ -61,6 +62,16 @@ def configure(path: str = None, per_rank_copy: bool = True) -> str:
         warnings.warn(f"geodiffuser_amd.miopen_cache: no find-db records under {src}; the first edit of this process runs MIOpen's "
                       "solver search for every convolution shape (tens of seconds)", RuntimeWarning, stacklevel=2)
     return use
+
+
+def seed_dir() -> str:
+    """The find-db seed in use: ``GD_MIOPEN_DB`` / the committed directory — or, when ``MIOPEN_USER_DB_PATH`` / ``GD_MIOPEN_CACHE=0`` overrode
+    the mechanism, whatever MIOpen was pointed at."""
+    if os.environ.get("GD_MIOPEN_CACHE", "1") != "1" or (not _STATE["dir"] and os.environ.get("MIOPEN_USER_DB_PATH")):
+        return os.environ.get("MIOPEN_USER_DB_PATH", "")
+    src = _STATE.get("seed") or os.environ.get("GD_MIOPEN_DB") or _DIR
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return os.path.relpath(src, here) if os.path.abspath(src).startswith(here) else src
 
 
 def check_db_used() -> bool:

@@ -146,7 +146,8 @@ int gd_rows_merge(const void* base, const void* act, const int32_t* pos, int H, 
  * counters; every launch leaves them zero), private to one stream at a time.  workspace == NULL, head dims other than 64, key counts
  * that are not a multiple of 256 and launches too short to split behave exactly like gd_attn_fwd.
  * gd_attn_fwd_set_even_split(0 = never, 1 = where the launcher's cost model says it pays (default), 2 = every launch that
- * can be split): tuning hook (benchmarks, tests; environment: GD_ATTN_EVEN_SPLIT). */
+ * can be split): tuning hook (benchmarks, tests; environment: GD_ATTN_EVEN_SPLIT).  Any other value returns GD_EINVAL (the
+ * hand-off development modes 10-12 exist only for processes that set GD_ATTN_DEV_MODES=1: tools/bench_handoff.py). */
 size_t gd_attn_fwd_workspace_bytes(int tot_bh, int N, int M);
 int gd_attn_fwd_ws(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, void* workspace, size_t workspace_bytes,
                    int dtype, void* stream);

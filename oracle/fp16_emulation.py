@@ -145,9 +145,10 @@ def main():
                                ("--g20-only", "G20_loop_cfg0", cases.LOOP_CFG0),
                                ("--g21-only", "G21_loop_cfg0_full", cases.LOOP_CFG0), ("--g22-only", "G22_loop_cfg1_full", cases.LOOP_CFG1),
                                ("--g23-only", "G23_loop_sd14", cases.LOOP), ("--g26-only", "G26_loop_remover_full", cases.LOOP),
-                               ("--g27-only", "G27_loop_sdxl", cases.LOOP_SDXL)):
+                               ("--g27-only", "G27_loop_sdxl", cases.LOOP_SDXL), ("--g28-only", "G28_loop_cfg1_t50", cases.LOOP_CFG1_T50),
+                               ("--g29-only", "G29_loop_remover768_t75", cases.LOOP_REM768_T75)):
         if flag in sys.argv:                       # the full-width loops (fixtures G21 / G22): add / refresh that entry only
-            torch.set_num_threads(8)
+            torch.set_num_threads(int(os.environ.get("GD_GEN_THREADS", "8")))
             R = ref_import.import_reference()
             out = json.load(open(path))
             g = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
@@ -156,7 +157,7 @@ def main():
             for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
                 if ("--" + dn) in sys.argv or not any(a in sys.argv for a in ("--fp16", "--bf16")):
                     lat, log, ce, _ = gen_golden.run_reference_loop(R, "geometry_remover" if "remover" in fixture else "geometry_editor", cfg,
-                                                                    prepare=emulate_16bit(dt), tiny=fixture.startswith(("G18", "G19", "G20", "G23", "G27")),
+                                                                    prepare=emulate_16bit(dt), tiny=fixture.startswith(("G18", "G19", "G20", "G23", "G27", "G28", "G29")),
                                                                     sdxl=fixture.startswith("G27"), sd14=fixture.startswith("G23"))
                     e["emulated_" + dn] = rel_l2(lat[-1:], ref[-1:])
                     e["emulated_" + dn + "_first_update"] = rel_l2(ce._recorded_updates[0], up32)

@@ -465,11 +465,13 @@ def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_ep
         x_T = x_T * (1.0 + x_T_eps * torch.randn(x_T.shape, generator=g))
     # record the latent update of every optimisation pass (-step * masked gradient): isolates ONE backward pass from the loop
     updates = []
+    weights = []           # adaptive removal weight in effect at each optimisation pass (U/optimization.py:7-105 edits it after the pass)
     orig_update = RE._update_latent
 
     def rec_update(latents, loss, step_size, mask=None, context=None, **kw):
         res = orig_update(latents, loss, step_size, mask, context, **kw)
         updates.append((res[0][-1:].detach() - latents[-1:].detach()).clone())
+        weights.append(float(ctrl.loss_weight_dict["self"]["removal"]))
         return res
 
     RE._update_latent = rec_update
@@ -484,10 +486,11 @@ def run_reference_loop(R, kind="geometry_editor", cfg=None, prepare=None, x_T_ep
     ap.reshape_transform_coords = orig_rtc
     RE._update_latent = orig_update
     ctrl._recorded_updates = updates
+    ctrl._recorded_weights = weights
     return lat.detach(), log, ctrl, pipe
 
 
-def g18_loop(R, kind="geometry_editor", cfg=None, name=None, tiny=True, sd14=False, sdxl=False):
+def g18_loop(R, kind="geometry_editor", cfg=None, name=None, tiny=True, sd14=False, sdxl=False, record_weights=False):
     """Records the final latents and the loss log of every optimisation step of run_reference_loop."""
     lat, log, ctrl, pipe = run_reference_loop(R, kind, cfg, tiny=tiny, sd14=sd14, sdxl=sdxl)
     out = {"latents": lat.detach(), "steps": np.array(sorted(log))}
@@ -500,6 +503,8 @@ def g18_loop(R, kind="geometry_editor", cfg=None, name=None, tiny=True, sd14=Fal
     out["weight_probe"] = w                                         # to recognise the same seeded weights on the test machine
     out["final_weights_self_removal"] = np.array(float(ctrl.loss_weight_dict["self"]["removal"]))
     out["first_update"] = ctrl._recorded_updates[0].numpy()          # latent update of the first optimisation pass
+    if record_weights:                                               # (G28 / G29: the whole trajectory of the adaptive schedule)
+        out["weights_self_removal"] = np.array(ctrl._recorded_weights, dtype=np.float64)
     save(name or ("G18_loop" if kind == "geometry_editor" else "G19_loop_remover"), **out)
 
 
@@ -626,6 +631,21 @@ def main():
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         torch.set_num_threads(8)
         print("G22"); g18_loop(R, "geometry_editor", cases.LOOP_CFG1, "G22_loop_cfg1_full", tiny=False)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "G28":
+        # BASELINE configs[1] at its stated length (512^2, 3-D rotation, 50 DDIM steps, 17 optimisation passes) through the reference's
+        # driver over the narrow SD2.1-topology UNet: pins the step-count-dependent gates at the benchmark's T
+        R = ref_import.import_reference()
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        torch.set_num_threads(int(os.environ.get("GD_GEN_THREADS", "8")))
+        print("G28"); g18_loop(R, "geometry_editor", cases.LOOP_CFG1_T50, "G28_loop_cfg1_t50", record_weights=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "G29":
+        # BASELINE configs[3] at its stated length (768^2 removal, 75 DDIM steps, 32 optimisation passes), narrow model, eps-prediction
+        R = ref_import.import_reference()
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        torch.set_num_threads(int(os.environ.get("GD_GEN_THREADS", "8")))
+        print("G29"); g18_loop(R, "geometry_remover", cases.LOOP_REM768_T75, "G29_loop_remover768_t75", record_weights=True)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "G17":
         R = ref_import.import_reference()

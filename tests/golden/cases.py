@@ -230,6 +230,21 @@ LOOP_CFG1 = dict(LOOP, size=512, steps=4, seed=79, transform="rotate", amodal_sh
 LOOP_SDXL = dict(LOOP_CFG1, seed=80)
 
 
+# BASELINE configs[1] at its stated LENGTH: 512^2, 3-D rotation, 50-step DDIM with the batch driver's geometry_editor column
+# (large_scale_editor.py:286-299: optimize 0.65 -> 17 optimisation passes, latent_replace 0.1, obj_edit_step 0.9, self / cross 0.95),
+# narrow model: pins the step-count-dependent integer gates at T = 50 (int(50*0.95) = 47, int(50*0.9) = 45, the 0.4 T / 0.8 T phases of the
+# adaptive schedule, the latent-replace window i < 5)
+LOOP_CFG1_T50 = dict(LOOP_CFG1, steps=50, seed=81, latent_replace=0.1)
+
+
+# BASELINE configs[3] at its stated length: object removal, 768^2 (96^2 / 48^2-token hooked layers), 75 steps, the batch driver's
+# geometry_remover column (large_scale_editor.py:199-212,254-262: guidance 5, optimize 0.85 -> 32 optimisation passes, latent_replace 0.4,
+# self / cross 0.9, obj_edit_step 1.0; l_eff = lr*(50 - i)*... changes sign at i > 50, U/editor.py:207), narrow model, eps-prediction
+# (the reference has no v-prediction path)
+LOOP_REM768_T75 = dict(LOOP, size=768, steps=75, seed=82, guidance=5.0, optimize_steps=0.85, latent_replace=0.4,
+                       ellipse=dict(cx=354.0, cy=393.0, ax=105.0, ay=87.0))
+
+
 def loop_inputs(c=None):
     """-> dict(mask [S,S] f32, coords [1,S,S,3] f32, x_T [1,4,S/8,S/8], ddim_latents list of steps+1 [1,4,S/8,S/8])."""
     c = c or LOOP
@@ -238,7 +253,7 @@ def loop_inputs(c=None):
         mask = ellipse_mask(size=size)
         coords = coords_rotate_y(mask=mask, size=size)
     else:
-        mask = ellipse_mask(cx=118.0, cy=131.0, ax=35.0, ay=29.0, size=size)
+        mask = ellipse_mask(size=size, **c.get("ellipse", dict(cx=118.0, cy=131.0, ax=35.0, ay=29.0)))
         coords = coords_translate(dx_px=32.0, dy_px=-12.0, z=0.5, size=size)
     rng = np.random.default_rng(c["seed"])
     traj = [rng.standard_normal((1, 4, size // 8, size // 8)).astype(np.float32) for _ in range(c["steps"] + 1)]

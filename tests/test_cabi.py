@@ -45,6 +45,11 @@ def test_argument_validation_without_gpu(lib):
     assert b"head dim" in lib.gd_last_error()
     assert lib.gd_error_string(-4) == b"unsupported configuration"
     assert lib.gd_rasterize_workspace_bytes(4096, 64, ctypes.c_float(1.3 / 64 * 2)) > 4096 * 4
+    # the even split's development hand-off modes (12 = no merge: wrong outputs) are not reachable from a production process
+    if os.environ.get("GD_ATTN_DEV_MODES") != "1":
+        assert lib.gd_attn_fwd_set_even_split(12) == -1 and b"development" in lib.gd_last_error()
+        assert lib.gd_attn_fwd_set_even_split(3) == -1
+    assert lib.gd_attn_fwd_set_even_split(1) == 0
 
 
 def test_ops_refuse_cpu_tensors():

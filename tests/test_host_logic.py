@@ -255,6 +255,44 @@ def test_bench_gpus_n_starts_its_own_ranks(tmp_path, monkeypatch):
         assert p.returncode == 2 and "only 0 GPU(s) visible" in p.stderr and not p.stdout.strip()
 
 
+def test_bench_gpus_2_dry_run_really_starts_two_ranks():
+    """VERDICT r03 #5: the `--gpus N` launcher's first contact, end to end and for real — ``python bench.py --gpus 2 --dry-run`` starts
+    ``python -m torch.distributed.run`` as a child, two rank processes rendezvous on 127.0.0.1 at the free port the launcher picked (gloo:
+    no GPU here), rank 0's weights are broadcast in buckets (each rank built DIFFERENT weights), every rank reports one stderr line,
+    and ONLY rank 0 prints the JSON line, with one entry per rank in the gathered fields.  The edit itself is a stub in this mode (the
+    hot path has no CPU implementation) and the line says so: it can never pass for a measurement."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                                   # rank 0 only
+    line = json.loads(lines[0])
+    assert line["dry_run"] is True and line["value"] is None and line["n_gpus"] == 2 and "DRY RUN" in line["metric"]
+    cfg = line["config"]
+    assert cfg["weights_broadcast_bytes"] > 0 and cfg["weights_equal_after_broadcast"] is True
+    assert len(cfg["per_rank_s"]) == 2 and len(cfg["first_warmup_edit_s"]) == 2
+    assert cfg["edits_by_rank"] == {"0": [0, 2, 4], "1": [1, 3, 5]}      # edit j -> rank j mod W, every edit exactly once
+    for r in (0, 1):
+        assert f"[bench rank {r}/2] device cpu (dry run)" in p.stderr
+
+
+def test_visible_gpu_count_reads_masks_without_hip(monkeypatch):
+    """The launcher counts devices from the visibility masks / the kernel driver's topology, never through the HIP runtime."""
+    from geodiffuser_amd import dist
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    base = dist.visible_gpu_count()
+    assert base >= -1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert dist.visible_gpu_count() == (3 if base < 0 else min(3, base))
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")
+    assert dist.visible_gpu_count() == (1 if base < 0 else min(1, base))
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert dist.visible_gpu_count() == 0
+
+
 def test_miopen_cache_works_on_a_scratch_copy(tmp_path, monkeypatch):
     """ADVICE r02: the committed find-db is a read-only seed (scratch copy per process), GD_MIOPEN_CACHE=0 is honoured everywhere, and a
     db written under ANOTHER MIOpen build name is reported (VERDICT r02 weak #12)."""

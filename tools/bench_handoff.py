@@ -1,5 +1,6 @@
 """What the even split's hand-off costs: forced split with and without the merge (mode 12: partial tiles written, no ticket / merge —
 wrong results, timing only) against the unsplit launch, 5 and 20 heads at 64^2, pre-scaled queries (development aid)."""
+import os as _os; _os.environ.setdefault('GD_ATTN_DEV_MODES', '1')  # development hand-off modes 10-12 of gd_attn_fwd_set_even_split
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from geodiffuser_amd import ops, _lib

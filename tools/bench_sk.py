@@ -1,6 +1,7 @@
 """Even split of the key tiles over the workgroups (gd_attn_fwd_ws, attn_fwd_mp.hip SK): correctness against the unsplit kernel and an
 fp32 formulation, bit-reproducibility, a hand-off stress (alternating inputs so that a stale part from the previous launch is WRONG data,
 with a second stream keeping the chip unevenly busy), then interleaved timing with the split on / off (development aid)."""
+import os as _os; _os.environ.setdefault('GD_ATTN_DEV_MODES', '1')  # development hand-off modes 10-12 of gd_attn_fwd_set_even_split
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from geodiffuser_amd import ops, _lib

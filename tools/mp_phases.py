@@ -1,5 +1,6 @@
 """Phase timeline of k_attn_fwd_mp (timing build with debug bit 32): 0 segment start, 1 loop start, 2 loop end, 3 key ranges merged,
 4 hand-off done, 5 output written; per workgroup, wave 0 (development aid)."""
+import os as _os; _os.environ.setdefault('GD_ATTN_DEV_MODES', '1')  # development hand-off modes 10-12 of gd_attn_fwd_set_even_split
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from geodiffuser_amd import ops, _lib

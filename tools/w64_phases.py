@@ -1,6 +1,7 @@
 """Phase timeline of k_attn_fwd_w64 from a timing build with debug bit 32 (tools/build_dbg.sh 32; GD_LIB=tools/ub/build/libgd_dbg32.so):
 per workgroup and segment the 100 MHz timestamps 0 segment start, 1 loop start, 2 loop end, 3 ticket done, 4 merge done, 5 output written
 (development aid)."""
+import os as _os; _os.environ.setdefault('GD_ATTN_DEV_MODES', '1')  # development hand-off modes 10-12 of gd_attn_fwd_set_even_split
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from geodiffuser_amd import ops, _lib

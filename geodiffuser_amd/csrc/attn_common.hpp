@@ -173,6 +173,28 @@ __device__ __forceinline__ typename elem_traits<T>::vec8 rd_tr(const char* lds, 
     return u.x;
 }
 
+// One direct-to-LDS piece: 64 lanes x 16 B = 1 KB, written to lds_dst + 16 * lane (wave-uniform destination; the per-lane SOURCE offset
+// carries the image's swizzle: the lane that fills 16-byte slot (row, c') of a tile image fetches global chunk c' ^ g(row) of that row)
+__device__ __forceinline__ void w64_dma(const __amdgpu_buffer_rsrc_t rsrc, char* lds_dst, uint32_t voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+#endif
+}
+
+// The same piece issued from inline asm: the compiler's wait-count pass then does not know that a load writes LDS at all, so it cannot
+// insert its conservative `s_waitcnt vmcnt(0)` in front of fragment reads while pieces of LATER stages are in flight (seen in
+// k_corr_max2: one drain per three chunks with the builtin, although the stages are separate __shared__ arrays).  The caller owns the
+// ordering: counted `s_waitcnt vmcnt(N)` + raw s_barrier (asm volatile with a memory clobber: never reordered against each other or
+// against memory accesses).  M0 = LDS byte address of the destination (what the builtin's expansion sets); M0 is a reserved register
+// the compiler only ever sets immediately in front of an instruction that reads it.
+typedef __attribute__((address_space(3))) char gd_lds_char;
+__device__ __forceinline__ void dma_asm(const __amdgpu_buffer_rsrc_t rsrc, char* lds_dst, uint32_t voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t m0v = (uint32_t)(uintptr_t)(gd_lds_char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+#endif
+}
+
 // This lane's query row as the four B fragments of S^T = K Q^T (8 channels at d = 16 s + 8 h).  With warp tables on the segment the row
 // is the warped, blended query of U/attention_processors.py:424,544 built here from the <= K splat slots of q_base (same code as
 // k_composite_tok: bit-identical to reading a q_warp tensor that gd_splat_composite wrote).

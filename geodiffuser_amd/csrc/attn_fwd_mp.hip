@@ -584,11 +584,7 @@ k_attn_fwd_mp(const FwdArgs a) {
 
 #define W64_SUM_LIMIT 1.152921504606847e18f       // 2^60
 
-__device__ __forceinline__ void w64_dma(const __amdgpu_buffer_rsrc_t rsrc, char* lds_dst, uint32_t voffset, int soffset) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
-#endif
-}
+// (w64_dma: attn_common.hpp)
 
 // Score MFMAs of the 64-query kernel.  With 512 registers per wave hipcc selects the accumulator-register form for every MFMA builtin
 // (D and C in a[...]); scores are consumed by v_exp_f32, which cannot read a[...]: 16 v_accvgpr_read per score tile and 16

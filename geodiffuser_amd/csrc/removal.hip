@@ -10,6 +10,7 @@
 //   k_bwd      : only the two arg-max rows of Pb carry gradient (U/attention_processors.py:259-268); softmax
 //                backward of the n_inp rows and the rank-1 updates of dq / dk.
 // MFMA-bound (k_corr_max): algorithmic FLOPs = 2 * H * R * N * M.
+#include <stdlib.h>
 #include "attn_common.hpp"
 
 #define CM_T 128   // rows of each operand tile
@@ -132,6 +133,183 @@ k_corr_max(const CorrArgs a) {
     }
 }
 
+
+// ---- k_corr_max2: the same contraction on direct-to-LDS staging -----------------------------------------------------------------
+// Round 4.  k_corr_max stages both operands through registers (8 global loads + 8 ds_write_b128 per wave and 64-deep chunk, 13 cycles of
+// the LDS store path each) and synchronises once per 16 MFMAs: 0.24-0.34 of the MFMA peak (profiles/r03_bwd_pmc.md: MFMA busy 25.6 %).
+// What the 64-query attention kernel learnt (DESIGN 4a') applied to a plain NT GEMM with a lane-local epilogue:
+//   * operands arrive by buffer_load ... lds (no staging registers, no ds_write): per 64-deep chunk AJ WJ / 2 + 2 swizzled 64-row tile
+//     images (Pb rows, then 2 of Pe), every wave fetching its 8-row pieces of every tile (w64_dma's addressing: the image's XOR moves
+//     to the source address; issued through dma_asm, see attn_common.hpp);
+//   * three stages in SEPARATE __shared__ arrays, chunk k + 2 issued right after the barrier that retires chunk k - 1; the barrier is
+//     the raw s_barrier behind a COUNTED s_waitcnt vmcnt (a __syncthreads() fence drains every direct-to-LDS load in flight,
+//     cdna_hip_programming.md "Pipelining across barriers"): one barrier per chunk, two chunks in flight across it;
+//   * wave tile (32 AJ) x 64 with 2 WJ waves: AJ + 2 fragment reads per 2 AJ MFMAs.
+// Same MFMA operand order and the same k order as k_corr_max: bit-identical sums, hence identical (value, index) pairs (tested).
+// Needs Mpad % 64 == 0 and N % (32 AJ WJ) == 0 (the self-attention layers: 4096 / 1024 keys); everything else stays on k_corr_max.
+// Ordering of a stage (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it"): a wave's pieces of
+// chunk k are retired by ITS vmcnt wait at the top of step k, the barrier that follows makes every wave's pieces visible to every
+// reader, the reads of step k come after that barrier; a stage is re-issued (chunk k + 2 into chunk k - 1's stage) after the SAME
+// barrier, which every wave reaches only once its fragment reads of chunk k - 1 have returned (lgkmcnt(0) in front of the barrier).
+template <typename T, int AJ, int WJ>
+__global__ void __launch_bounds__(128 * WJ, 1)
+k_corr_max2(const CorrArgs a) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    constexpr int NTA = AJ * WJ / 2;           // 64-row tile images of Pb per stage
+    constexpr int NT = NTA + 2;                // ... and two of Pe
+    constexpr int PPT = 4 / WJ;                // 8-row pieces per wave and tile (8 pieces per tile over 2 WJ waves)
+    constexpr int PPW = PPT * NT;              // direct-to-LDS pieces per wave and chunk
+    __shared__ __attribute__((aligned(16))) char st0[NT * ATT_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char st1[NT * ATT_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char st2[NT * ATT_TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wj = wave >> 1, wr = wave & 1;
+    // Dispatch order: the r-tile is the SLOWEST index — all (head, j-tile) pairs of r-tile 0, then of r-tile 1, ...  The list is padded
+    // (n_valid < R) and the r-tiles past it exit at once, but a workgroup that exits still took its turn in the dispatcher's queue:
+    // with the dead r-tiles interleaved (grid.x = j-tile x r-tile) 240 live workgroups out of 320 ran as TWO rounds of a one-per-CU
+    // kernel (100 us against 60 us for the same 240 launched alone, tools/bench_corr2.py); at the end of the grid they cost nothing.
+    // The per-r-tile count U is a multiple of 8, so the workgroups of one (head, j-tile) land on the same XCD for every r-tile (round
+    // robin over 8 XCDs) within one round: their reads of the same 256 rows of Pb meet in that XCD's L2.
+    const int U = a.jtiles;                                              // = 8 * ceil(j-tiles x heads / 8), set by the launcher
+    const int rt = blockIdx.x / U, u = blockIdx.x - rt * U;
+    const int jt_n = a.N / (32 * AJ * WJ);
+    if (u >= jt_n * a.H) return;
+    const int hd = u / jt_n, jt = u - hd * jt_n;
+    const int j0 = jt * (32 * AJ * WJ), r0 = rt * CM_T;
+    const int nv = a.n_valid ? (a.n_valid[0] < a.R ? a.n_valid[0] : a.R) : a.R;
+    if (r0 >= nv) return;
+    const bool live = (r0 + wr * 64) < nv;                              // this wave's 64 rows hold at least one live slot
+    const int Mpad = a.Mpad;
+    const T* __restrict__ pb = (const T*)a.Pb + ((size_t)hd * a.N + j0) * Mpad;
+    const T* __restrict__ pe = (const T*)a.Pe + ((size_t)hd * a.R + r0) * Mpad;
+    // raw buffers: rows of Pe past the padded list (a last tile of 64 rows) read as zeros
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, 0x7FFFFFFF, 0x00020000);
+    const long long be = (long long)(a.R - r0) * Mpad * (long long)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)pe, 0, (int)(be < 0x7FFFFFFF ? be : 0x7FFFFFFF), 0x00020000);
+    uint32_t voff[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int row = (PPT * wave + j) * 8 + (lane >> 3);
+        const int x = (row >> 1) & 7, g = (x & 2) | ((x & 1) << 2) | ((x >> 2) & 1);
+        voff[j] = (uint32_t)(((unsigned)row * (unsigned)Mpad + (unsigned)(((lane & 7) ^ g) * 8)) * (unsigned)sizeof(T));
+    }
+    const int tB = 64 * Mpad * (int)sizeof(T);                          // bytes from one 64-row tile to the next
+    const FragOffs fo = make_frag_offs(lane);
+
+    f32x16 acc[AJ][2];
+#pragma unroll
+    for (int x = 0; x < AJ; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[x][y][i] = 0.f;
+
+    const int KC = Mpad / CM_K;
+    // pieces [P0, P1) of chunk KCH (piece index = tile * PPT + p)
+#define CM2_ISSUE(ST, KCH, P0, P1)                                                                           \
+    {                                                                                                        \
+        const int kb_ = (KCH) * CM_K * (int)sizeof(T);                                                       \
+        _Pragma("unroll") for (int q_ = (P0); q_ < (P1); ++q_) {                                             \
+            const int t_ = q_ / PPT, p_ = q_ % PPT;                                                          \
+            dma_asm(t_ < NTA ? rsA : rsB, (ST) + t_ * ATT_TILE_BYTES + (PPT * wave + p_) * 1024, voff[p_],   \
+                    (t_ < NTA ? t_ : t_ - NTA) * tB + kb_);                                                  \
+        }                                                                                                    \
+    }
+#define CM2_FRAGS(ST, S_, B_)                                                                               \
+    {                                                                                                        \
+        _Pragma("unroll") for (int x_ = 0; x_ < AJ; ++x_) {                                                  \
+            const int gb_ = wj * AJ + x_;                                                                    \
+            af_[B_][x_] = rd_row<T>((ST) + (gb_ >> 1) * ATT_TILE_BYTES, fo, gb_ & 1, S_);                    \
+        }                                                                                                    \
+        _Pragma("unroll") for (int y_ = 0; y_ < 2; ++y_) bf_[B_][y_] = rd_row<T>((ST) + (NTA + wr) * ATT_TILE_BYTES, fo, y_, S_); \
+    }
+    // One chunk.  Top: this wave's pieces of chunk K have landed (chunk K + 1's may still be in flight) and its fragment reads of chunk
+    // K - 1 have returned; behind the barrier chunk K + 2 goes into chunk K - 1's stage, a quarter of the wave's pieces in front of each
+    // k-step's MFMAs (a piece costs ~60 cycles of issue: spread, not a 12-piece burst in front of the first MFMA).  Fragments of k-step
+    // s + 1 are requested before the MFMAs of k-step s are issued (two fragment sets; the sched_barriers pin that order: the scheduler
+    // otherwise sinks the reads back to their first use and the LDS latency of every k-step sits in front of its MFMAs).
+#define CM2_STEP(CUR, NXT, K)                                                                                \
+    if ((K) < KC) {                                                                                          \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");                                \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        asm volatile("" ::: "memory");                                                                       \
+        /* (past the end: a harmless repeat of the last chunk into a dead stage keeps the piece count of every step the same) */ \
+        const int kn_ = (K) + 2 < KC ? (K) + 2 : KC - 1;                                                     \
+        if (live) {                                                                                          \
+            V8 af_[2][AJ], bf_[2][2];                                                                        \
+            CM2_FRAGS(CUR, 0, 0)                                                                             \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                               \
+                CM2_ISSUE(NXT, kn_, s_ * PPW / 4, (s_ + 1) * PPW / 4)                                        \
+                if (s_ < 3) CM2_FRAGS(CUR, s_ + 1, (s_ + 1) & 1)                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                           \
+                _Pragma("unroll") for (int x_ = 0; x_ < AJ; ++x_)                                            \
+                    _Pragma("unroll") for (int y_ = 0; y_ < 2; ++y_)                                         \
+                        acc[x_][y_] = TR::mfma32(af_[s_ & 1][x_], bf_[s_ & 1][y_], acc[x_][y_]);             \
+                __builtin_amdgcn_sched_barrier(0);                                                           \
+            }                                                                                                \
+        } else {                                                                                             \
+            CM2_ISSUE(NXT, kn_, 0, PPW)                                                                      \
+        }                                                                                                    \
+    }
+    CM2_ISSUE(st0, 0, 0, PPW)
+    CM2_ISSUE(st1, KC > 1 ? 1 : 0, 0, PPW)
+#pragma unroll 1
+    for (int kc = 0; kc < KC; kc += 3) {
+        CM2_STEP(st0, st2, kc)
+        CM2_STEP(st1, st0, kc + 1)
+        CM2_STEP(st2, st1, kc + 2)
+    }
+#undef CM2_STEP
+#undef CM2_FRAGS
+#undef CM2_ISSUE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the repeats of the last chunk: nothing may land after the wave ends
+    if (!live) return;
+    // masked running max over j (lane-local), r on the lane — as k_corr_max
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        float b_in = -1.f, b_wo = -1.f;
+        int ji = 0, jw = 0;
+#pragma unroll
+        for (int x = 0; x < AJ; ++x)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int j = j0 + (wj * AJ + x) * 32 + acc_key(i, h);
+                const float v = acc[x][y][i];
+                const float vi = v * a.m_inp[j], vw = v * a.m_wo[j];
+                if (vi > b_in) { b_in = vi; ji = j; }
+                if (vw > b_wo) { b_wo = vw; jw = j; }
+            }
+        unsigned long long pi = b_in >= 0.f ? (((unsigned long long)__float_as_uint(b_in) << 32) | (0xFFFFFFFFu - (unsigned)ji)) : 0ull;
+        unsigned long long pw = b_wo >= 0.f ? (((unsigned long long)__float_as_uint(b_wo) << 32) | (0xFFFFFFFFu - (unsigned)jw)) : 0ull;
+        const unsigned long long oi = __shfl_xor(pi, 32, 64), ow = __shfl_xor(pw, 32, 64);
+        pi = pi > oi ? pi : oi;
+        pw = pw > ow ? pw : ow;
+        const int r = r0 + wr * 64 + y * 32 + (lane & 31);
+        if (h == 0 && r < a.R) {
+            unsigned long long* dst = a.best + ((size_t)hd * a.R + r) * 2;
+            atomicMax(dst, pi);
+            atomicMax(dst + 1, pw);
+        }
+    }
+}
+
+// variant selection: GD_CORR_MAX = "0" (k_corr_max), "42" / "24" / "22" (k_corr_max2 with AJ WJ = 4 x 2, 2 x 4, 2 x 2), unset: the
+// launcher's choice
+static int corr_variant(int H, int R, int N, int Mpad) {
+    if (Mpad % CM_K != 0 || Mpad < 4 * CM_K) return 0;
+    const char* e = getenv("GD_CORR_MAX");
+    const int want = e ? atoi(e) : -1;
+    if (want == 0) return 0;
+    if (want == 42 || want == 24) return (N % 256 == 0) ? want : 0;
+    if (want == 22) return (N % 128 == 0) ? want : 0;
+    // measured (tools/bench_corr.py, bench_corr2.py; 64^2: 5 heads x 4096 x 4096): eight waves of 64 x 64 beat four of 128 x 64 at every
+    // list length (44 against 50 us per round); the 32^2 layers (1024 keys: 16 chunks) are launch-bound and fastest on 128 x 128 tiles
+    if (N % 256 == 0 && N >= 2048) return 24;
+    return (N % 128 == 0) ? 22 : 0;
+}
+
 extern "C" int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
                                    int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream) {
     GD_REQUIRE(Pe && Pb && m_inp && m_wo && best, GD_EINVAL, "gd_removal_corr_max: null pointer");
@@ -144,6 +322,19 @@ extern "C" int gd_removal_corr_max(const void* Pe, const void* Pb, const float* 
     a.jtiles = (N + CM_T - 1) / CM_T;
     hipStream_t st = as_stream(stream);
     gd_zero_async(best, (size_t)H * R * 2 * sizeof(unsigned long long), st);
+    const int var = corr_variant(H, R, N, Mpad);
+    if (var) {
+        const int aj = var / 10, wjn = var % 10;
+        a.jtiles = ((N / (32 * aj * wjn)) * H + 7) / 8 * 8;             // (head, j-tile) pairs per r-tile, padded to the 8 XCDs
+        dim3 grid2(a.rtiles * a.jtiles, 1);
+#define GD_CM2(AJ_, WJ_)                                                                            \
+        if (dtype == GD_F16) k_corr_max2<f16_t, AJ_, WJ_><<<grid2, 128 * WJ_, 0, st>>>(a);          \
+        else k_corr_max2<bf16_t, AJ_, WJ_><<<grid2, 128 * WJ_, 0, st>>>(a)
+        if (var == 42) { GD_CM2(4, 2); } else if (var == 24) { GD_CM2(2, 4); } else { GD_CM2(2, 2); }
+#undef GD_CM2
+        GD_CHECK_LAUNCH("gd_removal_corr_max");
+        return GD_OK;
+    }
     dim3 grid(a.rtiles * a.jtiles, H);
     if (dtype == GD_F16) k_corr_max<f16_t><<<grid, 256, 0, st>>>(a);
     else k_corr_max<bf16_t><<<grid, 256, 0, st>>>(a);

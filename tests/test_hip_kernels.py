@@ -706,6 +706,42 @@ def test_removal_loss_forward_backward(ops, M):
     assert float(dq32.cpu()[:, (m_inp < 0.5)].abs().max()) == 0.0           # only inpaint rows receive gradient
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,N,R,nv", [(2, 1024, 70, None), (2, 1024, 192, 130), (1, 4096, 256, 200), (2, 4096, 512, 307), (1, 2304, 256, 256)])
+def test_corr_max_variants_are_bit_identical(ops, monkeypatch, dtype, H, N, R, nv):
+    """k_corr_max2 (direct-to-LDS staging, three stages, 4 x 2 / 2 x 4 / 2 x 2 blocks x waves) against k_corr_max (register staging): the
+    same MFMA operand order and the same k order, so the f32 correlations and with them every (value, arg-max) pair must be IDENTICAL —
+    live slots only (slots past n_valid are not computed by either).  N = 2304 (48^2 tokens: BASELINE configs[3]) is a multiple of 256
+    but its 36 key chunks are not a multiple of the three stages; R = 70 / 192 end inside a 128-row tile (rows past the list read as
+    zeros through the buffer descriptor)."""
+    g = torch.Generator(device=DEV).manual_seed(N + R)
+    Pb = torch.softmax(torch.randn(H, N, N, device=DEV, generator=g) * 2.0, -1).to(dtype)
+    Pe = torch.softmax(torch.randn(H, R, N, device=DEV, generator=g) * 2.0, -1).to(dtype)
+    if nv is not None and nv < R:
+        Pe[:, nv:] = float("nan")                         # what a skipped tile of gd_attn_probs leaves behind
+    m_inp = (torch.rand(N, device=DEV, generator=g) < 0.1).float()
+    m_wo = (1 - m_inp) * (torch.rand(N, device=DEV, generator=g) < 0.8).float()
+    rows = torch.randperm(N, device=DEV, generator=g)[:R].to(torch.int32).contiguous()
+    nvt = None if nv is None else torch.tensor([nv], dtype=torch.int32, device=DEV)
+    S = int(N ** 0.5)
+    live = R if nv is None else nv
+    res = {}
+    for var in ("0", "42", "24", "22"):
+        monkeypatch.setenv("GD_CORR_MAX", var)
+        aux, loss = ops.removal_fwd(Pe, Pb, m_inp, m_wo, rows, S, n_valid=nvt)
+        torch.cuda.synchronize()
+        res[var] = ({k: v[:, :live].clone() for k, v in aux.items()}, loss.clone())
+    monkeypatch.delenv("GD_CORR_MAX")
+    aux_d, loss_d = ops.removal_fwd(Pe, Pb, m_inp, m_wo, rows, S, n_valid=nvt)          # the launcher's own choice
+    res["default"] = ({k: v[:, :live].clone() for k, v in aux_d.items()}, loss_d.clone())
+    ref_aux, ref_loss = res["0"]
+    assert torch.isfinite(ref_loss).all() and float(ref_aux["p_wo"].min()) > 0
+    for var, (aux, loss) in res.items():
+        for k in ("p_in", "j_in", "p_wo", "j_wo", "wgt"):
+            assert torch.equal(aux[k], ref_aux[k]), (var, k)
+        assert torch.equal(loss, ref_loss), var
+
+
 # ------------------------------------------------------------------------------------------------ scheduler arithmetic
 def test_removal_loss_nan_rows_keep_indices_valid(ops):
     """Diverged latents give NaN probability rows; torch.max would return NaN, and so does the loss here — but the arg-max INDEX

@@ -88,6 +88,22 @@ def main():
         for n, a in own:
             fh.write(f"| `{n}` | {a[0]} | {a[1] * 1e-3:.1f} | {a[1] / a[0]:.1f} | {a[2]:.1f} | {a[3]:.1f} |\n")
         fh.write(f"\nown kernels total {sum(a[1] for _, a in own) * 1e-3:.1f} ms of {tot:.1f} ms\n")
+        # the hooked layer OUTSIDE the 64^2 self-attention forward: every kernel of the controllers except the 64^2
+        # forward launches counted below and the UNet harness (conv / norm / GEMM glue)
+        hooked = ("k_attn_fwd", "k_attn_fwd_mp", "k_blend", "k_blend_rows", "k_attn_bwd_dq", "k_attn_bwd_dq64", "k_removal_bwd", "k_corr_max", "k_corr_max2",
+                  "k_attn_probs", "k_attn_probs2", "k_losses_fwd", "k_losses_bwd", "k_gauss5", "k_removal_rowdot", "k_attn_bwd_dk", "k_removal_reduce",
+                  "k_attn_bwd_dk_reduce", "k_zero_u32", "k_removal_dq_fold", "k_losses_fold", "k_loss_assemble", "k_rows_merge",
+                  "k_removal_dk", "k_amodal_interp", "k_attn_bwd_dq_fold", "k_amodal", "k_losses_tail", "k_bwd_fold", "k_losses_bwd_rowdot",
+                  "k_bwd_dq_removal")
+        n_edits = max(1, int(__import__("os").environ.get("GD_PROF_EDITS", "2")))
+        w64_small = sum(a[1] for n, a in fam.items() if n == "k_attn_fwd_w64") - sum(v[1] for (b, _), v in self64.items() if b == "k_attn_fwd_w64")
+        mp_big = sum(v[1] for (b, _), v in self64.items() if b == "k_attn_fwd_mp")
+        hk = sum(a[1] for n, a in fam.items() if n in hooked) - mp_big + w64_small
+        hl = sum(a[0] for n, a in fam.items() if n in hooked)
+        fh.write(f"\n**hooked layer outside the 64^2 forward: {hk * 1e-3 / n_edits:.1f} ms per edit** ({hl // n_edits} launches per edit; "
+                 f"the kernels of `geodiffuser_amd/attention_processors.py` except the 64^2 self-attention launches below; {n_edits} edits in the region)\n")
+        big = sum(g for g, *_ in top_gaps if g >= 1000.0)
+        fh.write(f"\n**idle gaps >= 1 ms: {big * 1e-3 / n_edits:.1f} ms per edit; GPU idle {100 * (1 - busy / span):.1f} % of the region**\n")
         if self64:
             cnt = sum(v[0] for v in self64.values()); us = sum(v[1] for v in self64.values())
             fh.write("\n## 64^2 self-attention launches (N = M = 4096: the launches bench.py's `roofline` is computed from)\n\n"

@@ -19,7 +19,7 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 # per-file extras.  attn_fwd: -O3's SLP vectoriser packs the softmax's neighbouring f32 adds / multiplies into v_pk_*_f32, which cost
 # more issue time beside MFMAs than the single instructions they replace (MI355X_MICROARCH.md, per-instruction constants)
-EXTRA_FLAGS = {"attn_fwd.hip": ["-fno-slp-vectorize"], "attn_fwd_mp.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"attn_fwd.hip": ["-fno-slp-vectorize"], "attn_fwd_mp.hip": ["-fno-slp-vectorize"], "attn_bwd.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

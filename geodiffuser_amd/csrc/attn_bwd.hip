@@ -11,6 +11,7 @@
 //   k_attn_bwd_dk : cross-attention only (M <= 128 keys): key on the MFMA lane, query tiles streamed through LDS, per-chunk
 //                   partial dK summed by a second kernel (see below).
 // MFMA-bound (dq): algorithmic FLOPs = 6 * BH * N * M * D.
+#include <stdlib.h>
 #include "attn_common.hpp"
 
 struct BwdArgs {
@@ -159,6 +160,191 @@ k_attn_bwd_dq(const BwdArgs a) {
                 *(typename TR::vec4*)(dp + dblk * 32 + 8 * g + 4 * h) = w;
             }
     }
+}
+
+
+// ---- k_attn_bwd_dq2: the same arithmetic on direct-to-LDS staging --------------------------------------------------------------
+// Round 4 (what k_corr_max2 / the 64-query forward learnt): K and V tiles arrive by buffer_load ... lds into THREE stages (16 KB each:
+// one tile pair), tile t + 2 issued right behind the barrier that retires tile t - 1, counted s_waitcnt vmcnt + raw s_barrier (a
+// __syncthreads() fence would drain the loads in flight), no staging registers and no ds_write; two workgroups of four 32-query waves per
+// CU (two waves per SIMD: one wave's exponentials under the other's MFMAs).  The key tiles are cut into `kchunks` runs chosen so that the
+// launch is ONE round of <= 512 resident workgroups (5 heads at 64^2: 160 query tiles x 3 runs of 21-22 key tiles; k_attn_bwd_dq's
+// power-of-two split made 640 workgroups = 1.25 rounds).  Full key tiles only (M % 64 == 0), head dim 64.
+// Same MFMA operand order per tile as k_attn_bwd_dq; the partials of a row are summed in run order by the fold: results differ from the
+// unsplit kernel only by the f32 grouping of the key range.
+#define DQ2_PPW 4                                  // direct-to-LDS pieces per wave and tile pair: 2 of K, 2 of V
+// PRE: c == 1 exactly (the optimisation pass's queries carry scale * log2 e, attention_processors._project_qkv): the score accumulator
+// starts at -lse * log2 e, so p = exp2(acc) with no vector instruction in front.  Both variants start the dP accumulator at -delta
+// (dS = p * acc): two of the five vector instructions per probability move into the MFMAs' C operand, the loop becomes MFMA-bound
+// (32 probabilities per wave and tile: 14.5 + 8 issue cycles each against 24 MFMAs x 32).
+template <typename T, bool PRE>
+__global__ void __launch_bounds__(256, 2)
+k_attn_bwd_dq2(const BwdArgs a) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    __shared__ __attribute__((aligned(16))) char st0[2 * ATT_TILE_BYTES];      // [K | V]
+    __shared__ __attribute__((aligned(16))) char st1[2 * ATT_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char st2[2 * ATT_TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg0 = xcd_remap(blockIdx.x, a.nwg);
+    const int kc = wg0 % a.kchunks, wg = wg0 / a.kchunks;
+    const int bh = wg / a.tiles, tile = wg - bh * a.tiles;
+    const int N = a.N, M = a.M;
+    const T* __restrict__ qp = (const T*)a.q + (size_t)bh * N * ATT_D;
+    const T* __restrict__ op = (const T*)a.o + (size_t)bh * N * ATT_D;
+    const T* __restrict__ gp = (const T*)a.dout + (size_t)bh * N * ATT_D;
+    const int T_all = M / ATT_BN;
+    const int t_lo = kc * a.tpc;
+    const int t_hi = (t_lo + a.tpc) < T_all ? (t_lo + a.tpc) : T_all;
+    const int Tg = t_hi - t_lo;                                             // launcher: every run holds at least one tile
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)a.k + ((size_t)bh * M + (size_t)t_lo * ATT_BN) * ATT_D), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)a.v + ((size_t)bh * M + (size_t)t_lo * ATT_BN) * ATT_D), 0, 0x7FFFFFFF, 0x00020000);
+    uint32_t voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (2 * wave + j) * 8 + (lane >> 3);
+        const int x = (row >> 1) & 7, g = (x & 2) | ((x & 1) << 2) | ((x >> 2) & 1);
+        voff[j] = (uint32_t)((row * ATT_D + ((lane & 7) ^ g) * 8) * (int)sizeof(T));
+    }
+#define DQ2_ISSUE(ST, TI)                                                                        \
+    {                                                                                            \
+        const int so_ = (TI) * ATT_TILE_BYTES;                                                   \
+        dma_asm(rsK, (ST) + wave * 2048, voff[0], so_);                                          \
+        dma_asm(rsK, (ST) + wave * 2048 + 1024, voff[1], so_);                                   \
+        dma_asm(rsV, (ST) + ATT_TILE_BYTES + wave * 2048, voff[0], so_);                         \
+        dma_asm(rsV, (ST) + ATT_TILE_BYTES + wave * 2048 + 1024, voff[1], so_);                  \
+    }
+    DQ2_ISSUE(st0, 0)
+    DQ2_ISSUE(st1, Tg > 1 ? 1 : 0)
+
+    const int qrow = tile * ATT_BM + wave * 32 + (lane & 31);
+    const int qld = qrow < N ? qrow : N - 1;
+    V8 qf[4], gf[4];
+    float dpart = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = *(const V8*)(qp + (size_t)qld * ATT_D + 16 * s + 8 * h);
+        gf[s] = *(const V8*)(gp + (size_t)qld * ATT_D + 16 * s + 8 * h);
+        const V8 of = *(const V8*)(op + (size_t)qld * ATT_D + 16 * s + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dpart = __builtin_fmaf(TR::to_f32(gf[s][j]), TR::to_f32(of[j]), dpart);
+    }
+    const float delta = dpart + __shfl_xor(dpart, 32, 64);         // rowsum(dO o O)
+    const float lse2 = a.lse[(size_t)bh * N + qld] * a.l2e;
+    // The compiler counts only ITS loads: a wait it emits for q / dO / O / lse inside the loop (`vmcnt(0)`: "my last load") would drain
+    // the asm-issued pieces of later tiles on every trip.  Retire them here, once: an empty asm that reads every loaded register.
+    float delta_ = delta, lse2_ = lse2;
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(gf[0]), "+v"(gf[1]), "+v"(gf[2]), "+v"(gf[3]), "+v"(delta_), "+v"(lse2_));
+    f32x16 c_s, c_p;                     // the chains' C operands: -lse2 (PRE; else 0) and -delta in every register
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c_s[i] = PRE ? -lse2_ : 0.f; c_p[i] = -delta_; }
+    const FragOffs fo = make_frag_offs(lane);
+    f32x16 dq[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[j][i] = 0.f;
+
+    // One tile.  The fragment reads of a group are issued one group AHEAD of its MFMAs and the order is pinned (sched_barrier): left to
+    // itself the scheduler sinks every ds_read to just in front of the MFMA that consumes it (`s_waitcnt lgkmcnt(1)` before each of the
+    // 24 MFMAs of a tile: the LDS latency 24 times per tile; PMC of that build: MFMA busy 30 %, waves parked 39 % of their cycles).
+    //   read K / V rows of keys 0..31 | read rows of keys 32..63, MFMAs of keys 0..31 | read K^T (k-steps 0, 1), MFMAs of keys 32..63 beside
+    //   the exponentials of keys 0..31 | read K^T (k-steps 2, 3), exponentials of keys 32..63 beside dQ (k-steps 0, 1) | dQ (k-steps 2, 3)
+#define DQ2_SOFTMAX(SA, PA, D0, D1)                                                                          \
+    {                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                     \
+            const float p = __builtin_amdgcn_exp2f(PRE ? SA[i] : __builtin_fmaf(SA[i], a.c, -lse2_));        \
+            SA[i] = p * PA[i];                                                                               \
+        }                                                                                                    \
+        D0 = acc_to_frag<T>(SA, 0);                                                                          \
+        D1 = acc_to_frag<T>(SA, 1);                                                                          \
+    }
+#define DQ2_STEP(CUR, NXT, TT)                                                                               \
+    if ((TT) < Tg) {                                                                                         \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DQ2_PPW) : "memory");                            \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        asm volatile("" ::: "memory");                                                                       \
+        {                                                                                                    \
+            const int tn_ = (TT) + 2 < Tg ? (TT) + 2 : Tg - 1;      /* past the end: a harmless repeat into a dead stage */ \
+            DQ2_ISSUE(NXT, tn_)                                                                              \
+        }                                                                                                    \
+        const char* lk = (CUR);                                                                              \
+        const char* lv = (CUR) + ATT_TILE_BYTES;                                                             \
+        V8 ka[4], va[4], kb[4], vb[4], kt0[4], kt1[4], dsf[4];                                               \
+        f32x16 s0 = c_s, p0 = c_p, s1 = c_s, p1 = c_p;                                                       \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) { ka[s] = rd_row<T>(lk, fo, 0, s); va[s] = rd_row<T>(lv, fo, 0, s); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) { kb[s] = rd_row<T>(lk, fo, 1, s); vb[s] = rd_row<T>(lv, fo, 1, s); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) { s0 = TR::mfma32(ka[s], qf[s], s0); p0 = TR::mfma32(va[s], gf[s], p0); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        kt0[0] = rd_tr<T>(lk, fo, 0, 0); kt0[1] = rd_tr<T>(lk, fo, 0, 1); kt1[0] = rd_tr<T>(lk, fo, 1, 0); kt1[1] = rd_tr<T>(lk, fo, 1, 1); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) { s1 = TR::mfma32(kb[s], qf[s], s1); p1 = TR::mfma32(vb[s], gf[s], p1); } \
+        DQ2_SOFTMAX(s0, p0, dsf[0], dsf[1])                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        kt0[2] = rd_tr<T>(lk, fo, 0, 2); kt0[3] = rd_tr<T>(lk, fo, 0, 3); kt1[2] = rd_tr<T>(lk, fo, 1, 2); kt1[3] = rd_tr<T>(lk, fo, 1, 3); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        dq[0] = TR::mfma32(kt0[0], dsf[0], dq[0]); dq[1] = TR::mfma32(kt1[0], dsf[0], dq[1]);                \
+        dq[0] = TR::mfma32(kt0[1], dsf[1], dq[0]); dq[1] = TR::mfma32(kt1[1], dsf[1], dq[1]);                \
+        DQ2_SOFTMAX(s1, p1, dsf[2], dsf[3])                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        dq[0] = TR::mfma32(kt0[2], dsf[2], dq[0]); dq[1] = TR::mfma32(kt1[2], dsf[2], dq[1]);                \
+        dq[0] = TR::mfma32(kt0[3], dsf[3], dq[0]); dq[1] = TR::mfma32(kt1[3], dsf[3], dq[1]);                \
+    }
+#pragma unroll 1
+    for (int t = 0; t < Tg; t += 3) {
+        DQ2_STEP(st0, st2, t)
+        DQ2_STEP(st1, st0, t + 1)
+        DQ2_STEP(st2, st1, t + 2)
+    }
+#undef DQ2_STEP
+#undef DQ2_SOFTMAX
+#undef DQ2_ISSUE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the repeats of the last tile pair: nothing may land after the wave ends
+    if (qrow >= N) return;
+    if (a.kchunks > 1) {                 // f32 partial of this key run
+        const int n_bh = a.nwg / (a.kchunks * a.tiles);
+        float* __restrict__ pp = a.dq_part + (((size_t)kc * n_bh + bh) * N + qrow) * ATT_D;
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = dq[dblk][4 * g + j] * a.scale;
+                *(f32x4*)(pp + dblk * 32 + 8 * g + 4 * h) = w;
+            }
+        return;
+    }
+    T* __restrict__ dp = (T*)a.dq + ((size_t)bh * N + qrow) * ATT_D;
+#pragma unroll
+    for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            typename TR::vec4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = TR::from_f32(dq[dblk][4 * g + j] * a.scale);
+            *(typename TR::vec4*)(dp + dblk * 32 + 8 * g + 4 * h) = w;
+        }
+}
+
+// dq2's run count: the launch should be ONE round of at most 512 resident workgroups (two per CU), every run at least 8 key tiles
+static int dq2_kchunks(int BH, int N, int M) {
+    const long long wgs = (long long)((N + ATT_BM - 1) / ATT_BM) * BH;
+    const int t_all = M / ATT_BN;
+    int kc = (int)(512 / (wgs > 0 ? wgs : 1));
+    if (const char* e = getenv("GD_DQ2_KC")) { const int v = atoi(e); if (v > 0) return v < t_all ? v : t_all; }     // tuning hook (tools/bench_bwd.py)
+    if (kc > t_all / 8) kc = t_all / 8;
+    if (kc > 8) kc = 8;
+    return kc < 1 ? 1 : kc;
+}
+// GD_BWD_DQ = "1": k_attn_bwd_dq (register staging) everywhere; default: k_attn_bwd_dq2 where it applies (D = 64, full key tiles, >= 4 tiles)
+static bool dq2_applies(int M, int D) {
+    if (D != ATT_D || M % ATT_BN != 0 || M < 4 * ATT_BN) return false;
+    const char* e = getenv("GD_BWD_DQ");
+    return !(e && e[0] == '1');
 }
 
 // dq[i] = 16-bit( sum_c dq_part[c][i] ), c ascending (4 elements per thread)
@@ -512,7 +698,7 @@ static size_t bwd_dk_ws_bytes(int BH, int N, int M, int D, int need_dk) {
 }
 
 extern "C" size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk) {
-    const int kc = dq_kchunks(BH, N, M);
+    const int kc = dq2_applies(M, D) ? dq2_kchunks(BH, N, M) : dq_kchunks(BH, N, M);
     return bwd_dk_ws_bytes(BH, N, M, D, need_dk) + (kc > 1 ? (size_t)kc * BH * N * D * sizeof(float) : 0);
 }
 
@@ -531,15 +717,23 @@ extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const vo
     a.q = q; a.k = k; a.v = v; a.o = out; a.lse = lse; a.dout = dout; a.dq = dq; a.dk = dk_f32; a.dk_part = (float*)workspace;
     a.N = N; a.M = M;
     a.tiles = (N + ATT_BM - 1) / ATT_BM;
-    a.kchunks = dq_kchunks(BH, N, M);
+    const bool dq2 = dq2_applies(M, D);
+    a.kchunks = dq2 ? dq2_kchunks(BH, N, M) : dq_kchunks(BH, N, M);
     a.tpc = ((M + ATT_BN - 1) / ATT_BN + a.kchunks - 1) / a.kchunks;
+    while (a.kchunks > 1 && (long long)a.tpc * (a.kchunks - 1) >= (M + ATT_BN - 1) / ATT_BN) --a.kchunks;      // no empty run
     a.dq_part = (float*)((char*)workspace + bwd_dk_ws_bytes(BH, N, M, D, dk_f32 != nullptr));
     a.nwg = a.tiles * BH * a.kchunks;
     a.scale = scale;
     a.c = scale * 1.4426950408889634f;
     a.l2e = 1.4426950408889634f;
     hipStream_t st = as_stream(stream);
-    GD_LAUNCH_NCH(k_attn_bwd_dq, a.nwg, a);
+    if (dq2) {
+        const bool pre = a.c == 1.0f;
+        if (dtype == GD_F16) { if (pre) k_attn_bwd_dq2<f16_t, true><<<a.nwg, 256, 0, st>>>(a); else k_attn_bwd_dq2<f16_t, false><<<a.nwg, 256, 0, st>>>(a); }
+        else { if (pre) k_attn_bwd_dq2<bf16_t, true><<<a.nwg, 256, 0, st>>>(a); else k_attn_bwd_dq2<bf16_t, false><<<a.nwg, 256, 0, st>>>(a); }
+    } else {
+        GD_LAUNCH_NCH(k_attn_bwd_dq, a.nwg, a);
+    }
     if (a.kchunks > 1) {
         const long long n4 = (long long)BH * N * D / 4;
         const int fb = (int)((n4 + 255) / 256);

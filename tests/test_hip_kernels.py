@@ -563,6 +563,35 @@ def test_attention_backward(ops, dtype, BH, N, M, need_dk):
         assert rel_err(dk.cpu(), rk) < 3 * tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("BH,N,M", [(5, 4096, 4096), (3, 1024, 1024), (2, 576, 576), (1, 200, 448), (10, 1024, 1024), (2, 2304, 2304)])
+def test_attention_backward_dq_direct_to_lds_variant(ops, monkeypatch, dtype, BH, N, M):
+    """k_attn_bwd_dq2 (direct-to-LDS staging, three stages, key runs sized to one round) against k_attn_bwd_dq (register staging): the
+    same per-tile arithmetic, so the two differ only by the f32 grouping of the key range (partials per run) — far inside the 16-bit
+    output step — and both sit at the same distance from the fp64 reference.  Shapes: the benchmark's 64^2 x 5 heads (3 runs of 22 /
+    21 / 21 key tiles), 32^2 (16 tiles: 2 runs / 1 run), 9 and 7 tiles (not a multiple of the three stages; a ragged last query tile),
+    48^2 tokens (configs[3])."""
+    g_ = torch.Generator(device=DEV).manual_seed(N + M + BH)
+    q = (torch.randn(BH, N, 64, device=DEV, generator=g_) * 1.2).to(dtype); k = (torch.randn(BH, M, 64, device=DEV, generator=g_) * 1.2).to(dtype)
+    v = torch.randn(BH, M, 64, device=DEV, generator=g_).to(dtype); g = (torch.randn(BH, N, 64, device=DEV, generator=g_) * 0.1).to(dtype)
+    out = torch.empty_like(q); lse = torch.empty(BH, N, device=DEV)
+    ops.attn_fwd([(q, k, v, out, lse)], 0.125)
+    monkeypatch.setenv("GD_BWD_DQ", "1")
+    dq_old, _ = ops.attn_bwd(q, k, v, out, lse, g, 0.125, False)
+    monkeypatch.delenv("GD_BWD_DQ")
+    dq_new, _ = ops.attn_bwd(q, k, v, out, lse, g, 0.125, False)
+    dq_new2, _ = ops.attn_bwd(q, k, v, out, lse, g, 0.125, False)
+    torch.cuda.synchronize()
+    assert torch.equal(dq_new, dq_new2)                                      # fixed-order fold: bit-reproducible
+    assert rel_l2(dq_new.double(), dq_old.double()) < (1e-3 if dtype == torch.float16 else 6e-3)
+    if BH * N * M <= 3 * 1024 * 1024:
+        qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+        o = torch.einsum("bnm,bmd->bnd", torch.softmax(torch.einsum("bnd,bmd->bnm", qd, kd) * 0.125, -1), vd)
+        (rq,) = torch.autograd.grad((o * g.double()).sum(), [qd])
+        e_new, e_old = rel_l2(dq_new.double(), rq), rel_l2(dq_old.double(), rq)
+        assert e_new < 1.2 * e_old + 1e-4, (e_new, e_old)
+
+
 def test_attention_probs(ops):
     torch.manual_seed(3)
     for BH, N, M in ((2, 256, 256), (2, 1024, 77), (1, 300, 77)):

@@ -11,13 +11,24 @@ def bench(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 torch.manual_seed(0)
+LN2 = 0.6931471805599453
 for (H, N, M) in ((5, 4096, 4096), (5, 4096, 77), (10, 1024, 1024), (10, 1024, 77)):
     q = (torch.randn(H, N, 64, device=dev) * 1.2).to(dt); k = (torch.randn(H, M, 64, device=dev) * 1.2).to(dt); v = torch.randn(H, M, 64, device=dev).to(dt)
     g = (torch.randn(H, N, 64, device=dev) * 0.1).to(dt)
     out = torch.empty_like(q); lse = torch.empty(H, N, device=dev)
     ops.attn_fwd([(q, k, v, out, lse)], 0.125)
     t = bench(lambda: ops.attn_bwd(q, k, v, out, lse, g, 0.125, M == 77))
-    print(f"attn_bwd H={H} N={N} M={M} dk={M==77}: {t:8.1f} us")
+    os.environ["GD_BWD_DQ"] = "1"
+    t_old = bench(lambda: ops.attn_bwd(q, k, v, out, lse, g, 0.125, M == 77))
+    os.environ.pop("GD_BWD_DQ")
+    fl = 6.0 * H * N * M * 64
+    if M == N:      # the optimisation pass's form: queries carry scale * log2 e, scale = ln 2 (c == 1: the score chain starts at -lse)
+        qp = (q.float() * (0.125 * 1.4426950408889634)).to(dt); outp = torch.empty_like(q); lsep = torch.empty(H, N, device=dev)
+        ops.attn_fwd([(qp, k, v, outp, lsep)], LN2)
+        tp_ = bench(lambda: ops.attn_bwd(qp, k, v, outp, lsep, g, LN2, False))
+        print(f"   pre-scaled queries (scale = ln 2): {tp_:8.1f} us ({fl / tp_ * 1e-6 / 2500:4.2f})")
+    print(f"attn_bwd H={H} N={N} M={M} dk={M==77}: {t:8.1f} us = {fl / t * 1e-6:7.0f} TF/s ({fl / t * 1e-6 / 2500:4.2f} of the MFMA peak, dq + fold [+ dk]);  "
+          f"k_attn_bwd_dq (GD_BWD_DQ=1): {t_old:8.1f} us ({fl / t_old * 1e-6 / 2500:4.2f})")
     R = N * 3 // 40
     rows = torch.arange(0, R, device=dev, dtype=torch.int32) * 7 % N
     rows = torch.unique(rows).to(torch.int32); R = rows.numel()

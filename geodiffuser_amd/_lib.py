@@ -23,6 +23,30 @@ class GdAttnSeg(Structure):
                 ("q_rows", c_void_p), ("q_rows_n", c_void_p), ("q_rows_len", c_int32)]
 
 
+class GdProbs(Structure):                    # gd_probs_t
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("lse", c_void_p), ("rows", c_void_p), ("n_valid", c_void_p), ("P", c_void_p),
+                ("BH", c_int32), ("N", c_int32), ("R", c_int32), ("M", c_int32), ("Mpad", c_int32)]
+
+
+class GdEditLosses(Structure):               # gd_edit_losses_t
+    _fields_ = [("eo", c_void_p), ("ro", c_void_p), ("tgt", c_void_p), ("m_wo", c_void_p), ("m_edit", c_void_p), ("w_am", c_void_p),
+                ("m_amodal", c_void_p),
+                ("best", c_void_p), ("rows", c_void_p), ("n_valid", c_void_p),
+                ("p_in", c_void_p), ("j_in", c_void_p), ("p_wo", c_void_p), ("j_wo", c_void_p), ("wgt", c_void_p),
+                ("inv5", c_void_p), ("inv_rm", c_void_p), ("wv", c_void_p), ("inv5_bwd", c_void_p),
+                ("out12", c_void_p), ("workspace", c_void_p), ("ticket", c_void_p),
+                ("H", c_int32), ("S", c_int32), ("D", c_int32), ("R", c_int32), ("use_amodal", c_int32)]
+
+
+class GdRemovalBwd(Structure):               # gd_removal_bwd_t
+    _fields_ = [("Pe", c_void_p), ("Pb", c_void_p), ("q", c_void_p), ("k", c_void_p), ("rows", c_void_p),
+                ("p_in", c_void_p), ("j_in", c_void_p), ("p_wo", c_void_p), ("j_wo", c_void_p), ("wgt", c_void_p),
+                ("m_inp", c_void_p), ("m_wo", c_void_p), ("gscale", c_void_p), ("gscale2", c_void_p), ("n_valid", c_void_p),
+                ("dk_f32", c_void_p), ("workspace", c_void_p),
+                ("coef", c_float), ("scale", c_float),
+                ("H", c_int32), ("R", c_int32), ("N", c_int32), ("M", c_int32), ("Mpad", c_int32), ("D", c_int32)]
+
+
 class GeodiffError(RuntimeError):
     pass
 
@@ -81,6 +105,17 @@ SIGNATURES = {
     "gd_edit_losses_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gd_blend_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "gd_blend_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "gd_attn_probs_pair": (c_int, [POINTER(GdProbs), POINTER(GdProbs), c_int, c_float, c_void_p, c_size_t, c_int, c_void_p]),
+    "gd_removal_corr_max_nz": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_void_p, c_int, c_void_p]),
+    "gd_edit_losses_fused": (c_int, [POINTER(GdEditLosses), c_int, c_void_p]),
+    "gd_edit_losses_bwd_rowdot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, POINTER(GdRemovalBwd), c_int, c_void_p]),
+    "gd_removal_bwd_nofold": (c_int, [POINTER(GdRemovalBwd), c_int, c_void_p]),
+    "gd_attn_bwd_nofold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_float, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_int), POINTER(c_void_p), c_int, c_void_p]),
+    "gd_edit_dq_fold": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gd_group_norm_nhwc_scratch_floats": (c_int64, [c_int, c_int, c_int]),
     "gd_group_norm_set_single_launch": (c_int, [c_int]),
     "gd_group_norm_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
@@ -127,8 +162,8 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
             raise GeodiffError(f"libgeodiff_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.gd_version() != 3:
-        raise GeodiffError(f"ABI version mismatch: library {lib.gd_version()} != binding 3")
+    if lib.gd_version() != 4:
+        raise GeodiffError(f"ABI version mismatch: library {lib.gd_version()} != binding 4")
     _lib = lib
     return lib
 

@@ -191,6 +191,11 @@ FUSED_WARP = os.environ.get("GD_FUSED_WARP", "1") == "1"   # build the warped qu
 # Self-attention layers from 64^2 tokens up (below, the saved work is smaller than the merge launch).
 WARP_ROWS = os.environ.get("GD_WARP_ROWS", "1") == "1"
 WARP_ROWS_MIN_TOKENS = 64 ** 2
+# One hooked optimisation-pass layer in ~12 launches instead of ~20 (include/geodiff_hip.h "R6-R9 fused launches"): merge + blend in one
+# pass, both probability maps + the clear of the arg-max scratch in one launch, the loss sums with the removal reduce / fold / assemble
+# as the last workgroup's tail, the row dots beside the loss backward, one fold for the attention and removal dq partials.  Same
+# arithmetic in the same order; GD_FUSED_LAYER=0 restores the stand-alone launches (the parity tests run both).
+FUSED_LAYER = os.environ.get("GD_FUSED_LAYER", "1") == "1"
 
 
 def _tok_ok(attn, hidden_states) -> bool:
@@ -402,8 +407,15 @@ class _EditLayer(torch.autograd.Function):
                 segs.append((q_edit, k_edit, v_edit, ident_out, None))
         segs.append((q_edit, K, v_base, replace_out, lse_e))                # :433,557 / :791,883
         ops.attn_fwd(segs, scale)
+        fused = FUSED_LAYER
+        blend_done = False
         if (not remover) and edit_act is not None:
-            ops.rows_merge(out_full[b0 * f:b1 * f], edit_act, c["edit_pos"], out=edit_out)
+            if fused:      # rows outside the soft edit mask: the reference row's output; and the blend of :502-508,617-622, in the same pass
+                ops.blend_merge(out_full[b0 * f:b1 * f], edit_act, c["edit_pos"], replace_out if blend else None, c["m_edit"] if blend else None,
+                                eo_out=edit_out, out=out_full[cb:] if blend else None)
+                blend_done = blend
+            else:
+                ops.rows_merge(out_full[b0 * f:b1 * f], edit_act, c["edit_pos"], out=edit_out)
         if remover:
             edit_out = out_full[b0 * f:b1 * f].clone() if want_losses else out_full[b0 * f:b1 * f]
         if store:
@@ -418,28 +430,44 @@ class _EditLayer(torch.autograd.Function):
         if want_losses:
             kind = "cross" if is_cross else "self"
             R = c["rows"].numel()
-            rm = ops.zeros_f32(1, dev)
-            if R > 0:
-                Pb = ops.attn_probs(q_base, k_base, lse_van[b0 * f:b1 * f], None, scale)     # base_att (:307-317)
-                Pe = ops.attn_probs(q_edit, K, lse_e, c["rows"], scale, n_valid=c.get("n_rows"))   # replace_att[:, inpaint rows]
-                aux, rm = ops.removal_fwd(Pe, Pb, c["m_inp"], c["m_wo"], c["rows"], S, n_valid=c.get("n_rows"))
-                ctrl._last_removal_aux = aux          # diagnostics: arg-max indices / values of this layer
             use_amodal = (not remover) and N > 32 ** 2                                       # :479-480,596-597
-            if use_amodal:
-                tgt = ops.amodal_target(edit_out, c["nn_idx"], c["nn_w"], c["m_edit"], S)    # :291-293
             m_edit_l = c["m_edit"] if not remover else c["zeros"]
-            sums = ops.edit_losses_fwd(edit_out, replace_out, tgt, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), S)
             # Everything that depends on the (adaptive) loss weights stays on the device: a captured hipGraph of the
             # optimisation pass then follows the schedule without re-capture, and no host->device copy sits in the layer.
             wv = ctrl.loss_weights_device(kind, dev)                 # [sim, movement, removal, smoothness, amodal]
-            # terms = [sim, movement, removal, smoothness_h + smoothness_w, amodal | 0], loss = sum terms * wv,
-            # coefs = d(loss)/d(sum_i) for the backward (sim, movement, amodal, smooth_h, smooth_w), rm_coef = wv[removal] * inv_rm
-            terms, loss, coefs, rm_coef = ops.loss_assemble(sums, rm, c["inv5"], c["inv_rm"], wv, c["inv5_bwd"], use_amodal)
+            if fused:
+                best = None
+                if R > 0:
+                    best = torch.empty(f, R, 2, dtype=torch.int64, device=dev)
+                    # base_att (:307-317) and replace_att[:, inpaint rows] in one launch, which also clears `best`
+                    Pb, Pe = ops.attn_probs_pair(q_base, k_base, lse_van[b0 * f:b1 * f], q_edit, K, lse_e, c["rows"], c.get("n_rows"), scale, zero=best)
+                    ops.removal_corr_max_nz(Pe, Pb, c["m_inp"], c["m_wo"], c.get("n_rows"), best)
+                if use_amodal:
+                    tgt = ops.amodal_target(edit_out, c["nn_idx"], c["nn_w"], c["m_edit"], S)    # :291-293
+                terms, loss, coefs, rm_coef, aux = ops.edit_losses_fused(
+                    edit_out, replace_out, tgt, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), S, best, c["rows"] if R > 0 else None,
+                    c.get("n_rows"), c["inv5"], c["inv_rm"], wv, c["inv5_bwd"], use_amodal)
+                if aux is not None:
+                    ctrl._last_removal_aux = aux          # diagnostics: arg-max indices / values of this layer
+            else:
+                rm = ops.zeros_f32(1, dev)
+                if R > 0:
+                    Pb = ops.attn_probs(q_base, k_base, lse_van[b0 * f:b1 * f], None, scale)     # base_att (:307-317)
+                    Pe = ops.attn_probs(q_edit, K, lse_e, c["rows"], scale, n_valid=c.get("n_rows"))   # replace_att[:, inpaint rows]
+                    aux, rm = ops.removal_fwd(Pe, Pb, c["m_inp"], c["m_wo"], c["rows"], S, n_valid=c.get("n_rows"))
+                    ctrl._last_removal_aux = aux          # diagnostics: arg-max indices / values of this layer
+                if use_amodal:
+                    tgt = ops.amodal_target(edit_out, c["nn_idx"], c["nn_w"], c["m_edit"], S)    # :291-293
+                sums = ops.edit_losses_fwd(edit_out, replace_out, tgt, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), S)
+                # terms = [sim, movement, removal, smoothness_h + smoothness_w, amodal | 0], loss = sum terms * wv,
+                # coefs = d(loss)/d(sum_i) for the backward (sim, movement, amodal, smooth_h, smooth_w), rm_coef = wv[removal] * inv_rm
+                terms, loss, coefs, rm_coef = ops.loss_assemble(sums, rm, c["inv5"], c["inv_rm"], wv, c["inv5_bwd"], use_amodal)
 
         # output (:502-508,617-624 / :831-834,922-925)
         if not remover:
             if blend:
-                ops.blend_tokens(edit_out, replace_out, c["m_edit"], out=out_full[cb:])
+                if not blend_done:
+                    ops.blend_tokens(edit_out, replace_out, c["m_edit"], out=out_full[cb:])
             else:
                 out_full[cb:].copy_(replace_out)
         else:
@@ -452,7 +480,7 @@ class _EditLayer(torch.autograd.Function):
             ctx.save_for_backward(q_edit, K, v_base, replace_out, lse_e, edit_out if want_losses else None, tgt, Pe, Pb, coefs, rm_coef)
             ctx.aux, ctx.c = aux, c
             ctx.meta = dict(f=f, cb=cb, e0=e0, e1=e1, is_cross=is_cross, scale=scale, remover=remover, blend=blend,
-                            want_losses=want_losses, q_shape=q.shape, k_shape=k.shape, S=S)
+                            want_losses=want_losses, q_shape=q.shape, k_shape=k.shape, S=S, fused=fused)
         ctx.mark_non_differentiable(terms)
         return out_full, loss, terms
 
@@ -470,9 +498,6 @@ class _EditLayer(torch.autograd.Function):
         have_loss = m["want_losses"] and gscale is not None
         eo = edit_out if edit_out is not None else replace_out
         m_edit_l = c["m_edit"] if not m["remover"] else c["zeros"]
-        dro = ops.edit_losses_bwd(eo, replace_out, tgt if have_loss else None, c["m_wo"], m_edit_l, c.get("w_dist"),
-                                  c.get("m_amodal"), gout, coefs if have_loss else _zeros5(dev), gscale,
-                                  blend=(m["blend"] and not m["remover"]), S=S)
         # the reference rows receive no gradient (they are detached in the reference as well): dq is written straight into the edit rows of
         # the full-size gradient, the removal loss's contribution is folded into it in place (one rounding, as adding an f32 tensor would)
         e0f, e1f = m["e0"] * f, m["e1"] * f
@@ -482,10 +507,28 @@ class _EditLayer(torch.autograd.Function):
         if e1f < grad_q.shape[0]:
             grad_q[e1f:].zero_()
         dq_view = grad_q[e0f:e1f]
-        _, dk32 = ops.attn_bwd(q_edit, K, v_base, replace_out, lse_e, dro, m["scale"], need_dk=m["is_cross"] and not m["remover"], dq_out=dq_view)
-        if have_loss and Pe is not None:
-            ops.removal_bwd(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], 1.0, gscale * rm_coef, m["scale"], None, dk32,
-                            n_valid=c.get("n_rows"), dq16=dq_view)
+        need_dk = m["is_cross"] and not m["remover"]
+        with_rm = have_loss and Pe is not None
+        if m.get("fused") and with_rm:
+            # [loss backward + row dots] [dq (+ dk)] [removal dS K] [one fold of both sets of partials]
+            rm_args, rm_ws = ops.removal_bwd_args(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], 1.0, gscale, rm_coef, m["scale"],
+                                                  c.get("n_rows"), need_dk)
+            dro = ops.edit_losses_bwd_rowdot(eo, replace_out, tgt, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), gout, coefs, gscale,
+                                             blend=(m["blend"] and not m["remover"]), S=S, rm=rm_args)
+            dk32, kchunks, part_ptr, bwd_ws = ops.attn_bwd_nofold(q_edit, K, v_base, replace_out, lse_e, dro, m["scale"], need_dk, dq_view)
+            rm_args.dk_f32 = dk32.data_ptr() if dk32 is not None else None
+            ops.removal_bwd_nofold(rm_args, dt)
+            ops.edit_dq_fold(part_ptr if kchunks > 1 else None, kchunks, f, dq_view.shape[1], dq_view.shape[2], rm_ws, K.shape[1], c["rows"].numel(),
+                             c["inp_pos"], ctx.aux["wgt"], dq_view)
+            del bwd_ws
+        else:
+            dro = ops.edit_losses_bwd(eo, replace_out, tgt if have_loss else None, c["m_wo"], m_edit_l, c.get("w_dist"),
+                                      c.get("m_amodal"), gout, coefs if have_loss else _zeros5(dev), gscale,
+                                      blend=(m["blend"] and not m["remover"]), S=S)
+            _, dk32 = ops.attn_bwd(q_edit, K, v_base, replace_out, lse_e, dro, m["scale"], need_dk=need_dk, dq_out=dq_view)
+            if with_rm:
+                ops.removal_bwd(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], 1.0, gscale * rm_coef, m["scale"], None, dk32,
+                                n_valid=c.get("n_rows"), dq16=dq_view)
         grad_k = None
         if dk32 is not None:
             grad_k = torch.zeros(m["k_shape"], dtype=dt, device=dev)
@@ -658,6 +701,11 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             rows = _persist(pt, ("rows", S, rem, R_pad), torch.cat([rows, pad]).contiguous())
             c["n_rows"] = _persist(pt, ("n_rows", S, rem), torch.tensor([R], dtype=torch.int32, device=dev))
         c["rows"] = rows
+        # inverse of the inpaint-row list (row -> slot, -1 elsewhere; live slots only): what the merged dq fold looks rows up in
+        inp_pos = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        if R:
+            inp_pos[rows[:R].long()] = torch.arange(R, dtype=torch.int32, device=dev)
+        c["inp_pos"] = _persist(pt, ("inp_pos", S, rem), inp_pos)
         # reciprocals of the loss denominators (U/attention_processors.py:231-305) on the device: sim, movement, amodal, smooth_h,
         # smooth_w, removal
         use_amodal = (not rem) and N > 32 ** 2

@@ -702,9 +702,10 @@ extern "C" size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int n
     return bwd_dk_ws_bytes(BH, N, M, D, need_dk) + (kc > 1 ? (size_t)kc * BH * N * D * sizeof(float) : 0);
 }
 
-extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
+static int attn_bwd_launch(const void* q, const void* k, const void* v, const void* out, const float* lse,
                            const void* dout, int BH, int N, int M, int D, float scale,
-                           void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+                           void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int dtype, void* stream, bool fold,
+                           int* kchunks_out, float** dq_part_out) {
     GD_REQUIRE(q && k && v && out && lse && dout && dq, GD_EINVAL, "gd_attn_bwd: null pointer");
     GD_REQUIRE(GD_HEAD_DIM_OK(D), GD_EUNSUPPORTED, "gd_attn_bwd: head dim %d unsupported (64, 128, 192)", D);
     GD_REQUIRE(BH > 0 && N > 0 && M > 0, GD_EINVAL, "gd_attn_bwd: bad sizes");
@@ -734,7 +735,9 @@ extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const vo
     } else {
         GD_LAUNCH_NCH(k_attn_bwd_dq, a.nwg, a);
     }
-    if (a.kchunks > 1) {
+    if (kchunks_out) *kchunks_out = a.kchunks;
+    if (dq_part_out) *dq_part_out = a.dq_part;
+    if (a.kchunks > 1 && fold) {
         const long long n4 = (long long)BH * N * D / 4;
         const int fb = (int)((n4 + 255) / 256);
         if (dtype == GD_F16) k_attn_bwd_dq_fold<f16_t><<<fb, 256, 0, st>>>(a.dq_part, a.kchunks, n4, (f16_t*)dq);
@@ -748,4 +751,18 @@ extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const vo
     }
     GD_CHECK_LAUNCH("gd_attn_bwd");
     return GD_OK;
+}
+
+extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
+                           const void* dout, int BH, int N, int M, int D, float scale,
+                           void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    return attn_bwd_launch(q, k, v, out, lse, dout, BH, N, M, D, scale, dq, dk_f32, workspace, workspace_bytes, dtype, stream, true, nullptr, nullptr);
+}
+// ... that leaves the dq partials of a split key range to gd_edit_dq_fold
+extern "C" int gd_attn_bwd_nofold(const void* q, const void* k, const void* v, const void* out, const float* lse, const void* dout,
+                                  int BH, int N, int M, int D, float scale, void* dq, float* dk_f32, void* workspace, size_t workspace_bytes,
+                                  int* kchunks_out, float** dq_part_out, int dtype, void* stream) {
+    GD_REQUIRE(kchunks_out && dq_part_out, GD_EINVAL, "gd_attn_bwd_nofold: null pointer");
+    return attn_bwd_launch(q, k, v, out, lse, dout, BH, N, M, D, scale, dq, dk_f32, workspace, workspace_bytes, dtype, stream, false, kchunks_out,
+                           dq_part_out);
 }

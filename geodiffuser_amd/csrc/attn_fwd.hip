@@ -533,16 +533,12 @@ struct ProbsArgs {
 };
 
 template <typename T, int NCH>
-__global__ void __launch_bounds__(256, 2)
-k_attn_probs(const ProbsArgs a) {
+__device__ __forceinline__ void probs_body(const ProbsArgs& a, const int bid, char (&ldsk)[2][NCH * ATT_TILE_BYTES], T (&stage)[4][32][ATT_BN + 8]) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
     constexpr int D = ATT_D * NCH;
-    __shared__ __attribute__((aligned(16))) char ldsk[2][NCH * ATT_TILE_BYTES];
-    __shared__ __attribute__((aligned(16))) T stage[4][32][ATT_BN + 8];     // per-wave P tile, padded rows
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int wg0 = xcd_remap(blockIdx.x, a.nwg);
+    const int wg0 = xcd_remap(bid, a.nwg);
     const int kc = wg0 % a.kchunks, wg = wg0 / a.kchunks;
     const int bh = wg / a.tiles, tile = wg - bh * a.tiles;
     const int N = a.N, M = a.M, R = a.R;
@@ -617,13 +613,30 @@ k_attn_probs(const ProbsArgs a) {
     }
 }
 
-extern "C" int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t* rows, const int32_t* n_valid_dev,
-                             int BH, int N, int R, int M, int Mpad, int D, float scale, void* P, int dtype, void* stream) {
-    GD_REQUIRE(q && k && lse && P, GD_EINVAL, "gd_attn_probs: null pointer");
-    GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED, "gd_attn_probs: head dim %d unsupported (64, 128, 192)", D);
-    GD_REQUIRE(BH > 0 && N > 0 && R > 0 && M > 0 && Mpad >= M && (Mpad & 7) == 0, GD_EINVAL,
-               "gd_attn_probs: bad sizes (Mpad must be a multiple of 8 and >= M)");
-    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_probs: dtype must be f16/bf16");
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256, 2)
+k_attn_probs(const ProbsArgs a) {
+    __shared__ __attribute__((aligned(16))) char ldsk[2][NCH * ATT_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) T stage[4][32][ATT_BN + 8];     // per-wave P tile, padded rows
+    probs_body<T, NCH>(a, (int)blockIdx.x, ldsk, stage);
+}
+
+// two problems in one grid (a's workgroups first) + an optional clear of zero_n4 16-byte words (the first workgroups' threads)
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256, 2)
+k_attn_probs2(const ProbsArgs a, const ProbsArgs b, u32x4* __restrict__ zero_ptr, int zero_n4) {
+    __shared__ __attribute__((aligned(16))) char ldsk[2][NCH * ATT_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) T stage[4][32][ATT_BN + 8];
+    if (zero_ptr) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < zero_n4; i += (int)gridDim.x * 256) zero_ptr[i] = z;
+    }
+    if ((int)blockIdx.x < a.nwg) probs_body<T, NCH>(a, (int)blockIdx.x, ldsk, stage);
+    else probs_body<T, NCH>(b, (int)blockIdx.x - a.nwg, ldsk, stage);
+}
+
+static ProbsArgs probs_args(const void* q, const void* k, const float* lse, const int32_t* rows, const int32_t* n_valid_dev, int BH, int N, int R,
+                            int M, int Mpad, float scale, void* P) {
     ProbsArgs a;
     a.q = q; a.k = k; a.lse = lse; a.rows = rows; a.P = P; a.n_valid = n_valid_dev;
     a.N = N; a.R = R; a.M = M; a.Mpad = Mpad;
@@ -641,6 +654,17 @@ extern "C" int gd_attn_probs(const void* q, const void* k, const float* lse, con
     a.nwg = a.tiles * BH * a.kchunks;
     a.c = scale * 1.4426950408889634f;
     a.l2e = 1.4426950408889634f;
+    return a;
+}
+
+extern "C" int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t* rows, const int32_t* n_valid_dev,
+                             int BH, int N, int R, int M, int Mpad, int D, float scale, void* P, int dtype, void* stream) {
+    GD_REQUIRE(q && k && lse && P, GD_EINVAL, "gd_attn_probs: null pointer");
+    GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED, "gd_attn_probs: head dim %d unsupported (64, 128, 192)", D);
+    GD_REQUIRE(BH > 0 && N > 0 && R > 0 && M > 0 && Mpad >= M && (Mpad & 7) == 0, GD_EINVAL,
+               "gd_attn_probs: bad sizes (Mpad must be a multiple of 8 and >= M)");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_probs: dtype must be f16/bf16");
+    const ProbsArgs a = probs_args(q, k, lse, rows, n_valid_dev, BH, N, R, M, Mpad, scale, P);
     hipStream_t st = as_stream(stream);
     const int nch = D / ATT_D;
 #define GD_PROBS(NCH)                                                            \
@@ -649,5 +673,35 @@ extern "C" int gd_attn_probs(const void* q, const void* k, const float* lse, con
     if (nch == 1) { GD_PROBS(1); } else if (nch == 2) { GD_PROBS(2); } else { GD_PROBS(3); }
 #undef GD_PROBS
     GD_CHECK_LAUNCH("gd_attn_probs");
+    return GD_OK;
+}
+
+extern "C" int gd_attn_probs_pair(const gd_probs_t* pa, const gd_probs_t* pb, int D, float scale, void* zero_ptr, size_t zero_bytes, int dtype,
+                                  void* stream) {
+    GD_REQUIRE(pa && pb, GD_EINVAL, "gd_attn_probs_pair: null pointer");
+    GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED, "gd_attn_probs_pair: head dim %d unsupported (64, 128, 192)", D);
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_probs_pair: dtype must be f16/bf16");
+    GD_REQUIRE(!zero_ptr || (zero_bytes % 16 == 0 && ((uintptr_t)zero_ptr & 15) == 0 && zero_bytes < ((size_t)1 << 31)), GD_EINVAL,
+               "gd_attn_probs_pair: the clear must be 16-byte aligned and a multiple of 16 bytes");
+    const gd_probs_t* ps[2] = {pa, pb};
+    ProbsArgs args[2];
+    for (int i = 0; i < 2; ++i) {
+        const gd_probs_t* p = ps[i];
+        GD_REQUIRE(p->q && p->k && p->lse && p->P, GD_EINVAL, "gd_attn_probs_pair: problem %d: null pointer", i);
+        GD_REQUIRE(p->BH > 0 && p->N > 0 && p->R > 0 && p->M > 0 && p->Mpad >= p->M && (p->Mpad & 7) == 0, GD_EINVAL,
+                   "gd_attn_probs_pair: problem %d: bad sizes (Mpad must be a multiple of 8 and >= M)", i);
+        args[i] = probs_args(p->q, p->k, p->lse, p->rows, p->n_valid, p->BH, p->N, p->R, p->M, p->Mpad, scale, p->P);
+    }
+    hipStream_t st = as_stream(stream);
+    const int grid = args[0].nwg + args[1].nwg;
+    const int nch = D / ATT_D;
+    u32x4* zp = (u32x4*)zero_ptr;
+    const int zn = zero_ptr ? (int)(zero_bytes / 16) : 0;
+#define GD_PROBS2(NCH)                                                                            \
+    if (dtype == GD_F16) k_attn_probs2<f16_t, NCH><<<grid, 256, 0, st>>>(args[0], args[1], zp, zn); \
+    else k_attn_probs2<bf16_t, NCH><<<grid, 256, 0, st>>>(args[0], args[1], zp, zn)
+    if (nch == 1) { GD_PROBS2(1); } else if (nch == 2) { GD_PROBS2(2); } else { GD_PROBS2(3); }
+#undef GD_PROBS2
+    GD_CHECK_LAUNCH("gd_attn_probs_pair");
     return GD_OK;
 }

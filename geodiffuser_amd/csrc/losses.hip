@@ -8,6 +8,7 @@
 // torch launches and a dozen [f,N,D] temporaries per layer in the reference — by one pass each.
 // HBM-bound: forward reads eo + ro (+ target) once: 2 * H*N*D * sizeof(T) (+ 4 * H*N*D) bytes.
 #include "common.hpp"
+#include "edit_layer.hpp"
 
 // GaussianSmoothing(kernel_size=5): sigma = 5//2*2/6 = 2/3, exponent -((x-mean)/(2 sigma))^2 (U/generic_torch.py:32-54),
 // normalised to sum 1.  The 2-D kernel is the outer product of this 1-D profile (centre weight 0.18102).
@@ -259,6 +260,260 @@ extern "C" int gd_rows_merge(const void* base, const void* act, const int32_t* p
     k_rows_merge<f16_t><<<(int)((total + 255) / 256), 256, 0, as_stream(stream)>>>((const u32x4*)base, (const u32x4*)act, pos, H, N, R, D / 8,
                                                                                   (u32x4*)out);
     GD_CHECK_LAUNCH("gd_rows_merge");
+    return GD_OK;
+}
+
+// ============================================================================================================================
+// Fused launches of one hooked optimisation-pass layer (ABI 4, see edit_layer.hpp)
+// ============================================================================================================================
+
+// gd_rows_merge + gd_blend_tokens: one pass over the layer's [H,N,D] rows, 8 elements per thread
+template <typename T>
+__global__ void k_blend_merge(const u32x4* __restrict__ base, const u32x4* __restrict__ act, const int32_t* __restrict__ pos,
+                              const u32x4* __restrict__ ro, const float* __restrict__ m, int H, int N, int R, int D8,
+                              u32x4* __restrict__ eo_out, u32x4* __restrict__ out) {
+    using V8 = typename elem_traits<T>::vec8;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;                   // one 16-byte chunk of 8 elements
+    if (gid >= (long long)H * N * D8) return;
+    const int c = (int)(gid % D8);
+    const long long hn = gid / D8;
+    const int n = (int)(hn % N), h = (int)(hn / N);
+    const int p = act ? pos[n] : -1;
+    const u32x4 e = p >= 0 ? act[((long long)h * R + p) * D8 + c] : base[gid];
+    if (eo_out) eo_out[gid] = e;
+    if (out) {
+        // op-by-op in the tensor dtype, as torch evaluates  a*m + b*(1-m)  on 16-bit tensors (k_blend)
+        const V8 a8 = __builtin_bit_cast(V8, e), b8 = __builtin_bit_cast(V8, ro[gid]);
+        const float mm = (float)(T)m[n];
+        const float om = (float)(T)(1.0f - mm);
+        V8 o8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t1 = (float)(T)((float)a8[j] * mm);
+            const float t2 = (float)(T)((float)b8[j] * om);
+            o8[j] = (T)(t1 + t2);
+        }
+        out[gid] = __builtin_bit_cast(u32x4, o8);
+    }
+}
+
+extern "C" int gd_blend_merge(const void* base, const void* act, const int32_t* pos, const void* ro, const float* m, int H, int N, int R, int D,
+                              void* eo_out, void* out, int dtype, void* stream) {
+    GD_REQUIRE(base && (eo_out || out), GD_EINVAL, "gd_blend_merge: null pointer");
+    GD_REQUIRE(!act || (pos && R > 0), GD_EINVAL, "gd_blend_merge: act needs pos and R");
+    GD_REQUIRE(!out || (ro && m), GD_EINVAL, "gd_blend_merge: out needs ro and m");
+    GD_REQUIRE(H > 0 && N > 0 && D > 0 && D % 8 == 0, GD_EINVAL, "gd_blend_merge: bad sizes (D must be a multiple of 8)");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_blend_merge: dtype must be f16/bf16");
+    const long long total = (long long)H * N * (D / 8);
+    const int blocks = (int)((total + 255) / 256);
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16)
+        k_blend_merge<f16_t><<<blocks, 256, 0, st>>>((const u32x4*)base, (const u32x4*)act, pos, (const u32x4*)ro, m, H, N, R, D / 8, (u32x4*)eo_out, (u32x4*)out);
+    else
+        k_blend_merge<bf16_t><<<blocks, 256, 0, st>>>((const u32x4*)base, (const u32x4*)act, pos, (const u32x4*)ro, m, H, N, R, D / 8, (u32x4*)eo_out, (u32x4*)out);
+    GD_CHECK_LAUNCH("gd_blend_merge");
+    return GD_OK;
+}
+
+// k_losses_fwd's grid; the workgroup whose ticket comes last runs gd_removal_loss_reduce's body, k_losses_fold's sums and gd_loss_assemble
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_losses_fused(const gd_edit_losses_t a) {
+    const int S = a.S, D = a.D, H = a.H;
+    const int N = S * S;
+    const long long total = (long long)H * N * D;
+    const T* __restrict__ eo = (const T*)a.eo;
+    const T* __restrict__ ro = (const T*)a.ro;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
+        const long long t = gid / D;
+        const int n = (int)(t % N);
+        const int y = n / S, x = n - y * S;
+        const float r = (float)ro[gid], e = (float)eo[gid];
+        const float ad = fabsf(e - r);
+        s0 += ad * a.m_wo[n];
+        s1 += ad * a.m_edit[n];
+        if (a.tgt) s2 += fabsf(a.tgt[gid] - r) * a.w_am[n] * a.m_amodal[n];
+        if (y < S - 1) s3 += fabsf((float)ro[gid + (size_t)S * D] - r);
+        if (x < S - 1) s4 += fabsf((float)ro[gid + D] - r);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
+    __shared__ float part[4][5];
+    __shared__ float rpart[4];
+    __shared__ float sums[5];
+    __shared__ int is_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { part[wave][0] = s0; part[wave][1] = s1; part[wave][2] = s2; part[wave][3] = s3; part[wave][4] = s4; }
+    __syncthreads();
+    if (threadIdx.x < 5)
+        a.workspace[(size_t)blockIdx.x * 5 + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // release: this workgroup's partial is visible at agent scope before its ticket; acquire: the last arriver sees every partial
+        const int old = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);                            // (per-thread acquire for the loads below)
+    // ---- tail: one workgroup ----
+    float rm = 0.f;
+    if (a.best) rm = removal_reduce_body(a.best, a.rows, a.n_valid, H, a.R, S, a.p_in, a.j_in, a.p_wo, a.j_wo, a.wgt, rpart);
+    // k_losses_fold's order: column k lane-strided over the workgroups, then the wave tree (waves 0..3 take columns 0..3, wave 0 also 4)
+    const int nblocks = (int)gridDim.x;
+    for (int k = wave; k < 5; k += 4) {
+        float s = 0.f;
+        for (int b = lane; b < nblocks; b += 64) s += a.workspace[(size_t)b * 5 + k];
+        s = wave_sum(s);
+        if (lane == 0) sums[k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        loss_assemble_body(sums, rm, a.inv5, a.inv_rm, a.wv, a.inv5_bwd, a.use_amodal, a.out12);
+        __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // the next launch finds zero
+    }
+}
+
+extern "C" int gd_edit_losses_fused(const gd_edit_losses_t* a, int dtype, void* stream) {
+    GD_REQUIRE(a && a->eo && a->ro && a->m_wo && a->m_edit && a->workspace && a->ticket && a->out12 && a->inv5 && a->inv_rm && a->wv && a->inv5_bwd,
+               GD_EINVAL, "gd_edit_losses_fused: null pointer");
+    GD_REQUIRE(!a->tgt || (a->w_am && a->m_amodal), GD_EINVAL, "gd_edit_losses_fused: tgt needs w_am and m_amodal");
+    GD_REQUIRE(!a->best || (a->rows && a->p_in && a->j_in && a->p_wo && a->j_wo && a->wgt && a->R > 0), GD_EINVAL,
+               "gd_edit_losses_fused: best needs rows, R and the five aux outputs");
+    GD_REQUIRE(a->H > 0 && a->S > 0 && a->D > 0, GD_EINVAL, "gd_edit_losses_fused: bad sizes");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_fused: dtype must be f16/bf16");
+    const int blocks = losses_fwd_blocks(a->H, a->S, a->D);
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16) k_losses_fused<f16_t><<<blocks, 256, 0, st>>>(*a);
+    else k_losses_fused<bf16_t><<<blocks, 256, 0, st>>>(*a);
+    GD_CHECK_LAUNCH("gd_edit_losses_fused");
+    return GD_OK;
+}
+
+// k_losses_bwd's grid followed by k_removal_rowdot's (4 rows per workgroup): independent work, one launch
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_losses_bwd_rowdot(const T* __restrict__ eo, const T* __restrict__ ro, const float* __restrict__ tgt,
+                    const float* __restrict__ m_wo, const float* __restrict__ m_edit, const float* __restrict__ w_am,
+                    const float* __restrict__ m_amodal, const T* __restrict__ gout, const float* __restrict__ c, const float* __restrict__ gscale, int blend,
+                    int H, int S, int D, T* __restrict__ dro, int nb_loss, const gd_removal_bwd_t rm) {
+    if ((int)blockIdx.x >= nb_loss) {
+        removal_rowdot_body<T>(rm, ((int)blockIdx.x - nb_loss) * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), rm.workspace);
+        return;
+    }
+    const int N = S * S;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)H * N * D) return;
+    const long long t = gid / D;
+    const int n = (int)(t % N);
+    const int y = n / S, x = n - y * S;
+    const float r = (float)ro[gid], e = (float)eo[gid];
+    const float sg = -sgn(e - r);
+    const float me = m_edit[n];
+    float g = c[0] * sg * m_wo[n] + c[1] * sg * me;
+    if (tgt) g += c[2] * (-sgn(tgt[gid] - r)) * w_am[n] * m_amodal[n];
+    float gs = 0.f;
+    if (y < S - 1) gs -= sgn((float)ro[gid + (size_t)S * D] - r);
+    if (y > 0) gs += sgn(r - (float)ro[gid - (size_t)S * D]);
+    g += c[3] * gs;
+    gs = 0.f;
+    if (x < S - 1) gs -= sgn((float)ro[gid + D] - r);
+    if (x > 0) gs += sgn(r - (float)ro[gid - D]);
+    g += c[4] * gs;
+    if (gscale) g *= gscale[0];
+    if (gout) g += (float)gout[gid] * (blend ? (1.0f - me) : 1.0f);
+    dro[gid] = (T)g;
+}
+
+extern "C" int gd_edit_losses_bwd_rowdot(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
+                                         const float* w_am, const float* m_amodal, const void* gout, const float* coef_dev, const float* gscale_dev,
+                                         int blend, int H, int S, int D, void* dro, const gd_removal_bwd_t* rm, int dtype, void* stream) {
+    if (!rm) return gd_edit_losses_bwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coef_dev, gscale_dev, blend, H, S, D, dro, dtype, stream);
+    GD_REQUIRE(eo && ro && m_wo && m_edit && coef_dev && dro, GD_EINVAL, "gd_edit_losses_bwd_rowdot: null pointer");
+    GD_REQUIRE(!tgt || (w_am && m_amodal), GD_EINVAL, "gd_edit_losses_bwd_rowdot: tgt needs w_am and m_amodal");
+    GD_REQUIRE(H > 0 && S > 0 && D > 0, GD_EINVAL, "gd_edit_losses_bwd_rowdot: bad sizes");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_bwd_rowdot: dtype must be f16/bf16");
+    GD_REQUIRE(rm->Pe && rm->Pb && rm->p_in && rm->j_in && rm->p_wo && rm->j_wo && rm->wgt && rm->m_inp && rm->m_wo && rm->workspace, GD_EINVAL,
+               "gd_edit_losses_bwd_rowdot: removal arguments: null pointer");
+    GD_REQUIRE(rm->H > 0 && rm->R > 0 && rm->N > 0 && rm->M > 0 && rm->Mpad >= rm->M, GD_EINVAL, "gd_edit_losses_bwd_rowdot: removal arguments: bad sizes");
+    const long long total = (long long)H * S * S * D;
+    const int nb_loss = (int)((total + 255) / 256);
+    const int nb_dot = (rm->H * rm->R + 3) / 4;
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16)
+        k_losses_bwd_rowdot<f16_t><<<nb_loss + nb_dot, 256, 0, st>>>((const f16_t*)eo, (const f16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal,
+                                                                   (const f16_t*)gout, coef_dev, gscale_dev, blend, H, S, D, (f16_t*)dro, nb_loss, *rm);
+    else
+        k_losses_bwd_rowdot<bf16_t><<<nb_loss + nb_dot, 256, 0, st>>>((const bf16_t*)eo, (const bf16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal,
+                                                                    (const bf16_t*)gout, coef_dev, gscale_dev, blend, H, S, D, (bf16_t*)dro, nb_loss, *rm);
+    GD_CHECK_LAUNCH("gd_edit_losses_bwd_rowdot");
+    return GD_OK;
+}
+
+// dq16[h, n, :] = T( sum_c dq_part[c][h, n, :]  +  (n a live inpaint row ? sum_c rm_part[c][h, slot, :] : 0) ), c ascending, one rounding.
+// 4 elements per thread.  The removal partials lie at rm_workspace + H*R (gd_removal_bwd's layout: row dots first).
+// part == NULL (the dq kernel did not split its key range and wrote dq directly): only the live inpaint rows are touched, T(float(dq) + s).
+template <typename T>
+__global__ void k_edit_dq_fold(const float* __restrict__ part, int kchunks, int BH, int N, int D, const float* __restrict__ rm_part, int msplit, int R,
+                               const int32_t* __restrict__ inp_pos, const float* __restrict__ wgt, T* dq) {
+    using TR = elem_traits<T>;
+    const long long n4 = (long long)BH * N * D / 4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (part) {
+        acc = *(const f32x4*)(part + i * 4);
+        for (int c = 1; c < kchunks; ++c) {
+            const f32x4 p = *(const f32x4*)(part + ((long long)c * n4 + i) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += p[j];
+        }
+    }
+    bool touched = part != nullptr;
+    if (rm_part) {
+        const int d4 = D / 4;
+        const long long hn = i / d4;
+        const int dq4 = (int)(i - hn * d4);
+        const int n = (int)(hn % N), h = (int)(hn / N);
+        const int slot = inp_pos[n];
+        if (slot >= 0 && wgt[(size_t)h * R + slot] != 0.f) {
+            if (!part) {                 // unsplit dq kernel: the 16-bit gradient is the first term (gd_removal_bwd's in-place add)
+                const typename TR::vec4 cur = *(const typename TR::vec4*)(dq + i * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = TR::to_f32(cur[j]);
+            }
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < msplit; ++c) {
+                const f32x4 p = *(const f32x4*)(rm_part + (((size_t)c * BH + h) * R + slot) * D + dq4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += p[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += s[j];
+            touched = true;
+        }
+    }
+    if (!touched) return;
+    typename TR::vec4 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = TR::from_f32(acc[j]);
+    *(typename TR::vec4*)(dq + i * 4) = w;
+}
+
+extern "C" int gd_edit_dq_fold(const float* dq_part, int kchunks, int BH, int N, int D, const float* rm_workspace, int M, int R,
+                               const int32_t* inp_pos, const float* wgt, void* dq16, int dtype, void* stream) {
+    GD_REQUIRE(dq16 && kchunks >= 1 && (dq_part || rm_workspace), GD_EINVAL, "gd_edit_dq_fold: null pointer / kchunks < 1");
+    GD_REQUIRE(BH > 0 && N > 0 && D > 0 && D % 4 == 0, GD_EINVAL, "gd_edit_dq_fold: bad sizes");
+    GD_REQUIRE(!rm_workspace || (inp_pos && wgt && R > 0 && M > 0), GD_EINVAL, "gd_edit_dq_fold: removal partials need inp_pos, wgt, R, M");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_dq_fold: dtype must be f16/bf16");
+    const int msplit = rm_workspace ? (M + 511) / 512 : 0;           // RM_MCH keys per chunk (removal.hip)
+    const float* rm_part = rm_workspace ? rm_workspace + (size_t)BH * R : nullptr;
+    const long long n4 = (long long)BH * N * D / 4;
+    const int blocks = (int)((n4 + 255) / 256);
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16) k_edit_dq_fold<f16_t><<<blocks, 256, 0, st>>>(dq_part, kchunks, BH, N, D, rm_part, msplit, R, inp_pos, wgt, (f16_t*)dq16);
+    else k_edit_dq_fold<bf16_t><<<blocks, 256, 0, st>>>(dq_part, kchunks, BH, N, D, rm_part, msplit, R, inp_pos, wgt, (bf16_t*)dq16);
+    GD_CHECK_LAUNCH("gd_edit_dq_fold");
     return GD_OK;
 }
 

@@ -12,6 +12,7 @@
 // MFMA-bound (k_corr_max): algorithmic FLOPs = 2 * H * R * N * M.
 #include <stdlib.h>
 #include "attn_common.hpp"
+#include "edit_layer.hpp"
 
 #define CM_T 128   // rows of each operand tile
 #define CM_K 64    // k per chunk
@@ -310,8 +311,8 @@ static int corr_variant(int H, int R, int N, int Mpad) {
     return (N % 128 == 0) ? 22 : 0;
 }
 
-extern "C" int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
-                                   int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream) {
+static int corr_max_launch(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
+                           int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream, bool clear) {
     GD_REQUIRE(Pe && Pb && m_inp && m_wo && best, GD_EINVAL, "gd_removal_corr_max: null pointer");
     GD_REQUIRE(H > 0 && R > 0 && N > 0 && Mpad > 0 && (Mpad & 7) == 0, GD_EINVAL, "gd_removal_corr_max: bad sizes");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_corr_max: dtype must be f16/bf16");
@@ -321,7 +322,7 @@ extern "C" int gd_removal_corr_max(const void* Pe, const void* Pb, const float* 
     a.rtiles = (R + CM_T - 1) / CM_T;
     a.jtiles = (N + CM_T - 1) / CM_T;
     hipStream_t st = as_stream(stream);
-    gd_zero_async(best, (size_t)H * R * 2 * sizeof(unsigned long long), st);
+    if (clear) gd_zero_async(best, (size_t)H * R * 2 * sizeof(unsigned long long), st);
     const int var = corr_variant(H, R, N, Mpad);
     if (var) {
         const int aj = var / 10, wjn = var % 10;
@@ -342,11 +343,14 @@ extern "C" int gd_removal_corr_max(const void* Pe, const void* Pb, const float* 
     return GD_OK;
 }
 
-// pixel-centre distance of CoordinateDistances (U/generic_torch.py:126-140): centres (2i+1)/S - 1
-__device__ __forceinline__ float pix_dist(int a, int b, int S) {
-    const int ya = a / S, xa = a - ya * S, yb = b / S, xb = b - yb * S;
-    const float dx = (float)(2 * (xa - xb)) / (float)S, dy = (float)(2 * (ya - yb)) / (float)S;
-    return sqrtf(dx * dx + dy * dy + 1e-12f);
+extern "C" int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
+                                   int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream) {
+    return corr_max_launch(Pe, Pb, m_inp, m_wo, n_valid_dev, H, R, N, Mpad, best, dtype, stream, true);
+}
+// ... without the clear of `best` (gd_attn_probs_pair cleared it in the launch before)
+extern "C" int gd_removal_corr_max_nz(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
+                                      int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream) {
+    return corr_max_launch(Pe, Pb, m_inp, m_wo, n_valid_dev, H, R, N, Mpad, best, dtype, stream, false);
 }
 
 __global__ void k_removal_reduce(const unsigned long long* __restrict__ best, const int32_t* __restrict__ rows,
@@ -354,31 +358,10 @@ __global__ void k_removal_reduce(const unsigned long long* __restrict__ best, co
                                  float* __restrict__ p_in, int32_t* __restrict__ j_in, float* __restrict__ p_wo,
                                  int32_t* __restrict__ j_wo, float* __restrict__ wgt, float* __restrict__ loss_acc) {
     // ONE workgroup walks all H*R rows (a few thousand) in a fixed thread-strided order and folds the loss terms through the wave tree
-    // and the four wave sums in index order: bit-reproducible, no floating-point atomics
+    // and the four wave sums in index order: bit-reproducible, no floating-point atomics (body shared with gd_edit_losses_fused)
     __shared__ float part[4];
-    float term = 0.f;
-    for (int i = threadIdx.x; i < H * R; i += blockDim.x) {
-        const unsigned long long bi = best[(size_t)i * 2], bw = best[(size_t)i * 2 + 1];
-        // best == 0: no correlation value of this row compared greater than the initial -1, i.e. every one of them was NaN (diverged
-        // latents).  torch.max would return NaN there; do the same for the value and keep the INDEX valid — the backward addresses
-        // rows of Pb with it (an index of -1 here was an out-of-bounds read).
-        const float qnan = __uint_as_float(0x7FC00000u);
-        const float pi = bi ? __uint_as_float((unsigned)(bi >> 32)) : qnan, pw = bw ? __uint_as_float((unsigned)(bw >> 32)) : qnan;
-        int ji = bi ? (int)(0xFFFFFFFFu - (unsigned)(bi & 0xFFFFFFFFu)) : 0, jw = bw ? (int)(0xFFFFFFFFu - (unsigned)(bw & 0xFFFFFFFFu)) : 0;
-        ji = ji < 0 ? 0 : (ji >= S * S ? S * S - 1 : ji);
-        jw = jw < 0 ? 0 : (jw >= S * S ? S * S - 1 : jw);
-        const int r = i % R;
-        // slots r >= n_valid are padding (row list rounded up so that launch dimensions repeat across edits): weight 0 removes
-        // them from the loss and, through wgt, from every term of the backward
-        const bool live = !n_valid || r < n_valid[0];
-        const float w = live ? __expf(-pix_dist(rows[r], jw, S)) : 0.f;
-        p_in[i] = pi; j_in[i] = ji; p_wo[i] = pw; j_wo[i] = jw; wgt[i] = w;
-        term += live ? w * (-__logf(pw + 1e-4f) + __logf(pi + 1e-4f)) : 0.f;
-    }
-    term = wave_sum(term);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = term;
-    __syncthreads();
-    if (threadIdx.x == 0) loss_acc[0] += (part[0] + part[1]) + (part[2] + part[3]);
+    const float sum = removal_reduce_body(best, rows, n_valid, H, R, S, p_in, j_in, p_wo, j_wo, wgt, part);
+    if (threadIdx.x == 0) loss_acc[0] += sum;
 }
 
 extern "C" int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, const int32_t* n_valid_dev, int H, int R, int S,
@@ -396,33 +379,16 @@ extern "C" int gd_removal_loss_reduce(const unsigned long long* best, const int3
 struct RmBwdArgs {
     const void* Pe; const void* Pb; const void* q; const void* k; const int32_t* rows;
     const float* p_in; const int32_t* j_in; const float* p_wo; const int32_t* j_wo; const float* wgt;
-    const float* m_inp; const float* m_wo; float coef; const float* gscale;
+    const float* m_inp; const float* m_wo; float coef; const float* gscale; const float* gscale2;
     int H, R, N, M, Mpad, D; float scale; float* dq; float* dk; float* ds_ws; const float* rowdot; float* dq_part;
     const int32_t* n_valid;       // device scalar: slots [n_valid, R) of the row list are padding (weight 0) and are skipped; NULL: all R
 };
 
-// rowdot[h, r] = sum_m A[h,r,m] * dA[h,r,m]   (one wave per inpaint row; feeds the softmax backward below)
+// rowdot[h, r] = sum_m A[h,r,m] * dA[h,r,m]   (one wave per inpaint row; feeds the softmax backward below; body: edit_layer.hpp)
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_removal_rowdot(const RmBwdArgs a, float* __restrict__ rowdot) {
-    using TR = elem_traits<T>;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.H * a.R) return;
-    const int hd = row / a.R, r = row - hd * a.R;
-    if (a.n_valid && r >= a.n_valid[0]) return;
-    const float cf = a.gscale ? a.coef * a.gscale[0] : a.coef;
-    const int ji = a.j_in[row], jw = a.j_wo[row];
-    const float cw = -cf * a.wgt[row] * a.m_wo[jw] / (a.p_wo[row] + 1e-4f);
-    const float ci = cf * a.wgt[row] * a.m_inp[ji] / (a.p_in[row] + 1e-4f);
-    const T* __restrict__ pe = (const T*)a.Pe + ((size_t)hd * a.R + r) * a.Mpad;
-    const T* __restrict__ pbw = (const T*)a.Pb + ((size_t)hd * a.N + jw) * a.Mpad;
-    const T* __restrict__ pbi = (const T*)a.Pb + ((size_t)hd * a.N + ji) * a.Mpad;
-    float dot = 0.f;
-    for (int m = lane; m < a.M; m += 64)
-        dot = __builtin_fmaf(TR::to_f32(pe[m]), cw * TR::to_f32(pbw[m]) + ci * TR::to_f32(pbi[m]), dot);
-    dot = wave_sum(dot);
-    if (lane == 0) rowdot[row] = dot;
+    removal_rowdot_body<T>(a, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), rowdot);
 }
 
 #define RM_RB 8      // inpaint rows per wave: each K row fetched from L2 serves 8 rows
@@ -444,7 +410,7 @@ k_removal_bwd(const RmBwdArgs a) {
     const int hd = wb / blocks_per_head, r0 = (wb - hd * blocks_per_head) * RM_RB;
     const int nv = a.n_valid ? (a.n_valid[0] < a.R ? a.n_valid[0] : a.R) : a.R;      // live slots of the row list
     if (r0 >= nv) return;
-    const float cf = a.gscale ? a.coef * a.gscale[0] : a.coef;
+    const float cf = (a.gscale ? a.coef * a.gscale[0] : a.coef) * (a.gscale2 ? a.gscale2[0] : 1.0f);
     const T* __restrict__ kp = (const T*)a.k + (size_t)hd * a.M * a.D + dch * ATT_D;
     const T* pe[RM_RB]; const T* pbw[RM_RB]; const T* pbi[RM_RB];
     float cw[RM_RB], ci[RM_RB], dot[RM_RB], acc[RM_RB];
@@ -560,7 +526,7 @@ extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, con
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_bwd: dtype must be f16/bf16");
     RmBwdArgs a;
     a.Pe = Pe; a.Pb = Pb; a.q = q; a.k = k; a.rows = rows; a.p_in = p_in; a.j_in = j_in; a.p_wo = p_wo; a.j_wo = j_wo;
-    a.wgt = wgt; a.m_inp = m_inp; a.m_wo = m_wo; a.coef = coef; a.gscale = gscale_dev; a.H = H; a.R = R; a.N = N; a.M = M; a.Mpad = Mpad; a.D = D; a.n_valid = n_valid_dev;
+    a.wgt = wgt; a.m_inp = m_inp; a.m_wo = m_wo; a.coef = coef; a.gscale = gscale_dev; a.gscale2 = nullptr; a.H = H; a.R = R; a.N = N; a.M = M; a.Mpad = Mpad; a.D = D; a.n_valid = n_valid_dev;
     GD_REQUIRE(ds_ws, GD_EINVAL, "gd_removal_bwd: workspace of gd_removal_bwd_workspace_bytes() required");
     // workspace: rowdot [H*R] | dq partials [msplit, H, R, D] | dS [H, R, Mpad] (only with dk_f32)
     const int msplit = (M + RM_MCH - 1) / RM_MCH;
@@ -583,5 +549,36 @@ extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, con
         else k_removal_dk<bf16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const bf16_t*)q, rows, n_valid_dev, R, N, M, Mpad, D, dk_f32);
     }
     GD_CHECK_LAUNCH("gd_removal_bwd");
+    return GD_OK;
+}
+
+// The dS K products only (gd_edit_losses_bwd_rowdot computed the row dots into the workspace, gd_edit_dq_fold folds the partials)
+extern "C" int gd_removal_bwd_nofold(const gd_removal_bwd_t* rm, int dtype, void* stream) {
+    GD_REQUIRE(rm && rm->Pe && rm->Pb && rm->q && rm->k && rm->rows && rm->p_in && rm->j_in && rm->p_wo && rm->j_wo && rm->wgt && rm->m_inp && rm->m_wo
+               && rm->workspace, GD_EINVAL, "gd_removal_bwd_nofold: null pointer");
+    GD_REQUIRE(rm->D == 64 || rm->D == 128 || rm->D == 192, GD_EUNSUPPORTED, "gd_removal_bwd_nofold: head dim %d unsupported (64, 128, 192)", rm->D);
+    GD_REQUIRE(rm->H > 0 && rm->R > 0 && rm->N > 0 && rm->M > 0 && rm->Mpad >= rm->M, GD_EINVAL, "gd_removal_bwd_nofold: bad sizes");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_bwd_nofold: dtype must be f16/bf16");
+    RmBwdArgs a;
+    a.Pe = rm->Pe; a.Pb = rm->Pb; a.q = rm->q; a.k = rm->k; a.rows = rm->rows; a.p_in = rm->p_in; a.j_in = rm->j_in; a.p_wo = rm->p_wo; a.j_wo = rm->j_wo;
+    a.wgt = rm->wgt; a.m_inp = rm->m_inp; a.m_wo = rm->m_wo; a.coef = rm->coef; a.gscale = rm->gscale; a.gscale2 = rm->gscale2;
+    a.H = rm->H; a.R = rm->R; a.N = rm->N; a.M = rm->M; a.Mpad = rm->Mpad; a.D = rm->D; a.n_valid = rm->n_valid;
+    const int H = rm->H, R = rm->R, M = rm->M, D = rm->D;
+    const int msplit = (M + RM_MCH - 1) / RM_MCH;
+    a.rowdot = rm->workspace;
+    a.dq_part = rm->workspace + (size_t)H * R;
+    a.scale = rm->scale; a.dq = nullptr; a.dk = rm->dk_f32;
+    a.ds_ws = rm->dk_f32 ? a.dq_part + (size_t)msplit * H * R * D : nullptr;
+    const int waves = H * ((R + RM_RB - 1) / RM_RB) * msplit * (D / ATT_D);
+    const int blocks = (waves + 3) / 4;
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, st>>>(a);
+    else k_removal_bwd<bf16_t><<<blocks, 256, 0, st>>>(a);
+    if (rm->dk_f32) {
+        dim3 grid((M * D + 255) / 256, H);
+        if (dtype == GD_F16) k_removal_dk<f16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const f16_t*)rm->q, rm->rows, rm->n_valid, R, rm->N, M, rm->Mpad, D, rm->dk_f32);
+        else k_removal_dk<bf16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const bf16_t*)rm->q, rm->rows, rm->n_valid, R, rm->N, M, rm->Mpad, D, rm->dk_f32);
+    }
+    GD_CHECK_LAUNCH("gd_removal_bwd_nofold");
     return GD_OK;
 }

@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import GD_BF16, GD_CHANNEL_MAJOR, GD_F16, GD_F32, GD_TOKEN_MAJOR, GdAttnSeg, check
+from ._lib import GD_BF16, GD_CHANNEL_MAJOR, GD_F16, GD_F32, GD_TOKEN_MAJOR, GdAttnSeg, GdEditLosses, GdProbs, GdRemovalBwd, check
 
 _DT = {torch.float16: GD_F16, torch.bfloat16: GD_BF16, torch.float32: GD_F32}
 
@@ -475,6 +475,179 @@ def blend_tokens(a, b, m, out=None):
         out = torch.empty_like(a)
     check(lib.gd_blend_tokens(_p(a), _p(b), _p(m), H, N, D, _p(out), dt, _stream()), "gd_blend_tokens")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused launches of one hooked optimisation-pass layer (include/geodiff_hip.h, "R6-R9 fused launches", ABI 4)
+# ---------------------------------------------------------------------------------------------------
+def _ip(t):
+    return 0 if t is None else t.data_ptr()
+
+
+_TICKETS = {}        # device index -> one zeroed int32 (gd_edit_losses_fused's arrival ticket: zero before every launch, left zero by it)
+
+
+def _ticket(dev: torch.device) -> torch.Tensor:
+    t = _TICKETS.get(dev.index)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.GeodiffError("edit_losses_fused: the arrival ticket must exist before a graph capture (run one eager pass first)")
+        t = _TICKETS[dev.index] = torch.zeros(4, dtype=torch.int32, device=dev)
+    return t
+
+
+def blend_merge(base, act, pos, ro, m, eo_out=None, out=None):
+    """gd_rows_merge + gd_blend_tokens in one pass: e = act[h, pos[n]] where pos[n] >= 0 (act given) else base[h, n]; eo_out = e;
+    out = e*m + ro*(1-m).  Either output may be None."""
+    lib = _lib.load()
+    dt = _dt16(base, "base")
+    _need(base, "base")
+    H, N, D = base.shape
+    R = 0
+    if act is not None:
+        _need(act, "act", base.dtype); _need(pos, "pos", torch.int32)
+        R = act.shape[1]
+        if act.shape[0] != H or act.shape[2] != D or pos.numel() != N:
+            raise _lib.GeodiffError("blend_merge: shapes disagree")
+    for t, nm in ((ro, "ro"), (eo_out, "eo_out"), (out, "out")):
+        if t is not None:
+            _need(t, nm, base.dtype)
+            if t.shape != base.shape:
+                raise _lib.GeodiffError(f"blend_merge: {nm} must have base's shape")
+    if m is not None:
+        _need(m, "m", torch.float32)
+    check(lib.gd_blend_merge(_p(base), _p(act), _p(pos) if act is not None else None, _p(ro), _p(m), H, N, R, D, _p(eo_out), _p(out), dt, _stream()),
+          "gd_blend_merge")
+
+
+def attn_probs_pair(qb, kb, lse_b, qe, ke, lse_e, rows, n_valid, scale: float, zero: Optional[torch.Tensor] = None):
+    """-> (Pb [BH, N, Mpad_b] over all rows of (qb, kb), Pe [BH, R, Mpad_e] over rows[...] of (qe, ke)) in ONE launch, which also clears
+    ``zero`` (the `best` scratch of removal_corr_max_nz)."""
+    lib = _lib.load()
+    dt = _dt16(qb, "qb")
+    for t, nm in ((qb, "qb"), (kb, "kb"), (qe, "qe"), (ke, "ke")):
+        _need(t, nm, qb.dtype)
+    _need(lse_b, "lse_b", torch.float32); _need(lse_e, "lse_e", torch.float32); _need(rows, "rows", torch.int32)
+    if n_valid is not None:
+        _need(n_valid, "n_valid", torch.int32)
+    BH, N, D = qb.shape
+    Mb, Me = kb.shape[1], ke.shape[1]
+    R = rows.numel()
+    Pb = torch.empty(BH, N, (Mb + 7) // 8 * 8, dtype=qb.dtype, device=qb.device)
+    Pe = torch.empty(BH, R, (Me + 7) // 8 * 8, dtype=qb.dtype, device=qb.device)
+    a = GdProbs(qb.data_ptr(), kb.data_ptr(), lse_b.data_ptr(), 0, 0, Pb.data_ptr(), BH, N, N, Mb, Pb.shape[2])
+    b = GdProbs(qe.data_ptr(), ke.data_ptr(), lse_e.data_ptr(), rows.data_ptr(), _ip(n_valid), Pe.data_ptr(), BH, N, R, Me, Pe.shape[2])
+    zb = 0
+    if zero is not None:
+        _need(zero, "zero")
+        zb = zero.numel() * zero.element_size()
+    check(lib.gd_attn_probs_pair(ctypes.byref(a), ctypes.byref(b), D, scale, _p(zero), zb, dt, _stream()), "gd_attn_probs_pair")
+    return Pb, Pe
+
+
+def removal_corr_max_nz(Pe, Pb, m_inp, m_wo, n_valid, best):
+    """The correlation + masked arg-max into a ``best`` [H, R, 2] int64 scratch the CALLER cleared (attn_probs_pair's ``zero``)."""
+    lib = _lib.load()
+    dt = _dt16(Pe, "Pe")
+    _need(Pe, "Pe"); _need(Pb, "Pb", Pe.dtype); _need(m_inp, "m_inp", torch.float32); _need(m_wo, "m_wo", torch.float32)
+    _need(best, "best", torch.int64)
+    H, R, Mpad = Pe.shape
+    check(lib.gd_removal_corr_max_nz(_p(Pe), _p(Pb), _p(m_inp), _p(m_wo), _p(n_valid), H, R, Pb.shape[1], Mpad, _p(best), dt, _stream()),
+          "gd_removal_corr_max_nz")
+
+
+def edit_losses_fused(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int, best, rows, n_valid, inv5, inv_rm, wv, inv5_bwd, use_amodal: bool):
+    """edit_losses_fwd + removal_loss_reduce + the fold + loss_assemble in one launch.
+    -> (terms [5], loss (), coefs [5], rm_coef [1], aux | None) — what loss_assemble and removal_fwd return."""
+    lib = _lib.load()
+    dt = _dt16(eo, "eo")
+    _need(eo, "eo"); _need(ro, "ro", eo.dtype)
+    H, N, D = eo.shape
+    dev = eo.device
+    ws = torch.empty(lib.gd_edit_losses_fwd_workspace_bytes(H, S, D) // 4, dtype=torch.float32, device=dev)
+    out = torch.empty(12, dtype=torch.float32, device=dev)
+    aux = None
+    R = 0
+    if best is not None:
+        _need(best, "best", torch.int64); _need(rows, "rows", torch.int32)
+        Hr, R = best.shape[0], best.shape[1]
+        if Hr != H:
+            raise _lib.GeodiffError("edit_losses_fused: best must have eo's head count")
+        f32 = torch.empty(3, H, R, dtype=torch.float32, device=dev)
+        i32 = torch.empty(2, H, R, dtype=torch.int32, device=dev)
+        aux = dict(p_in=f32[0], p_wo=f32[1], wgt=f32[2], j_in=i32[0], j_wo=i32[1])
+    a = GdEditLosses(eo.data_ptr(), ro.data_ptr(), _ip(tgt), m_wo.data_ptr(), m_edit.data_ptr(), _ip(w_am), _ip(m_amodal),
+                     _ip(best), _ip(rows) if best is not None else 0, _ip(n_valid) if best is not None else 0,
+                     _ip(aux["p_in"]) if aux else 0, _ip(aux["j_in"]) if aux else 0, _ip(aux["p_wo"]) if aux else 0,
+                     _ip(aux["j_wo"]) if aux else 0, _ip(aux["wgt"]) if aux else 0,
+                     inv5.data_ptr(), inv_rm.data_ptr(), wv.data_ptr(), inv5_bwd.data_ptr(),
+                     out.data_ptr(), ws.data_ptr(), _ticket(dev).data_ptr(), H, S, D, R, int(bool(use_amodal)))
+    check(lib.gd_edit_losses_fused(ctypes.byref(a), dt, _stream()), "gd_edit_losses_fused")
+    return out[0:5], out[5], out[6:11], out[11:12], aux
+
+
+def removal_bwd_args(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, gscale2, scale: float, n_valid, need_dk: bool):
+    """-> (GdRemovalBwd, workspace tensor): the argument block the three removal-backward pieces share."""
+    lib = _lib.load()
+    H, R, Mpad = Pe.shape
+    N, D = q.shape[1], q.shape[2]
+    M = k.shape[1]
+    ws = torch.empty(lib.gd_removal_bwd_workspace_bytes(H, R, M, Mpad, D, int(need_dk)) // 4, dtype=torch.float32, device=Pe.device)
+    a = GdRemovalBwd(Pe.data_ptr(), Pb.data_ptr(), q.data_ptr(), k.data_ptr(), rows.data_ptr(),
+                     aux["p_in"].data_ptr(), aux["j_in"].data_ptr(), aux["p_wo"].data_ptr(), aux["j_wo"].data_ptr(), aux["wgt"].data_ptr(),
+                     m_inp.data_ptr(), m_wo.data_ptr(), _ip(gscale), _ip(gscale2), _ip(n_valid), 0, ws.data_ptr(),
+                     float(coef), float(scale), H, R, N, M, Mpad, D)
+    return a, ws
+
+
+def edit_losses_bwd_rowdot(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend: bool, S: int, rm):
+    """edit_losses_bwd's grid + the removal backward's row dots (into rm's workspace) in one launch; rm None: plain edit_losses_bwd."""
+    lib = _lib.load()
+    dt = _dt16(eo, "eo")
+    H, N, D = eo.shape
+    dro = torch.empty_like(ro)
+    _need(coefs, "coefs", torch.float32)
+    check(lib.gd_edit_losses_bwd_rowdot(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), _p(gout), _p(coefs), _p(gscale),
+                                        int(blend), H, S, D, _p(dro), ctypes.byref(rm) if rm is not None else None, dt, _stream()),
+          "gd_edit_losses_bwd_rowdot")
+    return dro
+
+
+def attn_bwd_nofold(q, k, v, out, lse, dout, scale: float, need_dk: bool, dq_out):
+    """attn_bwd that leaves the per-key-run dq partials of a split launch to edit_dq_fold.
+    -> (dk f32 | None, kchunks, address of the partials, workspace tensor that owns them)."""
+    lib = _lib.load()
+    dt = _dt16(q, "q")
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout"), (dq_out, "dq_out")):
+        _need(t, nm, q.dtype)
+    _need(lse, "lse", torch.float32)
+    BH, N, D = q.shape
+    M = k.shape[1]
+    dk = torch.zeros(BH, M, D, dtype=torch.float32, device=q.device) if need_dk else None
+    nbytes = lib.gd_attn_bwd_workspace_bytes(BH, N, M, D, int(need_dk))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device) if nbytes else None
+    kc = ctypes.c_int(0)
+    part = ctypes.c_void_p(0)
+    check(lib.gd_attn_bwd_nofold(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), BH, N, M, D, scale, _p(dq_out), _p(dk), _p(ws), nbytes,
+                                 ctypes.byref(kc), ctypes.byref(part), dt, _stream()), "gd_attn_bwd_nofold")
+    return dk, int(kc.value), part.value, ws
+
+
+def removal_bwd_nofold(rm, dtype: torch.dtype):
+    """The dS K products of the removal backward (row dots: edit_losses_bwd_rowdot; partials folded by edit_dq_fold)."""
+    lib = _lib.load()
+    check(lib.gd_removal_bwd_nofold(ctypes.byref(rm), _DT[dtype], _stream()), "gd_removal_bwd_nofold")
+
+
+def edit_dq_fold(dq_part_ptr, kchunks: int, BH: int, N: int, D: int, rm_ws, M: int, R: int, inp_pos, wgt, dq16):
+    """dq16 = T(sum of the attention partials (dq_part_ptr None / 0: dq16 itself) + the removal partials of live inpaint rows): one rounding."""
+    lib = _lib.load()
+    dt = _dt16(dq16, "dq16")
+    _need(dq16, "dq16")
+    if rm_ws is not None:
+        _need(inp_pos, "inp_pos", torch.int32); _need(wgt, "wgt", torch.float32)
+    check(lib.gd_edit_dq_fold(ctypes.c_void_p(dq_part_ptr) if dq_part_ptr else None, kchunks, BH, N, D, _p(rm_ws), M, R, _p(inp_pos) if rm_ws is not None else None,
+                              _p(wgt) if rm_ws is not None else None, _p(dq16), dt, _stream()), "gd_edit_dq_fold")
 
 
 def softsplat_fwd(tenIn, tenFlow):

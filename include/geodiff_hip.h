@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 3
+#define GD_ABI_VERSION 4
 
 enum { GD_F16 = 0, GD_BF16 = 1, GD_F32 = 2 };
 enum { GD_TOKEN_MAJOR = 0 /* [B, P, C] */, GD_CHANNEL_MAJOR = 1 /* [B, C, P] */ };
@@ -315,6 +315,80 @@ int gd_edit_losses_bwd(const void* eo, const void* ro, const float* tgt, const f
 
 /* out = a*m + b*(1-m) per token (U/attention_processors.py:504,619); m [N] f32; a,b,out [H,N,D]. */
 int gd_blend_tokens(const void* a, const void* b, const float* m, int H, int N, int D, void* out, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * R6-R9  fused launches of ONE hooked optimisation-pass layer (ABI 4).  The stand-alone entry points above stay; these run the same
+ * arithmetic in the same summation order (results identical bit for bit) in fewer launches: a lossy self-attention layer went from
+ * ~20 launches to 12 (forward 13 -> 7: attention, merge + blend, both probability maps + the clear of `best`, correlation, amodal
+ * target x 2, losses with the reduce / fold / assemble tail; backward 6 -> 4: losses backward + row dots, dq, removal backward, fold).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* gd_rows_merge + gd_blend_tokens in one pass (U/attention_processors.py:424-428,502-508,544-549,617-622):
+ *   e[h,n]   = (act != NULL && pos[n] >= 0) ? act[h, pos[n]] : base[h,n]          (the full edit_out: rows outside the soft edit mask
+ *                                                                                    are the reference rows' outputs, gd_attn_seg_t.q_rows)
+ *   eo_out   = e                                     (may be NULL)
+ *   out      = e*m + ro*(1-m), op by op in the tensor dtype like gd_blend_tokens   (may be NULL; then ro / m may be NULL)
+ * base, ro, eo_out, out [H,N,D]; act [H,R,D]; pos [N] i32; m [N] f32; D % 8 == 0. */
+int gd_blend_merge(const void* base, const void* act, const int32_t* pos, const void* ro, const float* m, int H, int N, int R, int D,
+                   void* eo_out, void* out, int dtype, void* stream);
+
+/* Two gd_attn_probs problems in one launch (the base map and the inpaint rows of the edit map of one layer) + an optional clear of
+ * zero_bytes bytes (multiple of 16) at zero_ptr — the `best` scratch of gd_removal_corr_max_nz, which this launch precedes. */
+typedef struct gd_probs {
+    const void* q; const void* k; const float* lse; const int32_t* rows; const int32_t* n_valid; void* P;
+    int32_t BH, N, R, M, Mpad;
+} gd_probs_t;
+int gd_attn_probs_pair(const gd_probs_t* a, const gd_probs_t* b, int D, float scale, void* zero_ptr, size_t zero_bytes, int dtype,
+                       void* stream);
+
+/* gd_removal_corr_max without the clear of `best` (the caller cleared it: gd_attn_probs_pair's zero_ptr). */
+int gd_removal_corr_max_nz(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
+                           int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream);
+
+/* gd_edit_losses_fwd + gd_removal_loss_reduce + the fold + gd_loss_assemble in ONE launch: the workgroup that finishes last (an
+ * arrival ticket, agent-scope release / acquire) unpacks `best` (best == NULL: no removal term, rm = 0), folds the per-workgroup
+ * partials of the five sums in the stand-alone kernels' order and writes out12 (gd_loss_assemble's layout).
+ * workspace: gd_edit_losses_fwd_workspace_bytes(H, S, D) bytes; ticket: ONE int32, zero before the launch, left zero by it. */
+typedef struct gd_edit_losses {
+    const void* eo; const void* ro; const float* tgt; const float* m_wo; const float* m_edit; const float* w_am; const float* m_amodal;
+    const unsigned long long* best; const int32_t* rows; const int32_t* n_valid;
+    float* p_in; int32_t* j_in; float* p_wo; int32_t* j_wo; float* wgt;
+    const float* inv5; const float* inv_rm; const float* wv; const float* inv5_bwd;
+    float* out12; float* workspace; int32_t* ticket;
+    int32_t H, S, D, R, use_amodal;
+} gd_edit_losses_t;
+int gd_edit_losses_fused(const gd_edit_losses_t* a, int dtype, void* stream);
+
+/* The removal loss's backward, split so that its pieces can share launches with the rest of the layer's backward:
+ *   gd_edit_losses_bwd_rowdot : gd_edit_losses_bwd's grid + the row dots sum_m A dA of the removal backward (rm == NULL: plain
+ *                               gd_edit_losses_bwd);
+ *   gd_removal_bwd_nofold     : the dS K products only — per-key-chunk partials left in rm->workspace (+ dk_f32 as gd_removal_bwd);
+ *   gd_edit_dq_fold           : dq16[h,n,:] = T( sum_c dq_part[c][h,n,:]  (+ sum_c removal partials of row n, if n is a live inpaint row) ),
+ *                               ONE rounding (gd_attn_bwd + gd_removal_bwd round twice).
+ * workspace: gd_removal_bwd_workspace_bytes(H, R, M, Mpad, D, dk_f32 != NULL) bytes; the fields mean what gd_removal_bwd's arguments mean. */
+typedef struct gd_removal_bwd {
+    const void* Pe; const void* Pb; const void* q; const void* k; const int32_t* rows;
+    const float* p_in; const int32_t* j_in; const float* p_wo; const int32_t* j_wo; const float* wgt;
+    const float* m_inp; const float* m_wo; const float* gscale; const float* gscale2 /* second optional device factor of coef */;
+    const int32_t* n_valid;
+    float* dk_f32; float* workspace;
+    float coef, scale;
+    int32_t H, R, N, M, Mpad, D;
+} gd_removal_bwd_t;
+int gd_edit_losses_bwd_rowdot(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
+                              const float* w_am, const float* m_amodal, const void* gout, const float* coef_dev, const float* gscale_dev,
+                              int blend, int H, int S, int D, void* dro, const gd_removal_bwd_t* rm, int dtype, void* stream);
+int gd_removal_bwd_nofold(const gd_removal_bwd_t* rm, int dtype, void* stream);
+/* gd_attn_bwd that leaves the dq kernel's per-key-run partials in the workspace when it splits the key range: *kchunks_out = number of
+ * runs, *dq_part_out = their address inside `workspace` ([kchunks, BH, N, D] f32).  kchunks == 1: dq (16-bit) was written directly. */
+int gd_attn_bwd_nofold(const void* q, const void* k, const void* v, const void* out, const float* lse, const void* dout,
+                       int BH, int N, int M, int D, float scale, void* dq, float* dk_f32, void* workspace, size_t workspace_bytes,
+                       int* kchunks_out, float** dq_part_out, int dtype, void* stream);
+/* inp_pos [N] i32: slot of row n in the inpaint-row list or -1; rm_workspace: the removal backward's workspace (its partials
+ * [msplit, H, R, D] f32 start H*R floats in, as gd_removal_bwd lays them out), NULL = none.  dq_part == NULL (kchunks == 1: the dq kernel
+ * wrote dq16 directly): only the live inpaint rows are touched, dq16 = T(float(dq16) + removal contribution) like gd_removal_bwd. */
+int gd_edit_dq_fold(const float* dq_part, int kchunks, int BH, int N, int D, const float* rm_workspace, int M, int R,
+                    const int32_t* inp_pos, const float* wgt, void* dq16, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * R10-R12  scheduler / latent arithmetic (f32 or 16-bit latents, n elements).

@@ -31,7 +31,7 @@ def test_header_symbols_all_exported_and_bound(lib):
         assert hasattr(lib, s), f"{s} declared in the header but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.gd_version() == 3
+    assert lib.gd_version() == 4
 
 
 def test_argument_validation_without_gpu(lib):

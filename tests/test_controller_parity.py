@@ -501,6 +501,41 @@ def test_edit_layer_is_bit_reproducible(name, dtype):
         assert r[4] == runs[0][4]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("name", ["edit_self_opt_32_d64", "edit_cross_opt_32_d64", "edit_self_opt_64_d64", "edit_cross_opt_64_d64", "rem_self_opt_32_d64"])
+def test_fused_layer_launches_equal_the_standalone_ones(name, dtype, monkeypatch):
+    """Round 4: one hooked optimisation-pass layer in ~12 launches (merge + blend, both probability maps + the scratch clear, losses with
+    the reduce / fold / assemble tail, row dots beside the loss backward, one fold for both sets of dq partials) against the ~20
+    stand-alone launches (GD_FUSED_LAYER=0).  Same arithmetic in the same summation order: outputs, the loss, every logged term and dk
+    must be IDENTICAL; dq differs by one rounding (the merged fold rounds sum(attention partials) + removal once, the stand-alone path
+    rounds the attention gradient and then the sum): one 16-bit rounding apart on the inpaint rows, identical elsewhere."""
+    from geodiffuser_amd import attention_processors as AP
+    case = ORACLE_CASES.get(name) or dict(ORACLE_CASES["edit_cross_opt_32_d64"], S=64)
+    q, k, v, mask, coords = case_inputs(case)
+    runs = {}
+    for fused in (False, True, True):
+        monkeypatch.setattr(AP, "FUSED_LAYER", fused)
+        ch = _make_hip_controller(case, mask)
+        _prebuild_tables(ch, case, q, coords, dtype)
+        gout = case_gout(case, (q.shape[0], q.shape[1], q.shape[2]))
+        res = _run_hip(ch, case, q, k, v, coords, 0.125, gout, dtype)
+        log = {kk: float(vv) for kk, vv in ch.loss_log_dict["cross" if case["cross"] else "self"].items()}
+        rows = ch.masks_cache_dict[case["S"]]["m_inp"].cpu() > 0.5
+        runs.setdefault(fused, []).append((res, log, rows))
+    (r0, log0, rows), (r1, log1, _), (r2, log2, _) = runs[False][0], runs[True][0], runs[True][1]
+    assert torch.equal(r1["out"], r2["out"]) and torch.equal(r1["dq"], r2["dq"]) and r1["loss"] == r2["loss"]     # the fused path is reproducible
+    assert torch.equal(r1["out"], r0["out"]) and r1["loss"] == r0["loss"] and log1 == log0
+    assert torch.equal(r1["dk"], r0["dk"])
+    f = case["f"]
+    e0 = 1 if not case["cfg"] else 3
+    dq0, dq1 = r0["dq"][e0 * f:], r1["dq"][e0 * f:]
+    assert torch.equal(dq1[:, ~rows], dq0[:, ~rows])
+    step = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7                 # relative size of one step of the storage type
+    # (the step is relative to the LARGER of the two terms that are added, which may cancel: bounded per row block, not per element)
+    a, b = dq1[:, rows].double(), dq0[:, rows].double()
+    assert float((a - b).abs().max()) <= 2 * step * float(b.abs().max()) and float((a - b).norm() / b.norm()) < step
+
+
 def test_two_live_controllers_cannot_share_the_persistent_tables():
     """the per-resolution tables live in process-wide buffers (so that captured graphs can be reused across edits);
     a second controller that builds its tables takes them over, and the first one must then refuse to run rather than read the other's

@@ -58,7 +58,7 @@ class AttnTimer:
         return (tuple((tuple(s[0].shape), tuple(s[1].shape), s[4] is not None,
                        int(s[5][0].shape[-1]) if len(s) > 5 and s[5] is not None else 0,
                        int(s[6][0].numel()) if len(s) > 6 and s[6] is not None else 0) for s in segs),
-                float(scale), heads, q0.dtype, bool(q_scaled))
+                float(scale), heads, q0.dtype, int(q_scaled))
 
     def _entry(self, cfg):
         e = self.cfgs.get(cfg)
@@ -129,8 +129,8 @@ class AttnTimer:
                 # unit-variance q / k (scaled scores ~ N(0, 1) nats, as at a freshly initialised layer); queries that arrive
                 # pre-scaled carry scale*log2(e) like the projection's output
                 q = torch.randn(qs, device="cuda")
-                if q_scaled:
-                    q = q * (scale * 1.4426950408889634)
+                if q_scaled:           # (the optimisation pass hands pre-scaled queries over with scale = ln 2: the factor is the layer's 0.125 log2 e either way)
+                    q = q * ((scale if abs(scale - 0.125) < 1e-9 else 0.125) * 1.4426950408889634)
                 elif abs(scale - 0.125) > 1e-9:            # the optimisation pass: queries pre-scaled by the projection, scale = ln 2 (head dim 64)
                     q = q * (0.125 / scale)                # same distribution of the scores: N(0, 1) nats
                 q = q.to(dt); k = torch.randn(ks, device="cuda").to(dt); v = torch.randn(ks, device="cuda").to(dt)
@@ -182,7 +182,7 @@ class AttnTimer:
                     us = 1e3 * sum(a.elapsed_time(b) for a, b, _ in e["rep"]) / sum(n for _, _, n in e["rep"])
                 else:
                     us = 1e3 * sum(a.elapsed_time(b) for a, b in e["ev"]) / len(e["ev"])
-                row = dict(heads=e["heads"], token_major=bool(cfg[2]), q_scaled=bool(cfg[4]),
+                row = dict(heads=e["heads"], token_major=bool(cfg[2]), q_scaled=int(cfg[4]),
                            fused_warp=any(sh[3] for sh in cfg[0]), warp_row_list=max(sh[4] for sh in cfg[0]), launches=e["count"], avg_us=us,
                            tflops=e["flops"] / us * 1e-6, tflops_executed=e["flops_exec"] / us * 1e-6)
                 if e["ev"]:

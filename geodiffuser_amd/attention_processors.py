@@ -196,6 +196,11 @@ WARP_ROWS_MIN_TOKENS = 64 ** 2
 # as the last workgroup's tail, the row dots beside the loss backward, one fold for the attention and removal dq partials.  Same
 # arithmetic in the same order; GD_FUSED_LAYER=0 restores the stand-alone launches (the parity tests run both).
 FUSED_LAYER = os.environ.get("GD_FUSED_LAYER", "1") == "1"
+# The optimisation pass's bf16 launches with pre-scaled queries run the forward's PRE-SCALED variant (fixed softmax reference, row sums on
+# the matrix pipe: k_attn_fwd_w64 LSUM) instead of the exact-scale rescue variant: with numerator and denominator summed over the same
+# rounded probabilities a dominant probability is exact again, which is what the rescue variant was kept for (DESIGN 4a').  fp16 stays on
+# the rescue variant (its probabilities must stay inside fp16's range).  GD_OPT_PRE=0: the round-3 routing.
+OPT_PRE = os.environ.get("GD_OPT_PRE", "1") == "1"
 
 
 def _tok_ok(attn, hidden_states) -> bool:
@@ -406,7 +411,7 @@ class _EditLayer(torch.autograd.Function):
                 ident_out = torch.empty(f, N, D, dtype=dt, device=dev)
                 segs.append((q_edit, k_edit, v_edit, ident_out, None))
         segs.append((q_edit, K, v_base, replace_out, lse_e))                # :433,557 / :791,883
-        ops.attn_fwd(segs, scale)
+        ops.attn_fwd(segs, scale, q_scaled=2 if (q_pre and OPT_PRE and dt == torch.bfloat16) else 0)
         fused = FUSED_LAYER
         blend_done = False
         if (not remover) and edit_act is not None:
@@ -813,7 +818,10 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
                 segs.append((q_edit, k_edit, v_edit, ident_out, None))
         segs.append((q_edit, K, v_base, replace_out, None))
         ops.attn_fwd(segs, scale, heads=heads, q_scaled=self.q_scaled_tok)
-        if edit_act is not None:                                # rows outside the soft edit mask: the reference row's output
+        if edit_act is not None and FUSED_LAYER:                # rows outside the soft edit mask: the reference row's output — merged and
+            ops.blend_merge(out_full[b0:b1], edit_act, c["edit_pos"], replace_out, c["m_edit"], eo_out=None, out=out_full[cb:])   # blended in one pass
+            return out_full
+        if edit_act is not None:
             ops.rows_merge(out_full[b0:b1], edit_act, c["edit_pos"], out=edit_out)
         if edit_out is not None:
             ops.blend_tokens(edit_out, replace_out, c["m_edit"], out=out_full[cb:])

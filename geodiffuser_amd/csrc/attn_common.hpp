@@ -112,6 +112,7 @@ struct FwdArgs {
     float c;                        // scale * log2(e)
     float scale;
     int q_prescaled;                // the queries already carry c (gd_attn_seg_t::q_scaled): scores arrive in the log2 domain
+    int lsum;                       // gd_attn_seg_t::q_scaled == 2: row sums over the ROUNDED probabilities (k_attn_fwd_w64 LSUM)
     // pipelined kernels: launch order of the heads.  order[g] = (segment << 12) | head-in-segment for the g-th head of the grid; heads
     // of different segments are interleaved (n_order == 0: segment after segment, via bh_end)
     int n_order;

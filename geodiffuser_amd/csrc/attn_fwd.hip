@@ -474,6 +474,7 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
     a.scale = scale;
     a.c = scale * 1.4426950408889634f;
     a.q_prescaled = segs[0].q_scaled != 0;
+    a.lsum = segs[0].q_scaled == 2;
     if (a.q_prescaled) {             // scores arrive as exponents of 2: nothing left to multiply; lse = m ln 2 + ln l
         a.c = 1.0f;
         a.scale = 0.6931471805599453f;

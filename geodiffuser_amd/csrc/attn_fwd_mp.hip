@@ -612,6 +612,16 @@ template <> struct score_mfma<bf16_t> {
     static __device__ __forceinline__ void acc_pad(f32x16& d, const bf16x8 a, const bf16x8 b) {
         asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
     }
+    // padded forms of the loop's MFMAs, for the peeled iterations behind the loop (see acc_pad)
+    static __device__ __forceinline__ void head_pad(f32x16& d, const bf16x8 a, const bf16x8 b, const f32x16& c) {
+        asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
+    }
+    static __device__ __forceinline__ void head_zero_pad(f32x16& d, const bf16x8 a, const bf16x8 b) {
+        asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(d) : "a"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void acc_vb_pad(f32x16& d, const bf16x8 a, const bf16x8 b) {
+        asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b));
+    }
 };
 // (acc_pad: for the code outside the loop, where the compiler may have just copied a fragment into a[...] with v_accvgpr_write — an
 // MFMA must not read such a register in the next wait states, and the hazard recogniser does not pad in front of asm.  Seen as NaNs in
@@ -636,6 +646,16 @@ template <> struct score_mfma<f16_t> {
     static __device__ __forceinline__ void acc_pad(f32x16& d, const f16x8 a, const f16x8 b) {
         asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
     }
+    // padded forms of the loop's MFMAs, for the peeled iterations behind the loop (see acc_pad)
+    static __device__ __forceinline__ void head_pad(f32x16& d, const f16x8 a, const f16x8 b, const f32x16& c) {
+        asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
+    }
+    static __device__ __forceinline__ void head_zero_pad(f32x16& d, const f16x8 a, const f16x8 b) {
+        asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(d) : "a"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void acc_vb_pad(f32x16& d, const f16x8 a, const f16x8 b) {
+        asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b));
+    }
 };
 
 // Two scores -> two probabilities.  Plain fp32 VALU on purpose: the packed forms (v_pk_fma_f32 for the exact-scale variant's
@@ -646,8 +666,7 @@ template <> struct score_mfma<f16_t> {
         const float p0_ = __builtin_amdgcn_exp2f(PRE ? SRC[i] : __builtin_fmaf(SRC[i], c, -m2[QI]));             \
         const float p1_ = __builtin_amdgcn_exp2f(PRE ? SRC[(i) + 1] : __builtin_fmaf(SRC[(i) + 1], c, -m2[QI])); \
         DST[(j) >> 1] = pack2<T>(p0_, p1_);                                                                      \
-        ps0 += p0_;                                                                                              \
-        ps1 += p1_;                                                                                              \
+        if (!LSUM) { ps0 += p0_; ps1 += p1_; }                                                                   \
     }
 // Cold path of the exact-scale variant (!PRE: the optimisation pass): a half step's probability sum left [0, 2^14] — raise the reference
 // by the half's maximum exponent, rescale O and l, recompute the half's probabilities, exactly like softmax_rescue of k_attn_fwd_mp.
@@ -684,7 +703,7 @@ __device__ __forceinline__ void w64_rescue(const f32x16& H, f32x16 (&o)[2], floa
 // end of a half step: row sums; pre-scaled variant: the running maximum of the half-step sums (checked once per segment, see
 // k_attn_fwd_w64); exact-scale variant: the in-loop rescue above
 #define W64_CHECK(H, QI, PF0, PF1)                                                                               \
-    {                                                                                                            \
+    if (!LSUM) {                                                                                                 \
         float ps = ps0 + ps1;                                                                                    \
         if (!PRE) {                                                                                              \
             if (!(GD_MP_DBG & 4) && __builtin_expect(__builtin_amdgcn_ballot_w64(!(ps <= P_SUM_LIMIT)) != 0, 0)) \
@@ -704,11 +723,31 @@ struct W64Stage {
     char* kdst; char* vdst;    // this wave's first piece of the destination tiles
 };
 
-template <typename T, bool LAST, bool PRE, bool DMA>
+// LSUM (pre-scaled variant only): the row sums come from the matrix pipe — l^T += 1 P^T, one MFMA per 16-key step and query block whose A
+// operand is a fragment of ones and whose B operand is the SAME 16-bit probability fragment the O products consume.  Two things follow:
+//   * the two v_add_f32 per pair of probabilities leave the vector pipe, which paces this loop (MFMA issue 8 + 2 x v_exp 16 + 2 x v_add 8
+//     + pack 4.5 = 36.5-40.5 cycles per 32-cycle MFMA gap, profiles/r03_ub_gap.log): 28.5 per gap, at the price of 8 more MFMAs per 64;
+//   * numerator and denominator are sums over the same ROUNDED probabilities: out = sum p~ v / sum p~, so a dominant probability gives
+//     out = v exactly whatever the softmax reference is — the property the exact-scale rescue variant was kept for in the optimisation
+//     pass (DESIGN 4a'), now without the rescue.
+// score MFMA of the iteration: PAD = the padded asm forms (peeled iterations: the compiler may copy a fragment into a[...] right in front of
+// a use there — seen with the row-sum variant's register pressure — and does not pad in front of asm)
+template <typename T, bool PRE, bool PAD>
+__device__ __forceinline__ void w64_head(f32x16& d, const typename elem_traits<T>::vec8 a, const typename elem_traits<T>::vec8 b, const f32x16& c) {
+    if (PRE) { if (PAD) score_mfma<T>::head_pad(d, a, b, c); else score_mfma<T>::head(d, a, b, c); }
+    else { if (PAD) score_mfma<T>::head_zero_pad(d, a, b); else score_mfma<T>::head_zero(d, a, b); }
+}
+template <typename T, bool PRE, bool PAD>
+__device__ __forceinline__ void w64_acc(f32x16& d, const typename elem_traits<T>::vec8 a, const typename elem_traits<T>::vec8 b) {
+    if (PRE) { if (PAD) score_mfma<T>::acc_pad(d, a, b); else score_mfma<T>::acc(d, a, b); }
+    else { if (PAD) score_mfma<T>::acc_vb_pad(d, a, b); else score_mfma<T>::acc_vb(d, a, b); }
+}
+template <typename T, bool LAST, bool PRE, bool DMA, bool LSUM, bool PAD = false>
 __device__ __forceinline__ void w64_iter(const char* lk, const char* lv, const FragOffs& fo, const typename elem_traits<T>::vec8 (&qf)[2][4],
                                          f32x16 (&X0)[2], f32x16 (&X1)[2], f32x16 (&Y0)[2], f32x16 (&Y1)[2], f32x16 (&negmu)[2],
                                          f32x16 (&o)[2][2], float (&m2)[2], float (&l_run)[2], const float c, u32x4 (&pb0)[2],
-                                         u32x4 (&pb1)[2], typename elem_traits<T>::vec8 (&vc)[4], const W64Stage& sg, float& chk) {
+                                         u32x4 (&pb1)[2], typename elem_traits<T>::vec8 (&vc)[4], const W64Stage& sg, float& chk,
+                                         f32x16 (&lacc)[2], const typename elem_traits<T>::vec8& ones) {
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
     u32x4 pa0[2], pa1[2];
@@ -717,6 +756,11 @@ __device__ __forceinline__ void w64_iter(const char* lk, const char* lv, const F
     // ---- gaps 1-8: second half of tile t-1 into O | probabilities of block A, keys 0..31 | K(t+1) rows 0..31 ----
     if (DMA && !(GD_MP_DBG & 1)) w64_dma(sg.kb, sg.kdst, sg.voff[0], sg.ksoff);
     if (!LAST) kf[0] = ((GD_MP_DBG & 8) ? qf[0][0] : rd_row<T>(lk, fo, 0, 0));
+    // (row-sum MFMAs FIRST in their group: an MFMA that is the LAST reader of a probability fragment, directly followed by the v_exp_f32 that
+    //  reuses the fragment's register, read the new value — wrong sums for query block B, bit-exact for block A; no such pair is left in any
+    //  instantiation: tests/test_cabi.py checks the assembly)
+    if (LSUM) { lacc[0] = TR::mfma32(ones, as_frag<T>(pb0[0]), lacc[0]); GD_SB(); lacc[1] = TR::mfma32(ones, as_frag<T>(pb0[1]), lacc[1]); GD_SB();
+                 lacc[0] = TR::mfma32(ones, as_frag<T>(pb1[0]), lacc[0]); GD_SB(); lacc[1] = TR::mfma32(ones, as_frag<T>(pb1[1]), lacc[1]); GD_SB(); }
     o[0][0] = TR::mfma32(vc[0], as_frag<T>(pb0[0]), o[0][0]); W64_EG2(X0[0], 0, pa0[0], 0, 0); GD_SB();
     o[1][0] = TR::mfma32(vc[0], as_frag<T>(pb0[1]), o[1][0]); W64_EG2(X0[0], 2, pa0[0], 2, 0); GD_SB();
     if (!LAST) kf[1] = ((GD_MP_DBG & 8) ? qf[0][1] : rd_row<T>(lk, fo, 0, 1));
@@ -733,30 +777,32 @@ __device__ __forceinline__ void w64_iter(const char* lk, const char* lv, const F
     // ---- gaps 9-16: scores of tile t+1, keys 0..31 | probabilities of block B, keys 0..31 | V(t) keys 0..31 ----
     if (DMA && !(GD_MP_DBG & 1)) w64_dma(sg.kb, sg.kdst + 1024, sg.voff[1], sg.ksoff);
     va[0] = ((GD_MP_DBG & 8) ? qf[1][0] : rd_tr<T>(lv, fo, 0, 0));
-    if (!LAST) { if (PRE) score_mfma<T>::head(Y0[0], kf[0], qf[0][0], negmu[0]); else score_mfma<T>::head_zero(Y0[0], kf[0], qf[0][0]); }
+    if (!LAST) w64_head<T, PRE, PAD>(Y0[0], kf[0], qf[0][0], negmu[0]);
     W64_EG2(X0[1], 0, pa0[1], 0, 1); GD_SB();
-    if (!LAST) { if (PRE) score_mfma<T>::head(Y0[1], kf[0], qf[1][0], negmu[1]); else score_mfma<T>::head_zero(Y0[1], kf[0], qf[1][0]); }
+    if (!LAST) w64_head<T, PRE, PAD>(Y0[1], kf[0], qf[1][0], negmu[1]);
     W64_EG2(X0[1], 2, pa0[1], 2, 1); GD_SB();
     va[1] = ((GD_MP_DBG & 8) ? qf[1][0] : rd_tr<T>(lv, fo, 1, 0));
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[0], kf[1], qf[0][1]); else score_mfma<T>::acc_vb(Y0[0], kf[1], qf[0][1]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y0[0], kf[1], qf[0][1]);
     W64_EG2(X0[1], 4, pa0[1], 4, 1); GD_SB();
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[1], kf[1], qf[1][1]); else score_mfma<T>::acc_vb(Y0[1], kf[1], qf[1][1]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y0[1], kf[1], qf[1][1]);
     W64_EG2(X0[1], 6, pa0[1], 6, 1); GD_SB();
     va[2] = ((GD_MP_DBG & 8) ? qf[1][1] : rd_tr<T>(lv, fo, 0, 1));
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[0], kf[2], qf[0][2]); else score_mfma<T>::acc_vb(Y0[0], kf[2], qf[0][2]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y0[0], kf[2], qf[0][2]);
     W64_EG2(X0[1], 8, pa1[1], 0, 1); GD_SB();
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[1], kf[2], qf[1][2]); else score_mfma<T>::acc_vb(Y0[1], kf[2], qf[1][2]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y0[1], kf[2], qf[1][2]);
     W64_EG2(X0[1], 10, pa1[1], 2, 1); GD_SB();
     va[3] = ((GD_MP_DBG & 8) ? qf[1][1] : rd_tr<T>(lv, fo, 1, 1));
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[0], kf[3], qf[0][3]); else score_mfma<T>::acc_vb(Y0[0], kf[3], qf[0][3]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y0[0], kf[3], qf[0][3]);
     W64_EG2(X0[1], 12, pa1[1], 4, 1); GD_SB();
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y0[1], kf[3], qf[1][3]); else score_mfma<T>::acc_vb(Y0[1], kf[3], qf[1][3]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y0[1], kf[3], qf[1][3]);
     W64_EG2(X0[1], 14, pa1[1], 6, 1); GD_SB();
     W64_CHECK(X0[1], 1, pa0[1], pa1[1])
     GD_SB();
     // ---- gaps 17-24: first half of tile t into O | probabilities of block A, keys 32..63 | K(t+1) rows 32..63 ----
     if (DMA && !(GD_MP_DBG & 1)) w64_dma(sg.vb, sg.vdst, sg.voff[0], sg.vsoff);
     if (!LAST) kf[0] = ((GD_MP_DBG & 8) ? qf[0][0] : rd_row<T>(lk, fo, 1, 0));
+    if (LSUM) { lacc[0] = TR::mfma32(ones, as_frag<T>(pa0[0]), lacc[0]); GD_SB(); lacc[1] = TR::mfma32(ones, as_frag<T>(pa0[1]), lacc[1]); GD_SB();
+                 lacc[0] = TR::mfma32(ones, as_frag<T>(pa1[0]), lacc[0]); GD_SB(); lacc[1] = TR::mfma32(ones, as_frag<T>(pa1[1]), lacc[1]); GD_SB(); }
     o[0][0] = TR::mfma32(va[0], as_frag<T>(pa0[0]), o[0][0]); W64_EG2(X1[0], 0, pb0[0], 0, 0); GD_SB();
     o[1][0] = TR::mfma32(va[0], as_frag<T>(pa0[1]), o[1][0]); W64_EG2(X1[0], 2, pb0[0], 2, 0); GD_SB();
     if (!LAST) kf[1] = ((GD_MP_DBG & 8) ? qf[0][1] : rd_row<T>(lk, fo, 1, 1));
@@ -773,31 +819,32 @@ __device__ __forceinline__ void w64_iter(const char* lk, const char* lv, const F
     // ---- gaps 25-32: scores of tile t+1, keys 32..63 | probabilities of block B, keys 32..63 | V(t) keys 32..63 ----
     if (DMA && !(GD_MP_DBG & 1)) w64_dma(sg.vb, sg.vdst + 1024, sg.voff[1], sg.vsoff);
     vc[0] = ((GD_MP_DBG & 8) ? qf[1][2] : rd_tr<T>(lv, fo, 0, 2));
-    if (!LAST) { if (PRE) score_mfma<T>::head(Y1[0], kf[0], qf[0][0], negmu[0]); else score_mfma<T>::head_zero(Y1[0], kf[0], qf[0][0]); }
+    if (!LAST) w64_head<T, PRE, PAD>(Y1[0], kf[0], qf[0][0], negmu[0]);
     W64_EG2(X1[1], 0, pb0[1], 0, 1); GD_SB();
-    if (!LAST) { if (PRE) score_mfma<T>::head(Y1[1], kf[0], qf[1][0], negmu[1]); else score_mfma<T>::head_zero(Y1[1], kf[0], qf[1][0]); }
+    if (!LAST) w64_head<T, PRE, PAD>(Y1[1], kf[0], qf[1][0], negmu[1]);
     W64_EG2(X1[1], 2, pb0[1], 2, 1); GD_SB();
     vc[1] = ((GD_MP_DBG & 8) ? qf[1][2] : rd_tr<T>(lv, fo, 1, 2));
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[0], kf[1], qf[0][1]); else score_mfma<T>::acc_vb(Y1[0], kf[1], qf[0][1]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y1[0], kf[1], qf[0][1]);
     W64_EG2(X1[1], 4, pb0[1], 4, 1); GD_SB();
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[1], kf[1], qf[1][1]); else score_mfma<T>::acc_vb(Y1[1], kf[1], qf[1][1]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y1[1], kf[1], qf[1][1]);
     W64_EG2(X1[1], 6, pb0[1], 6, 1); GD_SB();
     vc[2] = ((GD_MP_DBG & 8) ? qf[1][3] : rd_tr<T>(lv, fo, 0, 3));
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[0], kf[2], qf[0][2]); else score_mfma<T>::acc_vb(Y1[0], kf[2], qf[0][2]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y1[0], kf[2], qf[0][2]);
     W64_EG2(X1[1], 8, pb1[1], 0, 1); GD_SB();
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[1], kf[2], qf[1][2]); else score_mfma<T>::acc_vb(Y1[1], kf[2], qf[1][2]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y1[1], kf[2], qf[1][2]);
     W64_EG2(X1[1], 10, pb1[1], 2, 1); GD_SB();
     vc[3] = ((GD_MP_DBG & 8) ? qf[1][3] : rd_tr<T>(lv, fo, 1, 3));
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[0], kf[3], qf[0][3]); else score_mfma<T>::acc_vb(Y1[0], kf[3], qf[0][3]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y1[0], kf[3], qf[0][3]);
     W64_EG2(X1[1], 12, pb1[1], 4, 1); GD_SB();
-    if (!LAST) { if (PRE) score_mfma<T>::acc(Y1[1], kf[3], qf[1][3]); else score_mfma<T>::acc_vb(Y1[1], kf[3], qf[1][3]); }
+    if (!LAST) w64_acc<T, PRE, PAD>(Y1[1], kf[3], qf[1][3]);
     W64_EG2(X1[1], 14, pb1[1], 6, 1); GD_SB();
     W64_CHECK(X1[1], 1, pb0[1], pb1[1])
 }
 
-template <typename T, bool PRE, bool SK>
+template <typename T, bool PRE, bool SK, bool LSUM = false>
 __global__ void __launch_bounds__(256, 1)
 k_attn_fwd_w64(const FwdArgs a) {
+    static_assert(PRE || !LSUM, "row sums on the matrix pipe: pre-scaled variant only (the rescue variant needs the half-step sums on the vector pipe)");
     using TR = elem_traits<T>;
     using V8 = typename TR::vec8;
     // set = {Ka, Kb, Va, Vb} of one tile pair.  Two separate arrays: the compiler can then prove that the direct-to-LDS stores into one
@@ -928,6 +975,10 @@ k_attn_fwd_w64(const FwdArgs a) {
     const float c = (PRE || a.q_prescaled) ? 1.0f : a.c;
 
     f32x16 o[2][2], X0[2], X1[2], Y0[2], Y1[2], negmu[2];
+    f32x16 lacc[2];                   // LSUM: row sums as MFMA accumulators (every row of the 32 x 32 tile holds the same sum)
+    V8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = TR::from_f32(1.0f);
     float m2[2], l_run[2];
     u32x4 pb0[2], pb1[2];
     // wait states around the asm score MFMAs outside the loop.  The X tiles are OPERANDS of the pad: an asm with only a memory clobber
@@ -979,7 +1030,7 @@ k_attn_fwd_w64(const FwdArgs a) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o[b][0][i] = 0.f; o[b][1][i] = 0.f; X0[b][i] = 0.f; X1[b][i] = 0.f; Y0[b][i] = 0.f; Y1[b][i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { o[b][0][i] = 0.f; o[b][1][i] = 0.f; X0[b][i] = 0.f; X1[b][i] = 0.f; Y0[b][i] = 0.f; Y1[b][i] = 0.f; lacc[b][i] = 0.f; }
     }
     W64_PAD("s_nop 7")
     {
@@ -1022,8 +1073,9 @@ k_attn_fwd_w64(const FwdArgs a) {
     __syncthreads();                  // (and every wave has read K(0) before the next pair's pieces land on its tile)
     W64_STAMP(1)
 
-#define W64_ITER(LAST_, DMA_, LK, LV, SA0, SA1, SB0, SB1) \
-    w64_iter<T, LAST_, PRE, DMA_>(LK, LV, fo, qf, SA0, SA1, SB0, SB1, negmu, o, m2, l_run, c, pb0, pb1, vc, st, chk)
+#define W64_ITER_P(LAST_, DMA_, PAD_, LK, LV, SA0, SA1, SB0, SB1) \
+    w64_iter<T, LAST_, PRE, DMA_, LSUM, PAD_>(LK, LV, fo, qf, SA0, SA1, SB0, SB1, negmu, o, m2, l_run, c, pb0, pb1, vc, st, chk, lacc, ones)
+#define W64_ITER(LAST_, DMA_, LK, LV, SA0, SA1, SB0, SB1) W64_ITER_P(LAST_, DMA_, false, LK, LV, SA0, SA1, SB0, SB1)
 #define W64_STAGE(KT, VT, KDST, VDST) { st.ksoff = (KT) * tB; st.vsoff = (VT) * tB; st.kdst = (KDST) + wave * 2048; st.vdst = (VDST) + wave * 2048; }
     int t = 0;                        // first tile of the pair on set A
 #pragma unroll 1
@@ -1036,13 +1088,21 @@ k_attn_fwd_w64(const FwdArgs a) {
         W64_STAGE(t + 6, t + 5, ldsA[1], ldsA[3]) W64_ITER(false, true, ldsB[1], ldsB[3], Y0, Y1, X0, X1);
         if (!(GD_MP_DBG & 2)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
     }
-    W64_STAGE(t + 3, t + 2, ldsB[0], ldsB[2]) W64_ITER(false, true, ldsA[0], ldsA[2], X0, X1, Y0, Y1);
-    W64_STAGE(t + 3, t + 3, ldsB[1], ldsB[3]) W64_ITER(false, true, ldsA[1], ldsA[3], Y0, Y1, X0, X1);   // no K(Tg): a harmless repeat of K(Tg-1)
+    // (the four iterations behind the loop: padded score MFMAs)
+    W64_STAGE(t + 3, t + 2, ldsB[0], ldsB[2]) W64_ITER_P(false, true, true, ldsA[0], ldsA[2], X0, X1, Y0, Y1);
+    W64_STAGE(t + 3, t + 3, ldsB[1], ldsB[3]) W64_ITER_P(false, true, true, ldsA[1], ldsA[3], Y0, Y1, X0, X1);   // no K(Tg): a harmless repeat of K(Tg-1)
     if (!(GD_MP_DBG & 2)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
-    W64_ITER(false, false, ldsB[0], ldsB[2], X0, X1, Y0, Y1);
-    W64_ITER(true, false, ldsB[1], ldsB[3], Y0, Y1, X0, X1);
+    W64_ITER_P(false, false, true, ldsB[0], ldsB[2], X0, X1, Y0, Y1);
+    W64_ITER_P(true, false, true, ldsB[1], ldsB[3], Y0, Y1, X0, X1);
 #undef W64_ITER
+#undef W64_ITER_P
 #undef W64_STAGE
+    // The bias tiles stay LIVE to here.  Their last reader is an asm score MFMA of the second-to-last iteration, and the compiler — which
+    // treats an asm as complete when it is issued — may hand a tile's registers to the very next vector instruction while the MFMA is
+    // still reading them as SrcC (16 passes): seen in the first row-sum build, whose register pressure made it reuse negmu[1] for the
+    // packed probabilities two instructions behind the MFMA — wrong scores for the last tile of query block B only, exact for block A
+    // (tests/test_cabi.py now scans every instantiation for a vector write into an asm MFMA's sources behind it).
+    asm volatile("" ::"v"(negmu[0]), "v"(negmu[1]));
     // second half of the last tile
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -1050,6 +1110,19 @@ k_attn_fwd_w64(const FwdArgs a) {
         o[b][1] = TR::mfma32(vc[1], as_frag<T>(pb0[b]), o[b][1]);
         o[b][0] = TR::mfma32(vc[2], as_frag<T>(pb1[b]), o[b][0]);
         o[b][1] = TR::mfma32(vc[3], as_frag<T>(pb1[b]), o[b][1]);
+        if (LSUM) {
+            lacc[b] = TR::mfma32(ones, as_frag<T>(pb0[b]), lacc[b]);
+            lacc[b] = TR::mfma32(ones, as_frag<T>(pb1[b]), lacc[b]);
+        }
+    }
+    if (LSUM) {
+        // every lane holds the full row sum (both key halves of a k-step are summed by the MFMA); the code below adds the two lane
+        // halves' l_run, so each gets half.  A sum that left [0, 2^60] or is NaN sends the segment to the exact-maxima attempt.
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            l_run[b] = 0.5f * lacc[b][0];
+            chk = fmaxf(chk, fabsf(lacc[b][0]) == fabsf(lacc[b][0]) ? lacc[b][0] : __builtin_inff());
+        }
     }
     W64_STAMP(2)
     if (attempt) break;
@@ -1296,9 +1369,19 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
         }
     }
 #define GD_W64_LAUNCH(T_, PRE_, SK_) k_attn_fwd_w64<T_, PRE_, SK_><<<a.nwg, 256, 0, st>>>(a)
+#define GD_W64_LAUNCH_L(T_, SK_) k_attn_fwd_w64<T_, true, SK_, true><<<a.nwg, 256, 0, st>>>(a)
+    // pre-scaled variant with the row sums on the matrix pipe: where the caller asks for it (gd_attn_seg_t::q_scaled == 2: the
+    // optimisation pass, whose L1 losses need numerator and denominator over the same rounded probabilities).  Measured (tools/
+    // bench_lsum.py): no faster than the vector-pipe sums on the no-grad launches (15 heads 59 -> 62-66 us: the 8 extra MFMAs per tile cost
+    // what the 32 v_add_f32 saved), 10-11 us faster than the exact-scale rescue variant it replaces in the optimisation pass (71 -> 60).
+    // GD_ATTN_LSUM = 0: never, 2: every pre-scaled launch (experiments).
+    static int lsum_env = -1;
+    if (lsum_env < 0) { const char* e = getenv("GD_ATTN_LSUM"); lsum_env = e ? atoi(e) : 1; }
+    const bool lsum = lsum_env == 2 || (lsum_env == 1 && a.lsum);
 #define GD_W64_T(T_)                                                          \
     {                                                                         \
-        if (pre) { if (sk) GD_W64_LAUNCH(T_, true, true); else GD_W64_LAUNCH(T_, true, false); }   \
+        if (pre && lsum) { if (sk) GD_W64_LAUNCH_L(T_, true); else GD_W64_LAUNCH_L(T_, false); }   \
+        else if (pre) { if (sk) GD_W64_LAUNCH(T_, true, true); else GD_W64_LAUNCH(T_, true, false); }   \
         else { if (sk) GD_W64_LAUNCH(T_, false, true); else GD_W64_LAUNCH(T_, false, false); }     \
     }
     // fp16: always the rescue variant — its probabilities stay below the half-step limit of 2^14, inside fp16's range, where the fixed
@@ -1306,6 +1389,7 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
     if (dtype == GD_F16) { if (sk) GD_W64_LAUNCH(f16_t, false, true); else GD_W64_LAUNCH(f16_t, false, false); }
     else GD_W64_T(bf16_t)
 #undef GD_W64_T
+#undef GD_W64_LAUNCH_L
 #undef GD_W64_LAUNCH
     GD_CHECK_LAUNCH("gd_attn_fwd");
     return GD_OK;

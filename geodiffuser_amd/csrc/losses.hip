@@ -7,6 +7,7 @@
 // (GeoDiffuser/utils/generic_torch.py:145-154) and the blend at U/attention_processors.py:504,619 — about thirty
 // torch launches and a dozen [f,N,D] temporaries per layer in the reference — by one pass each.
 // HBM-bound: forward reads eo + ro (+ target) once: 2 * H*N*D * sizeof(T) (+ 4 * H*N*D) bytes.
+#include <stdlib.h>
 #include "common.hpp"
 #include "edit_layer.hpp"
 
@@ -68,6 +69,66 @@ __global__ void k_gauss5(const float* __restrict__ tmp, int H, int S, int D, flo
     out[gid] = acc;
 }
 
+// Both steps in one launch (round 4): a workgroup owns an 8 x 8 pixel tile of one head, builds the interpolated / overwritten features of
+// the 12 x 12 pixels its 5 x 5 windows reach in LDS (zeros outside the image: the stand-alone kernel skips those taps, adding w * 0 is
+// the same sum) and runs the 25 taps from there in k_gauss5's order — the same values bit for bit, without the [H,N,D] f32 round trip
+// through HBM and its 25 strided re-reads per output (k_gauss5 alone: 20 us at 64^2 x 5 heads).  D <= 64.
+#define AM_T 8
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_amodal_fused(const T* __restrict__ eo, const int32_t* __restrict__ nn_idx, const float* __restrict__ nn_w, const float* __restrict__ fg,
+               int S, int D, int tiles_x, float* __restrict__ out) {
+    __shared__ float tile[(AM_T + 4) * (AM_T + 4) * 64];
+    const int N = S * S;
+    const int h = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * AM_T, x0 = tx * AM_T;
+    const T* e = eo + (size_t)h * N * D;
+    constexpr int W = AM_T + 4;
+    for (int i = threadIdx.x; i < W * W * D; i += 256) {
+        const int d = i % D, pp = i / D;
+        const int py = pp / W, px = pp - py * W;
+        const int y = y0 - 2 + py, x = x0 - 2 + px;
+        float r = 0.f;
+        if (y >= 0 && y < S && x >= 0 && x < S) {
+            const int n = y * S + x;
+            if (fg[n] > 0.5f) {
+                r = (float)e[(size_t)n * D + d];
+            } else {
+                float acc = 0.f, ws = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float w = nn_w[n * 4 + k];
+                    acc += (float)e[(size_t)nn_idx[n * 4 + k] * D + d] * w;
+                    ws += w;
+                }
+                r = acc / (ws + 1e-12f);
+            }
+        }
+        tile[pp * D + d] = r;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < AM_T * AM_T * D; i += 256) {
+        const int d = i % D, pp = i / D;
+        const int oy = pp / AM_T, ox = pp - oy * AM_T;
+        const int y = y0 + oy, x = x0 + ox;
+        if (y >= S || x >= S) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= S) continue;
+#pragma unroll
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= S) continue;
+                acc += (c_g1[dy + 2] * c_g1[dx + 2]) * tile[((oy + dy + 2) * W + (ox + dx + 2)) * D + d];
+            }
+        }
+        out[((size_t)h * N + (size_t)y * S + x) * D + d] = acc;
+    }
+}
+
 extern "C" int gd_amodal_target(const void* eo, const int32_t* nn_idx, const float* nn_w, const float* fg,
                                 int H, int S, int D, float* tmp, float* target, int dtype, void* stream) {
     GD_REQUIRE(eo && nn_idx && nn_w && fg && tmp && target, GD_EINVAL, "gd_amodal_target: null pointer");
@@ -75,6 +136,15 @@ extern "C" int gd_amodal_target(const void* eo, const int32_t* nn_idx, const flo
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_amodal_target: dtype must be f16/bf16");
     hipStream_t st = as_stream(stream);
     const int N = S * S;
+    const char* two = getenv("GD_AMODAL_TWO_PASS");          // tests: the stand-alone pair of kernels
+    if (D <= 64 && !(two && two[0] == '1')) {
+        const int tiles_x = (S + AM_T - 1) / AM_T;
+        dim3 grid(tiles_x * tiles_x, H);
+        if (dtype == GD_F16) k_amodal_fused<f16_t><<<grid, 256, 0, st>>>((const f16_t*)eo, nn_idx, nn_w, fg, S, D, tiles_x, target);
+        else k_amodal_fused<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)eo, nn_idx, nn_w, fg, S, D, tiles_x, target);
+        GD_CHECK_LAUNCH("gd_amodal_target");
+        return GD_OK;
+    }
     const long long total = (long long)H * N * D;
     const int blocks = (int)((total + 255) / 256);
     if (dtype == GD_F16) k_amodal_interp<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)eo, nn_idx, nn_w, fg, H, N, D, tmp);

@@ -58,6 +58,38 @@ def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None, ctx_s
     return out
 
 
+_TEXT_CACHE = {}       # id(text_encoder) -> (weakref, weights version, {(token ids) -> embeddings})
+TEXT_CACHE = os.environ.get("GD_TEXT_CACHE", "1") == "1"
+
+
+@torch.no_grad()
+def encode_text(model, input_ids: torch.Tensor) -> torch.Tensor:
+    """``model.text_encoder(input_ids)[0]`` (U/editor.py:116-121, U/inversion.py:213-224 call it four times per edit) with the result kept per
+    token-id tuple: the embedding is a pure function of the ids and the encoder's weights, the batch driver passes the same prompt ("")
+    for every edit, and a 23-layer text tower at batch 1 is ~300 eagerly dispatched launches during which the GPU idles at the start of
+    every edit.  The cache dies with the encoder and is dropped when any of its parameters is modified in place (version counters).
+    Callers get a fresh copy (nothing downstream writes into it, but a cached tensor must not depend on that).  GD_TEXT_CACHE=0: off."""
+    enc = model.text_encoder
+    ids = input_ids.to(model.device)
+    if not TEXT_CACHE or not isinstance(enc, torch.nn.Module):
+        return enc(ids)[0]
+    import weakref
+    params = list(enc.parameters())
+    ver = (tuple(p._version for p in params), params[0].dtype if params else None, str(model.device))
+    ent = _TEXT_CACHE.get(id(enc))
+    if ent is None or ent[0]() is not enc or ent[1] != ver:
+        ent = _TEXT_CACHE[id(enc)] = (weakref.ref(enc), ver, {})
+        for k in [k for k, e in _TEXT_CACHE.items() if e[0]() is None]:
+            del _TEXT_CACHE[k]
+    key = tuple(input_ids.reshape(-1).tolist()) + tuple(input_ids.shape)
+    emb = ent[2].get(key)
+    if emb is None:
+        if len(ent[2]) >= 64:
+            ent[2].clear()
+        emb = ent[2][key] = enc(ids)[0].detach()
+    return emb.clone()
+
+
 def _sched_step(scheduler, eps_uncond, t, sample, eps_cond, guidance_scale):
     """scheduler.step with the classifier-free-guidance combine.  The repo's own schedulers fuse the combine into the DDIM kernel
     (``eps_cond`` / ``guidance_scale`` keywords of gd_ddim_step); any other scheduler object (e.g. a diffusers ``DDIMScheduler`` a

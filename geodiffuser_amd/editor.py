@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from . import ops, vis_utils, warp_utils
 from .attention_processors import (AttentionGeometryEdit, AttentionGeometryRemover, VanillaAttentionProcessor,
                                    register_attention_control_diffusers, set_attn_processor_for_edit)
-from .diffusion import diffusion_step, image2latent, latent2image, load_model
+from .diffusion import diffusion_step, encode_text, image2latent, latent2image, load_model
 from .generic_torch import binarize_tensor, norm_tensor, reshape_transform_coords, torch_erode
 from .image_processing import masked_histogram_matching
 from .inversion import NullInversion
@@ -114,11 +114,11 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
 
     tok = model.tokenizer
     text_input = tok(prompt, padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt")
-    text_embeddings = model.text_encoder(text_input.input_ids.to(model.device))[0]
+    text_embeddings = encode_text(model, text_input.input_ids)
     max_length = text_input.input_ids.shape[-1]
     if uncond_embeddings is None:
         uncond_input = tok([UNCOND_TEXT] * batch_size, padding="max_length", max_length=max_length, return_tensors="pt", truncation=True)
-        uncond_embeddings_ = model.text_encoder(uncond_input.input_ids.to(model.device))[0]
+        uncond_embeddings_ = encode_text(model, uncond_input.input_ids)
     else:
         uncond_embeddings_ = None
 

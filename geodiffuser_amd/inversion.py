@@ -8,6 +8,7 @@ import torch
 
 from . import graphs
 from .attention_processors import VanillaAttentionProcessor
+from .diffusion import encode_text
 from .scheduler import DDIMInverseScheduler, DDIMScheduler
 
 
@@ -46,9 +47,9 @@ class NullInversion:
     def init_prompt(self, prompt: str):
         tok = self.model.tokenizer
         uncond_input = tok([self.uncond_text], padding="max_length", max_length=tok.model_max_length, return_tensors="pt")
-        uncond_embeddings = self.model.text_encoder(uncond_input.input_ids.to(self.model.device))[0]
+        uncond_embeddings = encode_text(self.model, uncond_input.input_ids)
         text_input = tok([prompt], padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt")
-        text_embeddings = self.model.text_encoder(text_input.input_ids.to(self.model.device))[0]
+        text_embeddings = encode_text(self.model, text_input.input_ids)
         self.context = torch.cat([uncond_embeddings, text_embeddings])
         self.prompt = prompt
 

@@ -191,7 +191,7 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
     q*(1-m) + m*half(sum_k w*q[idx]) built inside the kernel (U/attention_processors.py:424-428,544-549) — the fused
     attention-warp launch; bit-identical to passing splat_composite(q, idx, w, m) as q.
     q_scaled: every q already carries scale*log2(e) (applied by the projection GEMM before its rounding, see attention_processors
-    ``_project_qkv``); ``scale`` is then ignored."""
+    ``_project_qkv``); ``scale`` is then ignored.  2: additionally row sums over the rounded probabilities (gd_attn_seg_t.q_scaled)."""
     lib = _lib.load()
     n = len(segs)
     arr = (GdAttnSeg * n)()
@@ -235,7 +235,7 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
                 _need(t_m, "warp m", torch.float32)
             widx, ww, wm = t_idx.data_ptr(), t_w.data_ptr(), 0 if t_m is None else t_m.data_ptr()
         arr[i] = GdAttnSeg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 0 if lse is None else lse.data_ptr(), bh, heads,
-                           widx, ww, wm, wK, int(bool(q_scaled)), rl, rn, 0 if qrows is None else No)
+                           widx, ww, wm, wK, int(q_scaled) if q_scaled in (0, 1, 2) else int(bool(q_scaled)), rl, rn, 0 if qrows is None else No)
     if nsplit is None:
         nsplit, ws_bytes = _attn_plan(lib, tot_bh, N, M) if SPLIT_KV else (1, 0)
     else:
@@ -420,8 +420,9 @@ def amodal_target(eo, nn_idx, nn_w, fg, S: int):
     dt = _dt16(eo, "eo")
     _need(eo, "eo"); _need(nn_idx, "nn_idx", torch.int32); _need(nn_w, "nn_w", torch.float32); _need(fg, "fg", torch.float32)
     H, N, D = eo.shape
-    tmp = torch.empty(H, N, D, dtype=torch.float32, device=eo.device)
-    tgt = torch.empty_like(tmp)
+    tgt = torch.empty(H, N, D, dtype=torch.float32, device=eo.device)
+    # (scratch of the two-launch form only: head dims above 64, or GD_AMODAL_TWO_PASS=1)
+    tmp = torch.empty_like(tgt) if (D > 64 or os.environ.get("GD_AMODAL_TWO_PASS") == "1") else tgt
     check(lib.gd_amodal_target(_p(eo), _p(nn_idx), _p(nn_w), _p(fg), H, S, D, _p(tmp), _p(tgt), dt, _stream()), "gd_amodal_target")
     return tgt
 

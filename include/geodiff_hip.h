@@ -113,7 +113,11 @@ typedef struct {
     /* Nonzero: q already holds scale*log2(e)*q — the query projection applied that factor in its fp32 GEMM epilogue, BEFORE the one
      * rounding to 16 bits.  The kernels then take the scores as exponents of 2 directly (p = exp2(q.k - mu): one vector instruction
      * per probability instead of two on the vector-issue-bound D = 64 path) and `scale` is ignored.  All segments of a launch must
-     * agree.  lse stays the natural-log sum-exp of the scaled scores. */
+     * agree.  lse stays the natural-log sum-exp of the scaled scores.
+     * 2 (as 1, and): the row sums are taken over the ROUNDED 16-bit probabilities the P.V products consume (on the matrix pipe, one extra
+     * MFMA per 16-key step), so out = sum p~ v / sum p~ exactly: a dominant probability reproduces its value row whatever the softmax
+     * reference is.  For launches whose outputs are compared with each other by L1 losses (the optimisation pass); lse then carries the
+     * rounding of the probabilities (~1e-3 relative).  Honoured by the 64-query kernel (64^2-token launches); elsewhere the same as 1. */
     int32_t q_scaled;
     /* Query ROW LIST (at most one segment of a launch; NULL: all N rows).  The segment attends only with rows q_rows[0 .. *q_rows_n) of q
      * (taken from the full [.., N, ..] tensor; the warp tables, if any, are indexed by the same row ids) and writes a DENSE result:

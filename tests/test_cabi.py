@@ -99,7 +99,8 @@ def test_w64_main_loop_has_no_register_file_copies(tmp_path):
             m = re.search(r"s_(?:cbranch_\w+|branch) (\.LBB\d+_\d+)", ln)
             if m and labels.get(m.group(1), 1 << 30) < i:
                 ops_ = Counter(x.split()[0] for x in (y.strip() for y in body[labels[m.group(1)]:i]) if x and x[0] not in ";.")
-                if sum(v for k, v in ops_.items() if k.startswith("v_mfma")) == 128:
+                # (160: the instantiations whose row sums run on the matrix pipe — 8 more MFMAs per tile, LSUM)
+                if sum(v for k, v in ops_.items() if k.startswith("v_mfma")) in (128, 160):
                     found = True
                     assert not any(k.startswith("v_accvgpr") for k in ops_), (text[st], {k: v for k, v in ops_.items() if k.startswith("v_accvgpr")})
                     break
@@ -128,3 +129,25 @@ def test_w64_main_loop_has_no_register_file_copies(tmp_path):
                 m = re.match(r"s_nop (\d+)", prev)
                 ws += int(m.group(1)) + 1 if m else 1
         assert n_asm >= 128, (text[st], n_asm)
+    # ... and the other direction (round 4): no vector instruction may WRITE a source register of an asm-form MFMA shortly BEHIND it.  The
+    # compiler treats an asm as complete when issued; the MFMA reads SrcC over its 16 passes.  (The first row-sum build reused a bias
+    # tile's registers for packed probabilities two instructions after the tile's last score MFMA: wrong scores for one query block.)
+    def _vregs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+    for st in starts:
+        end = next(i for i in range(st, len(text)) if text[i].startswith(".Lfunc_end"))
+        ins = [y for y in (x.strip() for x in text[st:end]) if y and y[0] not in ";." and not y.endswith(":")]
+        for k, ln in enumerate(ins):
+            if not re.match(r"v_mfma\S+ v\[", ln):
+                continue
+            tok = ln.replace(",", " ").split()
+            src = set().union(*(_vregs(t) for t in tok[2:])) - _vregs(tok[1])          # (C == D chains: the MFMA's own result)
+            for nx in ins[k + 1:k + 25]:
+                q = nx.replace(",", " ").split()
+                if q[0].startswith(("s_", "buffer_", "global_", "v_mfma")):
+                    continue
+                assert not (len(q) > 1 and _vregs(q[1]) & src), (text[st], ln, nx)

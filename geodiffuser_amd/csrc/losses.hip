@@ -78,42 +78,58 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_amodal_fused(const T* __restrict__ eo, const int32_t* __restrict__ nn_idx, const float* __restrict__ nn_w, const float* __restrict__ fg,
                int S, int D, int tiles_x, float* __restrict__ out) {
-    __shared__ float tile[(AM_T + 4) * (AM_T + 4) * 64];
+    // (first form: one channel per thread and step — 2-byte loads, ~1,000 dependent wave loads per workgroup: 50 us, slower than the
+    //  pair it replaced.  Now 8 channels per thread: 16-byte feature loads, 32-byte LDS accesses.)
+    using V8 = typename elem_traits<T>::vec8;
+    __shared__ __attribute__((aligned(16))) float tile[(AM_T + 4) * (AM_T + 4) * 64];
     const int N = S * S;
     const int h = blockIdx.y;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * AM_T, x0 = tx * AM_T;
     const T* e = eo + (size_t)h * N * D;
     constexpr int W = AM_T + 4;
-    for (int i = threadIdx.x; i < W * W * D; i += 256) {
-        const int d = i % D, pp = i / D;
+    const int D8 = D / 8;
+    for (int i = threadIdx.x; i < W * W * D8; i += 256) {
+        const int c = i % D8, pp = i / D8;
         const int py = pp / W, px = pp - py * W;
         const int y = y0 - 2 + py, x = x0 - 2 + px;
-        float r = 0.f;
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = 0.f;
         if (y >= 0 && y < S && x >= 0 && x < S) {
             const int n = y * S + x;
             if (fg[n] > 0.5f) {
-                r = (float)e[(size_t)n * D + d];
+                const V8 v = *(const V8*)(e + (size_t)n * D + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (float)v[j];
             } else {
-                float acc = 0.f, ws = 0.f;
+                const f32x4 w4 = *(const f32x4*)(nn_w + n * 4);
+                float ws = 0.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float w = nn_w[n * 4 + k];
-                    acc += (float)e[(size_t)nn_idx[n * 4 + k] * D + d] * w;
-                    ws += w;
+                    const V8 v = *(const V8*)(e + (size_t)nn_idx[n * 4 + k] * D + c * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r[j] += (float)v[j] * w4[k];
+                    ws += w4[k];
                 }
-                r = acc / (ws + 1e-12f);
+                const float den = ws + 1e-12f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = r[j] / den;
             }
         }
-        tile[pp * D + d] = r;
+        float* dst = tile + pp * D + c * 8;
+        *(f32x4*)dst = f32x4{r[0], r[1], r[2], r[3]};
+        *(f32x4*)(dst + 4) = f32x4{r[4], r[5], r[6], r[7]};
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < AM_T * AM_T * D; i += 256) {
-        const int d = i % D, pp = i / D;
+    for (int i = threadIdx.x; i < AM_T * AM_T * D8; i += 256) {
+        const int c = i % D8, pp = i / D8;
         const int oy = pp / AM_T, ox = pp - oy * AM_T;
         const int y = y0 + oy, x = x0 + ox;
         if (y >= S || x >= S) continue;
-        float acc = 0.f;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
         for (int dy = -2; dy <= 2; ++dy) {
             const int yy = y + dy;
@@ -122,10 +138,16 @@ k_amodal_fused(const T* __restrict__ eo, const int32_t* __restrict__ nn_idx, con
             for (int dx = -2; dx <= 2; ++dx) {
                 const int xx = x + dx;
                 if (xx < 0 || xx >= S) continue;
-                acc += (c_g1[dy + 2] * c_g1[dx + 2]) * tile[((oy + dy + 2) * W + (ox + dx + 2)) * D + d];
+                const float g = c_g1[dy + 2] * c_g1[dx + 2];
+                const float* src = tile + ((oy + dy + 2) * W + (ox + dx + 2)) * D + c * 8;
+                const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[j] += g * a[j]; acc[4 + j] += g * b[j]; }
             }
         }
-        out[((size_t)h * N + (size_t)y * S + x) * D + d] = acc;
+        float* o = out + ((size_t)h * N + (size_t)y * S + x) * D + c * 8;
+        *(f32x4*)o = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *(f32x4*)(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
     }
 }
 
@@ -137,7 +159,7 @@ extern "C" int gd_amodal_target(const void* eo, const int32_t* nn_idx, const flo
     hipStream_t st = as_stream(stream);
     const int N = S * S;
     const char* two = getenv("GD_AMODAL_TWO_PASS");          // tests: the stand-alone pair of kernels
-    if (D <= 64 && !(two && two[0] == '1')) {
+    if (D <= 64 && D % 8 == 0 && !(two && two[0] == '1')) {
         const int tiles_x = (S + AM_T - 1) / AM_T;
         dim3 grid(tiles_x * tiles_x, H);
         if (dtype == GD_F16) k_amodal_fused<f16_t><<<grid, 256, 0, st>>>((const f16_t*)eo, nn_idx, nn_w, fg, S, D, tiles_x, target);
@@ -157,26 +179,63 @@ extern "C" int gd_amodal_target(const void* eo, const int32_t* nn_idx, const flo
 // ---- losses forward ----------------------------------------------------------------------------------
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
+
+// Per-thread partial sums of the five feature-loss reductions over a grid-stride range of 8-channel chunks (16-byte loads of eo / ro,
+// 32-byte loads of the amodal target).  Shared by k_losses_fwd and k_losses_fused: one summation order, identical sums.
+template <typename T>
+__device__ __forceinline__ void losses_partial(const T* __restrict__ eo, const T* __restrict__ ro, const float* __restrict__ tgt,
+                                               const float* __restrict__ m_wo, const float* __restrict__ m_edit,
+                                               const float* __restrict__ w_am, const float* __restrict__ m_amodal, int H, int S, int D,
+                                               float (&s)[5]) {
+    using V8 = typename elem_traits<T>::vec8;
+    const int N = S * S, D8 = D / 8;
+    const long long total8 = (long long)H * N * D8;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[k] = 0.f;
+    for (long long c8 = (long long)blockIdx.x * blockDim.x + threadIdx.x; c8 < total8; c8 += (long long)gridDim.x * blockDim.x) {
+        const long long t = c8 / D8;
+        const int n = (int)(t % N);
+        const int y = n / S, x = n - y * S;
+        const long long gid = c8 * 8;
+        const V8 r8 = *(const V8*)(ro + gid), e8 = *(const V8*)(eo + gid);
+        const float mw = m_wo[n], me = m_edit[n];
+        float ad = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ad += fabsf((float)e8[j] - (float)r8[j]);
+        s[0] += ad * mw;
+        s[1] += ad * me;
+        if (tgt) {
+            const f32x4 t0 = *(const f32x4*)(tgt + gid), t1 = *(const f32x4*)(tgt + gid + 4);
+            float am = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) am += fabsf(t0[j] - (float)r8[j]) + fabsf(t1[j] - (float)r8[4 + j]);
+            s[2] += am * (w_am[n] * m_amodal[n]);
+        }
+        if (y < S - 1) {
+            const V8 d8 = *(const V8*)(ro + gid + (size_t)S * D);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += fabsf((float)d8[j] - (float)r8[j]);
+            s[3] += a;
+        }
+        if (x < S - 1) {
+            const V8 d8 = *(const V8*)(ro + gid + D);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += fabsf((float)d8[j] - (float)r8[j]);
+            s[4] += a;
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_losses_fwd(const T* __restrict__ eo, const T* __restrict__ ro, const float* __restrict__ tgt, const float* __restrict__ m_wo,
              const float* __restrict__ m_edit, const float* __restrict__ w_am, const float* __restrict__ m_amodal,
              int H, int S, int D, float* __restrict__ sums /* [gridDim.x, 5] partials */) {
-    const int N = S * S;
-    const long long total = (long long)H * N * D;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
-        const long long t = gid / D;
-        const int n = (int)(t % N);
-        const int y = n / S, x = n - y * S;
-        const float r = (float)ro[gid], e = (float)eo[gid];
-        const float ad = fabsf(e - r);
-        s0 += ad * m_wo[n];
-        s1 += ad * m_edit[n];
-        if (tgt) s2 += fabsf(tgt[gid] - r) * w_am[n] * m_amodal[n];
-        if (y < S - 1) s3 += fabsf((float)ro[gid + (size_t)S * D] - r);
-        if (x < S - 1) s4 += fabsf((float)ro[gid + D] - r);
-    }
+    float sp[5];
+    losses_partial<T>(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, H, S, D, sp);
+    float s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
     __shared__ float part[4][5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -200,10 +259,10 @@ k_losses_fold(const float* __restrict__ partial, int nblocks, float* __restrict_
 }
 
 static int losses_fwd_blocks(int H, int S, int D) {
-    const long long total = (long long)H * S * S * D;
-    int blocks = (int)((total + 256 * 8 - 1) / (256 * 8));
+    const long long total8 = (long long)H * S * S * D / 8;
+    int blocks = (int)((total8 + 255) / 256);
     if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;              // one workgroup per CU: 256 arrival tickets, a 256-row fold in gd_edit_losses_fused's tail
     return blocks;
 }
 
@@ -216,7 +275,7 @@ extern "C" int gd_edit_losses_fwd(const void* eo, const void* ro, const float* t
                                   int dtype, void* stream) {
     GD_REQUIRE(eo && ro && m_wo && m_edit && sums && workspace, GD_EINVAL, "gd_edit_losses_fwd: null pointer");
     GD_REQUIRE(!tgt || (w_am && m_amodal), GD_EINVAL, "gd_edit_losses_fwd: tgt needs w_am and m_amodal");
-    GD_REQUIRE(H > 0 && S > 0 && D > 0, GD_EINVAL, "gd_edit_losses_fwd: bad sizes");
+    GD_REQUIRE(H > 0 && S > 0 && D > 0 && D % 8 == 0, GD_EINVAL, "gd_edit_losses_fwd: bad sizes (D must be a multiple of 8)");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_fwd: dtype must be f16/bf16");
     const int blocks = losses_fwd_blocks(H, S, D);
     hipStream_t st = as_stream(stream);
@@ -389,24 +448,10 @@ extern "C" int gd_blend_merge(const void* base, const void* act, const int32_t* 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_losses_fused(const gd_edit_losses_t a) {
-    const int S = a.S, D = a.D, H = a.H;
-    const int N = S * S;
-    const long long total = (long long)H * N * D;
-    const T* __restrict__ eo = (const T*)a.eo;
-    const T* __restrict__ ro = (const T*)a.ro;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
-        const long long t = gid / D;
-        const int n = (int)(t % N);
-        const int y = n / S, x = n - y * S;
-        const float r = (float)ro[gid], e = (float)eo[gid];
-        const float ad = fabsf(e - r);
-        s0 += ad * a.m_wo[n];
-        s1 += ad * a.m_edit[n];
-        if (a.tgt) s2 += fabsf(a.tgt[gid] - r) * a.w_am[n] * a.m_amodal[n];
-        if (y < S - 1) s3 += fabsf((float)ro[gid + (size_t)S * D] - r);
-        if (x < S - 1) s4 += fabsf((float)ro[gid + D] - r);
-    }
+    const int S = a.S, H = a.H;
+    float sp[5];
+    losses_partial<T>((const T*)a.eo, (const T*)a.ro, a.tgt, a.m_wo, a.m_edit, a.w_am, a.m_amodal, H, S, a.D, sp);
+    float s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
     __shared__ float part[4][5];
     __shared__ float rpart[4];
@@ -450,7 +495,7 @@ extern "C" int gd_edit_losses_fused(const gd_edit_losses_t* a, int dtype, void* 
     GD_REQUIRE(!a->tgt || (a->w_am && a->m_amodal), GD_EINVAL, "gd_edit_losses_fused: tgt needs w_am and m_amodal");
     GD_REQUIRE(!a->best || (a->rows && a->p_in && a->j_in && a->p_wo && a->j_wo && a->wgt && a->R > 0), GD_EINVAL,
                "gd_edit_losses_fused: best needs rows, R and the five aux outputs");
-    GD_REQUIRE(a->H > 0 && a->S > 0 && a->D > 0, GD_EINVAL, "gd_edit_losses_fused: bad sizes");
+    GD_REQUIRE(a->H > 0 && a->S > 0 && a->D > 0 && a->D % 8 == 0, GD_EINVAL, "gd_edit_losses_fused: bad sizes (D must be a multiple of 8)");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_fused: dtype must be f16/bf16");
     const int blocks = losses_fwd_blocks(a->H, a->S, a->D);
     hipStream_t st = as_stream(stream);

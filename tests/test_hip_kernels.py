@@ -657,13 +657,14 @@ def test_feature_losses_forward_backward(ops):
     # the kernels below are checked with the oracle's own table (the tie choice is an input here)
     nn_idx, nn_w = top.indices[0].to(torch.int32).contiguous().to(DEV), top.values[0].contiguous().to(DEV)
     tgt = ops.amodal_target(eo_d, nn_idx, nn_w, fl(m_edit), S)
-    # the one-launch form (8 x 8 tiles through LDS) equals the stand-alone interpolation + 5 x 5 blur pair bit for bit
+    # the one-launch form (8 x 8 tiles through LDS, 8 channels per thread) against the stand-alone interpolation + 5 x 5 blur pair: the same
+    # taps in the same order (the compiler's contraction of the vectorised loop may differ in the last bit)
     os.environ["GD_AMODAL_TWO_PASS"] = "1"
     try:
         tgt_two = ops.amodal_target(eo_d, nn_idx, nn_w, fl(m_edit), S)
     finally:
         os.environ.pop("GD_AMODAL_TWO_PASS")
-    assert torch.equal(tgt, tgt_two)
+    assert rel_err(tgt.cpu(), tgt_two.cpu()) < 1e-6
     w_dist = w_dist.cpu()
     interp, w_ref = O.interpolate_from_mask(eo, m_edit, dist)
     fg = m_edit[0, 0, :, 0] > 0.5

@@ -78,9 +78,14 @@ __device__ __forceinline__ void removal_rowdot_body(const A& a, int row, int lan
     const T* __restrict__ pe = (const T*)a.Pe + ((size_t)hd * a.R + r) * a.Mpad;
     const T* __restrict__ pbw = (const T*)a.Pb + ((size_t)hd * a.N + jw) * a.Mpad;
     const T* __restrict__ pbi = (const T*)a.Pb + ((size_t)hd * a.N + ji) * a.Mpad;
+    // 8 keys per lane and step (16-byte loads; the padding columns M .. Mpad of a probability row are zeros, gd_attn_probs)
+    using V8 = typename TR::vec8;
     float dot = 0.f;
-    for (int m = lane; m < a.M; m += 64)
-        dot = __builtin_fmaf(TR::to_f32(pe[m]), cw * TR::to_f32(pbw[m]) + ci * TR::to_f32(pbi[m]), dot);
+    for (int m = lane * 8; m < a.Mpad; m += 64 * 8) {
+        const V8 e8 = *(const V8*)(pe + m), w8 = *(const V8*)(pbw + m), i8 = *(const V8*)(pbi + m);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dot = __builtin_fmaf(TR::to_f32(e8[j]), cw * TR::to_f32(w8[j]) + ci * TR::to_f32(i8[j]), dot);
+    }
     dot = wave_sum(dot);
     if (lane == 0) rowdot[row] = dot;
 }

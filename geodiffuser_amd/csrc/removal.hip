@@ -466,6 +466,125 @@ k_removal_bwd(const RmBwdArgs a) {
         if ((r0 + i) < nv) a.dq_part[(((size_t)mc * a.H + hd) * a.R + r0 + i) * a.D + dch * ATT_D + lane] = acc[i];
 }
 
+// ---- k_removal_bwd2: the dS K product on the matrix pipe (self-attention layers: head dim 64, full key tiles) -------------------
+// k_removal_bwd walks every (row, key) pair on the vector pipe (one v_readlane + one v_fma per key, row and 64 channels: 78 us at 64^2
+// with 307 rows, VALU-bound at 47 % busy).  Here the inpaint row sits on the MFMA lane like the query in the attention backward:
+//   dS^T[m, r] = A[r, m] (cw_r Pb[j_wo(r), m] + ci_r Pb[j_in(r), m] - dot_r) scale        16-bit, built per lane from three row reads
+//   dq^T[d, r] += K^T[d, m] dS^T[m, r]                                                   K^T by the hardware-transposed LDS read
+// One workgroup = (head, 128 list slots, one run of RM_MCH keys): four waves of 32 rows share the K tiles, which arrive by
+// direct-to-LDS loads (two stages).  The partials keep k_removal_bwd's layout [key run][head][slot][64] f32, so both folds
+// (k_removal_dq_fold, gd_edit_dq_fold) stay as they are.  dS is rounded to 16 bits before the product (the vector-pipe kernel keeps it in
+// f32): the same rounding the attention backward applies to its dS.
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+k_removal_bwd2(const RmBwdArgs a) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    using V4 = typename TR::vec4;
+    __shared__ __attribute__((aligned(16))) char st0[ATT_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char st1[ATT_TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int msplit = a.M / RM_MCH;                                  // launcher: M % RM_MCH == 0
+    const int rblocks = (a.R + 127) / 128;
+    int wg = blockIdx.x;
+    const int mc = wg % msplit; wg /= msplit;
+    const int rb = wg % rblocks; const int hd = wg / rblocks;
+    const int nv = a.n_valid ? (a.n_valid[0] < a.R ? a.n_valid[0] : a.R) : a.R;
+    if (rb * 128 >= nv) return;
+    const int r = rb * 128 + wave * 32 + (lane & 31);
+    const bool live = r < nv;
+    const int rc = live ? r : nv - 1;
+    const int row = hd * a.R + rc;
+    const float cf = (a.gscale ? a.coef * a.gscale[0] : a.coef) * (a.gscale2 ? a.gscale2[0] : 1.0f);
+    const int ji = a.j_in[row], jw = a.j_wo[row];
+    const float cw = live ? -cf * a.wgt[row] * a.m_wo[jw] / (a.p_wo[row] + 1e-4f) : 0.f;
+    const float ci = live ? cf * a.wgt[row] * a.m_inp[ji] / (a.p_in[row] + 1e-4f) : 0.f;
+    const float dot = a.rowdot[row];
+    const int m_lo = mc * RM_MCH;
+    const T* __restrict__ pe = (const T*)a.Pe + ((size_t)hd * a.R + rc) * a.Mpad + m_lo + 4 * h;
+    const T* __restrict__ pbw = (const T*)a.Pb + ((size_t)hd * a.N + jw) * a.Mpad + m_lo + 4 * h;
+    const T* __restrict__ pbi = (const T*)a.Pb + ((size_t)hd * a.N + ji) * a.Mpad + m_lo + 4 * h;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)a.k + ((size_t)hd * a.M + m_lo) * ATT_D), 0, 0x7FFFFFFF, 0x00020000);
+    uint32_t voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rw = (2 * wave + j) * 8 + (lane >> 3);
+        const int x = (rw >> 1) & 7, g = (x & 2) | ((x & 1) << 2) | ((x >> 2) & 1);
+        voff[j] = (uint32_t)((rw * ATT_D + ((lane & 7) ^ g) * 8) * (int)sizeof(T));
+    }
+#define RM2_ISSUE(ST, TI)                                                                  \
+    {                                                                                      \
+        dma_asm(rsK, (ST) + wave * 2048, voff[0], (TI) * ATT_TILE_BYTES);                  \
+        dma_asm(rsK, (ST) + wave * 2048 + 1024, voff[1], (TI) * ATT_TILE_BYTES);           \
+    }
+    constexpr int NTL = RM_MCH / ATT_BN;                              // key tiles per run
+    RM2_ISSUE(st0, 0)
+    const FragOffs fo = make_frag_offs(lane);
+    f32x16 dq[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[j][i] = 0.f;
+    // this lane's probabilities of one tile: per 16-key step the keys 4 h .. 4 h + 3 and 8 + 4 h .. 8 + 4 h + 3 (the k order of rd_tr)
+    V4 ae[8], bw[8], bi[8];
+#define RM2_LOAD(TI)                                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                           \
+        _Pragma("unroll") for (int q2 = 0; q2 < 2; ++q2) {                                                     \
+            const int o_ = (TI) * ATT_BN + 16 * ks + 8 * q2;                                                   \
+            ae[2 * ks + q2] = *(const V4*)(pe + o_); bw[2 * ks + q2] = *(const V4*)(pbw + o_); bi[2 * ks + q2] = *(const V4*)(pbi + o_); \
+        }
+    RM2_LOAD(0)
+#define RM2_STEP(CUR, NXT, TT)                                                                                \
+    {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        asm volatile("" ::: "memory");                                                                        \
+        V8 dsf[4];                                                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                       \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
+                const float A_ = TR::to_f32(ae[2 * ks + (j >> 2)][j & 3]);                                     \
+                const float g_ = cw * TR::to_f32(bw[2 * ks + (j >> 2)][j & 3]) + ci * TR::to_f32(bi[2 * ks + (j >> 2)][j & 3]); \
+                dsf[ks][j] = TR::from_f32(A_ * (g_ - dot) * a.scale);                                          \
+            }                                                                                                 \
+        if ((TT) + 1 < NTL) { RM2_ISSUE(NXT, (TT) + 1) RM2_LOAD((TT) + 1) }                                   \
+        _Pragma("unroll") for (int dblk = 0; dblk < 2; ++dblk)                                                 \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                   \
+                dq[dblk] = TR::mfma32(rd_tr<T>((CUR), fo, dblk, ks), dsf[ks], dq[dblk]);                       \
+    }
+#pragma unroll 1
+    for (int t = 0; t < NTL; t += 2) {
+        RM2_STEP(st0, st1, t)
+        RM2_STEP(st1, st0, t + 1)
+    }
+#undef RM2_STEP
+#undef RM2_LOAD
+#undef RM2_ISSUE
+    if (!live) return;
+    float* __restrict__ pp = a.dq_part + (((size_t)mc * a.H + hd) * a.R + r) * ATT_D;
+#pragma unroll
+    for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = dq[dblk][4 * g + j];
+            *(f32x4*)(pp + dblk * 32 + 8 * g + 4 * h) = w;
+        }
+}
+
+// GD_REMOVAL_BWD = "1": k_removal_bwd everywhere; default: k_removal_bwd2 where it applies (D = 64, M a multiple of RM_MCH, no dk)
+static bool rm_bwd2_applies(int M, int D, bool need_dk) {
+    if (D != ATT_D || M % RM_MCH != 0 || need_dk) return false;
+    const char* e = getenv("GD_REMOVAL_BWD");
+    return !(e && e[0] == '1');
+}
+template <typename T>
+static void rm_bwd2_launch(const RmBwdArgs& a, hipStream_t st) {
+    const int grid = a.H * ((a.R + 127) / 128) * (a.M / RM_MCH);
+    k_removal_bwd2<T><<<grid, 256, 0, st>>>(a);
+}
+
 // dq[h, rows[r], :] += sum_c dq_part[c, h, r, :]  (c ascending).  Padding slots of the row list (weight 0, contribution exactly 0) are
 // skipped, so every live row has exactly one writer.
 // T16 != void: the sum is added IN PLACE to a 16-bit gradient (dq16 = T16(float(dq16) + s): the rounding of adding an f32 tensor and
@@ -539,7 +658,8 @@ extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, con
     hipStream_t st = as_stream(stream);
     if (dtype == GD_F16) k_removal_rowdot<f16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rowdot);
     else k_removal_rowdot<bf16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rowdot);
-    if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, st>>>(a);
+    if (rm_bwd2_applies(M, D, dk_f32 != nullptr)) { if (dtype == GD_F16) rm_bwd2_launch<f16_t>(a, st); else rm_bwd2_launch<bf16_t>(a, st); }
+    else if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, st>>>(a);
     else k_removal_bwd<bf16_t><<<blocks, 256, 0, st>>>(a);
     if (dtype == GD_F16) k_removal_dq_fold<f16_t><<<(H * R * D + 255) / 256, 256, 0, st>>>(a.dq_part, rows, wgt, msplit, H, R, N, D, dq_f32, (f16_t*)dq16_inout);
     else k_removal_dq_fold<bf16_t><<<(H * R * D + 255) / 256, 256, 0, st>>>(a.dq_part, rows, wgt, msplit, H, R, N, D, dq_f32, (bf16_t*)dq16_inout);
@@ -572,7 +692,8 @@ extern "C" int gd_removal_bwd_nofold(const gd_removal_bwd_t* rm, int dtype, void
     const int waves = H * ((R + RM_RB - 1) / RM_RB) * msplit * (D / ATT_D);
     const int blocks = (waves + 3) / 4;
     hipStream_t st = as_stream(stream);
-    if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, st>>>(a);
+    if (rm_bwd2_applies(M, D, rm->dk_f32 != nullptr)) { if (dtype == GD_F16) rm_bwd2_launch<f16_t>(a, st); else rm_bwd2_launch<bf16_t>(a, st); }
+    else if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, st>>>(a);
     else k_removal_bwd<bf16_t><<<blocks, 256, 0, st>>>(a);
     if (rm->dk_f32) {
         dim3 grid((M * D + 255) / 256, H);

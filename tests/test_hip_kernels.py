@@ -781,6 +781,41 @@ def test_corr_max_variants_are_bit_identical(ops, monkeypatch, dtype, H, N, R, n
         assert torch.equal(loss, ref_loss), var
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,N,R,nv", [(2, 1024, 70, None), (2, 1024, 192, 130), (5, 4096, 512, 307), (1, 4096, 256, 256)])
+def test_removal_backward_on_the_matrix_pipe(ops, monkeypatch, dtype, H, N, R, nv):
+    """k_removal_bwd2 (inpaint row on the MFMA lane, dS in 16 bits, K^T by the transposed LDS read) against k_removal_bwd (vector pipe, dS in
+    f32): the same gradient up to the 16-bit rounding of dS — far inside the storage step of the 16-bit dq it is folded into — on full
+    lists, padded lists (slots past n_valid untouched) and a list that ends inside a 128-slot block."""
+    g = torch.Generator(device=DEV).manual_seed(N + R + 1)
+    q = (torch.randn(H, N, 64, device=DEV, generator=g) * 1.2).to(dtype); k = (torch.randn(H, N, 64, device=DEV, generator=g) * 1.2).to(dtype)
+    v = torch.randn(H, N, 64, device=DEV, generator=g).to(dtype)
+    out = torch.empty_like(q); lse = torch.empty(H, N, device=DEV)
+    ops.attn_fwd([(q, k, v, out, lse)], 0.125)
+    rows = torch.randperm(N, device=DEV, generator=g)[:R].to(torch.int32).contiguous()
+    nvt = None if nv is None else torch.tensor([nv], dtype=torch.int32, device=DEV)
+    live = R if nv is None else nv
+    m_inp = torch.zeros(N, device=DEV); m_inp[rows[:live].long()] = 1
+    m_wo = (1 - m_inp) * (torch.rand(N, device=DEV, generator=g) < 0.8).float()
+    Pb = ops.attn_probs(q, k, lse, None, 0.125); Pe = ops.attn_probs(q, k, lse, rows, 0.125, n_valid=nvt)
+    aux, _ = ops.removal_fwd(Pe, Pb, m_inp, m_wo, rows, int(N ** 0.5), n_valid=nvt)
+    res = {}
+    for var in ("1", None):
+        if var is None:
+            monkeypatch.delenv("GD_REMOVAL_BWD", raising=False)
+        else:
+            monkeypatch.setenv("GD_REMOVAL_BWD", var)
+        dq = torch.zeros(H, N, 64, device=DEV)
+        ops.removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, 0.37, None, 0.125, dq, None, n_valid=nvt)
+        torch.cuda.synchronize()
+        res[var] = dq.clone()
+    a, b = res[None], res["1"]
+    assert float(b.abs().max()) > 0 and torch.isfinite(a).all()
+    untouched = torch.ones(N, dtype=torch.bool, device=DEV); untouched[rows[:live].long()] = False
+    assert float(a[:, untouched].abs().max()) == 0.0 and float(b[:, untouched].abs().max()) == 0.0
+    assert rel_l2(a.double(), b.double()) < (1e-3 if dtype == torch.float16 else 6e-3)
+
+
 # ------------------------------------------------------------------------------------------------ scheduler arithmetic
 def test_removal_loss_nan_rows_keep_indices_valid(ops):
     """Diverged latents give NaN probability rows; torch.max would return NaN, and so does the loss here — but the arg-max INDEX

@@ -570,7 +570,15 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         if ent is None:
             ent = _WEIGHT_VECTORS[key] = [None, torch.zeros(5, dtype=torch.float32, device=dev)]
         if ent[0] != host:
-            ent[1].copy_(torch.tensor(host, dtype=torch.float32))
+            # pinned staging + non-blocking copy: a pageable source makes the copy wait for everything queued before it (the whole CFG
+            # pass in front of an optimisation pass: 7 ms of host stall per pass, then an idle device while the host catches up)
+            if len(ent) < 3:
+                ent.append([torch.empty(5, dtype=torch.float32).pin_memory() for _ in range(4)])
+                ent.append(0)
+            stage = ent[2][ent[3] % 4]
+            ent[3] += 1
+            stage.copy_(torch.tensor(host, dtype=torch.float32))
+            ent[1].copy_(stage, non_blocking=True)
             ent[0] = host
         return ent[1]
 

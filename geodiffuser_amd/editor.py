@@ -58,15 +58,16 @@ def clear_controller_loss(controller):
         controller.initialize_loss_log_dict()
 
 
-def convert_loss_log_to_numpy(loss_log_dict):
-    """generic.py:50-60 — one host sync for the whole dict instead of one ``.item()`` per term."""
+def _log_keys_vals(loss_log_dict):
     keys, vals = [], []
     for att_type in ("self", "cross"):
         for key, v in loss_log_dict[att_type].items():
             keys.append((att_type, key))
             vals.append(v if torch.is_tensor(v) else torch.tensor(float(v)))
-    dev = next((v.device for v in vals if v.is_cuda), torch.device("cpu"))
-    host = torch.stack([v.detach().float().to(dev).reshape(()) for v in vals]).tolist()
+    return keys, vals
+
+
+def _log_from_host(loss_log_dict, keys, host):
     out = {"self": {}, "cross": {}}
     for (a, k), x in zip(keys, host):
         out[a][k] = x
@@ -74,6 +75,60 @@ def convert_loss_log_to_numpy(loss_log_dict):
         if k not in ("self", "cross"):
             out[k] = v
     return out
+
+
+def convert_loss_log_to_numpy(loss_log_dict):
+    """generic.py:50-60 — one host sync for the whole dict instead of one ``.item()`` per term."""
+    keys, vals = _log_keys_vals(loss_log_dict)
+    dev = next((v.device for v in vals if v.is_cuda), torch.device("cpu"))
+    host = torch.stack([v.detach().float().to(dev).reshape(()) for v in vals]).tolist()
+    return _log_from_host(loss_log_dict, keys, host)
+
+
+_PINNED_LOGS = []          # small ring of pinned host buffers for the asynchronous read of the loss log
+
+
+def loss_log_to_host_async(loss_log_dict):
+    """First half of convert_loss_log_to_numpy for device-resident logs: the terms are gathered and copied to pinned host memory behind the
+    work queued so far, an event marks the copy.  -> handle for ``loss_log_finish`` (None: nothing on the device, convert synchronously)."""
+    keys, vals = _log_keys_vals(loss_log_dict)
+    dev = next((v.device for v in vals if v.is_cuda), None)
+    if dev is None:
+        return None
+    stacked = torch.stack([v.detach().float().to(dev).reshape(()) for v in vals])
+    if len(_PINNED_LOGS) < 4:
+        _PINNED_LOGS.append(torch.empty(64, dtype=torch.float32).pin_memory())
+    buf = _PINNED_LOGS[0]
+    _PINNED_LOGS.append(_PINNED_LOGS.pop(0))            # rotate: a buffer is reused four reads later, long after its copy has been read
+    host = buf[:stacked.numel()]
+    host.copy_(stacked, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return loss_log_dict, keys, host, ev
+
+
+def loss_log_finish(handle):
+    loss_log_dict, keys, host, ev = handle
+    ev.synchronize()
+    return _log_from_host(loss_log_dict, keys, host.tolist())
+
+
+LATE_LOSS_SYNC = os.environ.get("GD_LATE_LOSS_SYNC", "1") == "1"
+
+
+def _after_opt_pass(controller, log_dev, i, skip_optim_steps, edit_type, use_adaptive_optimization, removal_loss_value_in, global_loss_log_dict,
+                    handle=None):
+    """:284-306 — the logged terms to the host (the one sync of an optimisation step) and the adaptive weight schedule.  ``handle``: the
+    read was started earlier (loss_log_to_host_async): only its event is waited for."""
+    out_loss_log_dict = loss_log_finish(handle) if handle is not None else convert_loss_log_to_numpy(log_dev)     # :284 (host sync)
+    if use_adaptive_optimization:
+        if edit_type == "geometry_editor":
+            adaptive_optimization_step_editing(controller, i, skip_optim_steps, out_loss_log_dict, num_ddim_steps=NUM_DDIM_STEPS,
+                                               removal_loss_value_in=removal_loss_value_in)
+        elif edit_type == "geometry_remover":
+            adaptive_optimization_step_remover(controller, i, skip_optim_steps, out_loss_log_dict, num_ddim_steps=NUM_DDIM_STEPS,
+                                               removal_loss_value_in=removal_loss_value_in)
+    global_loss_log_dict[i] = out_loss_log_dict
 
 
 def init_latent(latent, model, height, width, generator, batch_size):
@@ -198,15 +253,16 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
                 if num_optim_steps == 1:
                     latents_new, context_new = lat_upd, ctx_upd
                 lat_cur, ctx_cur = lat_upd.detach(), ctx_upd.detach()
-                out_loss_log_dict = convert_loss_log_to_numpy(controller.loss_log_dict)                   # :284 (host sync)
-                if use_adaptive_optimization:
-                    if edit_type == "geometry_editor":
-                        adaptive_optimization_step_editing(controller, i, skip_optim_steps, out_loss_log_dict, num_ddim_steps=NUM_DDIM_STEPS,
-                                                           removal_loss_value_in=removal_loss_value_in)
-                    elif edit_type == "geometry_remover":
-                        adaptive_optimization_step_remover(controller, i, skip_optim_steps, out_loss_log_dict, num_ddim_steps=NUM_DDIM_STEPS,
-                                                           removal_loss_value_in=removal_loss_value_in)
-                global_loss_log_dict[i] = out_loss_log_dict
+                # The loss log is read on the host (:284, one sync) for the adaptive schedule, which only edits the loss WEIGHTS — used by the
+                # next optimisation pass, not by the CFG pass that follows (no losses there).  With one optimisation iteration per step
+                # (every driver of the reference) the copy to (pinned) host memory is queued HERE, behind the optimisation pass, and
+                # waited for only after that CFG pass has been queued too: the device works through the CFG pass while the host runs the
+                # schedule and prepares the next step, instead of idling while the host does (LATE_LOSS_SYNC).
+                log_dev = controller.loss_log_dict
+                late = LATE_LOSS_SYNC and num_optim_steps == 1
+                log_handle = loss_log_to_host_async(log_dev) if late else None
+                if not late:
+                    _after_opt_pass(controller, log_dev, i, skip_optim_steps, edit_type, use_adaptive_optimization, removal_loss_value_in, global_loss_log_dict)
                 clear_controller_loss(controller)
                 controller.cur_step -= 1                                                                   # :307
                 controller.rows_identical = False
@@ -218,6 +274,9 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
                 context = context_new.detach()
                 context_save = context
             latents = cfg_pass(latents, context, t)                                                          # :343-351
+            if late:
+                _after_opt_pass(controller, log_dev, i, skip_optim_steps, edit_type, use_adaptive_optimization, removal_loss_value_in, global_loss_log_dict,
+                                handle=log_handle)
         elif i < fast_start_steps * T:
             pass
         else:

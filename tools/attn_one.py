@@ -22,6 +22,23 @@ if os.environ.get("FORM") == "cfg":
             (q[1:2], k[1:2], v[1:2], act, None, (idx, w, m), (rows_p, n_dev)), (q[2:3], k[1:2], v[1:2], o[2], None)]
     for _ in range(reps):
         ops.attn_fwd(segs, 0.125, heads=heads, q_scaled=True)        # the product path: even-split workspace, parts for the row-list units
+elif os.environ.get("FORM") == "opt":
+    # the optimisation pass's launch (head-major, 5 heads: reference rows + LSE, row-list edit rows with the fused warp, replace rows + LSE;
+    # pre-scaled queries with row sums over the rounded probabilities: q_scaled = 2, k_attn_fwd_w64 LSUM)
+    f, K = 5, 15
+    q = (torch.randn(2 * f, N, 64, device="cuda") * 0.2).bfloat16(); k = torch.randn(f, N, 64, device="cuda").bfloat16(); v = torch.randn(f, N, 64, device="cuda").bfloat16()
+    yy, xx = torch.meshgrid(torch.arange(64), torch.arange(64), indexing="ij")
+    m = (((yy - 33) ** 2 + (xx - 33) ** 2) < 13 ** 2).float().reshape(-1).cuda()
+    idx = torch.full((N, K), -1, dtype=torch.int32, device="cuda"); w = torch.zeros(N, K, device="cuda")
+    for j in range(4):
+        idx[:, j] = torch.where(m > 0, (torch.arange(N, device="cuda") + 64 * 3 + 5 + j) % N, torch.full((N,), -1, device="cuda")).int(); w[:, j] = 0.25
+    rows = torch.nonzero(m > 0).reshape(-1).int(); R = rows.numel(); Rp = -(-R // 256) * 256
+    rows_p = torch.cat([rows, torch.zeros(Rp - R, dtype=torch.int32, device="cuda")]).contiguous(); n_dev = torch.tensor([R], dtype=torch.int32, device="cuda")
+    o0 = torch.empty_like(q[:f]); o2 = torch.empty_like(q[:f]); act = torch.empty(f, Rp, 64, device="cuda", dtype=torch.bfloat16)
+    l0 = torch.empty(f, N, device="cuda"); l2 = torch.empty(f, N, device="cuda")
+    segs = [(q[:f], k, v, o0, l0), (q[:f], k, v, act, None, (idx, w, m), (rows_p, n_dev)), (q[f:], k, v, o2, l2)]
+    for _ in range(reps):
+        ops.attn_fwd(segs, 0.6931471805599453, q_scaled=2)
 else:
     q = (torch.randn(BH, N, 64, device="cuda") * 1.2).bfloat16(); k = (torch.randn(BH, M, 64, device="cuda") * 1.2).bfloat16(); v = torch.randn(BH, M, 64, device="cuda").bfloat16()
     out = torch.empty_like(q); lse = torch.empty(BH, N, device="cuda")

@@ -47,6 +47,15 @@ class GdRemovalBwd(Structure):               # gd_removal_bwd_t
                 ("H", c_int32), ("R", c_int32), ("N", c_int32), ("M", c_int32), ("Mpad", c_int32), ("D", c_int32)]
 
 
+class GdHeadsSplit(Structure):               # gd_heads_split_t
+    _fields_ = [("src", c_void_p * 3), ("dst", c_void_p * 3), ("rows", c_int32 * 3), ("n", c_int32), ("B", c_int32), ("heads", c_int32), ("D", c_int32)]
+
+
+class GdHeadsMerge(Structure):               # gd_heads_merge_t
+    _fields_ = [("src", c_void_p * 4), ("blend_b", c_void_p), ("m", c_void_p), ("out", c_void_p),
+                ("blend_row", c_int32), ("src_f32", c_int32), ("B", c_int32), ("rows", c_int32), ("heads", c_int32), ("D", c_int32)]
+
+
 class GeodiffError(RuntimeError):
     pass
 
@@ -115,6 +124,8 @@ SIGNATURES = {
     "gd_removal_bwd_nofold": (c_int, [POINTER(GdRemovalBwd), c_int, c_void_p]),
     "gd_attn_bwd_nofold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_float, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_int), POINTER(c_void_p), c_int, c_void_p]),
+    "gd_heads_split": (c_int, [c_void_p, c_int, c_void_p]),
+    "gd_heads_merge": (c_int, [c_void_p, c_int, c_void_p]),
     "gd_edit_dq_fold": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gd_group_norm_nhwc_scratch_floats": (c_int64, [c_int, c_int, c_int]),
     "gd_group_norm_set_single_launch": (c_int, [c_int]),

@@ -75,7 +75,7 @@ def set_attn_processor_for_edit(model, perform_edit=True, coords_base=(2, 3), co
         proc.controller.n_batch = n_batch
 
 
-def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_major=False, scaled_q_head_major=False):
+def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_major=False, scaled_q_head_major=False, batched_ok=True):
     """Shared front half of both processors (attention_processors.py:85-120 / :165-203).  ``scaled_q_head_major``: the caller's
     head-major consumer (_EditLayer: the optimisation pass) takes pre-scaled queries too."""
     args = () if USE_PEFT_BACKEND else (scale,)
@@ -91,7 +91,7 @@ def _project_qkv(attn, hidden_states, encoder_hidden_states, temb, scale, token_
         hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
     lin_args = args if getattr(attn, "linear_takes_scale", False) else ()
     q_scaled = False
-    if token_major and BATCHED_QKV and SCALED_Q and not lin_args and getattr(attn, "norm_cross", None) in (None, False):
+    if token_major and batched_ok and BATCHED_QKV and SCALED_Q and not lin_args and getattr(attn, "norm_cross", None) in (None, False):
         fused = _batched_qkv(attn, hidden_states, encoder_hidden_states)
         if fused is not None:
             return fused[:4] + (shape4,) + fused[5:]
@@ -201,6 +201,12 @@ FUSED_LAYER = os.environ.get("GD_FUSED_LAYER", "1") == "1"
 # rounded probabilities a dominant probability is exact again, which is what the rescue variant was kept for (DESIGN 4a').  fp16 stays on
 # the rescue variant (its probabilities must stay inside fp16's range).  GD_OPT_PRE=0: the round-3 routing.
 OPT_PRE = os.environ.get("GD_OPT_PRE", "1") == "1"
+# The passes that accumulate losses (use_cfg False: the optimisation pass) hand the layer token-major q / k / v as the projections produce
+# them and take a token-major output back: the head_to_batch_dim / batch_to_head_dim permutes of the reference (:201-203,213) and their
+# autograd — per layer three copies forward, one back, the gradient's copy and zero fills, and for cross-attention the assembly of the
+# key gradient: ~190 launches of ~5 us per pass — become ONE gd_heads_split forward, ONE gd_heads_merge (which also does the blend
+# :502-508,617-622) and the same two launches in the backward.  The kernels in between stay head-major.  GD_TOK_OPT=0: the permutes.
+TOK_OPT = os.environ.get("GD_TOK_OPT", "1") == "1"
 
 
 def _tok_ok(attn, hidden_states) -> bool:
@@ -254,25 +260,31 @@ class EditProcessor:
         # losses (use_cfg False) and stored maps stay on the head-major path
         tok = _tok_ok(attn, hidden_states) and (not self.perform_edit or (
             getattr(ctrl, "supports_token_major", False) and ctrl.use_cfg and not getattr(ctrl, "store_attention_maps", False)))
+        # the head-major layer fed with token-major tensors (TOK_OPT): 64-wide heads, 16-bit, the geometry controllers
+        tokg = (TOK_OPT and TOKEN_MAJOR and self.perform_edit and not tok and hidden_states.is_cuda
+                and hidden_states.dtype in (torch.float16, torch.bfloat16) and attn.to_q.out_features == attn.heads * 64
+                and getattr(ctrl, "supports_token_major", False) and not ctrl.use_cfg and not getattr(ctrl, "rows_identical", False))
         q, k, v, is_cross, shape4, lin_args, qs = _project_qkv(
-            attn, hidden_states, encoder_hidden_states, temb, scale, tok,
-            scaled_q_head_major=self.perform_edit and not tok and getattr(ctrl, "supports_scaled_q_head_major", False))
+            attn, hidden_states, encoder_hidden_states, temb, scale, tok or tokg,
+            scaled_q_head_major=self.perform_edit and not tok and getattr(ctrl, "supports_scaled_q_head_major", False), batched_ok=tok)
         if self.perform_edit:
             if tok:
                 ctrl.heads_tok = attn.heads
                 ctrl.q_scaled_tok = qs
             else:
                 ctrl.q_scaled_hm = qs
+                ctrl.heads_opt = attn.heads if tokg else 0
             try:
                 out = ctrl(q, k, v, is_cross=is_cross, place_in_unet=self.place_in_unet,
                            transform_coords=self.transform_coords, scale=attn.scale, mask=None)
             finally:
                 ctrl.heads_tok = 0
+                ctrl.heads_opt = 0
                 ctrl.q_scaled_tok = False
                 ctrl.q_scaled_hm = False
         else:
             out = attention_tok(q, k, v, attn.scale, attn.heads, q_scaled=qs) if tok else attention(q, k, v, attn.scale)
-        return _finish(attn, out, residual, shape4, lin_args, tok)
+        return _finish(attn, out, residual, shape4, lin_args, tok or tokg)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -360,7 +372,7 @@ class _EditLayer(torch.autograd.Function):
     replace_{self,cross}_attention inlined).  Returns (out [(cb+1)*f, N, D], layer_loss [] f32, terms [5] f32)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, ctrl, is_cross, scale, c, q_pre=False):
+    def forward(ctx, q, k, v, ctrl, is_cross, scale, c, q_pre=False, heads=0):
         # q_pre: the queries carry scale*log2(e) and ``scale`` is ln 2 (controller forward): every kernel computes
         # exp(scale * q.k - lse) as it stands.  The forward is NOT told (gd_attn_seg_t::q_scaled stays 0, its multiplier becomes
         # ln2 * log2(e) = 1): the pre-scaled variant of the 64-query kernel takes the first key tile's maximum as the softmax reference
@@ -368,7 +380,13 @@ class _EditLayer(torch.autograd.Function):
         # is exactly 1.0 in 16 bits, as in any online softmax.  The no-grad passes do without that (outputs within the storage
         # rounding either way); the L1 loss terms between two nearly equal attention outputs measure exactly that rounding (the
         # `sim` term of an SDXL-shaped bf16 case moved by 1.6 %), so the optimisation pass pays the 6-9 us per 64^2 launch.
+        # heads > 0 (TOK_OPT): q / k / v arrive token-major [B, rows, heads*64] and the output leaves token-major; one split launch here,
+        # one merge launch at the end (which also does the blend), everything in between on head-major tensors as before
         f = c["f"]
+        tok_shapes = None
+        if heads:
+            tok_shapes = (q.shape, k.shape)
+            q, k, v = ops.heads_split((q, k, v), heads)
         remover = ctrl._is_remover
         (b0, b1), (e0, e1) = ctrl.coords_base, ctrl.coords_edit
         cb = ctrl.coords_base[-1] * f
@@ -381,7 +399,7 @@ class _EditLayer(torch.autograd.Function):
 
         q_base, k_base, v_base = q[b0 * f:b1 * f], k[b0 * f:b1 * f], v[b0 * f:b1 * f]
         q_edit, k_edit, v_edit = q[e0 * f:e1 * f], k[e0 * f:e1 * f], v[e0 * f:e1 * f]
-        out_full = torch.empty(cb + f, N, D, dtype=dt, device=dev)
+        out_full = torch.empty(cb if heads else cb + f, N, D, dtype=dt, device=dev)
         lse_van = torch.empty(cb, N, dtype=torch.float32, device=dev) if want_losses else None
         segs = [(q[:cb], k[:cb], v[:cb], out_full[:cb], lse_van)]
         replace_out = torch.empty(f, N, D, dtype=dt, device=dev)
@@ -416,9 +434,10 @@ class _EditLayer(torch.autograd.Function):
         blend_done = False
         if (not remover) and edit_act is not None:
             if fused:      # rows outside the soft edit mask: the reference row's output; and the blend of :502-508,617-622, in the same pass
-                ops.blend_merge(out_full[b0 * f:b1 * f], edit_act, c["edit_pos"], replace_out if blend else None, c["m_edit"] if blend else None,
-                                eo_out=edit_out, out=out_full[cb:] if blend else None)
-                blend_done = blend
+                own_blend = blend and not heads         # token-major output: the merge launch at the end blends
+                ops.blend_merge(out_full[b0 * f:b1 * f], edit_act, c["edit_pos"], replace_out if own_blend else None,
+                                c["m_edit"] if own_blend else None, eo_out=edit_out, out=out_full[cb:] if own_blend else None)
+                blend_done = own_blend
             else:
                 ops.rows_merge(out_full[b0 * f:b1 * f], edit_act, c["edit_pos"], out=edit_out)
         if remover:
@@ -469,7 +488,16 @@ class _EditLayer(torch.autograd.Function):
                 terms, loss, coefs, rm_coef = ops.loss_assemble(sums, rm, c["inv5"], c["inv_rm"], wv, c["inv5_bwd"], use_amodal)
 
         # output (:502-508,617-624 / :831-834,922-925)
-        if not remover:
+        if heads:
+            last, blend_with = replace_out, None
+            if (not remover) and blend:
+                last, blend_with = edit_out, (replace_out, c["m_edit"])
+            elif remover and not blend:
+                last, blend_with = ident_out, (replace_out, c["m_inp"])
+            nb_ = cb // f
+            out_full = ops.heads_merge([out_full[i * f:(i + 1) * f] for i in range(nb_)] + [last], heads, N, D, dt, dev,
+                                       blend=None if blend_with is None else (nb_, blend_with[0], blend_with[1]))
+        elif not remover:
             if blend:
                 if not blend_done:
                     ops.blend_tokens(edit_out, replace_out, c["m_edit"], out=out_full[cb:])
@@ -485,7 +513,7 @@ class _EditLayer(torch.autograd.Function):
             ctx.save_for_backward(q_edit, K, v_base, replace_out, lse_e, edit_out if want_losses else None, tgt, Pe, Pb, coefs, rm_coef)
             ctx.aux, ctx.c = aux, c
             ctx.meta = dict(f=f, cb=cb, e0=e0, e1=e1, is_cross=is_cross, scale=scale, remover=remover, blend=blend,
-                            want_losses=want_losses, q_shape=q.shape, k_shape=k.shape, S=S, fused=fused)
+                            want_losses=want_losses, q_shape=q.shape, k_shape=k.shape, S=S, fused=fused, heads=heads, tok_shapes=tok_shapes)
         ctx.mark_non_differentiable(terms)
         return out_full, loss, terms
 
@@ -498,7 +526,11 @@ class _EditLayer(torch.autograd.Function):
         if m["remover"] and not m["blend"]:
             raise NotImplementedError("gradient through the remover's identity attention (cur_step >= obj_edit_step) is "
                                       "never taken by the reference driver (optimize_steps <= obj_edit_step)")
-        gout = g_out[cb:].contiguous() if g_out is not None else None
+        heads = m.get("heads", 0)
+        if heads and g_out is not None:           # token-major [B, N, heads*D]: the edit row's slice, head-major in one launch
+            gout = ops.heads_split((g_out[cb // f:].contiguous(),), heads)[0]
+        else:
+            gout = g_out[cb:].contiguous() if g_out is not None else None
         gscale = g_loss.reshape(1).float().contiguous() if (m["want_losses"] and g_loss is not None) else None
         have_loss = m["want_losses"] and gscale is not None
         eo = edit_out if edit_out is not None else replace_out
@@ -506,12 +538,16 @@ class _EditLayer(torch.autograd.Function):
         # the reference rows receive no gradient (they are detached in the reference as well): dq is written straight into the edit rows of
         # the full-size gradient, the removal loss's contribution is folded into it in place (one rounding, as adding an f32 tensor would)
         e0f, e1f = m["e0"] * f, m["e1"] * f
-        grad_q = torch.empty(m["q_shape"], dtype=dt, device=dev)
-        if e0f:
-            grad_q[:e0f].zero_()
-        if e1f < grad_q.shape[0]:
-            grad_q[e1f:].zero_()
-        dq_view = grad_q[e0f:e1f]
+        if heads:
+            grad_q = None
+            dq_view = torch.empty(f, m["q_shape"][1], m["q_shape"][2], dtype=dt, device=dev)
+        else:
+            grad_q = torch.empty(m["q_shape"], dtype=dt, device=dev)
+            if e0f:
+                grad_q[:e0f].zero_()
+            if e1f < grad_q.shape[0]:
+                grad_q[e1f:].zero_()
+            dq_view = grad_q[e0f:e1f]
         need_dk = m["is_cross"] and not m["remover"]
         with_rm = have_loss and Pe is not None
         if m.get("fused") and with_rm:
@@ -535,10 +571,16 @@ class _EditLayer(torch.autograd.Function):
                 ops.removal_bwd(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], 1.0, gscale * rm_coef, m["scale"], None, dk32,
                                 n_valid=c.get("n_rows"), dq16=dq_view)
         grad_k = None
-        if dk32 is not None:
+        if heads:          # token-major gradients, zero rows included, one launch each (dk: f32 -> 16-bit in the same pass)
+            (Bq, Nq, _), (Bk, Mk, _) = m["tok_shapes"]
+            D = m["q_shape"][2]
+            grad_q = ops.heads_merge([dq_view if b == m["e0"] else None for b in range(Bq)], heads, Nq, D, dt, dev)
+            if dk32 is not None:
+                grad_k = ops.heads_merge([dk32 if b == m["e0"] else None for b in range(Bk)], heads, Mk, D, dt, dev)
+        elif dk32 is not None:
             grad_k = torch.zeros(m["k_shape"], dtype=dt, device=dev)
             grad_k[m["e0"] * f:m["e1"] * f] = dk32.to(dt)
-        return grad_q, grad_k, None, None, None, None, None, None
+        return grad_q, grad_k, None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -770,6 +812,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
 
     supports_token_major = True
     heads_tok = 0
+    heads_opt = 0                # > 0: forward() was handed token-major q / k / v by a pass that accumulates losses (TOK_OPT)
     q_scaled_tok = False
     q_scaled_hm = False
     supports_scaled_q_head_major = True
@@ -847,24 +890,30 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             if is_cross:
                 _ = self.cross_replace_alpha[self.cur_step]
             return self._forward_tok(q, k, v, is_cross, transform_coords, float(scale), heads)
-        f = q.shape[0] // nb
+        ho = self.heads_opt              # token-major q / k / v [B, N, heads*64] (EditProcessor, TOK_OPT)
+        f = ho if ho else q.shape[0] // nb
         self._place_in_unet = place_in_unet
         q_pre = bool(self.q_scaled_hm)
         if q_pre:                        # q carries scale*log2(e) (_project_qkv): s = ln2 * q'.k for everything that takes a scale
             scale = LN2
         if not active:
+            if ho:
+                B, N, C = q.shape
+                hm = lambda t: t.view(B, t.shape[1], ho, C // ho).permute(0, 2, 1, 3).reshape(B * ho, t.shape[1], C // ho)
+                return attention(hm(q), hm(k), hm(v), scale).view(B, ho, N, C // ho).permute(0, 2, 1, 3).reshape(B, N, C)
             return attention(q, k, v, scale)                                   # :646-647
         if is_cross:
             _ = self.cross_replace_alpha[self.cur_step]                        # :654 (indexing only; value unused)
         S = int(math.isqrt(q.shape[1]))
-        D = q.shape[2]
+        D = 64 if ho else q.shape[2]
         c = self._tables(S, f, q, transform_coords, D)
         if self.rows_identical and torch.is_grad_enabled():
             q, k, v = (self._tie_rows(t, f) for t in (q, k, v))
         if D % 64:      # SD1.x heads (40 / 80 / 160): zero columns up to the kernels' 64 / 128 / 192; the loss normalisers keep the true D
             q, k, v = pad_head_dim(q), pad_head_dim(k), pad_head_dim(v)
-        out, loss, terms = _EditLayer.apply(q.contiguous(), k.contiguous(), v.contiguous(), self, is_cross, float(scale), c, q_pre)
-        out = out[..., :D]
+        out, loss, terms = _EditLayer.apply(q.contiguous(), k.contiguous(), v.contiguous(), self, is_cross, float(scale), c, q_pre, ho)
+        if not ho:
+            out = out[..., :D]
         if (q.shape[1] >= 32 ** 2) and (not self.use_cfg):
             kind = "cross" if is_cross else "self"
             self.loss = self.loss + loss                                       # :494,604 / :822,914

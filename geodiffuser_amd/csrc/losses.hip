@@ -343,6 +343,7 @@ extern "C" int gd_edit_losses_bwd(const void* eo, const void* ro, const float* t
 template <typename T>
 __global__ void k_blend(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ m, int H, int N, int D,
                         T* __restrict__ out) {
+#pragma clang fp contract(off)      // each product and the sum are rounded to the tensor dtype: no fused multiply-add across the roundings
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)H * N * D) return;
     const int n = (int)((gid / D) % N);
@@ -401,6 +402,7 @@ template <typename T>
 __global__ void k_blend_merge(const u32x4* __restrict__ base, const u32x4* __restrict__ act, const int32_t* __restrict__ pos,
                               const u32x4* __restrict__ ro, const float* __restrict__ m, int H, int N, int R, int D8,
                               u32x4* __restrict__ eo_out, u32x4* __restrict__ out) {
+#pragma clang fp contract(off)      // as k_blend
     using V8 = typename elem_traits<T>::vec8;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;                   // one 16-byte chunk of 8 elements
     if (gid >= (long long)H * N * D8) return;
@@ -441,6 +443,103 @@ extern "C" int gd_blend_merge(const void* base, const void* act, const int32_t* 
     else
         k_blend_merge<bf16_t><<<blocks, 256, 0, st>>>((const u32x4*)base, (const u32x4*)act, pos, (const u32x4*)ro, m, H, N, R, D / 8, (u32x4*)eo_out, (u32x4*)out);
     GD_CHECK_LAUNCH("gd_blend_merge");
+    return GD_OK;
+}
+
+// ---- the layer's layout boundary: token-major [B, rows, heads*D] <-> head-major [B*heads, rows, D], one launch each way ----------------
+// one 16-byte chunk (8 x 16-bit) per thread, destination-linear (stores coalesced; loads are 128-byte row pieces)
+__global__ void k_heads_split(const gd_heads_split_t a, long long c0, long long c1, long long c2) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= c2) return;
+    const int i = gid < c0 ? 0 : (gid < c1 ? 1 : 2);
+    const long long l = gid - (i == 0 ? 0 : (i == 1 ? c0 : c1));
+    const int D8 = a.D >> 3, rows = a.rows[i], heads = a.heads;
+    const int c = (int)(l % D8);
+    long long t = l / D8;
+    const int r = (int)(t % rows); t /= rows;
+    const int h = (int)(t % heads);
+    const long long b = t / heads;
+    const u32x4* __restrict__ src = (const u32x4*)a.src[i];
+    u32x4* __restrict__ dst = (u32x4*)a.dst[i];
+    dst[l] = src[((b * rows + r) * heads + h) * D8 + c];
+}
+
+extern "C" int gd_heads_split(const gd_heads_split_t* a, int dtype, void* stream) {
+    GD_REQUIRE(a && a->n >= 1 && a->n <= 3, GD_EINVAL, "gd_heads_split: 1..3 tensors");
+    GD_REQUIRE(a->B > 0 && a->heads > 0 && a->D > 0 && a->D % 8 == 0, GD_EINVAL, "gd_heads_split: bad sizes (D must be a multiple of 8)");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_heads_split: dtype must be f16/bf16");
+    long long cum[3] = {0, 0, 0}, tot = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (i < a->n) {
+            GD_REQUIRE(a->src[i] && a->dst[i] && a->rows[i] > 0, GD_EINVAL, "gd_heads_split: null pointer / no rows");
+            tot += (long long)a->B * a->rows[i] * a->heads * (a->D / 8);
+        }
+        cum[i] = tot;
+    }
+    const int blocks = (int)((tot + 255) / 256);
+    k_heads_split<<<blocks, 256, 0, as_stream(stream)>>>(*a, cum[0], cum[1], cum[2]);
+    GD_CHECK_LAUNCH("gd_heads_split");
+    return GD_OK;
+}
+
+template <typename T, bool SRC32>
+__global__ void k_heads_merge(const gd_heads_merge_t a) {
+#pragma clang fp contract(off)      // as k_blend
+    using V8 = typename elem_traits<T>::vec8;
+    const int D8 = a.D >> 3, rows = a.rows, heads = a.heads;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)a.B * rows * heads * D8) return;
+    const int c = (int)(gid % D8);
+    long long t = gid / D8;
+    const int h = (int)(t % heads); t /= heads;
+    const int r = (int)(t % rows);
+    const int b = (int)(t / rows);
+    const void* sp = b == 0 ? a.src[0] : (b == 1 ? a.src[1] : (b == 2 ? a.src[2] : a.src[3]));
+    const long long si = ((long long)h * rows + r) * D8 + c;
+    V8 o8;
+    if (!sp) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = (T)0.f;
+    } else if (SRC32) {
+        const f32x4 lo = ((const f32x4*)sp)[2 * si], hi = ((const f32x4*)sp)[2 * si + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o8[j] = (T)lo[j]; o8[4 + j] = (T)hi[j]; }
+    } else {
+        o8 = __builtin_bit_cast(V8, ((const u32x4*)sp)[si]);
+        if (b == a.blend_row) {          // a*m + b*(1-m), op by op in the tensor dtype (k_blend)
+            const V8 b8 = __builtin_bit_cast(V8, ((const u32x4*)a.blend_b)[si]);
+            const float mm = (float)(T)a.m[r];
+            const float om = (float)(T)(1.0f - mm);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t1 = (float)(T)((float)o8[j] * mm);
+                const float t2 = (float)(T)((float)b8[j] * om);
+                o8[j] = (T)(t1 + t2);
+            }
+        }
+    }
+    ((u32x4*)a.out)[gid] = __builtin_bit_cast(u32x4, o8);
+}
+
+extern "C" int gd_heads_merge(const gd_heads_merge_t* a, int dtype, void* stream) {
+    GD_REQUIRE(a && a->out, GD_EINVAL, "gd_heads_merge: null pointer");
+    GD_REQUIRE(a->B >= 1 && a->B <= 4 && a->rows > 0 && a->heads > 0 && a->D > 0 && a->D % 8 == 0, GD_EINVAL,
+               "gd_heads_merge: bad sizes (B <= 4, D a multiple of 8)");
+    GD_REQUIRE(a->blend_row < a->B, GD_EINVAL, "gd_heads_merge: blend_row outside the batch");
+    GD_REQUIRE(a->blend_row < 0 || (!a->src_f32 && a->blend_b && a->m && a->src[a->blend_row]), GD_EINVAL,
+               "gd_heads_merge: the blend needs 16-bit sources, blend_b and m");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_heads_merge: dtype must be f16/bf16");
+    const long long tot = (long long)a->B * a->rows * a->heads * (a->D / 8);
+    const int blocks = (int)((tot + 255) / 256);
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16) {
+        if (a->src_f32) k_heads_merge<f16_t, true><<<blocks, 256, 0, st>>>(*a);
+        else k_heads_merge<f16_t, false><<<blocks, 256, 0, st>>>(*a);
+    } else {
+        if (a->src_f32) k_heads_merge<bf16_t, true><<<blocks, 256, 0, st>>>(*a);
+        else k_heads_merge<bf16_t, false><<<blocks, 256, 0, st>>>(*a);
+    }
+    GD_CHECK_LAUNCH("gd_heads_merge");
     return GD_OK;
 }
 

@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import GD_BF16, GD_CHANNEL_MAJOR, GD_F16, GD_F32, GD_TOKEN_MAJOR, GdAttnSeg, GdEditLosses, GdProbs, GdRemovalBwd, check
+from ._lib import GD_BF16, GD_CHANNEL_MAJOR, GD_F16, GD_F32, GD_TOKEN_MAJOR, GdAttnSeg, GdEditLosses, GdHeadsMerge, GdHeadsSplit, GdProbs, GdRemovalBwd, check
 
 _DT = {torch.float16: GD_F16, torch.bfloat16: GD_BF16, torch.float32: GD_F32}
 
@@ -519,6 +519,67 @@ def blend_merge(base, act, pos, ro, m, eo_out=None, out=None):
         _need(m, "m", torch.float32)
     check(lib.gd_blend_merge(_p(base), _p(act), _p(pos) if act is not None else None, _p(ro), _p(m), H, N, R, D, _p(eo_out), _p(out), dt, _stream()),
           "gd_blend_merge")
+
+
+def heads_split(tensors: Sequence[torch.Tensor], heads: int) -> List[torch.Tensor]:
+    """Token-major [B, rows_i, heads*D] -> head-major [B*heads, rows_i, D] for up to three tensors of one batch size in ONE launch
+    (head_to_batch_dim of q, k and v: U/attention_processors.py:118-120,201-203)."""
+    lib = _lib.load()
+    t0 = tensors[0]
+    dt = _dt16(t0, "tensor 0")
+    if not 1 <= len(tensors) <= 3:
+        raise _lib.GeodiffError("heads_split: 1..3 tensors")
+    B, _, C = t0.shape
+    if C % heads or (C // heads) % 8:
+        raise _lib.GeodiffError("heads_split: channels must be heads x (a multiple of 8)")
+    D = C // heads
+    a = GdHeadsSplit()
+    outs = []
+    for i, t in enumerate(tensors):
+        _need(t, f"tensor {i}", t0.dtype)
+        if t.dim() != 3 or t.shape[0] != B or t.shape[2] != C:
+            raise _lib.GeodiffError("heads_split: tensors must be [B, rows, heads*D] with one B and one width")
+        o = torch.empty(B * heads, t.shape[1], D, dtype=t.dtype, device=t.device)
+        a.src[i], a.dst[i], a.rows[i] = t.data_ptr(), o.data_ptr(), t.shape[1]
+        outs.append(o)
+    a.n, a.B, a.heads, a.D = len(tensors), B, heads, D
+    check(lib.gd_heads_split(ctypes.byref(a), dt, _stream()), "gd_heads_split")
+    return outs
+
+
+def heads_merge(srcs: Sequence[Optional[torch.Tensor]], heads: int, rows: int, D: int, dtype: torch.dtype, device, blend: Optional[tuple] = None):
+    """-> token-major [B, rows, heads*D]: batch row b from the head-major srcs[b] [heads, rows, D] (16-bit, or f32 for all: rounded once),
+    zeros where srcs[b] is None.  blend = (row, b, m): that row is srcs[row]*m + b*(1-m) as blend_tokens computes it.  One launch
+    (batch_to_head_dim of the output, the blend before it, and the autograd of head_to_batch_dim with its zero rows)."""
+    lib = _lib.load()
+    B = len(srcs)
+    if not 1 <= B <= 4:
+        raise _lib.GeodiffError("heads_merge: 1..4 batch rows")
+    out = torch.empty(B, rows, heads * D, dtype=dtype, device=device)
+    dt = _dt16(out, "out")
+    a = GdHeadsMerge()
+    f32 = None
+    for b, t in enumerate(srcs):
+        if t is None:
+            a.src[b] = None
+            continue
+        is32 = t.dtype == torch.float32
+        if f32 is None:
+            f32 = is32
+        _need(t, f"source {b}", torch.float32 if f32 else dtype)
+        if tuple(t.shape) != (heads, rows, D):
+            raise _lib.GeodiffError("heads_merge: sources must be [heads, rows, D]")
+        a.src[b] = t.data_ptr()
+    a.blend_row = -1
+    if blend is not None:
+        row, bb, m = blend
+        _need(bb, "blend b", dtype); _need(m, "blend m", torch.float32)
+        if tuple(bb.shape) != (heads, rows, D) or m.numel() != rows or f32 or srcs[row] is None:
+            raise _lib.GeodiffError("heads_merge: blend operands disagree")
+        a.blend_row, a.blend_b, a.m = row, bb.data_ptr(), m.data_ptr()
+    a.out, a.src_f32, a.B, a.rows, a.heads, a.D = out.data_ptr(), int(bool(f32)), B, rows, heads, D
+    check(lib.gd_heads_merge(ctypes.byref(a), dt, _stream()), "gd_heads_merge")
+    return out
 
 
 def attn_probs_pair(qb, kb, lse_b, qe, ke, lse_e, rows, n_valid, scale: float, zero: Optional[torch.Tensor] = None):

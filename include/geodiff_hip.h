@@ -394,6 +394,25 @@ int gd_attn_bwd_nofold(const void* q, const void* k, const void* v, const void* 
 int gd_edit_dq_fold(const float* dq_part, int kchunks, int BH, int N, int D, const float* rm_workspace, int M, int R,
                     const int32_t* inp_pos, const float* wgt, void* dq16, int dtype, void* stream);
 
+/* The layer's layout boundary in ONE launch each way (U/attention_processors.py:118-120,201-203 head_to_batch_dim of q / k / v and
+ * :124,213 batch_to_head_dim of the output, and their autograd): the projections hand over token-major [B, rows, heads*D] tensors, the
+ * optimisation pass's kernels work on head-major [B*heads, rows, D] ones.
+ *   gd_heads_split : n <= 3 tensors at once, dst[i][(b*heads + h), r, :] = src[i][b, r, h*D : (h+1)*D]   (rows[i] rows each; 16-bit)
+ *   gd_heads_merge : out[b, r, h*D:(h+1)*D] = src[b][h, r, :] for every batch row b < B (<= 4) whose source is non-NULL, zeros for a NULL
+ *                    source (the rows that receive no gradient); src_f32 != 0: the sources are f32 and are rounded once (the key
+ *                    gradient); blend_row >= 0: that row is  src[blend_row]*m + blend_b*(1-m)  op by op in the tensor dtype, exactly
+ *                    gd_blend_tokens (U/attention_processors.py:502-508,617-622) — the blend and the layout change in one pass. */
+typedef struct gd_heads_split {
+    const void* src[3]; void* dst[3]; int32_t rows[3];
+    int32_t n, B, heads, D;
+} gd_heads_split_t;
+int gd_heads_split(const gd_heads_split_t* a, int dtype, void* stream);
+typedef struct gd_heads_merge {
+    const void* src[4]; const void* blend_b; const float* m; void* out;
+    int32_t blend_row, src_f32, B, rows, heads, D;
+} gd_heads_merge_t;
+int gd_heads_merge(const gd_heads_merge_t* a, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * R10-R12  scheduler / latent arithmetic (f32 or 16-bit latents, n elements).
  * ---------------------------------------------------------------------------------------------- */

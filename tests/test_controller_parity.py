@@ -537,6 +537,49 @@ def test_fused_layer_launches_equal_the_standalone_ones(name, dtype, monkeypatch
         assert float((a - b).abs().max()) <= 2 * step * float(b.abs().max()) and float((a - b).norm() / b.norm()) < step
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("name", ["edit_self_opt_32_d64", "edit_cross_opt_32_d64", "edit_self_opt_64_d64", "edit_cross_opt_64_d64", "rem_self_opt_32_d64",
+                                  "edit_self_opt_16", "edit_cross_opt_16_past_blend", "rem_cross_opt_32"])
+def test_token_major_boundary_of_the_optimisation_pass_equals_the_permutes(name, dtype):
+    """Round 4 (TOK_OPT): the layer handed token-major q / k / v [B, N, heads*64] — one gd_heads_split forward, one gd_heads_merge that also
+    blends, the same two launches in the backward (zero rows of the gradients and the f32 -> 16-bit rounding of dk included) — against the
+    reference's head_to_batch_dim / batch_to_head_dim permutes around the head-major layer: output, loss, every logged term, dq and dk
+    IDENTICAL bit for bit."""
+    extra = {"edit_self_opt_16": dict(kind="edit", S=16, f=4, D=64, cross=False, cfg=False, cur_step=3, coords="rotate", quant=True, seed=51),
+             "edit_cross_opt_16_past_blend": dict(kind="edit", S=16, f=4, D=64, cross=True, cfg=False, cur_step=46, coords="scale", quant=True, seed=52),
+             "rem_cross_opt_32": dict(kind="remover", S=32, f=2, D=64, cross=True, cfg=False, cur_step=3, coords="translate", quant=False, seed=53),
+             "edit_cross_opt_64_d64": dict(ORACLE_CASES["edit_cross_opt_32_d64"], S=64)}
+    case = ORACLE_CASES.get(name) or extra[name]
+    q, k, v, mask, coords = case_inputs(case)
+    f = case["f"]
+    B = q.shape[0] // f
+    gout = case_gout(case, (q.shape[0], q.shape[1], q.shape[2]))
+    to_tok = lambda t: t.view(B, f, t.shape[1], t.shape[2]).permute(0, 2, 1, 3).reshape(B, t.shape[1], f * t.shape[2]).contiguous()
+    ch = _make_hip_controller(case, mask)
+    _prebuild_tables(ch, case, q, coords, dtype)
+    r0 = _run_hip(ch, case, q, k, v, coords, 0.125, gout, dtype)
+    log0 = {kk: float(vv) for kk, vv in ch.loss_log_dict["cross" if case["cross"] else "self"].items()}
+    ch = _make_hip_controller(case, mask)
+    _prebuild_tables(ch, case, q, coords, dtype)
+    ch.heads_opt = f
+    qd, kd, vd = (to_tok(t.to(dtype)).to(DEV) for t in (q, k, v))
+    qd.requires_grad_(True); kd.requires_grad_(True)
+    with torch.enable_grad():
+        out = ch(qd, kd, vd, is_cross=case["cross"], place_in_unet="up", transform_coords=coords, scale=0.125)
+        assert out.shape == qd.shape
+        e0 = ch.coords_edit[0]
+        total = (out[e0:].float() * to_tok(gout)[e0:].to(DEV)).sum()
+        if torch.is_tensor(ch.loss):
+            total = total + ch.loss
+        dq, dk = torch.autograd.grad(total, [qd, kd], allow_unused=True)
+    log1 = {kk: float(vv) for kk, vv in ch.loss_log_dict["cross" if case["cross"] else "self"].items()}
+    assert torch.equal(out.detach().float().cpu(), to_tok(r0["out"]))
+    if "loss" in r0:
+        assert float(ch.loss) == r0["loss"] and log1 == log0
+    assert torch.equal(dq.float().cpu(), to_tok(r0["dq"]))
+    assert torch.equal((dk.float().cpu() if dk is not None else torch.zeros_like(to_tok(k))), to_tok(r0["dk"]))
+
+
 def test_two_live_controllers_cannot_share_the_persistent_tables():
     """the per-resolution tables live in process-wide buffers (so that captured graphs can be reused across edits);
     a second controller that builds its tables takes them over, and the first one must then refuse to run rather than read the other's

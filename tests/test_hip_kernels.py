@@ -1611,3 +1611,33 @@ def test_layer_norm_backward_and_transformer_block_autograd(ops, dtype):
 
     (y0, g0), (y1, g1) = run(False), run(True)
     assert rel_err(y1, y0) < 4 * tol(dtype) and rel_l2(g1, g0) < 4 * tol(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ the layer's layout boundary
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_heads_split_and_merge_are_the_permutes(ops, dtype):
+    """gd_heads_split / gd_heads_merge against torch's head_to_batch_dim / batch_to_head_dim arithmetic (U/attention_processors.py:118-124):
+    pure data movement, so bit-exact; the merge's blend against gd_blend_tokens, its f32 sources against one torch rounding, its NULL
+    sources against zeros."""
+    g = torch.Generator().manual_seed(9)
+    B, heads, D, N, M = 3, 5, 64, 200, 77
+    C = heads * D
+    q, k, v = (torch.randn(B, n, C, generator=g).to(dtype).to(DEV) for n in (N, M, M))
+    hm = lambda t: t.view(B, t.shape[1], heads, D).permute(0, 2, 1, 3).reshape(B * heads, t.shape[1], D)
+    for tensors in ((q, k, v), (q,), (k, q)):
+        for got, src in zip(ops.heads_split(tensors, heads), tensors):
+            assert torch.equal(got, hm(src))
+    a, b = hm(q)[:heads].contiguous(), hm(q)[heads:2 * heads].contiguous()
+    m = torch.rand(N, generator=g).to(DEV)
+    m[:7] = 0.0; m[7:13] = 1.0
+    out = ops.heads_merge([a, None, b], heads, N, D, dtype, DEV)
+    assert torch.equal(out[0], q[0]) and torch.equal(out[2], q[1]) and int(out[1].ne(0).sum()) == 0
+    out = ops.heads_merge([a, b], heads, N, D, dtype, DEV, blend=(1, a, m))
+    ref = torch.empty_like(a)
+    ops.blend_tokens(b, a, m, out=ref)                     # b*m + a*(1-m), the reference's op order
+    assert torch.equal(out[0], q[0]) and torch.equal(out[1], ref.view(heads, N, D).permute(1, 0, 2).reshape(N, C))
+    d32 = torch.randn(heads, M, D, generator=g).to(DEV)
+    out = ops.heads_merge([None, d32], heads, M, D, dtype, DEV)
+    assert int(out[0].ne(0).sum()) == 0 and torch.equal(out[1], d32.to(dtype).permute(1, 0, 2).reshape(M, C))
+    with pytest.raises(Exception):
+        ops.heads_merge([a, d32[:, :N]], heads, N, D, dtype, DEV)          # mixed 16-bit / f32 sources

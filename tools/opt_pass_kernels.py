@@ -53,3 +53,24 @@ rows = [e for e in ka if e.key in ("aten::copy_", "aten::contiguous", "aten::clo
 rows.sort(key=lambda e: -e.device_time_total)
 for e in rows[:40]:
     print(f"{e.count:4d} x {e.device_time_total / max(1, e.count):6.1f} us  {e.key:18s} {str(e.input_shapes)[:110]}")
+
+print("\n== elementwise / copy / fill / cat launches by the innermost geodiffuser_amd source line that issued them ==")
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], with_stack=True) as prof2:
+    one(); torch.cuda.synchronize()
+import collections
+by_line = collections.defaultdict(lambda: [0, 0.0])
+OPS = ("aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::mul_", "aten::zero_", "aten::fill_", "aten::cat", "aten::sub", "aten::div", "aten::neg",
+       "aten::silu", "aten::sum", "aten::index_put_", "aten::_to_copy", "aten::silu_backward", "aten::masked_fill_", "aten::where", "aten::sigmoid", "aten::exp",
+       "aten::cos", "aten::sin", "aten::mean", "aten::native_dropout", "aten::gelu", "aten::slice_backward", "aten::select_backward", "aten::sum_to_size")
+for e in prof2.events():
+    if e.name in OPS and e.device_time_total > 0 and not any(c.name in OPS and c.device_time_total > 0 for c in e.cpu_children):
+        where = "(autograd engine / no package frame)"
+        for fr in e.stack:
+            if "geodiffuser_amd" in fr:
+                where = fr.split("geodiffuser_amd/")[-1]; break
+        a = by_line[(where, e.name)]
+        a[0] += len(e.kernels) or 1; a[1] += e.device_time_total
+tot = sum(a[1] for a in by_line.values()); n = sum(a[0] for a in by_line.values())
+print(f"{n} launches, {tot / 1e3:.2f} ms")
+for (where, name), a in sorted(by_line.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f"{a[0]:4d} x {a[1] / a[0]:6.1f} us = {a[1] / 1e3:6.3f} ms  {name:22s} {where[:110]}")

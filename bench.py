@@ -512,7 +512,19 @@ def main():
         warm_s.append(time.perf_counter() - tw)
     torch.cuda.synchronize()
     db_ok = miopen_cache.check_db_used()          # warns when the committed find-db is keyed to another MIOpen build
+    # Host heap: pauses of CPython's cyclic collector inside the timed region are counted (measured: one to four pauses of < 0.1 ms per
+    # 8 edits, with or without gc.freeze() after the warm-up — not a source of idle device time)
+    import gc
+    gc_stat = {"pauses": 0, "ms": 0.0, "max_ms": 0.0, "t": 0.0}
+
+    def _gc_cb(phase, info):
+        if phase == "start":
+            gc_stat["t"] = time.perf_counter()
+        else:
+            d = 1e3 * (time.perf_counter() - gc_stat["t"])
+            gc_stat["pauses"] += 1; gc_stat["ms"] += d; gc_stat["max_ms"] = max(gc_stat["max_ms"], d)
     gdist.barrier()
+    gc.callbacks.append(_gc_cb)
     timer.enabled = rank == 0
     mark = os.environ.get("GD_BENCH_MARK") == "1"   # profiling aid: a uniquely named kernel brackets the timed region in a trace
     if mark:
@@ -524,13 +536,15 @@ def main():
     torch.cuda.synchronize()
     gdist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.callbacks.remove(_gc_cb)
     if mark:
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
     timer.enabled = False
     # one line per rank on stderr: which device it drove and what its first edit cost (first contact with an N-GPU node)
     print(f"[bench rank {rank}/{world}] device {dev} ({torch.cuda.get_device_name(local)}), first warm-up edit "
-          f"{(warm_s[0] if warm_s else float('nan')):.2f} s, timed region {elapsed:.3f} s for {args.steps} edit(s)", file=sys.stderr, flush=True)
+          f"{(warm_s[0] if warm_s else float('nan')):.2f} s, timed region {elapsed:.3f} s for {args.steps} edit(s), cyclic-collector pauses "
+          f"{gc_stat['pauses']} x, {gc_stat['ms']:.1f} ms in all, longest {gc_stat['max_ms']:.1f} ms", file=sys.stderr, flush=True)
     per_rank = gdist.gather_over_ranks(elapsed, device=dev)
     first_edit = gdist.gather_over_ranks(warm_s[0] if warm_s else 0.0, device=dev)
     elapsed = gdist.max_over_ranks(elapsed, device=dev)
@@ -555,6 +569,8 @@ def main():
                        # multi-GPU reporting: seconds of the timed region on every rank (value uses their max) and of each rank's
                        # FIRST warm-up edit (solver search unless the find-db has the shapes, graph captures, allocator growth)
                        "per_rank_s": per_rank, "first_warmup_edit_s": first_edit,
+                       "gc": {"pauses": gc_stat["pauses"],
+                              "pause_ms_per_edit": round(gc_stat["ms"] / max(1, args.steps), 2), "longest_ms": round(gc_stat["max_ms"], 2)},
                        # the find-db seed in use (GD_MIOPEN_DB / the committed one) and the directory MIOpen works in (a per-process copy)
                        "miopen_db": miopen_cache.seed_dir(), "miopen_db_work_dir": miopen_db, "miopen_db_matched": db_ok},
         }

@@ -35,6 +35,7 @@ class GdEditLosses(Structure):               # gd_edit_losses_t
                 ("p_in", c_void_p), ("j_in", c_void_p), ("p_wo", c_void_p), ("j_wo", c_void_p), ("wgt", c_void_p),
                 ("inv5", c_void_p), ("inv_rm", c_void_p), ("wv", c_void_p), ("inv5_bwd", c_void_p),
                 ("out12", c_void_p), ("workspace", c_void_p), ("ticket", c_void_p),
+                ("log_acc", c_void_p), ("loss_in", c_void_p), ("loss_out", c_void_p),
                 ("H", c_int32), ("S", c_int32), ("D", c_int32), ("R", c_int32), ("use_amodal", c_int32)]
 
 

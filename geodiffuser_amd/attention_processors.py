@@ -207,6 +207,11 @@ OPT_PRE = os.environ.get("GD_OPT_PRE", "1") == "1"
 # key gradient: ~190 launches of ~5 us per pass — become ONE gd_heads_split forward, ONE gd_heads_merge (which also does the blend
 # :502-508,617-622) and the same two launches in the backward.  The kernels in between stay head-major.  GD_TOK_OPT=0: the permutes.
 TOK_OPT = os.environ.get("GD_TOK_OPT", "1") == "1"
+# `self.loss = self.loss + loss` (:494,604) and the four `log[key] = log[key] + term` of generic.py:34-39 — 100 one-float torch launches
+# per optimisation pass — are done by the fused loss launch's tail (gd_edit_losses_t.log_acc / loss_in / loss_out): the same f32 adds in
+# the same layer order.  GD_TAIL_SUMS=0: the torch adds.
+TAIL_SUMS = os.environ.get("GD_TAIL_SUMS", "1") == "1"
+LOG_KEYS = ("sim", "movement", "removal", "smoothness")
 
 
 def _tok_ok(attn, hidden_states) -> bool:
@@ -372,7 +377,7 @@ class _EditLayer(torch.autograd.Function):
     replace_{self,cross}_attention inlined).  Returns (out [(cb+1)*f, N, D], layer_loss [] f32, terms [5] f32)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, ctrl, is_cross, scale, c, q_pre=False, heads=0):
+    def forward(ctx, q, k, v, ctrl, is_cross, scale, c, q_pre=False, heads=0, running=False, log_acc=None):
         # q_pre: the queries carry scale*log2(e) and ``scale`` is ln 2 (controller forward): every kernel computes
         # exp(scale * q.k - lse) as it stands.  The forward is NOT told (gd_attn_seg_t::q_scaled stays 0, its multiplier becomes
         # ln2 * log2(e) = 1): the pre-scaled variant of the 64-query kernel takes the first key tile's maximum as the softmax reference
@@ -468,9 +473,14 @@ class _EditLayer(torch.autograd.Function):
                     ops.removal_corr_max_nz(Pe, Pb, c["m_inp"], c["m_wo"], c.get("n_rows"), best)
                 if use_amodal:
                     tgt = ops.amodal_target(edit_out, c["nn_idx"], c["nn_w"], c["m_edit"], S)    # :291-293
-                terms, loss, coefs, rm_coef, aux = ops.edit_losses_fused(
+                res = ops.edit_losses_fused(
                     edit_out, replace_out, tgt, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), S, best, c["rows"] if R > 0 else None,
-                    c.get("n_rows"), c["inv5"], c["inv_rm"], wv, c["inv5_bwd"], use_amodal)
+                    c.get("n_rows"), c["inv5"], c["inv_rm"], wv, c["inv5_bwd"], use_amodal, log_acc=log_acc,
+                    running=running.detach() if torch.is_tensor(running) else running)
+                terms, loss, coefs, rm_coef, aux = res[:5]
+                if running is not False:       # the tail added this layer's loss to the controller's running loss: that sum is what leaves
+                    loss = res[5]
+                    ctrl._tail_summed = True
                 if aux is not None:
                     ctrl._last_removal_aux = aux          # diagnostics: arg-max indices / values of this layer
             else:
@@ -580,7 +590,8 @@ class _EditLayer(torch.autograd.Function):
         elif dk32 is not None:
             grad_k = torch.zeros(m["k_shape"], dtype=dt, device=dev)
             grad_k[m["e0"] * f:m["e1"] * f] = dk32.to(dt)
-        return grad_q, grad_k, None, None, None, None, None, None, None
+        g_run = g_loss if (len(ctx.needs_input_grad) > 9 and ctx.needs_input_grad[9]) else None      # d(running + loss) / d running = 1
+        return grad_q, grad_k, None, None, None, None, None, None, None, g_run, None
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -911,16 +922,42 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             q, k, v = (self._tie_rows(t, f) for t in (q, k, v))
         if D % 64:      # SD1.x heads (40 / 80 / 160): zero columns up to the kernels' 64 / 128 / 192; the loss normalisers keep the true D
             q, k, v = pad_head_dim(q), pad_head_dim(k), pad_head_dim(v)
-        out, loss, terms = _EditLayer.apply(q.contiguous(), k.contiguous(), v.contiguous(), self, is_cross, float(scale), c, q_pre, ho)
+        lossy = (q.shape[1] >= 32 ** 2) and (not self.use_cfg)
+        kind = "cross" if is_cross else "self"
+        running, log_acc = False, None
+        if lossy and TAIL_SUMS and FUSED_LAYER and q.is_cuda:
+            # the running loss and the logged sums are kept by the loss launch's tail (TAIL_SUMS).  The log of this kind is either fresh
+            # (all 0.0: first lossy layer of the pass -> its entries become views of a zeroed device vector) or already those views.
+            log = self.loss_log_dict[kind]
+            acc = self.__dict__.get("_log_acc_" + kind)
+            if all((not torch.is_tensor(x)) and x == 0.0 for x in log.values()):
+                acc = self.__dict__["_log_acc_" + kind] = ops.zeros_f32(4, q.device)
+                for i, key in enumerate(LOG_KEYS):
+                    if key in log:
+                        log[key] = acc[i]
+            views = acc is not None and all(torch.is_tensor(log[key]) and log[key].data_ptr() == acc[i].data_ptr()
+                                            for i, key in enumerate(LOG_KEYS) if key in log)
+            lo = self.loss
+            if torch.is_tensor(lo):
+                ok_loss = lo.is_cuda and lo.dtype == torch.float32 and lo.numel() == 1
+            else:
+                ok_loss, lo = (lo == 0.0), None
+            if views and ok_loss:
+                running, log_acc = lo, acc
+        self._tail_summed = False
+        out, loss, terms = _EditLayer.apply(q.contiguous(), k.contiguous(), v.contiguous(), self, is_cross, float(scale), c, q_pre, ho,
+                                            running, log_acc)
         if not ho:
             out = out[..., :D]
-        if (q.shape[1] >= 32 ** 2) and (not self.use_cfg):
-            kind = "cross" if is_cross else "self"
-            self.loss = self.loss + loss                                       # :494,604 / :822,914
-            log = self.loss_log_dict[kind]
-            named = {"sim": terms[0], "movement": terms[1], "removal": terms[2], "smoothness": terms[3]}
-            for key in log:                                                    # generic.py:34-39
-                log[key] = log[key] + named[key]
+        if lossy:
+            if self._tail_summed:
+                self.loss = loss                                               # already self.loss + this layer's loss
+            else:
+                self.loss = self.loss + loss                                   # :494,604 / :822,914
+                log = self.loss_log_dict[kind]
+                named = {"sim": terms[0], "movement": terms[1], "removal": terms[2], "smoothness": terms[3]}
+                for key in log:                                                # generic.py:34-39
+                    log[key] = log[key] + named[key]
             self.loss_log_dict["num_layers"] += 1
         return out
 

@@ -495,14 +495,15 @@ k_attn_bwd_dk(const BwdArgs a) {
     }
 }
 
-__global__ void k_attn_bwd_dk_reduce(const float* __restrict__ part, int nchunks, int MD, float* __restrict__ dk) {
+__global__ void k_attn_bwd_dk_reduce(const float* __restrict__ part, int nchunks, int MD, float* __restrict__ dk, int store) {
     const int bh = blockIdx.y;
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= MD) return;
     const float* p = part + (size_t)bh * nchunks * MD + o;
     float acc = 0.f;
     for (int c = 0; c < nchunks; ++c) acc += p[(size_t)c * MD];
-    dk[(size_t)bh * MD + o] += acc;
+    if (store) dk[(size_t)bh * MD + o] = 0.0f + acc;     // what the accumulating form leaves in a zeroed buffer, without the caller's fill launch
+    else dk[(size_t)bh * MD + o] += acc;
 }
 
 // ---- dK and dV for any key count (the full backward of vanilla attention) -------------------------------------------------
@@ -684,8 +685,8 @@ extern "C" int gd_attn_bwd_dkv(const void* q, const void* k, const void* v, cons
     dim3 grid(a.nchunks, (M + 127) / 128, BH);
     GD_LAUNCH_NCH(k_attn_bwd_dkv, grid, a);
     dim3 rgrid((M * D + 255) / 256, BH);
-    k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>(a.dk_part, a.nchunks, M * D, dk_f32);
-    k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>(a.dv_part, a.nchunks, M * D, dv_f32);
+    k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>(a.dk_part, a.nchunks, M * D, dk_f32, 0);
+    k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>(a.dv_part, a.nchunks, M * D, dv_f32, 0);
     GD_CHECK_LAUNCH("gd_attn_bwd_dkv");
     return GD_OK;
 }
@@ -747,7 +748,7 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
         dim3 grid((N + DK_QCHUNK - 1) / DK_QCHUNK, BH);
         GD_LAUNCH_NCH(k_attn_bwd_dk, grid, a);
         dim3 rgrid((M * D + 255) / 256, BH);
-        k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>((const float*)workspace, (int)grid.x, M * D, dk_f32);
+        k_attn_bwd_dk_reduce<<<rgrid, 256, 0, st>>>((const float*)workspace, (int)grid.x, M * D, dk_f32, fold ? 0 : 1);
     }
     GD_CHECK_LAUNCH("gd_attn_bwd");
     return GD_OK;

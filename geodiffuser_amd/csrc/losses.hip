@@ -584,6 +584,11 @@ k_losses_fused(const gd_edit_losses_t a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         loss_assemble_body(sums, rm, a.inv5, a.inv_rm, a.wv, a.inv5_bwd, a.use_amodal, a.out12);
+        if (a.log_acc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a.log_acc[k] = a.log_acc[k] + a.out12[k];
+        }
+        if (a.loss_out) a.loss_out[0] = (a.loss_in ? a.loss_in[0] : 0.0f) + a.out12[5];
         __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // the next launch finds zero
     }
 }

@@ -618,16 +618,23 @@ def removal_corr_max_nz(Pe, Pb, m_inp, m_wo, n_valid, best):
           "gd_removal_corr_max_nz")
 
 
-def edit_losses_fused(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int, best, rows, n_valid, inv5, inv_rm, wv, inv5_bwd, use_amodal: bool):
+def edit_losses_fused(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int, best, rows, n_valid, inv5, inv_rm, wv, inv5_bwd, use_amodal: bool,
+                      log_acc=None, running=None):
     """edit_losses_fwd + removal_loss_reduce + the fold + loss_assemble in one launch.
-    -> (terms [5], loss (), coefs [5], rm_coef [1], aux | None) — what loss_assemble and removal_fwd return."""
+    -> (terms [5], loss (), coefs [5], rm_coef [1], aux | None) — what loss_assemble and removal_fwd return.
+    log_acc (f32 [>= 4], updated in place): += the four logged terms.  running: False = no running loss; None or a 0-d / [1] f32 tensor =
+    the controller's loss so far (None: 0) — a sixth result, running + loss, is appended."""
     lib = _lib.load()
     dt = _dt16(eo, "eo")
     _need(eo, "eo"); _need(ro, "ro", eo.dtype)
     H, N, D = eo.shape
     dev = eo.device
     ws = torch.empty(lib.gd_edit_losses_fwd_workspace_bytes(H, S, D) // 4, dtype=torch.float32, device=dev)
-    out = torch.empty(12, dtype=torch.float32, device=dev)
+    out = torch.empty(13 if running is not False else 12, dtype=torch.float32, device=dev)
+    if log_acc is not None:
+        _need(log_acc, "log_acc", torch.float32)
+    if running is not None and running is not False:
+        _need(running, "running", torch.float32)
     aux = None
     R = 0
     if best is not None:
@@ -643,8 +650,12 @@ def edit_losses_fused(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int, best, r
                      _ip(aux["p_in"]) if aux else 0, _ip(aux["j_in"]) if aux else 0, _ip(aux["p_wo"]) if aux else 0,
                      _ip(aux["j_wo"]) if aux else 0, _ip(aux["wgt"]) if aux else 0,
                      inv5.data_ptr(), inv_rm.data_ptr(), wv.data_ptr(), inv5_bwd.data_ptr(),
-                     out.data_ptr(), ws.data_ptr(), _ticket(dev).data_ptr(), H, S, D, R, int(bool(use_amodal)))
+                     out.data_ptr(), ws.data_ptr(), _ticket(dev).data_ptr(),
+                     _ip(log_acc), 0 if running is False else _ip(running), 0 if running is False else out[12:].data_ptr(),
+                     H, S, D, R, int(bool(use_amodal)))
     check(lib.gd_edit_losses_fused(ctypes.byref(a), dt, _stream()), "gd_edit_losses_fused")
+    if running is not False:
+        return out[0:5], out[5], out[6:11], out[11:12], aux, out[12]
     return out[0:5], out[5], out[6:11], out[11:12], aux
 
 
@@ -685,7 +696,7 @@ def attn_bwd_nofold(q, k, v, out, lse, dout, scale: float, need_dk: bool, dq_out
     _need(lse, "lse", torch.float32)
     BH, N, D = q.shape
     M = k.shape[1]
-    dk = torch.zeros(BH, M, D, dtype=torch.float32, device=q.device) if need_dk else None
+    dk = torch.empty(BH, M, D, dtype=torch.float32, device=q.device) if need_dk else None
     nbytes = lib.gd_attn_bwd_workspace_bytes(BH, N, M, D, int(need_dk))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device) if nbytes else None
     kc = ctypes.c_int(0)

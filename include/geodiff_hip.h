@@ -359,6 +359,10 @@ typedef struct gd_edit_losses {
     float* p_in; int32_t* j_in; float* p_wo; int32_t* j_wo; float* wgt;
     const float* inv5; const float* inv_rm; const float* wv; const float* inv5_bwd;
     float* out12; float* workspace; int32_t* ticket;
+    /* the controller's running sums, updated by the same tail (each may be NULL): log_acc[k] += terms[k] for the four logged terms
+     * (sim, movement, removal, smoothness: generic.py:34-39) and loss_out[0] = (loss_in ? loss_in[0] : 0) + loss
+     * (U/attention_processors.py:494,604 `self.loss = self.loss + loss`) — plain f32 adds in layer order, as the 0-d torch adds were */
+    float* log_acc; const float* loss_in; float* loss_out;
     int32_t H, S, D, R, use_amodal;
 } gd_edit_losses_t;
 int gd_edit_losses_fused(const gd_edit_losses_t* a, int dtype, void* stream);
@@ -384,7 +388,8 @@ int gd_edit_losses_bwd_rowdot(const void* eo, const void* ro, const float* tgt, 
                               int blend, int H, int S, int D, void* dro, const gd_removal_bwd_t* rm, int dtype, void* stream);
 int gd_removal_bwd_nofold(const gd_removal_bwd_t* rm, int dtype, void* stream);
 /* gd_attn_bwd that leaves the dq kernel's per-key-run partials in the workspace when it splits the key range: *kchunks_out = number of
- * runs, *dq_part_out = their address inside `workspace` ([kchunks, BH, N, D] f32).  kchunks == 1: dq (16-bit) was written directly. */
+ * runs, *dq_part_out = their address inside `workspace` ([kchunks, BH, N, D] f32).  kchunks == 1: dq (16-bit) was written directly.
+ * dk_f32 is OVERWRITTEN here (0 + the sum, i.e. what gd_attn_bwd leaves in a zeroed buffer): the caller needs no fill launch. */
 int gd_attn_bwd_nofold(const void* q, const void* k, const void* v, const void* out, const float* lse, const void* dout,
                        int BH, int N, int M, int D, float scale, void* dq, float* dk_f32, void* workspace, size_t workspace_bytes,
                        int* kchunks_out, float** dq_part_out, int dtype, void* stream);

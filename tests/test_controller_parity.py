@@ -580,6 +580,43 @@ def test_token_major_boundary_of_the_optimisation_pass_equals_the_permutes(name,
     assert torch.equal((dk.float().cpu() if dk is not None else torch.zeros_like(to_tok(k))), to_tok(r0["dk"]))
 
 
+@pytest.mark.parametrize("kind", ["edit", "remover"])
+def test_running_loss_and_logged_sums_in_the_loss_launch_equal_the_torch_adds(kind, monkeypatch):
+    """Round 4 (TAIL_SUMS): three lossy layers of one pass (self, cross, self) — `self.loss = self.loss + loss` and the four logged sums per
+    kind are kept by the fused loss launch's tail instead of 0-d torch adds: the same f32 adds in the same layer order, so the pass's loss,
+    every logged term and the gradients of all three layers are IDENTICAL to the torch adds; the log entries are device scalars either way."""
+    from geodiffuser_amd import attention_processors as AP
+    base = dict(kind=kind, S=32, f=2, D=64, cfg=False, cur_step=3, coords="translate", quant=kind == "edit")
+    layer_cases = [dict(base, cross=False, seed=61), dict(base, cross=True, seed=62), dict(base, cross=False, seed=63)]
+    runs = {}
+    for tail in (False, True):
+        monkeypatch.setattr(AP, "TAIL_SUMS", tail)
+        ch = None
+        leaves, outs = [], []
+        for case in layer_cases:
+            q, k, v, mask, coords = case_inputs(case)
+            if ch is None:
+                ch = _make_hip_controller(case, mask)
+                _prebuild_tables(ch, case, q, coords, torch.bfloat16)
+            qd, kd, vd = (t.to(torch.bfloat16).to(DEV).contiguous() for t in (q, k, v))
+            qd.requires_grad_(True); kd.requires_grad_(True)
+            with torch.enable_grad():
+                outs.append(ch(qd, kd, vd, is_cross=case["cross"], place_in_unet="up", transform_coords=coords, scale=0.125))
+            leaves += [qd, kd]
+        assert torch.is_tensor(ch.loss) and ch.loss_log_dict["num_layers"] == 3
+        total = ch.loss + sum((o[2:].float() * 0.01).sum() for o in outs)
+        grads = torch.autograd.grad(total, leaves, allow_unused=True)
+        log = {a: {kk: float(vv) for kk, vv in ch.loss_log_dict[a].items()} for a in ("self", "cross")}
+        assert all(torch.is_tensor(vv) for a in ("self", "cross") for vv in ch.loss_log_dict[a].values())
+        runs[tail] = (float(ch.loss), log, [None if g is None else g.float().cpu() for g in grads], [o.detach().float().cpu() for o in outs])
+    (l0, log0, g0, o0), (l1, log1, g1, o1) = runs[False], runs[True]
+    assert l1 == l0 and log1 == log0 and l0 != 0.0
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    for a, b in zip(g0, g1):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+
+
 def test_two_live_controllers_cannot_share_the_persistent_tables():
     """the per-resolution tables live in process-wide buffers (so that captured graphs can be reused across edits);
     a second controller that builds its tables takes them over, and the first one must then refuse to run rather than read the other's

@@ -35,7 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_MFMA_16BIT = 2.5e15     # dense bf16/fp16 MFMA peak of MI355X, /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_TABLE = "r03_attn_traffic.json"   # PMC-measured HBM bytes per launch of the attention kernel, by head count (profiles/)
+TRAFFIC_TABLE = "r04_attn_traffic.json"   # PMC-measured HBM bytes per launch of the attention kernel, by head count (profiles/)
 
 
 class AttnTimer:

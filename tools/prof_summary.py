@@ -94,7 +94,7 @@ def main():
                   "k_attn_probs", "k_attn_probs2", "k_losses_fwd", "k_losses_bwd", "k_gauss5", "k_removal_rowdot", "k_attn_bwd_dk", "k_removal_reduce",
                   "k_attn_bwd_dk_reduce", "k_zero_u32", "k_removal_dq_fold", "k_losses_fold", "k_loss_assemble", "k_rows_merge",
                   "k_removal_dk", "k_amodal_interp", "k_attn_bwd_dq_fold", "k_amodal_fused", "k_losses_fused", "k_edit_dq_fold", "k_losses_bwd_rowdot",
-                  "k_blend_merge", "k_attn_bwd_dq2", "k_removal_bwd2")
+                  "k_blend_merge", "k_attn_bwd_dq2", "k_removal_bwd2", "k_heads_split", "k_heads_merge")
         n_edits = max(1, int(__import__("os").environ.get("GD_PROF_EDITS", "2")))
         w64_small = sum(a[1] for n, a in fam.items() if n == "k_attn_fwd_w64") - sum(v[1] for (b, _), v in self64.items() if b == "k_attn_fwd_w64")
         mp_big = sum(v[1] for (b, _), v in self64.items() if b == "k_attn_fwd_mp")

@@ -158,6 +158,9 @@ TOLS = {torch.float16: dict(out=1e-3, loss=5e-4, gl2=8e-3, gmax=2.5e-2, tie=2e-3
 TOLS_GOLDEN = dict(out=1e-3, loss=5e-3, gl2=1.5e-2, gmax=0.1)      # fixtures: fp32 inputs on the reference side, fp16-rounded here
 
 
+MEASURED = []          # gradient errors of the last comparisons (read by tools/parity_report.py)
+
+
 def _check_losses_and_grads(case, ch, co, res, loss_ref, log_ref, dq_ref, dk_ref, fac_d, tols=None, regrad=None):
     """Shared by the golden and the oracle comparison.  ``fac_d`` = D_true / D_run for the D-normalised loss terms.
     ``regrad(j_in, j_wo) -> (dq, dk)``: the oracle's gradient with the removal loss evaluated at GIVEN arg-max indices — used when the
@@ -185,7 +188,8 @@ def _check_losses_and_grads(case, ch, co, res, loss_ref, log_ref, dq_ref, dk_ref
     if not same:                  # a different (equally maximal) arg-max moves its rows' gradient: compare at the device's indices
         assert regrad is not None, "arg-max differs from the fixture's and no oracle re-evaluation was supplied"
         dq_ref, dk_ref = regrad(ch._last_removal_aux["j_in"].cpu(), ch._last_removal_aux["j_wo"].cpu())
-    assert rel_l2(res["dq"][e0 * f:], dq_ref[e0 * f:]) < lim_l2 and rel_err(res["dq"][e0 * f:], dq_ref[e0 * f:]) < lim_max
+    MEASURED.append(dict(dq_l2=rel_l2(res["dq"][e0 * f:], dq_ref[e0 * f:]), dq_max=rel_err(res["dq"][e0 * f:], dq_ref[e0 * f:]), same_argmax=same))
+    assert MEASURED[-1]["dq_l2"] < lim_l2 and MEASURED[-1]["dq_max"] < lim_max
     assert float(res["dq"][: e0 * f].abs().max()) == 0.0
     if dk_ref is not None and case["cross"] and case["kind"] == "edit":
         assert rel_l2(res["dk"][e0 * f:], dk_ref[e0 * f:]) < lim_l2

@@ -35,3 +35,20 @@ for name, case in T.ORACLE_CASES.items():
         else:
             row += ["-", "-", "-", "-"]
         print("| " + " | ".join(row) + " |", flush=True)
+
+print("\n## reference-recorded fixtures (G6: fp32 inputs on the reference side, fp16-rounded inputs on the device; bounds TOLS_GOLDEN)\n")
+print("| fixture | dq rel-L2 | dq rel-max | arg-max identical |")
+print("|---|---|---|---|")
+import cases
+for name, case in cases.CONTROLLER_CASES.items():
+    if case["cfg"]:
+        continue
+    n0 = len(T.MEASURED)
+    try:
+        T.test_controller_vs_golden(name)
+        st = ""
+    except AssertionError as e:
+        st = " (ASSERTION FAILED)"
+    if len(T.MEASURED) > n0:
+        m = T.MEASURED[-1]
+        print(f"| G6_{name}{st} | {m['dq_l2']:.2e} | {m['dq_max']:.2e} | {m['same_argmax']} |", flush=True)

@@ -537,10 +537,11 @@ class _EditLayer(torch.autograd.Function):
             raise NotImplementedError("gradient through the remover's identity attention (cur_step >= obj_edit_step) is "
                                       "never taken by the reference driver (optimize_steps <= obj_edit_step)")
         heads = m.get("heads", 0)
-        if heads and g_out is not None:           # token-major [B, N, heads*D]: the edit row's slice, head-major in one launch
-            gout = ops.heads_split((g_out[cb // f:].contiguous(),), heads)[0]
+        if heads and g_out is not None:           # token-major [B, N, heads*D]: the loss backward reads the edit row's slice in place
+            gout = g_out[cb // f:].contiguous()
         else:
             gout = g_out[cb:].contiguous() if g_out is not None else None
+        gtok = bool(heads)
         gscale = g_loss.reshape(1).float().contiguous() if (m["want_losses"] and g_loss is not None) else None
         have_loss = m["want_losses"] and gscale is not None
         eo = edit_out if edit_out is not None else replace_out
@@ -565,7 +566,7 @@ class _EditLayer(torch.autograd.Function):
             rm_args, rm_ws = ops.removal_bwd_args(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], 1.0, gscale, rm_coef, m["scale"],
                                                   c.get("n_rows"), need_dk)
             dro = ops.edit_losses_bwd_rowdot(eo, replace_out, tgt, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), gout, coefs, gscale,
-                                             blend=(m["blend"] and not m["remover"]), S=S, rm=rm_args)
+                                             blend=(m["blend"] and not m["remover"]), S=S, rm=rm_args, gout_tok=gtok)
             dk32, kchunks, part_ptr, bwd_ws = ops.attn_bwd_nofold(q_edit, K, v_base, replace_out, lse_e, dro, m["scale"], need_dk, dq_view)
             rm_args.dk_f32 = dk32.data_ptr() if dk32 is not None else None
             ops.removal_bwd_nofold(rm_args, dt)
@@ -575,7 +576,7 @@ class _EditLayer(torch.autograd.Function):
         else:
             dro = ops.edit_losses_bwd(eo, replace_out, tgt if have_loss else None, c["m_wo"], m_edit_l, c.get("w_dist"),
                                       c.get("m_amodal"), gout, coefs if have_loss else _zeros5(dev), gscale,
-                                      blend=(m["blend"] and not m["remover"]), S=S)
+                                      blend=(m["blend"] and not m["remover"]), S=S, gout_tok=gtok)
             _, dk32 = ops.attn_bwd(q_edit, K, v_base, replace_out, lse_e, dro, m["scale"], need_dk=need_dk, dq_out=dq_view)
             if with_rm:
                 ops.removal_bwd(Pe, Pb, q_edit, K, c["rows"], ctx.aux, c["m_inp"], c["m_wo"], 1.0, gscale * rm_coef, m["scale"], None, dk32,

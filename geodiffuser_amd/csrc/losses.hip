@@ -315,7 +315,10 @@ __global__ void k_losses_bwd(const T* __restrict__ eo, const T* __restrict__ ro,
     if (x > 0) gs += sgn(r - (float)ro[gid - D]);
     g += c[4] * gs;
     if (gscale) g *= gscale[0];
-    if (gout) g += (float)gout[gid] * (blend ? (1.0f - me) : 1.0f);
+    if (gout) {       // blend bit 1: gout is the token-major row [N, H*D] (the layer's boundary, gd_heads_split of it folded in here)
+        const long long gi = (blend & 2) ? (((long long)n * H + (int)(t / N)) * D + (int)(gid - t * D)) : gid;
+        g += (float)gout[gi] * ((blend & 1) ? (1.0f - me) : 1.0f);
+    }
     dro[gid] = (T)g;
 }
 
@@ -640,7 +643,10 @@ k_losses_bwd_rowdot(const T* __restrict__ eo, const T* __restrict__ ro, const fl
     if (x > 0) gs += sgn(r - (float)ro[gid - D]);
     g += c[4] * gs;
     if (gscale) g *= gscale[0];
-    if (gout) g += (float)gout[gid] * (blend ? (1.0f - me) : 1.0f);
+    if (gout) {       // blend bit 1: gout is the token-major row [N, H*D] (the layer's boundary, gd_heads_split of it folded in here)
+        const long long gi = (blend & 2) ? (((long long)n * H + (int)(t / N)) * D + (int)(gid - t * D)) : gid;
+        g += (float)gout[gi] * ((blend & 1) ? (1.0f - me) : 1.0f);
+    }
     dro[gid] = (T)g;
 }
 

@@ -453,11 +453,22 @@ def edit_losses_fwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int):
     return sums
 
 
-def edit_losses_bwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend: bool, S: int):
+def _gout_flag(gout, eo, blend, gout_tok: bool) -> int:
+    """blend bit 0 + the layout bit of gout (bit 1: the token-major row [1, N, H*D] of the layer's output gradient)."""
+    H, N, D = eo.shape
+    if gout is not None:
+        _need(gout, "gout", eo.dtype)
+        if gout.numel() != eo.numel() or (gout_tok and tuple(gout.shape[-2:]) != (N, H * D)) or ((not gout_tok) and gout.shape != eo.shape):
+            raise _lib.GeodiffError("edit_losses_bwd: gout must be [H, N, D] (or [1, N, H*D] with gout_tok)")
+    return int(bool(blend)) | (2 if (gout_tok and gout is not None) else 0)
+
+
+def edit_losses_bwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend: bool, S: int, gout_tok: bool = False):
     """coefs: device f32 [5] tensor (or a host sequence, uploaded here — not capture-safe)."""
     lib = _lib.load()
     dt = _dt16(eo, "eo")
     H, N, D = eo.shape
+    blend = _gout_flag(gout, eo, blend, gout_tok)
     dro = torch.empty_like(ro)
     if not isinstance(coefs, torch.Tensor):
         coefs = torch.tensor([float(x) for x in coefs], dtype=torch.float32, device=eo.device)
@@ -673,11 +684,12 @@ def removal_bwd_args(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, 
     return a, ws
 
 
-def edit_losses_bwd_rowdot(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend: bool, S: int, rm):
+def edit_losses_bwd_rowdot(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend: bool, S: int, rm, gout_tok: bool = False):
     """edit_losses_bwd's grid + the removal backward's row dots (into rm's workspace) in one launch; rm None: plain edit_losses_bwd."""
     lib = _lib.load()
     dt = _dt16(eo, "eo")
     H, N, D = eo.shape
+    blend = _gout_flag(gout, eo, blend, gout_tok)
     dro = torch.empty_like(ro)
     _need(coefs, "coefs", torch.float32)
     check(lib.gd_edit_losses_bwd_rowdot(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), _p(gout), _p(coefs), _p(gscale),

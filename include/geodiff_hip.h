@@ -311,7 +311,8 @@ int gd_edit_losses_fwd(const void* eo, const void* ro, const float* tgt, const f
  * coef_dev: c[5] f32 in DEVICE memory (loss weight / denominator; on the device so that a captured hipGraph of the
  * optimisation pass follows the adaptive weight schedule without re-capture), all multiplied by the optional DEVICE
  * scalar gscale_dev[0] (upstream gradient of the loss); gout [H,N,D] 16-bit (may be NULL);
- * dro [H,N,D] 16-bit.
+ * dro [H,N,D] 16-bit.  `blend`: bit 0 = the blend factor above; bit 1 (ABI 4) = gout is the token-major row [N, H*D] of the layer's
+ * output gradient (batch_to_head_dim's autograd, U/attention_processors.py:213, read in place instead of a permuted copy).
  */
 int gd_edit_losses_bwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
                        const float* w_am, const float* m_amodal, const void* gout, const float* coef_dev, const float* gscale_dev,

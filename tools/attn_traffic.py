@@ -7,7 +7,8 @@ out = sys.argv[1]
 res = {"comment": "Attention forward at HEAD (round 4), N = M = 4096, D = 64, bf16: HBM bytes per launch = 2*FETCH_SIZE*1024 (gfx950 half-count "
                   "correction for wide reads) + WRITE_SIZE*1024; rocprofv3 --pmc, one counter per pass (tools/pmc_attn.sh -> tools/attn_one.py; tables: "
                   "profiles/pmc_r04_*.md).  '5' / '15_plain' / '32': plain head-major launches with pre-scaled queries; '20': the CFG pass's launch as an edit "
-                  "issues it (4 token-major segments x 5 heads, fused warp + row list); XX,
+                  "issues it (4 token-major segments x 5 heads, fused warp + row list); '15': the optimisation pass's launch (3 segments x 5 heads, "
+                  "row list, LSE, row sums over the rounded probabilities).",
        "algorithmic_bytes_per_launch": {"5": 10485760, "15": 31457280, "15_plain": 31457280, "20": 41943040, "32": 67108864},
        "bytes_per_launch": {}, "raw_KB": {}}
 for arg in sys.argv[2:]:

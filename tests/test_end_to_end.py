@@ -514,7 +514,11 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
                     tol_rel = 2.0 * emu_terms[f"{kind}/{k}"] + (0.03 if dtype == torch.float16 else 0.05)
                 else:                     # fixture whose emulation has not been re-recorded with the per-term deviations yet
                     tol_rel = (0.3 if cfg0 else 0.15) * (1.0 if dtype == torch.float16 else 2.0)
-                assert abs(float(v) - ref) <= tol_rel * abs(ref) + 1e-3, (kind, k, float(v), ref, tol_rel)
+                # absolute floor: the per-call class of the dtype, as for the first pass above (the removal term is a DIFFERENCE of
+                # two log-maxima of correlations of stored 16-bit maps: its absolute error follows the maps' rounding step, not its own
+                # size — G28 cross / removal, a term of -0.0194, over 12 runs per dtype: |dev| up to 3.1e-3 in bf16, 1.2e-3 in fp16;
+                # tools/flake_g28.sh, profiles/r04_loop_spread.md)
+                assert abs(float(v) - ref) <= tol_rel * abs(ref) + (2e-3 if dtype == torch.float16 else 4e-3), (kind, k, float(v), ref, tol_rel)
         assert w_rm == pytest.approx(float(g["final_weights_self_removal"]), rel=1e-6)   # the adaptive schedule took the same branches
         assert lat.shape == ref_lat.shape
         assert torch.equal(lat[0], ref_lat[0].to(dtype).float())                        # reference row = the trajectory's last replacement

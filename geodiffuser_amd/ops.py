@@ -630,7 +630,7 @@ def removal_corr_max_nz(Pe, Pb, m_inp, m_wo, n_valid, best):
 
 
 def edit_losses_fused(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int, best, rows, n_valid, inv5, inv_rm, wv, inv5_bwd, use_amodal: bool,
-                      log_acc=None, running=None):
+                      log_acc=None, running=False):
     """edit_losses_fwd + removal_loss_reduce + the fold + loss_assemble in one launch.
     -> (terms [5], loss (), coefs [5], rm_coef [1], aux | None) — what loss_assemble and removal_fwd return.
     log_acc (f32 [>= 4], updated in place): += the four logged terms.  running: False = no running loss; None or a 0-d / [1] f32 tensor =

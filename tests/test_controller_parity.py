@@ -155,7 +155,9 @@ def _make_regrad(case, q, k, v, mask, coords, scale, gout, nn_ties="topk"):
 # for both scale conventions) — bounded by 2^-9 (one bf16 rounding step, relative).
 TOLS = {torch.float16: dict(out=1e-3, loss=5e-4, gl2=8e-3, gmax=2.5e-2, tie=2e-3),
         torch.bfloat16: dict(out=8e-3, loss=1e-3, gl2=4e-2, gmax=5e-2, tie=1.6e-2, loss_removal=2e-3)}
-TOLS_GOLDEN = dict(out=1e-3, loss=5e-3, gl2=1.5e-2, gmax=0.1)      # fixtures: fp32 inputs on the reference side, fp16-rounded here
+# fixtures: fp32 inputs on the reference side, fp16-rounded here.  Measured (profiles/r04_parity_report.md, second table): dq rel-L2 <= 6.4e-3,
+# dq rel-max <= 6.4e-2 (a single element of the 32^2 cases, where the input rounding flips one L1 sign; <= 2.5e-2 on the others)
+TOLS_GOLDEN = dict(out=1e-3, loss=5e-3, gl2=1.5e-2, gmax=0.1)
 
 
 MEASURED = []          # gradient errors of the last comparisons (read by tools/parity_report.py)

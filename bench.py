@@ -530,9 +530,16 @@ def main():
     if mark:
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
+    per_edit = os.environ.get("GD_BENCH_PER_EDIT") == "1"    # development aid: a synchronize after every edit (changes the measurement)
     t0 = time.perf_counter()
     for j in range(args.steps):
+        te = time.perf_counter()
         one_edit(j)
+        if os.environ.get("GD_BENCH_PER_EDIT") == "2":       # host-side time of the edit, no synchronize
+            print(f"[bench] edit {j} (host): {1e3 * (time.perf_counter() - te):.1f} ms", file=sys.stderr, flush=True)
+        if per_edit:
+            torch.cuda.synchronize()
+            print(f"[bench] edit {j}: {1e3 * (time.perf_counter() - te):.1f} ms", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     gdist.barrier()
     elapsed = time.perf_counter() - t0

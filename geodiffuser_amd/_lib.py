@@ -125,6 +125,7 @@ SIGNATURES = {
     "gd_removal_bwd_nofold": (c_int, [POINTER(GdRemovalBwd), c_int, c_void_p]),
     "gd_attn_bwd_nofold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_float, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_int), POINTER(c_void_p), c_int, c_void_p]),
+    "gd_attn_fwd_pair": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "gd_heads_split": (c_int, [c_void_p, c_int, c_void_p]),
     "gd_heads_merge": (c_int, [c_void_p, c_int, c_void_p]),
     "gd_edit_dq_fold": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

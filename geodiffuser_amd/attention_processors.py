@@ -211,6 +211,10 @@ TOK_OPT = os.environ.get("GD_TOK_OPT", "1") == "1"
 # per optimisation pass — are done by the fused loss launch's tail (gd_edit_losses_t.log_acc / loss_in / loss_out): the same f32 adds in
 # the same layer order.  GD_TAIL_SUMS=0: the torch adds.
 TAIL_SUMS = os.environ.get("GD_TAIL_SUMS", "1") == "1"
+# No-grad passes, layers with at most 128 keys (every cross-attention layer: 77 text keys; the 8^2 self-attention layer): the edit rows'
+# two attention outputs and their blend (:502-508,617-622 / :831-834) in ONE launch — one workgroup computes both sides for its queries
+# and blends in registers (gd_attn_fwd_pair) — instead of two segments + a blend launch.  GD_PAIR_BLEND=0: the two launches.
+PAIR_BLEND = os.environ.get("GD_PAIR_BLEND", "1") == "1"
 LOG_KEYS = ("sim", "movement", "removal", "smoothness")
 
 
@@ -860,6 +864,16 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         segs = [(q[:cb], k[:cb], v[:cb], out_full[:cb], None)]
         replace_out = out_full[cb:]
         edit_out = ident_out = edit_act = None
+        if PAIR_BLEND and FUSED_WARP and k.shape[1] <= 128 and q.shape[2] == heads * 64 and ((not remover and blend) or (remover and not blend)):
+            # short key lists: both attention outputs of the edit rows and their blend in one launch
+            if not remover:
+                side_a = (q_base, k_base, v_base, out_full[cb:], None, (c["idx"], c["w"], c["m_edit"]))    # edit_out (:427-428,548-549)
+                side_b, m_blend = (q_edit, k_edit if is_cross else k_base, v_base), c["m_edit"]           # replace_out (:433,557)
+            else:
+                side_a = (q_edit, k_edit, v_edit, out_full[cb:], None)                                     # identity attention (:793-796)
+                side_b, m_blend = (q_edit, k_base, v_base), c["m_inp"]                                     # replace_out (:791,883)
+            ops.attn_fwd_pair(segs + [side_a], side_b, m_blend, scale, heads=heads, q_scaled=self.q_scaled_tok)
+            return out_full
         if not remover:
             K = k_edit if is_cross else k_base
             if blend:

@@ -274,6 +274,207 @@ k_attn_fwd(const FwdArgs a) {
     }
 }
 
+// ---- short-key launches with the blend inside: gd_attn_fwd_pair ------------------------------------------------------------------
+// Round 4.  In a no-grad pass every cross-attention layer (77 text keys) and the 8^2 self-attention layer computed the edit rows twice
+// — with the warped reference queries (edit_out) and with the edit latent's own queries (replace_out), two segments of one launch — and
+// a second launch blended them: out = edit_out*m + replace_out*(1-m) (U/attention_processors.py:502-508,617-622; for the remover past
+// its blend window the identity attention and replace_out under m_inp, :831-834): 1,200 blend launches of ~5 us per edit.  With at
+// most two key tiles there is no loop to speak of, so the two sides of a 64-query tile share a workgroup: waves 0-1 run side A, waves
+// 2-3 side B (each wave exactly the chain of loads and MFMAs it ran as a wave of the two-segment launch, both sides' K / V tiles staged
+// by all four waves), side B's waves hand their rounded 16-bit rows over through LDS, side A's waves blend op by op like k_blend and
+// store.  Bit-identical to the two launches, one launch less.  (First version: one 128-query workgroup running side A then side B —
+// 20 instead of 25 heads of workgroups, but the two dependent chains in a row made the launch 2 us slower than attention + blend.)
+struct PairArgs {
+    gd_attn_seg_t seg[GD_ATTN_MAX_SEGS];      // seg[nseg - 1] is side A of the pair; its `out` receives the blend
+    gd_attn_seg_t b;                          // side B (same bh / heads as side A; out unused)
+    const float* m;                           // [N] blend mask
+    int bh_end[GD_ATTN_MAX_SEGS];
+    int nseg, N, M, tiles, tiles_p, nwg_plain, nwg;
+    float c;
+};
+
+// a16 / b16: the two attention outputs as the two-segment launch stored them; every product and the sum rounded to the tensor dtype
+// like k_blend
+template <typename T>
+__device__ __forceinline__ typename elem_traits<T>::vec4 pair_blend4(typename elem_traits<T>::vec4 a16, typename elem_traits<T>::vec4 b16, float mraw) {
+#pragma clang fp contract(off)
+    const float mm = (float)(T)mraw;
+    const float om = (float)(T)(1.0f - mm);
+    typename elem_traits<T>::vec4 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float t1 = (float)(T)((float)a16[j] * mm);
+        const float t2 = (float)(T)((float)b16[j] * om);
+        w[j] = (T)(t1 + t2);
+    }
+    return w;
+}
+
+#define PAIR_XROW 136                          // bytes per exchanged row (128 + 8: the 32 rows of a wave fall into distinct banks)
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+k_attn_fwd_pair(const PairArgs a) {
+    using TR = elem_traits<T>;
+    using V8 = typename TR::vec8;
+    using V4 = typename TR::vec4;
+    constexpr int D = ATT_D;
+    __shared__ __attribute__((aligned(16))) char lds[2][2][2][ATT_TILE_BYTES];   // [side][key tile][K|V]
+    __shared__ __attribute__((aligned(16))) char xch[64 * PAIR_XROW];           // side B's rounded rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int wg = xcd_remap(blockIdx.x, a.nwg);
+    const bool paired = wg >= a.nwg_plain;                                    // workgroup-uniform
+    int sidx, bh, tile;
+    if (!paired) {
+        const int gbh = wg / a.tiles;
+        tile = wg - gbh * a.tiles;
+        sidx = 0;
+#pragma unroll
+        for (int i = 0; i < GD_ATTN_MAX_SEGS - 1; ++i)
+            if (i < a.nseg - 2 && gbh >= a.bh_end[i]) sidx = i + 1;
+        bh = gbh - (sidx ? a.bh_end[sidx - 1] : 0);
+    } else {
+        const int w2 = wg - a.nwg_plain;
+        bh = w2 / a.tiles_p;
+        tile = w2 - bh * a.tiles_p;
+        sidx = a.nseg - 1;
+    }
+    const int side = paired ? (wave >> 1) : 0;                                // wave-uniform
+    const gd_attn_seg_t sa = a.seg[sidx];
+    const gd_attn_seg_t sg = (paired && side) ? a.b : sa;                     // the segment THIS wave attends with
+    const int N = a.N, M = a.M;
+    const int rs = sa.heads > 0 ? sa.heads * D : D;
+    size_t qoff, koff;
+    if (sa.heads > 0) {
+        const int b = bh / sa.heads, hh = bh - b * sa.heads;
+        qoff = (size_t)b * N * rs + (size_t)hh * D;
+        koff = (size_t)b * M * rs + (size_t)hh * D;
+    } else {
+        qoff = (size_t)bh * N * D;
+        koff = (size_t)bh * M * D;
+    }
+    const int qrow = paired ? tile * 64 + (wave & 1) * 32 + (lane & 31) : tile * ATT_BM + wave * 32 + (lane & 31);
+    const int qld = qrow < N ? qrow : N - 1;
+    const FragOffs fo = make_frag_offs(lane);
+    const int T_all = (M + ATT_BN - 1) / ATT_BN;                              // 1 or 2 (launcher)
+    const int T_full = M / ATT_BN;
+    const bool same_k = !paired || a.b.k == sa.k, same_v = !paired || a.b.v == sa.v;
+
+    // every wave's own queries (side A: the gather-composite prologue when the segment carries warp tables) and, by all four waves, the
+    // K / V tiles of side A and whichever of side B's differ: one round trip, as in the two-segment launch
+    V8 qf[4];
+    {
+        u32x4 kr[2][2], vr[2][2], kbr[2][2], vbr[2][2];
+        const T* __restrict__ kp = (const T*)sa.k + koff;
+        const T* __restrict__ vp = (const T*)sa.v + koff;
+        const T* __restrict__ kbp = (const T*)a.b.k + koff;
+        const T* __restrict__ vbp = (const T*)a.b.v + koff;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (t < T_all) {
+                tile_load<T>(kp, t * ATT_BN, M, tid, kr[t], rs);
+                tile_load<T>(vp, t * ATT_BN, M, tid, vr[t], rs);
+                if (!same_k) tile_load<T>(kbp, t * ATT_BN, M, tid, kbr[t], rs);
+                if (!same_v) tile_load<T>(vbp, t * ATT_BN, M, tid, vbr[t], rs);
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (t < T_all) {
+                tile_store(lds[0][t][0], tid, kr[t]); tile_store(lds[0][t][1], tid, vr[t]);
+                if (!same_k) tile_store(lds[1][t][0], tid, kbr[t]);
+                if (!same_v) tile_store(lds[1][t][1], tid, vbr[t]);
+            }
+    }
+    load_q_frags<T>(sg, (const T*)sg.q + qoff, rs, qld, h, qf);
+    const float mraw = (paired && !side) ? a.m[qld] : 0.f;
+    __syncthreads();
+
+    const int sk = (side && !same_k) ? 1 : 0, sv = (side && !same_v) ? 1 : 0;
+    f32x16 o[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[j][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int t = 0; t < T_full; ++t) fwd_tile<T, false, 1>(lds[sk][t][0], lds[sv][t][1], fo, qf, o, m_run, l_run, a.c, t * ATT_BN, M, h);
+    if (T_full < T_all) fwd_tile<T, true, 1>(lds[sk][T_full][0], lds[sv][T_full][1], fo, qf, o, m_run, l_run, a.c, T_full * ATT_BN, M, h);
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+    // the rounded outputs, exactly as the stand-alone kernel stores them: an f32 product, then ONE conversion.  (Where the 16-bit value
+    // feeds 16-bit arithmetic hipcc would select v_fma_mixlo_f16 for fp16 — product and conversion with a single rounding, one ulp away
+    // from the stored value in ~5e-5 of the elements; the empty asm keeps the product an f32 register value.)
+    V4 w16[2][4];
+#pragma unroll
+    for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pr = o[dblk][4 * g + j] * inv;
+                asm volatile("" : "+v"(pr));
+                w16[dblk][g][j] = TR::from_f32(pr);
+            }
+    T* __restrict__ op = (T*)sa.out + qoff + (size_t)qrow * rs;
+    if (!paired) {
+        if (qrow < N) {
+#pragma unroll
+            for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(V4*)(op + dblk * 32 + 8 * g + 4 * h) = w16[dblk][g];
+        }
+        return;
+    }
+    char* xr = xch + ((wave & 1) * 32 + (lane & 31)) * PAIR_XROW;              // the row both sides' lanes of this query share
+    if (side) {
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(V4*)(xr + (dblk * 32 + 8 * g + 4 * h) * (int)sizeof(T)) = w16[dblk][g];
+    }
+    __syncthreads();
+    if (side || qrow >= N) return;
+#pragma unroll
+    for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const V4 wb = *(const V4*)(xr + (dblk * 32 + 8 * g + 4 * h) * (int)sizeof(T));
+            *(V4*)(op + dblk * 32 + 8 * g + 4 * h) = pair_blend4<T>(w16[dblk][g], wb, mraw);
+        }
+}
+
+extern "C" int gd_attn_fwd_pair(const gd_attn_seg_t* segs, int nseg, const gd_attn_seg_t* side_b, const float* blend_m, int N, int M, int D,
+                                float scale, int dtype, void* stream) {
+    GD_REQUIRE(segs && side_b && blend_m && nseg >= 1 && nseg <= GD_ATTN_MAX_SEGS, GD_EINVAL, "gd_attn_fwd_pair: null pointer or nseg=%d (1..%d)", nseg,
+               GD_ATTN_MAX_SEGS);
+    GD_REQUIRE(D == ATT_D && M > 0 && M <= 2 * ATT_BN && N > 0, GD_EUNSUPPORTED, "gd_attn_fwd_pair: head dim 64 and at most %d keys (D=%d, M=%d)", 2 * ATT_BN, D, M);
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_fwd_pair: dtype must be f16/bf16");
+    PairArgs a;
+    memset(&a, 0, sizeof(a));
+    int tot = 0;
+    for (int i = 0; i < nseg; ++i) {
+        GD_REQUIRE(segs[i].q && segs[i].k && segs[i].v && segs[i].out && segs[i].bh > 0, GD_EINVAL, "gd_attn_fwd_pair: segment %d has a null pointer or bh<=0", i);
+        GD_REQUIRE(!segs[i].lse && !segs[i].q_rows, GD_EUNSUPPORTED, "gd_attn_fwd_pair: no LSE output and no query row list on this path");
+        GD_REQUIRE((segs[i].q_scaled != 0) == (segs[0].q_scaled != 0), GD_EINVAL, "gd_attn_fwd_pair: segments disagree on q_scaled");
+        a.seg[i] = segs[i];
+        tot += segs[i].bh;
+        a.bh_end[i] = tot;
+    }
+    const gd_attn_seg_t& sa = segs[nseg - 1];
+    GD_REQUIRE(side_b->q && side_b->k && side_b->v && side_b->bh == sa.bh && side_b->heads == sa.heads && !side_b->lse && !side_b->q_rows &&
+               (side_b->q_scaled != 0) == (sa.q_scaled != 0), GD_EINVAL, "gd_attn_fwd_pair: side B must match side A's head count, layout and query scaling");
+    a.b = *side_b;
+    a.m = blend_m;
+    a.nseg = nseg; a.N = N; a.M = M;
+    a.tiles = (N + ATT_BM - 1) / ATT_BM;
+    a.tiles_p = (N + 63) / 64;                                                // the pair's workgroups hold 64 queries (two waves per side)
+    a.nwg_plain = a.tiles * (tot - sa.bh);
+    a.nwg = a.nwg_plain + a.tiles_p * sa.bh;
+    a.c = segs[0].q_scaled ? 1.0f : scale * 1.4426950408889634f;
+    hipStream_t st = as_stream(stream);
+    if (dtype == GD_F16) k_attn_fwd_pair<f16_t><<<a.nwg, 256, 0, st>>>(a);
+    else k_attn_fwd_pair<bf16_t><<<a.nwg, 256, 0, st>>>(a);
+    GD_CHECK_LAUNCH("gd_attn_fwd_pair");
+    return GD_OK;
+}
+
 // merge the split-KV partials: one thread per (row, 4 channels)
 template <typename T>
 __global__ void k_attn_combine(const FwdArgs a) {

@@ -183,16 +183,8 @@ def _attn_plan(lib, tot_bh: int, N: int, M: int):
     return p
 
 
-def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Optional[int] = None, q_scaled: bool = False) -> None:
-    """segs: list of (q, k, v, out, lse | None[, warp]); one launch.
-    heads == 0: q/out [bh,N,D], k/v [bh,M,D] (head-major).  heads > 0: token-major q/out [B,N,heads*D], k/v [B,M,heads*D]
-    exactly as to_q/to_k/to_v produce them (no head_to_batch_dim copies); lse [B*heads, N].
-    warp = (idx [N,K] i32, w [N,K] f32, m [N] f32 | None): the segment attends with the warped, blended queries
-    q*(1-m) + m*half(sum_k w*q[idx]) built inside the kernel (U/attention_processors.py:424-428,544-549) — the fused
-    attention-warp launch; bit-identical to passing splat_composite(q, idx, w, m) as q.
-    q_scaled: every q already carries scale*log2(e) (applied by the projection GEMM before its rounding, see attention_processors
-    ``_project_qkv``); ``scale`` is then ignored.  2: additionally row sums over the rounded probabilities (gd_attn_seg_t.q_scaled)."""
-    lib = _lib.load()
+def _attn_seg_array(segs: Sequence[tuple], heads: int, q_scaled, what: str = "attn_fwd"):
+    """-> (GdAttnSeg array, n, N, M, D, dtype code, tot_bh) for a list of (q, k, v, out | None, lse | None[, warp[, q_rows]]) tuples."""
     n = len(segs)
     arr = (GdAttnSeg * n)()
     q0, k0 = segs[0][0], segs[0][1]
@@ -204,17 +196,17 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
         q, k, v, o, lse = seg[:5]
         warp = seg[5] if len(seg) > 5 else None
         qrows = seg[6] if len(seg) > 6 else None          # (rows i32 [R], n_valid i32 [1] on the device): see gd_attn_seg_t.q_rows
-        for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "out")):
+        for t, nm in ((q, "q"), (k, "k"), (v, "v")) + (((o, "out"),) if o is not None else ()):
             _need(t, nm, q0.dtype)
         No = N if qrows is None else int(qrows[0].numel())
         if heads:
             ok = q.shape[1:] == (N, heads * D) and k.shape[1:] == (M, heads * D) and v.shape == k.shape and k.shape[0] == q.shape[0] \
-                and tuple(o.shape) == (q.shape[0], No, heads * D)
+                and (o is None or tuple(o.shape) == (q.shape[0], No, heads * D))
         else:
             ok = q.shape[1:] == (N, D) and k.shape[1:] == (M, D) and v.shape == k.shape and k.shape[0] == q.shape[0] \
-                and tuple(o.shape) == (q.shape[0], No, D)
+                and (o is None or tuple(o.shape) == (q.shape[0], No, D))
         if not ok:
-            raise _lib.GeodiffError("attn_fwd: segment shapes disagree")
+            raise _lib.GeodiffError(f"{what}: segment shapes disagree")
         if lse is not None:
             _need(lse, "lse", torch.float32)
         rl = rn = 0
@@ -230,12 +222,41 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
             _need(t_idx, "warp idx", torch.int32); _need(t_w, "warp w", torch.float32)
             wK = t_idx.shape[-1]
             if t_idx.numel() != N * wK or t_w.numel() != N * wK or (t_m is not None and t_m.numel() != N):
-                raise _lib.GeodiffError("attn_fwd: warp tables must have N rows")
+                raise _lib.GeodiffError(f"{what}: warp tables must have N rows")
             if t_m is not None:
                 _need(t_m, "warp m", torch.float32)
             widx, ww, wm = t_idx.data_ptr(), t_w.data_ptr(), 0 if t_m is None else t_m.data_ptr()
-        arr[i] = GdAttnSeg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 0 if lse is None else lse.data_ptr(), bh, heads,
+        arr[i] = GdAttnSeg(q.data_ptr(), k.data_ptr(), v.data_ptr(), 0 if o is None else o.data_ptr(), 0 if lse is None else lse.data_ptr(), bh, heads,
                            widx, ww, wm, wK, int(q_scaled) if q_scaled in (0, 1, 2) else int(bool(q_scaled)), rl, rn, 0 if qrows is None else No)
+    return arr, n, N, M, D, dt, tot_bh
+
+
+def attn_fwd_pair(segs: Sequence[tuple], side_b: tuple, m: torch.Tensor, scale: float, heads: int = 0, q_scaled: bool = False) -> None:
+    """Short-key launches (at most 128 keys) with the blend inside: ``segs`` as attn_fwd (no LSE, no row lists); the LAST segment is side A of
+    a pair, ``side_b`` = (q, k, v[, warp]) its side B: segs[-1]'s out = A*m + B*(1-m) as blend_tokens computes it from the two attention
+    outputs (gd_attn_fwd_pair).  m [N] f32."""
+    lib = _lib.load()
+    arr, n, N, M, D, dt, _ = _attn_seg_array(segs, heads, q_scaled, "attn_fwd_pair")
+    b = (side_b[0], side_b[1], side_b[2], None, None) + tuple(side_b[3:4])
+    arr_b, _, Nb, Mb, _, _, _ = _attn_seg_array([b], heads, q_scaled, "attn_fwd_pair")
+    _need(m, "m", torch.float32)
+    if Nb != N or Mb != M or m.numel() != N or b[0].shape != segs[-1][0].shape:
+        raise _lib.GeodiffError("attn_fwd_pair: side B / mask do not match side A")
+    check(lib.gd_attn_fwd_pair(arr, n, arr_b, _p(m), N, M, D, scale, dt, _stream()), "gd_attn_fwd_pair")
+
+
+def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Optional[int] = None, q_scaled: bool = False) -> None:
+    """segs: list of (q, k, v, out, lse | None[, warp]); one launch.
+    heads == 0: q/out [bh,N,D], k/v [bh,M,D] (head-major).  heads > 0: token-major q/out [B,N,heads*D], k/v [B,M,heads*D]
+    exactly as to_q/to_k/to_v produce them (no head_to_batch_dim copies); lse [B*heads, N].
+    warp = (idx [N,K] i32, w [N,K] f32, m [N] f32 | None): the segment attends with the warped, blended queries
+    q*(1-m) + m*half(sum_k w*q[idx]) built inside the kernel (U/attention_processors.py:424-428,544-549) — the fused
+    attention-warp launch; bit-identical to passing splat_composite(q, idx, w, m) as q.
+    q_scaled: every q already carries scale*log2(e) (applied by the projection GEMM before its rounding, see attention_processors
+    ``_project_qkv``); ``scale`` is then ignored.  2: additionally row sums over the rounded probabilities (gd_attn_seg_t.q_scaled)."""
+    lib = _lib.load()
+    arr, n, N, M, D, dt, tot_bh = _attn_seg_array(segs, heads, q_scaled)
+    q0 = segs[0][0]
     if nsplit is None:
         nsplit, ws_bytes = _attn_plan(lib, tot_bh, N, M) if SPLIT_KV else (1, 0)
     else:

@@ -171,6 +171,15 @@ int gd_attn_fwd_set_config(int qb, int ks);
 int gd_attn_fwd_splitkv(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
                         size_t workspace_bytes, int dtype, void* stream);
 
+/* Short-key launches (M <= 128: the 77-key text context of every cross-attention layer, the 8^2 self-attention layer) with the blend
+ * of U/attention_processors.py:502-508,617-622 (remover: :831-834) inside the launch.  segs[0 .. nseg-2]: plain segments as
+ * gd_attn_fwd; segs[nseg-1] is side A of ONE pair and `side_b` its side B (same bh / heads / layout; lse, row lists unsupported; its
+ * `out` is ignored): segs[nseg-1].out = A*m + B*(1-m), A = attention(side A), B = attention(side B), both rounded to the tensor dtype
+ * first and blended op by op like gd_blend_tokens — bit-identical to gd_attn_fwd over nseg + 1 segments followed by gd_blend_tokens.
+ * blend_m [N] f32.  D = 64 only. */
+int gd_attn_fwd_pair(const gd_attn_seg_t* segs, int nseg, const gd_attn_seg_t* side_b, const float* blend_m, int N, int M, int D,
+                     float scale, int dtype, void* stream);
+
 /*
  * Backward of out = softmax(scale q k^T) v w.r.t. q (always) and k (dk_f32 != NULL).
  *   dout [BH,N,D] 16-bit; lse from the forward; dq [BH,N,D] 16-bit (overwritten);

@@ -1641,3 +1641,47 @@ def test_heads_split_and_merge_are_the_permutes(ops, dtype):
     assert int(out[0].ne(0).sum()) == 0 and torch.equal(out[1], d32.to(dtype).permute(1, 0, 2).reshape(M, C))
     with pytest.raises(Exception):
         ops.heads_merge([a, d32[:, :N]], heads, N, D, dtype, DEV)          # mixed 16-bit / f32 sources
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("form", ["cross64", "cross32_f16", "self8", "remover_cross16", "head_major"])
+def test_pair_launch_equals_two_segments_and_the_blend(ops, dtype, form):
+    """gd_attn_fwd_pair (short key lists: both attention outputs of the edit rows and their blend in one workgroup) against the launch it
+    replaces — gd_attn_fwd over one more segment followed by gd_blend_tokens: IDENTICAL bits, plain segments included."""
+    g = torch.Generator().manual_seed(17)
+    S, heads, M, warp, diff_v, tok = dict(cross64=(64, 5, 77, True, False, True), cross32_f16=(32, 10, 77, True, False, True), self8=(8, 20, 64, True, False, True),
+                                          remover_cross16=(16, 20, 77, False, True, True), head_major=(16, 4, 77, True, False, False))[form]
+    N, D = S * S, 64
+    C = heads * D
+    mk = lambda rows, n: (torch.randn(rows, n, C, generator=g) * (0.3 if n == N else 1.0)).to(dtype).to(DEV)
+    q, k, v = mk(4, N), mk(4, M), mk(4, M)
+    if not tok:                                        # head-major [rows * heads, n, D]
+        hm = lambda t: t.view(4, t.shape[1], heads, D).permute(0, 2, 1, 3).reshape(4 * heads, t.shape[1], D).contiguous()
+        q, k, v = hm(q), hm(k), hm(v)
+    f = 1 if tok else heads
+    m = torch.rand(N, generator=g).to(DEV)
+    m[: N // 3] = 0.0; m[N // 3: N // 2] = 1.0
+    K = 15
+    idx = torch.randint(0, N, (N, K), generator=g, dtype=torch.int32); idx[:, 5:] = -1
+    w = torch.rand(N, K, generator=g); w[:, 5:] = 0.0
+    idx, w = idx.to(DEV), w.to(DEV)
+    wt = (idx, w, m) if warp else None
+    hk = dict(heads=heads) if tok else {}
+    base = (q[:2 * f], k[:2 * f], v[:2 * f])
+    qa, ka, va = q[2 * f:3 * f], k[2 * f:3 * f], v[2 * f:3 * f]
+    qb, kb, vb = q[3 * f:], k[3 * f:], (v[3 * f:] if diff_v else va)
+    # the two launches
+    o_base, o_a, o_b = torch.empty_like(base[0]), torch.empty_like(qa), torch.empty_like(qa)
+    seg_a = (qa, ka, va, o_a, None) + ((wt,) if warp else ())
+    ops.attn_fwd([base + (o_base, None), seg_a, (qb, kb, vb, o_b, None)], 0.125, q_scaled=True, **hk)
+    ref = torch.empty_like(o_a)
+    H3 = (o_a.reshape(heads, N, D) if not tok else o_a.reshape(1, N, C))
+    ops.blend_tokens(H3, o_b.reshape(H3.shape), m, out=ref.reshape(H3.shape))
+    # the pair launch
+    p_base, p_out = torch.empty_like(o_base), torch.empty_like(o_a)
+    ops.attn_fwd_pair([base + (p_base, None), (qa, ka, va, p_out, None) + ((wt,) if warp else ())], (qb, kb, vb), m, 0.125, q_scaled=True, **hk)
+    assert torch.equal(p_base, o_base)
+    assert torch.equal(p_out, ref)
+    assert float((o_a.float() - o_b.float()).abs().max()) > 1e-3           # the two sides do differ
+    with pytest.raises(Exception):
+        ops.attn_fwd_pair([(qa, ka, va, p_out, torch.empty(f * (heads if tok else 1), N, device=DEV))], (qb, kb, vb), m, 0.125, **hk)     # no LSE on this path

@@ -40,6 +40,7 @@ def main():
     fam = collections.defaultdict(lambda: [0, 0.0, 1e30, 0.0])          # own kernels per base name (k_x / gd_x), both spellings merged
     busy, cur_end, prev_name = 0.0, t_first, "(region start)"
     gaps = collections.Counter()
+    gap_after = collections.defaultdict(lambda: [0, 0.0])       # idle time by the kernel that ran BEFORE the gap (gaps of 5 us .. 1 ms)
     top_gaps = []
     self64 = collections.defaultdict(lambda: [0, 0.0])                  # 64^2 self-attention launches by (kernel, workgroups)
     for s, e, n, wgs in rows:
@@ -57,6 +58,9 @@ def main():
         if s > cur_end:
             g = (s - cur_end) * 1e-3
             gaps["<5us" if g < 5 else "5-20us" if g < 20 else "20-100us" if g < 100 else "0.1-1ms" if g < 1000 else ">1ms"] += g
+            if 5 <= g < 1000:
+                ga = gap_after[(prev_name, b)]
+                ga[0] += 1; ga[1] += g
             if g >= 300:
                 top_gaps.append((g, (cur_end - t_first) * 1e-6, prev_name, b))
             busy += (e - s) * 1e-6
@@ -94,7 +98,7 @@ def main():
                   "k_attn_probs", "k_attn_probs2", "k_losses_fwd", "k_losses_bwd", "k_gauss5", "k_removal_rowdot", "k_attn_bwd_dk", "k_removal_reduce",
                   "k_attn_bwd_dk_reduce", "k_zero_u32", "k_removal_dq_fold", "k_losses_fold", "k_loss_assemble", "k_rows_merge",
                   "k_removal_dk", "k_amodal_interp", "k_attn_bwd_dq_fold", "k_amodal_fused", "k_losses_fused", "k_edit_dq_fold", "k_losses_bwd_rowdot",
-                  "k_blend_merge", "k_attn_bwd_dq2", "k_removal_bwd2", "k_heads_split", "k_heads_merge")
+                  "k_blend_merge", "k_attn_bwd_dq2", "k_removal_bwd2", "k_heads_split", "k_heads_merge", "k_attn_fwd_pair")
         n_edits = max(1, int(__import__("os").environ.get("GD_PROF_EDITS", "2")))
         w64_small = sum(a[1] for n, a in fam.items() if n == "k_attn_fwd_w64") - sum(v[1] for (b, _), v in self64.items() if b == "k_attn_fwd_w64")
         mp_big = sum(v[1] for (b, _), v in self64.items() if b == "k_attn_fwd_mp")
@@ -113,6 +117,10 @@ def main():
                      "| kernel | workgroups | launches | total ms | avg us |\n|---|---|---|---|---|\n")
             for (b, wgs), (c, u) in sorted(self64.items(), key=lambda kv: -kv[1][1]):
                 fh.write(f"| `{b}` | {wgs} | {c} | {u * 1e-3:.1f} | {u / c:.1f} |\n")
+        if gap_after:
+            fh.write("\n## idle time in gaps of 5 us .. 1 ms by the kernels around the gap (top 14)\n\n| after kernel | before kernel | gaps | total ms | avg us |\n|---|---|---|---|---|\n")
+            for (pn, nn), (c, u) in sorted(gap_after.items(), key=lambda kv: -kv[1][1])[:14]:
+                fh.write(f"| `{pn[:40]}` | `{nn[:40]}` | {c} | {u * 1e-3:.1f} | {u / c:.1f} |\n")
         if top_gaps:
             fh.write("\n## idle gaps >= 0.3 ms (host work between launches)\n\n| at ms | gap ms | after kernel | before kernel |\n|---|---|---|---|\n")
             for g, at, pn, nn in sorted(top_gaps, key=lambda x: x[1])[:80]:

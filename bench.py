@@ -524,6 +524,9 @@ def main():
             d = 1e3 * (time.perf_counter() - gc_stat["t"])
             gc_stat["pauses"] += 1; gc_stat["ms"] += d; gc_stat["max_ms"] = max(gc_stat["max_ms"], d)
     gdist.barrier()
+    from geodiffuser_amd import graphs as _graphs
+    cap0 = dict(_graphs.CAPTURES)
+    ms0 = torch.cuda.memory_stats(dev) if torch.cuda.is_available() else {}
     gc.callbacks.append(_gc_cb)
     timer.enabled = rank == 0
     mark = os.environ.get("GD_BENCH_MARK") == "1"   # profiling aid: a uniquely named kernel brackets the timed region in a trace
@@ -543,6 +546,10 @@ def main():
     torch.cuda.synchronize()
     gdist.barrier()
     elapsed = time.perf_counter() - t0
+    captures = {k: _graphs.CAPTURES[k] - cap0[k] for k in cap0}       # passes captured INSIDE the timed region (new row-list lengths)
+    ms1 = torch.cuda.memory_stats(dev) if torch.cuda.is_available() else {}
+    alloc = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+    alloc["reserved_GiB"] = round(ms1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2)
     gc.callbacks.remove(_gc_cb)
     if mark:
         torch.cuda._sleep(1000)
@@ -576,6 +583,7 @@ def main():
                        # multi-GPU reporting: seconds of the timed region on every rank (value uses their max) and of each rank's
                        # FIRST warm-up edit (solver search unless the find-db has the shapes, graph captures, allocator growth)
                        "per_rank_s": per_rank, "first_warmup_edit_s": first_edit,
+                       "graph_captures_in_timed_region": captures, "device_allocator_in_timed_region": alloc,
                        "gc": {"pauses": gc_stat["pauses"],
                               "pause_ms_per_edit": round(gc_stat["ms"] / max(1, args.steps), 2), "longest_ms": round(gc_stat["max_ms"], 2)},
                        # the find-db seed in use (GD_MIOPEN_DB / the committed one) and the directory MIOpen works in (a per-process copy)

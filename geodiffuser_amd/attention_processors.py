@@ -272,7 +272,7 @@ class EditProcessor:
         # the head-major layer fed with token-major tensors (TOK_OPT): 64-wide heads, 16-bit, the geometry controllers
         tokg = (TOK_OPT and TOKEN_MAJOR and self.perform_edit and not tok and hidden_states.is_cuda
                 and hidden_states.dtype in (torch.float16, torch.bfloat16) and attn.to_q.out_features == attn.heads * 64
-                and getattr(ctrl, "supports_token_major", False) and not ctrl.use_cfg and not getattr(ctrl, "rows_identical", False))
+                and getattr(ctrl, "supports_token_major", False) and not ctrl.use_cfg)
         q, k, v, is_cross, shape4, lin_args, qs = _project_qkv(
             attn, hidden_states, encoder_hidden_states, temb, scale, tok or tokg,
             scaled_q_head_major=self.perform_edit and not tok and getattr(ctrl, "supports_scaled_q_head_major", False), batched_ok=tok)
@@ -934,7 +934,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         D = 64 if ho else q.shape[2]
         c = self._tables(S, f, q, transform_coords, D)
         if self.rows_identical and torch.is_grad_enabled():
-            q, k, v = (self._tie_rows(t, f) for t in (q, k, v))
+            q, k, v = (self._tie_rows(t, 1 if ho else f) for t in (q, k, v))       # token-major: one batch row per latent
         if D % 64:      # SD1.x heads (40 / 80 / 160): zero columns up to the kernels' 64 / 128 / 192; the loss normalisers keep the true D
             q, k, v = pad_head_dim(q), pad_head_dim(k), pad_head_dim(v)
         lossy = (q.shape[1] >= 32 ** 2) and (not self.use_cfg)

@@ -44,6 +44,9 @@ def _src_version(ctx_src):
     return ctx_src, ctx_src._version
 
 
+CAPTURES = {"unet": 0, "opt": 0}      # hipGraph captures so far in this process (no-grad passes / optimisation passes): reporting only
+
+
 class GraphedUNet:
     """``runner(key, x, t, ctx) -> noise_pred``; the returned tensor is a static buffer that the next replay overwrites."""
 
@@ -112,6 +115,7 @@ class GraphedUNet:
                 self._refresh_kv(e)
                 e.kv_src, e.kv_ver = _src_version(ctx_src)
             torch.cuda.synchronize()
+            CAPTURES["unet"] += 1
             g = torch.cuda.CUDAGraph()
             ops.zero_pool_reset()
             from . import attention_processors as _ap
@@ -216,6 +220,7 @@ class GraphedOptPass:
             st = {"lat": lat.detach().clone().requires_grad_(True), "ctx": ctx.detach().clone().requires_grad_(True),
                   "t": torch.tensor([int(t)], device=dev, dtype=torch.long)}
             torch.cuda.synchronize()
+            CAPTURES["opt"] += 1
             g = torch.cuda.CUDAGraph()
             ops.zero_pool_reset()
             with torch.cuda.graph(g):

@@ -545,7 +545,7 @@ def test_fused_layer_launches_equal_the_standalone_ones(name, dtype, monkeypatch
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("name", ["edit_self_opt_32_d64", "edit_cross_opt_32_d64", "edit_self_opt_64_d64", "edit_cross_opt_64_d64", "rem_self_opt_32_d64",
-                                  "edit_self_opt_16", "edit_cross_opt_16_past_blend", "rem_cross_opt_32"])
+                                  "edit_self_opt_16", "edit_cross_opt_16_past_blend", "rem_cross_opt_32", "rem_self_opt_32_tied", "edit_cross_opt_32_tied"])
 def test_token_major_boundary_of_the_optimisation_pass_equals_the_permutes(name, dtype):
     """Round 4 (TOK_OPT): the layer handed token-major q / k / v [B, N, heads*64] — one gd_heads_split forward, one gd_heads_merge that also
     blends, the same two launches in the backward (zero rows of the gradients and the f32 -> 16-bit rounding of dk included) — against the
@@ -555,17 +555,22 @@ def test_token_major_boundary_of_the_optimisation_pass_equals_the_permutes(name,
              "edit_cross_opt_16_past_blend": dict(kind="edit", S=16, f=4, D=64, cross=True, cfg=False, cur_step=46, coords="scale", quant=True, seed=52),
              "rem_cross_opt_32": dict(kind="remover", S=32, f=2, D=64, cross=True, cfg=False, cur_step=3, coords="translate", quant=False, seed=53),
              "edit_cross_opt_64_d64": dict(ORACLE_CASES["edit_cross_opt_32_d64"], S=64)}
-    case = ORACLE_CASES.get(name) or extra[name]
+    tied = name.endswith("_tied")            # the first optimisation pass of an edit: identical reference and edit rows, tied (rows_identical)
+    case = ORACLE_CASES.get(name) or extra.get(name) or dict(ORACLE_CASES[name[:-5] + "_d64"], cur_step=0)
     q, k, v, mask, coords = case_inputs(case)
     f = case["f"]
+    if tied:
+        q, k, v = (torch.cat([t[:f], t[:f]]) for t in (q, k, v))
     B = q.shape[0] // f
     gout = case_gout(case, (q.shape[0], q.shape[1], q.shape[2]))
     to_tok = lambda t: t.view(B, f, t.shape[1], t.shape[2]).permute(0, 2, 1, 3).reshape(B, t.shape[1], f * t.shape[2]).contiguous()
     ch = _make_hip_controller(case, mask)
+    ch.rows_identical = tied
     _prebuild_tables(ch, case, q, coords, dtype)
     r0 = _run_hip(ch, case, q, k, v, coords, 0.125, gout, dtype)
     log0 = {kk: float(vv) for kk, vv in ch.loss_log_dict["cross" if case["cross"] else "self"].items()}
     ch = _make_hip_controller(case, mask)
+    ch.rows_identical = tied
     _prebuild_tables(ch, case, q, coords, dtype)
     ch.heads_opt = f
     qd, kd, vd = (to_tok(t.to(dtype)).to(DEV) for t in (q, k, v))

@@ -374,8 +374,9 @@ def dry_run(args) -> int:
     real on a box without GPUs; the printed line says dry_run and carries no metric value."""
     from geodiffuser_amd import dist as gdist
     rank, world, local = gdist.init(backend="gloo")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ppg = gdist.procs_per_gpu()
+    if world != args.gpus * ppg:
+        raise SystemExit(f"--gpus {args.gpus} x {ppg} edit(s) in flight per GPU but WORLD_SIZE={world}")
     from geodiffuser_amd.pipeline import build_random_sd21
     from geodiffuser_amd.synthetic import make_edit
     # every rank builds ITS OWN weights (seed = rank): after the broadcast they must equal rank 0's
@@ -405,8 +406,9 @@ def dry_run(args) -> int:
     elapsed = gdist.max_over_ranks(elapsed, device="cpu")
     if rank == 0:
         print(json.dumps({"metric": "DRY RUN - no edit executed (launcher / rendezvous / broadcast / reporting check)", "value": None,
-                          "unit": "edits/sec", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": 0, "scaling": "weak",
-                          "config": {"weights_broadcast_bytes": nbytes, "per_rank_s": per_rank, "first_warmup_edit_s": first,
+                          "unit": "edits/sec", "dry_run": True, "n_gpus": args.gpus, "steps": args.steps, "warmup": 0, "scaling": "weak",
+                          "config": {"edits_in_flight_per_gpu": ppg, "device_of_rank": [gdist.local_device_index(r) for r in range(world)],
+                                     "weights_broadcast_bytes": nbytes, "per_rank_s": per_rank, "first_warmup_edit_s": first,
                                      "weights_equal_after_broadcast": all(abs(p - probes[0]) < 1e-9 for p in probes),
                                      "edits_by_rank": {str(r): [j * world + r for j in range(args.steps)] for r in range(world)}}}), flush=True)
     return 0
@@ -438,7 +440,8 @@ def spawn_ranks(n: int, argv, device_count=None, run=None) -> int:
         return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+    ppg = max(1, int(env.get("GD_EDITS_IN_FLIGHT", "1")))             # ranks per GPU (--edits-in-flight)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n * ppg}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
     return (run or subprocess.call)(cmd, env=env)
 
@@ -459,8 +462,13 @@ def main():
                          "stub (there is no CPU path for it).  The line it prints is marked dry_run and is not a measurement")
     ap.add_argument("--model", default="sd21", choices=["sd21", "sdxl"],
                     help="sd21 = BASELINE configs[1] (the benchmark); sdxl = SDXL-base-shaped UNet, use with --size 1024 (configs[4] shape, bf16 path)")
+    ap.add_argument("--edits-in-flight", type=int, default=1,
+                    help="P > 1: P independent edits in flight per GPU (P ranks per device; gloo control plane).  A THROUGHPUT mode for the batch "
+                         "driver, reported separately: the headline configuration is one edit at a time (P = 1)")
     args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.edits_in_flight > 1:
+        os.environ["GD_EDITS_IN_FLIGHT"] = str(args.edits_in_flight)
+    if (args.gpus > 1 or args.edits_in_flight > 1) and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (before anything touches the GPU)
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:], device_count=args.gpus if args.dry_run else None))
     if args.dry_run:
@@ -476,8 +484,10 @@ def main():
     miopen_db = miopen_cache.configure()
     from geodiffuser_amd import dist as gdist
     rank, world, local = gdist.init()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ppg = gdist.procs_per_gpu()
+    local = gdist.local_device_index(local)
+    if world != args.gpus * ppg:
+        raise SystemExit(f"--gpus {args.gpus} x {ppg} edit(s) in flight per GPU but WORLD_SIZE={world}")
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
     from geodiffuser_amd import _lib, editor
@@ -571,11 +581,11 @@ def main():
         line = {
             "metric": "geometry edits/sec (512^2, 50-step DDIM, SD2.1)" if args.model == "sd21" else f"geometry edits/sec ({args.size}^2, SDXL shape)",
             "value": value, "unit": "edits/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"configs[1]: single {args.size}x{args.size} image, 3-D {args.kind} edit, {args.ddim_steps}-step DDIM "
+            "config": {"edits_in_flight_per_gpu": ppg, "workload": (f"configs[1]: single {args.size}x{args.size} image, 3-D {args.kind} edit, {args.ddim_steps}-step DDIM "
                                     f"inversion + edit (17 optimisation passes), SD2.1-base-shaped UNet/VAE/text-encoder, random-init, "
-                                    f"one edit per GPU") if args.model == "sd21" else
+                                    f"{'one edit' if ppg == 1 else str(ppg) + ' independent edits in flight'} per GPU") if args.model == "sd21" else
                                    (f"configs[4] shape on the bf16 path: single {args.size}x{args.size} image, 3-D {args.kind} edit, "
                                     f"{args.ddim_steps}-step DDIM inversion + edit, SDXL-base-shaped UNet (2.57 B parameters) / two text towers / "
                                     f"VAE, random-init, one edit per GPU"), "edits_per_min": 60.0 * value, "weights_broadcast_bytes": nbytes,

@@ -202,6 +202,7 @@ def main(argv=None):
     from . import miopen_cache
     miopen_cache.configure()                                                  # committed find-db: no per-rank solver search
     rank, world, local = gdist.init()
+    local = gdist.local_device_index(local)              # GD_EDITS_IN_FLIGHT = P: P ranks (independent edits) share every GPU
     # (the edit itself needs the HIP extension and fails loudly without a GPU; the driver around it — sharding, broadcast, result
     #  files — is device-agnostic so that the world-size-2 gloo test can run it on CPU with a stubbed edit)
     dev = f"cuda:{local}" if torch.cuda.is_available() else "cpu"

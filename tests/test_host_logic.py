@@ -278,6 +278,31 @@ def test_bench_gpus_2_dry_run_really_starts_two_ranks():
         assert f"[bench rank {r}/2] device cpu (dry run)" in p.stderr
 
 
+def test_edits_in_flight_starts_p_ranks_per_gpu():
+    """VERDICT r03 #7 (the batch driver's throughput mode): ``--edits-in-flight P`` starts P ranks per GPU — rank r drives device
+    LOCAL_RANK // P, the control plane runs over gloo (RCCL takes one rank per device) with the weight broadcast staged through the host,
+    and the line reports the GPU count, not the rank count.  Dry run on CPU: launcher, rendezvous, broadcast, sharding and reporting."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "GD_EDITS_IN_FLIGHT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--edits-in-flight", "3", "--steps", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and cfg["edits_in_flight_per_gpu"] == 3 and cfg["device_of_rank"] == [0, 0, 0]
+    assert len(cfg["per_rank_s"]) == 3 and cfg["weights_equal_after_broadcast"] is True
+    assert cfg["edits_by_rank"] == {"0": [0, 3], "1": [1, 4], "2": [2, 5]}
+    from geodiffuser_amd import dist as gdist
+    os.environ["GD_EDITS_IN_FLIGHT"] = "2"
+    try:
+        assert gdist.procs_per_gpu() == 2 and [gdist.local_device_index(r) for r in range(6)] == [0, 0, 1, 1, 2, 2]
+    finally:
+        del os.environ["GD_EDITS_IN_FLIGHT"]
+    assert gdist.procs_per_gpu() == 1 and gdist.local_device_index(5) == 5
+
+
 def test_visible_gpu_count_reads_masks_without_hip(monkeypatch):
     """The launcher counts devices from the visibility masks / the kernel driver's topology, never through the HIP runtime."""
     from geodiffuser_amd import dist

@@ -328,6 +328,24 @@ def test_attention_unit_parts_with_segments_warp_and_row_list(ops, heads):
         assert float((a.float() - b.float()).abs().max()) < 1e-2 and float(b.float().abs().max()) > 0.1
     for a, b in zip(outs[0][3:], outs[1][3:]):
         assert float((a - b).abs().max()) < 1e-4
+    # ... and the split launch itself against the fp32 formulation (softmax over exp2 of the pre-scaled scores), so that this test pins
+    # the part-split form by itself and not only relative to the unsplit one: plain segments, their LSE, and the row-list segment, whose
+    # queries are the warped ones of splat_composite
+    def ref(qb, rows_sel=None):
+        qh = qb.float().view(N, heads, 64).permute(1, 0, 2)
+        kh, vh = (t[0].float().view(N, heads, 64).permute(1, 0, 2) for t in (k, v))
+        if rows_sel is not None:
+            qh = qh[:, rows_sel]
+        s = torch.einsum("hnd,hmd->hnm", qh, kh) * math.log(2.0)
+        return torch.einsum("hnm,hmd->hnd", torch.softmax(s, -1), vh).permute(1, 0, 2).reshape(qh.shape[1], C), torch.logsumexp(s, -1)
+    o0, o1, act_s, l0, l1 = outs[1]
+    for ob, lb, qb in ((o0, l0, q[0]), (o1, l1, q[1])):
+        r, lse = ref(qb)
+        assert rel_err(ob[0].float().cpu(), r.cpu()) < 8e-3 and float((lb - lse).abs().max()) < 2e-3
+    from geodiffuser_amd._lib import GD_TOKEN_MAJOR
+    q_warp = ops.splat_composite(q[0:1], idx, w, m, GD_TOKEN_MAJOR)[0]
+    r, _ = ref(q_warp, rows[:int(nv)].long())
+    assert rel_err(act_s[0].float().cpu(), r.cpu()) < 8e-3
 
 
 @pytest.mark.parametrize("cfg", [(4, 1), (8, 1)])

@@ -12,9 +12,9 @@ for (H, N, M) in (SHAPES[os.environ.get("BWD_SHAPE", "self")],):
     g = (torch.randn(H, N, 64, device=dev) * 0.1).to(dt)
     out = torch.empty_like(q); lse = torch.empty(H, N, device=dev)
     ops.attn_fwd([(q, k, v, out, lse)], 0.125)
-    R = 640                                                   # inpaint rows of a typical object mask at 64^2 (bucketed to 256)
+    R = int(os.environ.get("BWD_ROWS", "640"))                 # inpaint rows of a typical object mask at 64^2 (bucketed to 256)
     rows = (torch.arange(0, R, device=dev, dtype=torch.int32) * 5 % N).contiguous()
-    nv = torch.tensor([R - 100], dtype=torch.int32, device=dev)
+    nv = torch.tensor([int(os.environ.get("BWD_NV", str(R - 100)))], dtype=torch.int32, device=dev)
     m_inp = torch.zeros(N, device=dev); m_inp[rows.long()] = 1; m_wo = 1 - m_inp
     for _ in range(reps):
         dq, dk = ops.attn_bwd(q, k, v, out, lse, g, 0.125, M == 77)

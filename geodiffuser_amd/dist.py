@@ -84,6 +84,33 @@ def visible_gpu_count() -> int:
     return -1 if n_kfd is None else n_kfd
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n_gpus: int, per_gpu: int, target: Sequence[str], argv: Sequence[str], run=None) -> int:
+    """Start ``n_gpus * per_gpu`` ranks of ``target`` (["-m", module] or [script path]) on this node through ``torch.distributed.run`` as a
+    CHILD process — call it before anything touches the GPU — with a free rendezvous port on 127.0.0.1, and return the child's exit code.
+    ``per_gpu`` > 1 exports GD_EDITS_IN_FLIGHT (see procs_per_gpu).  Refuses when fewer than ``n_gpus`` devices are visible (counted
+    without HIP).  ``run``: injection point of the CPU tests."""
+    import subprocess
+    import sys
+    have = visible_gpu_count()
+    if 0 <= have < n_gpus:
+        print(f"launch_ranks: {n_gpus} GPU(s) asked for but only {have} visible on this node", file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if per_gpu > 1:
+        env["GD_EDITS_IN_FLIGHT"] = str(per_gpu)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus * per_gpu}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), *target, *argv]
+    return (run or subprocess.call)(cmd, env=env)
+
+
 def shard(items: Sequence[T], rank: int, world: int) -> List[T]:
     """edit j -> rank j mod world."""
     return [x for j, x in enumerate(items) if j % world == rank]

@@ -195,9 +195,23 @@ def main(argv=None):
     ap.add_argument("--exp-type", default=None, choices=[None, "geometry_editor", "geometry_remover"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--limit", type=int, default=0, help="process at most this many experiments in total (0 = all)")
+    ap.add_argument("--gpus", type=int, default=0, help="start this many GPUs' worth of ranks here (0: run as the one process / rank this is)")
+    ap.add_argument("--edits-in-flight", type=int, default=1,
+                    help="with --gpus: independent edits in flight per GPU = ranks per device (4 gives 1.85 x the edits/min of 1 on an MI355X)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
-    from . import dist as gdist, editor
+    from . import dist as gdist
+    if args.gpus > 0 and "WORLD_SIZE" not in os.environ:
+        # our own launcher (before anything touches the GPU): gpus x edits-in-flight ranks of this module, experiments sharded j mod W
+        import sys
+        tail = [a for a in (sys.argv[1:] if argv is None else list(argv))]
+        for flag in ("--gpus", "--edits-in-flight"):
+            while flag in tail:
+                i = tail.index(flag)
+                del tail[i:i + 2]
+        raise SystemExit(gdist.launch_ranks(args.gpus, max(1, args.edits_in_flight), ["-m", "geodiffuser_amd.large_scale_editor"], tail,
+                                            run=getattr(main, "_run", None)))
+    from . import editor
     from .diffusion import load_model
     from . import miopen_cache
     miopen_cache.configure()                                                  # committed find-db: no per-rank solver search

@@ -389,3 +389,27 @@ def test_dist_init_needs_a_port_from_the_launcher(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "0"); monkeypatch.delenv("MASTER_PORT", raising=False)
     with pytest.raises(RuntimeError, match="MASTER_PORT"):
         dist.init("gloo")
+
+
+def test_batch_driver_starts_its_own_ranks(monkeypatch):
+    """``python -m geodiffuser_amd.large_scale_editor --gpus N --edits-in-flight P``: the batch driver's own launcher — N x P ranks of the
+    module through torch.distributed.run as a child, GD_EDITS_IN_FLIGHT exported, the launcher flags stripped from the ranks' arguments,
+    a refusal when fewer devices are visible (counted without HIP)."""
+    from geodiffuser_amd import dist as gdist, large_scale_editor as L
+    calls = []
+    monkeypatch.setattr(L.main, "_run", lambda cmd, env: calls.append((cmd, env)) or 0, raising=False)
+    monkeypatch.setattr(gdist, "visible_gpu_count", lambda: 8)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as ex:
+        L.main(["--root", "/data/x", "--gpus", "2", "--edits-in-flight", "4", "--dtype", "fp16"])
+    assert ex.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd and env["GD_EDITS_IN_FLIGHT"] == "4"
+    i = cmd.index("geodiffuser_amd.large_scale_editor")
+    assert cmd[i - 1] == "-m" and cmd[i + 1:] == ["--root", "/data/x", "--dtype", "fp16"]
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    monkeypatch.setattr(gdist, "visible_gpu_count", lambda: 1)
+    with pytest.raises(SystemExit) as ex:
+        L.main(["--root", "/data/x", "--gpus", "2"])
+    assert ex.value.code == 2 and len(calls) == 1

@@ -6,9 +6,8 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import graphs
+from . import diffusion, graphs
 from .attention_processors import VanillaAttentionProcessor
-from .diffusion import encode_text
 from .scheduler import DDIMInverseScheduler, DDIMScheduler
 
 
@@ -47,9 +46,9 @@ class NullInversion:
     def init_prompt(self, prompt: str):
         tok = self.model.tokenizer
         uncond_input = tok([self.uncond_text], padding="max_length", max_length=tok.model_max_length, return_tensors="pt")
-        uncond_embeddings = encode_text(self.model, uncond_input.input_ids)
+        uncond_embeddings = diffusion.encode_text(self.model, uncond_input.input_ids)
         text_input = tok([prompt], padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt")
-        text_embeddings = encode_text(self.model, text_input.input_ids)
+        text_embeddings = diffusion.encode_text(self.model, text_input.input_ids)
         self.context = torch.cat([uncond_embeddings, text_embeddings])
         self.prompt = prompt
 

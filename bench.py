@@ -367,6 +367,43 @@ def cpu_baseline_configs0(cores, sample_steps=4):
                         f"{c['steps']} inversion) = {total:.0f} s per 256^2 / 20-step edit"))
 
 
+def _edit(pipe, tok, sched, inp, args):
+    from geodiffuser_amd import editor
+    from geodiffuser_amd.synthetic import editor_kwargs
+    image, depth, mask, T = inp
+    kw = editor_kwargs()
+    kw.update(num_ddim_steps=args.ddim_steps, ldm_stable_model=pipe, tokenizer_model=tok, scheduler_in=sched)
+    return editor.run_geodiffuser(image, depth, mask, T, **kw)
+
+
+def fp16_leg(args, timer, inputs, dev, one_edit_with, warmup=2, steps=4):
+    """The same workload with the SAME seeded weights held in fp16 (the reference's autocast dtype): `warmup` untimed edits, `steps`
+    timed ones, and the attention forward's roofline fraction for the fp16 launches.  Outside ms_per_step by construction (runs after the
+    timed region has been closed and reported)."""
+    from geodiffuser_amd.diffusion import load_model
+    pipe, tok, sched = load_model("stabilityai/stable-diffusion-xl-base-1.0" if args.model == "sdxl" else "stabilityai/stable-diffusion-2-1-base",
+                                  device=dev, dtype=torch.float16, tiny=args.tiny)
+    steps = min(steps, args.steps)
+    for j in range(warmup):
+        one_edit_with(pipe, tok, sched, j % max(1, args.steps))
+    torch.cuda.synchronize()
+    timer.cfgs = {}
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for j in range(steps):
+        one_edit_with(pipe, tok, sched, j)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    timer.replay()
+    roof = timer.summary()
+    out = {"ms_per_step": 1e3 * elapsed / steps, "edits_per_min": 60.0 * steps / elapsed, "steps": steps, "warmup": warmup, "dtype": "fp16"}
+    if roof:
+        out.update(frac=roof["achieved_executed"] / PEAK_MFMA_16BIT, frac_algorithmic=roof["achieved"] / PEAK_MFMA_16BIT,
+                   avg_launch_us=roof["avg_us"], launches=roof["launches"])
+    return out
+
+
 def dry_run(args) -> int:
     """``--dry-run``: everything around the edit on CPU / gloo — the rendezvous the launcher set up, the bucketed weight broadcast from
     rank 0, the barrier + max-over-ranks timing, the per-rank gathers and the rank-0-only JSON line — with the edit itself replaced by a
@@ -456,6 +493,8 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--kind", default="rotate", choices=["rotate", "translate", "mixed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp16-leg", action="store_true",
+                    help="skip the short fp16 leg (2 warm-ups + 4 edits after the timed region; reported under `fp16`, never in ms_per_step)")
     ap.add_argument("--tiny", action="store_true", help="narrow model (debug only; the result is not a benchmark number)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / broadcast / reporting check WITHOUT a GPU: gloo, narrow model on the CPU, the edit replaced by a "
@@ -507,12 +546,9 @@ def main():
     inputs = {j: make_edit(j * world + rank, size=args.size, kind=args.kind) for j in list(range(args.steps)) + [1000 + w for w in range(args.warmup)]}
 
     def one_edit(j):
-        image, depth, mask, T = inputs[j]
-        # fresh keyword arguments per edit: like the reference, the controller aliases the caller's loss_weights_dict and the adaptive
+        # fresh keyword arguments per edit (_edit): like the reference, the controller aliases the caller's loss_weights_dict and the adaptive
         # schedule edits it in place (attention_processors.py:667-668) — a shared dict would leak one edit's weights into the next
-        kw = editor_kwargs()
-        kw.update(num_ddim_steps=args.ddim_steps, ldm_stable_model=pipe, tokenizer_model=tok, scheduler_in=sched)
-        return editor.run_geodiffuser(image, depth, mask, T, **kw)
+        return _edit(pipe, tok, sched, inputs[j], args)
 
     warm_s = []
     for j in range(args.warmup):
@@ -611,6 +647,13 @@ def main():
                                 "achieved_algorithmic": roof["achieved"] / 1e12, "frac_algorithmic": roof["achieved"] / PEAK_MFMA_16BIT,
                                 "configs": roof["configs"],
                                 "flops_per_launch": roof["flops_per_launch"]}
+        if args.dtype == "bf16" and world == 1 and not args.no_fp16_leg and args.steps > 0:
+            # fp16 is the reference's autocast dtype and the one that meets the 1e-3 per-layer tolerance; the headline stays bf16
+            # (configs[1]).  A short leg AFTER the timed region so that the dtype has a driver-timed number of its own.
+            try:
+                line["fp16"] = fp16_leg(args, timer, inputs, dev, one_edit_with=lambda pp, tk, sc, j: _edit(pp, tk, sc, inputs[j], args))
+            except Exception as e:  # noqa: BLE001
+                line["fp16"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline()

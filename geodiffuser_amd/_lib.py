@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libgeodiff_hip.so")
 GD_F16, GD_BF16, GD_F32 = 0, 1, 2
 GD_TOKEN_MAJOR, GD_CHANNEL_MAJOR = 0, 1
 GD_ATTN_MAX_SEGS = 4
+GD_ABI_VERSION = 5
 
 
 class GdAttnSeg(Structure):
@@ -21,6 +22,14 @@ class GdAttnSeg(Structure):
                 ("bh", c_int32), ("heads", c_int32),
                 ("warp_idx", c_void_p), ("warp_w", c_void_p), ("warp_m", c_void_p), ("warp_K", c_int32), ("q_scaled", c_int32),
                 ("q_rows", c_void_p), ("q_rows_n", c_void_p), ("q_rows_len", c_int32)]
+
+
+class GdAttnCfg(Structure):                  # gd_attn_cfg_t (defaults = GD_ATTN_CFG_DEFAULT)
+    _fields_ = [("even_split", c_int32), ("qb", c_int32), ("ks", c_int32), ("nsplit", c_int32), ("handoff", c_int32)]
+
+
+class GdConv3x3Cfg(Structure):               # gd_conv3x3_cfg_t (defaults = GD_CONV3X3_CFG_DEFAULT)
+    _fields_ = [("pi", c_int32), ("ki", c_int32), ("ksplit", c_int32), ("dma", c_int32)]
 
 
 class GdProbs(Structure):                    # gd_probs_t
@@ -45,7 +54,7 @@ class GdRemovalBwd(Structure):               # gd_removal_bwd_t
                 ("m_inp", c_void_p), ("m_wo", c_void_p), ("gscale", c_void_p), ("gscale2", c_void_p), ("n_valid", c_void_p),
                 ("dk_f32", c_void_p), ("workspace", c_void_p),
                 ("coef", c_float), ("scale", c_float),
-                ("H", c_int32), ("R", c_int32), ("N", c_int32), ("M", c_int32), ("Mpad", c_int32), ("D", c_int32)]
+                ("H", c_int32), ("R", c_int32), ("N", c_int32), ("M", c_int32), ("Mpad", c_int32), ("D", c_int32), ("variant", c_int32)]
 
 
 class GdHeadsSplit(Structure):               # gd_heads_split_t
@@ -74,17 +83,12 @@ SIGNATURES = {
     "gd_splat_composite": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_int, c_void_p]),
     "gd_mesh_coverage": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "gd_attn_fwd": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
-    "gd_rows_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "gd_attn_fwd": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, POINTER(GdAttnCfg), c_void_p, c_size_t, c_int, c_void_p]),
     "gd_attn_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "gd_attn_fwd_ws": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_int, c_void_p]),
-    "gd_attn_fwd_set_even_split": (c_int, [c_int]),
     "gd_attn_fwd_plan": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
-    "gd_attn_fwd_set_config": (c_int, [c_int, c_int]),
-    "gd_attn_fwd_splitkv": (c_int, [POINTER(GdAttnSeg), c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_int, c_void_p]),
-    "gd_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "gd_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "gd_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                            c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+                            c_float, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_int), POINTER(c_void_p), c_int, c_int, c_void_p]),
     "gd_attn_bwd_dkv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gd_attn_bwd_dkv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
@@ -95,56 +99,39 @@ SIGNATURES = {
                                     c_int, c_void_p]),
     "gd_attn_fwd_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                 c_void_p, c_void_p, c_int, c_void_p]),
-    "gd_attn_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                              c_float, c_void_p, c_int, c_void_p]),
+    "gd_attn_probs": (c_int, [POINTER(GdProbs), POINTER(GdProbs), c_int, c_float, c_void_p, c_size_t, c_int, c_void_p]),
     "gd_removal_corr_max": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                    c_void_p, c_int, c_void_p]),
+                                    c_void_p, c_int, c_int, c_int, c_void_p]),
     "gd_removal_loss_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
-    "gd_removal_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                               c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "gd_removal_bwd": (c_int, [POINTER(GdRemovalBwd), c_void_p, c_void_p, c_int, c_void_p]),
     "gd_nn_table": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_amodal_target": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_int, c_void_p]),
     "gd_loss_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gd_edit_losses_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "gd_edit_losses_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "gd_edit_losses_fwd": (c_int, [POINTER(GdEditLosses), c_int, c_void_p]),
     "gd_removal_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "gd_edit_losses_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
-    "gd_blend_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, POINTER(GdRemovalBwd), c_int, c_void_p]),
     "gd_blend_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
-    "gd_attn_probs_pair": (c_int, [POINTER(GdProbs), POINTER(GdProbs), c_int, c_float, c_void_p, c_size_t, c_int, c_void_p]),
-    "gd_removal_corr_max_nz": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                       c_void_p, c_int, c_void_p]),
-    "gd_edit_losses_fused": (c_int, [POINTER(GdEditLosses), c_int, c_void_p]),
-    "gd_edit_losses_bwd_rowdot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, POINTER(GdRemovalBwd), c_int, c_void_p]),
-    "gd_removal_bwd_nofold": (c_int, [POINTER(GdRemovalBwd), c_int, c_void_p]),
-    "gd_attn_bwd_nofold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                   c_float, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_int), POINTER(c_void_p), c_int, c_void_p]),
     "gd_attn_fwd_pair": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "gd_heads_split": (c_int, [c_void_p, c_int, c_void_p]),
     "gd_heads_merge": (c_int, [c_void_p, c_int, c_void_p]),
     "gd_edit_dq_fold": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gd_group_norm_nhwc_scratch_floats": (c_int64, [c_int, c_int, c_int]),
-    "gd_group_norm_set_single_launch": (c_int, [c_int]),
-    "gd_group_norm_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
-                                   c_int, c_void_p]),
-    "gd_group_norm_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
+    "gd_group_norm_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p,
+                                   c_void_p, c_int, c_void_p]),
+    "gd_group_norm_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gd_bias_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "gd_geglu": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "gd_geglu_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "gd_layer_norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_int, c_void_p]),
     "gd_add_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
-    "gd_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "gd_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
-                           c_int, c_void_p]),
-    "gd_conv3x3_set_config": (c_int, [c_int, c_int, c_int]),
-    "gd_conv3x3_set_dma": (c_int, [c_int]),
+    "gd_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, POINTER(GdConv3x3Cfg)]),
+    "gd_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(GdConv3x3Cfg),
+                           c_void_p, c_size_t, c_int, c_void_p]),
     "gd_softsplat_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gd_softsplat_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gd_hist_match": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -175,8 +162,8 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
             raise GeodiffError(f"libgeodiff_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.gd_version() != 4:
-        raise GeodiffError(f"ABI version mismatch: library {lib.gd_version()} != binding 4")
+    if lib.gd_version() != GD_ABI_VERSION:
+        raise GeodiffError(f"ABI version mismatch: library {lib.gd_version()} != binding {GD_ABI_VERSION}")
     _lib = lib
     return lib
 

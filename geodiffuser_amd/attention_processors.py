@@ -187,7 +187,7 @@ LOG2E = 1.4426950408889634
 FUSED_WARP = os.environ.get("GD_FUSED_WARP", "1") == "1"   # build the warped queries inside the attention launch
 # The edit attention with warped queries (q*(1-m) + m*splat(q), U/attention_processors.py:424-428,544-549) is computed only for the rows
 # where the soft edit mask m is non-zero (~10 % of a 64^2 map): for m == 0 the warped query IS the reference query, so that row of
-# edit_out equals the reference row's attention output, which the same launch computes anyway.  gd_attn_seg_t.q_rows + gd_rows_merge.
+# edit_out equals the reference row's attention output, which the same launch computes anyway.  gd_attn_seg_t.q_rows + gd_blend_merge.
 # Self-attention layers from 64^2 tokens up (below, the saved work is smaller than the merge launch).
 WARP_ROWS = os.environ.get("GD_WARP_ROWS", "1") == "1"
 WARP_ROWS_MIN_TOKENS = 64 ** 2

@@ -335,17 +335,12 @@ static int dq2_kchunks(int BH, int N, int M) {
     const long long wgs = (long long)((N + ATT_BM - 1) / ATT_BM) * BH;
     const int t_all = M / ATT_BN;
     int kc = (int)(512 / (wgs > 0 ? wgs : 1));
-    if (const char* e = getenv("GD_DQ2_KC")) { const int v = atoi(e); if (v > 0) return v < t_all ? v : t_all; }     // tuning hook (tools/bench_bwd.py)
     if (kc > t_all / 8) kc = t_all / 8;
     if (kc > 8) kc = 8;
     return kc < 1 ? 1 : kc;
 }
-// GD_BWD_DQ = "1": k_attn_bwd_dq (register staging) everywhere; default: k_attn_bwd_dq2 where it applies (D = 64, full key tiles, >= 4 tiles)
-static bool dq2_applies(int M, int D) {
-    if (D != ATT_D || M % ATT_BN != 0 || M < 4 * ATT_BN) return false;
-    const char* e = getenv("GD_BWD_DQ");
-    return !(e && e[0] == '1');
-}
+// k_attn_bwd_dq2 where it applies (D = 64, full key tiles, >= 4 tiles); k_attn_bwd_dq (register staging) serves every other shape
+static bool dq2_applies(int M, int D, int variant) { return variant != 1 && D == ATT_D && M % ATT_BN == 0 && M >= 4 * ATT_BN; }
 
 // dq[i] = 16-bit( sum_c dq_part[c][i] ), c ascending (4 elements per thread)
 template <typename T>
@@ -698,28 +693,28 @@ static size_t bwd_dk_ws_bytes(int BH, int N, int M, int D, int need_dk) {
     return (size_t)BH * chunks * M * D * sizeof(float);
 }
 
-extern "C" size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk) {
-    const int kc = dq2_applies(M, D) ? dq2_kchunks(BH, N, M) : dq_kchunks(BH, N, M);
+extern "C" size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk, int variant) {
+    const int kc = dq2_applies(M, D, variant) ? dq2_kchunks(BH, N, M) : dq_kchunks(BH, N, M);
     return bwd_dk_ws_bytes(BH, N, M, D, need_dk) + (kc > 1 ? (size_t)kc * BH * N * D * sizeof(float) : 0);
 }
 
 static int attn_bwd_launch(const void* q, const void* k, const void* v, const void* out, const float* lse,
                            const void* dout, int BH, int N, int M, int D, float scale,
                            void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int dtype, void* stream, bool fold,
-                           int* kchunks_out, float** dq_part_out) {
+                           int* kchunks_out, float** dq_part_out, int variant) {
     GD_REQUIRE(q && k && v && out && lse && dout && dq, GD_EINVAL, "gd_attn_bwd: null pointer");
     GD_REQUIRE(GD_HEAD_DIM_OK(D), GD_EUNSUPPORTED, "gd_attn_bwd: head dim %d unsupported (64, 128, 192)", D);
     GD_REQUIRE(BH > 0 && N > 0 && M > 0, GD_EINVAL, "gd_attn_bwd: bad sizes");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_bwd: dtype must be f16/bf16");
     GD_REQUIRE(!dk_f32 || M <= 128, GD_EUNSUPPORTED, "gd_attn_bwd: dK is only implemented for M <= 128 keys (cross-attention); M=%d", M);
     BwdArgs a;
-    const size_t need_ws = gd_attn_bwd_workspace_bytes(BH, N, M, D, dk_f32 != nullptr);
+    const size_t need_ws = gd_attn_bwd_workspace_bytes(BH, N, M, D, dk_f32 != nullptr, variant);
     GD_REQUIRE(need_ws == 0 || (workspace && workspace_bytes >= need_ws), GD_EWORKSPACE,
                "gd_attn_bwd: needs a workspace of gd_attn_bwd_workspace_bytes() = %zu bytes", need_ws);
     a.q = q; a.k = k; a.v = v; a.o = out; a.lse = lse; a.dout = dout; a.dq = dq; a.dk = dk_f32; a.dk_part = (float*)workspace;
     a.N = N; a.M = M;
     a.tiles = (N + ATT_BM - 1) / ATT_BM;
-    const bool dq2 = dq2_applies(M, D);
+    const bool dq2 = dq2_applies(M, D, variant);
     a.kchunks = dq2 ? dq2_kchunks(BH, N, M) : dq_kchunks(BH, N, M);
     a.tpc = ((M + ATT_BN - 1) / ATT_BN + a.kchunks - 1) / a.kchunks;
     while (a.kchunks > 1 && (long long)a.tpc * (a.kchunks - 1) >= (M + ATT_BN - 1) / ATT_BN) --a.kchunks;      // no empty run
@@ -754,16 +749,13 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, const vo
     return GD_OK;
 }
 
+// kchunks_out == NULL: complete (dq folded here, dk accumulated); != NULL: the dq partials of a split key range are left to gd_edit_dq_fold
 extern "C" int gd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                            const void* dout, int BH, int N, int M, int D, float scale,
-                           void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
-    return attn_bwd_launch(q, k, v, out, lse, dout, BH, N, M, D, scale, dq, dk_f32, workspace, workspace_bytes, dtype, stream, true, nullptr, nullptr);
-}
-// ... that leaves the dq partials of a split key range to gd_edit_dq_fold
-extern "C" int gd_attn_bwd_nofold(const void* q, const void* k, const void* v, const void* out, const float* lse, const void* dout,
-                                  int BH, int N, int M, int D, float scale, void* dq, float* dk_f32, void* workspace, size_t workspace_bytes,
-                                  int* kchunks_out, float** dq_part_out, int dtype, void* stream) {
-    GD_REQUIRE(kchunks_out && dq_part_out, GD_EINVAL, "gd_attn_bwd_nofold: null pointer");
-    return attn_bwd_launch(q, k, v, out, lse, dout, BH, N, M, D, scale, dq, dk_f32, workspace, workspace_bytes, dtype, stream, false, kchunks_out,
-                           dq_part_out);
+                           void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int* kchunks_out, float** dq_part_out,
+                           int variant, int dtype, void* stream) {
+    GD_REQUIRE((kchunks_out == nullptr) == (dq_part_out == nullptr), GD_EINVAL, "gd_attn_bwd: kchunks_out and dq_part_out go together");
+    GD_REQUIRE(variant == 0 || variant == 1, GD_EINVAL, "gd_attn_bwd: variant %d (0, 1)", variant);
+    return attn_bwd_launch(q, k, v, out, lse, dout, BH, N, M, D, scale, dq, dk_f32, workspace, workspace_bytes, dtype, stream,
+                           kchunks_out == nullptr, kchunks_out, dq_part_out, variant);
 }

@@ -518,7 +518,7 @@ __global__ void k_attn_combine(const FwdArgs a) {
     if (sg.lse && dq == 0) sg.lse[(size_t)bh * a.N + row] = mref * a.scale + __logf(L);
 }
 
-static void mp_config(long long blocks, int N, int M, int* qb, int* ks, int q_prescaled = 1);
+static void mp_config(long long blocks, int N, int M, int* qb, int* ks, int q_prescaled = 1, int cfg_qb = -1, int cfg_ks = 0);
 
 // Split-KV plan: how many key splits make a launch of tot_bh heads fill the chip (1 = none), and the workspace they need.
 extern "C" int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_bytes) {
@@ -541,38 +541,15 @@ extern "C" int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_byte
     return ns;
 }
 
-static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
-                           size_t workspace_bytes, int dtype, void* stream);
-
 // Which pipelined configuration serves a launch of tot_bh heads: QB query blocks (32 rows each) x KS key ranges per workgroup; qb = 0:
-// use k_attn_fwd (key tails, short key lists).  GD_ATTN_CFG="QBxKS" forces one (development / benchmarking), "0" disables the kernel.
-static int env_qb = -2, env_ks = 0;
-
-extern "C" int gd_attn_fwd_set_config(int qb, int ks) {
-    if (qb > 0) {
-        const int cfg = qb * 10 + ks;
-        GD_REQUIRE(cfg == 41 || cfg == 22 || cfg == 42 || cfg == 24 || cfg == 81, GD_EINVAL, "gd_attn_fwd_set_config: no kernel for QB=%d KS=%d", qb, ks);
-    }
-    env_qb = qb < 0 ? -1 : qb;
-    env_ks = qb > 0 ? ks : 0;
-    return GD_OK;
-}
-
-static void mp_config(long long blocks, int N, int M, int* qb, int* ks, int q_prescaled) {
-    if (env_qb == -2) {
-        const char* e = getenv("GD_ATTN_CFG");
-        int q = -1, k = 0;
-        if (e && e[0] == '0' && e[1] == 0) q = 0;
-        else if (e && sscanf(e, "%dx%d", &q, &k) != 2) q = -1;
-        env_ks = k;
-        env_qb = q;
-    }
+// use k_attn_fwd (key tails, short key lists).  cfg_qb / cfg_ks: the caller's gd_attn_cfg_t (qb < 0: the heuristics below, 0: never).
+static void mp_config(long long blocks, int N, int M, int* qb, int* ks, int q_prescaled, int cfg_qb, int cfg_ks) {
     *qb = 0; *ks = 0;
     const int T = M / ATT_BN;
-    if (M % ATT_BN != 0 || env_qb == 0) return;
-    if (env_qb > 0) {
-        if (env_qb == 8) { if (T % 4 == 0) { *qb = 8; *ks = 1; } return; }
-        if (T % (2 * env_ks) == 0) { *qb = env_qb; *ks = env_ks; }
+    if (M % ATT_BN != 0 || cfg_qb == 0) return;
+    if (cfg_qb > 0) {
+        if (cfg_qb == 8) { if (T % 4 == 0) { *qb = 8; *ks = 1; } return; }
+        if (T % (2 * cfg_ks) == 0) { *qb = cfg_qb; *ks = cfg_ks; }
         return;
     }
     if (T % 2 != 0) return;
@@ -594,44 +571,25 @@ static void mp_config(long long blocks, int N, int M, int* qb, int* ks, int q_pr
     *qb = 4; *ks = 1;
 }
 
-extern "C" int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int dtype, void* stream) {
-    return attn_fwd_launch(segs, nseg, N, M, D, scale, 1, nullptr, 0, dtype, stream);
-}
-
-// Even split (attn_fwd_mp.hip, SK): 1 = where it pays (default; GD_ATTN_EVEN_SPLIT=0 in the environment turns it off), 0 = never
-static int env_sk = -1, env_sk_mode = 1, env_sk_force = 0;
-extern "C" int gd_attn_fwd_set_even_split(int on) {
-    // 0 = never, 1 = where it pays (default), 2 = every launch that can be split.  Development values, refused unless the process
-    // sets GD_ATTN_DEV_MODES=1 (tools/bench_handoff.py does): 10 = as 2 with release / acquire fences around the ticket (k_attn_fwd_mp
-    // only), 11 = as 2 with device-scope stores / loads only (what 1 and 2 use), 12 = no merge (timing only: WRONG outputs)
-    if (on > 2 || on < 0) {
-        const char* dev = getenv("GD_ATTN_DEV_MODES");
-        GD_REQUIRE(dev && dev[0] == '1' && on >= 10 && on <= 12, GD_EINVAL,
-                   "gd_attn_fwd_set_even_split: mode %d (0, 1, 2; the development modes 10-12 need GD_ATTN_DEV_MODES=1)", on);
-    }
-    env_sk = on ? 1 : 0;
-    env_sk_force = on >= 2;
-    env_sk_mode = on >= 10 ? on - 10 : 1;
-    return GD_OK;
-}
 extern "C" size_t gd_attn_fwd_workspace_bytes(int tot_bh, int N, int M) { return gd_attn_sk_workspace_bytes(tot_bh, N, M); }
 
-extern "C" int gd_attn_fwd_ws(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, void* workspace,
-                              size_t workspace_bytes, int dtype, void* stream) {
-    return attn_fwd_launch(segs, nseg, N, M, D, scale, -1, workspace, workspace_bytes, dtype, stream);
-}
-
-extern "C" int gd_attn_fwd_splitkv(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
-                                   size_t workspace_bytes, int dtype, void* stream) {
-    return attn_fwd_launch(segs, nseg, N, M, D, scale, nsplit, workspace, workspace_bytes, dtype, stream);
-}
-
-static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
+// The one forward entry point (ABI 5): split-KV with cfg->nsplit > 1, otherwise the even split where a workspace is given, otherwise plain.
+// No process-wide state: everything that selects a kernel variant arrives in `cfg`.
+extern "C" int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, const gd_attn_cfg_t* cfg_in, void* workspace,
                            size_t workspace_bytes, int dtype, void* stream) {
+    gd_attn_cfg_t cfg = GD_ATTN_CFG_DEFAULT;
+    if (cfg_in) cfg = *cfg_in;
+    if (cfg.qb > 0) {
+        const int c = cfg.qb * 10 + cfg.ks;
+        GD_REQUIRE(c == 41 || c == 22 || c == 42 || c == 24 || c == 81, GD_EINVAL, "gd_attn_fwd: cfg: no kernel for QB=%d KS=%d", cfg.qb, cfg.ks);
+    }
+    GD_REQUIRE(cfg.even_split >= -1 && cfg.even_split <= 2 && cfg.handoff >= 0 && cfg.handoff <= 2, GD_EINVAL,
+               "gd_attn_fwd: cfg: even_split=%d (-1..2), handoff=%d (0..2)", cfg.even_split, cfg.handoff);
+    int nsplit = cfg.nsplit > 1 ? cfg.nsplit : 1;
     GD_REQUIRE(segs && nseg >= 1 && nseg <= GD_ATTN_MAX_SEGS, GD_EINVAL, "gd_attn_fwd: nseg=%d (1..%d)", nseg, GD_ATTN_MAX_SEGS);
     GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED,
                "gd_attn_fwd: head dim %d unsupported (64, 128, 192; zero-pad 40 / 80 / 160 and pass the true scale)", D);
-    GD_REQUIRE(D == ATT_D || nsplit == 1 || nsplit == -1, GD_EUNSUPPORTED, "gd_attn_fwd_splitkv: head dim %d unsupported (only 64)", D);
+    GD_REQUIRE(D == ATT_D || nsplit == 1, GD_EUNSUPPORTED, "gd_attn_fwd: split-KV: head dim %d unsupported (only 64)", D);
     GD_REQUIRE(N > 0 && M > 0, GD_EINVAL, "gd_attn_fwd: bad sizes N=%d M=%d", N, M);
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_fwd: dtype must be f16/bf16");
     FwdArgs a;
@@ -651,15 +609,13 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
             a.cseg = i;
         }
     }
-    // nsplit == -1: gd_attn_fwd_ws — the workspace is the even split's (arrival counters, zero before the first launch, + part slots)
+    // without split-KV a workspace is the even split's (arrival counters, zero before the first launch, + part slots)
     bool sk_ws_ok = false;
-    if (nsplit == -1) {
-        nsplit = 1;
-        if (env_sk < 0) { const char* e = getenv("GD_ATTN_EVEN_SPLIT"); const int v = e ? atoi(e) : 1; env_sk = v ? 1 : 0; env_sk_force = v >= 2; }
-        if (workspace && env_sk) {
+    if (nsplit == 1) {
+        if (workspace && cfg.even_split != 0) {
             const size_t need = gd_attn_sk_workspace_bytes(tot, N, M);
             GD_REQUIRE(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0, GD_EINVAL,
-                       "gd_attn_fwd_ws: workspace %zu B < %zu B (gd_attn_fwd_workspace_bytes) or not 256-byte aligned", workspace_bytes, need);
+                       "gd_attn_fwd: workspace %zu B < %zu B (gd_attn_fwd_workspace_bytes) or not 256-byte aligned", workspace_bytes, need);
             sk_ws_ok = true;
         }
         workspace = sk_ws_ok ? workspace : nullptr;
@@ -669,8 +625,8 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
     if (sk_ws_ok) {
         a.sk_ws = (f32x4*)workspace;
         a.sk_cnt = (int*)((char*)workspace + GD_SK_SLOT_BYTES);
-        a.sk_mode = env_sk_mode;
-        a.sk_force = env_sk_force;
+        a.sk_mode = cfg.handoff;
+        a.sk_force = cfg.even_split == 2;
     }
     a.scale = scale;
     a.c = scale * 1.4426950408889634f;
@@ -687,7 +643,7 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
     GD_REQUIRE((long long)a.tps * (nsplit - 1) < t_all, GD_EINVAL, "gd_attn_fwd: nsplit=%d leaves an empty split for %d key tiles", nsplit, t_all);
     if (nsplit > 1) {
         const size_t need = (size_t)nsplit * tot * N * (ATT_D + 2) * sizeof(float);
-        GD_REQUIRE(workspace && workspace_bytes >= need, GD_EINVAL, "gd_attn_fwd_splitkv: workspace %zu B < %zu B", workspace_bytes, need);
+        GD_REQUIRE(workspace && workspace_bytes >= need, GD_EINVAL, "gd_attn_fwd: split-KV workspace %zu B < %zu B (gd_attn_fwd_plan)", workspace_bytes, need);
         a.ws_o = (float*)workspace;
         a.ws_ml = a.ws_o + (size_t)nsplit * tot * N * ATT_D;
     }
@@ -697,7 +653,7 @@ static int attn_fwd_launch(const gd_attn_seg_t* segs, int nseg, int N, int M, in
         // 32-query blocks of the launch (a row-list segment counts its list, not N)
         long long blocks = (long long)((N + 31) / 32) * tot;
         if (a.cseg >= 0) blocks -= (long long)((N + 31) / 32 - (segs[a.cseg].q_rows_len + 31) / 32) * segs[a.cseg].bh;
-        mp_config(blocks, N, M, &qb, &ks, a.q_prescaled);
+        mp_config(blocks, N, M, &qb, &ks, a.q_prescaled, cfg.qb, cfg.ks);
         if (qb > 0) return gd_attn_fwd_mp_launch(a, qb, ks, dtype, st);       // software-pipelined kernels (attn_fwd_mp.hip)
     }
     GD_REQUIRE(a.cseg < 0, GD_EUNSUPPORTED, "gd_attn_fwd: a query row list needs head dim 64 and full key tiles (M=%d, D=%d)", M, D);
@@ -815,15 +771,7 @@ __device__ __forceinline__ void probs_body(const ProbsArgs& a, const int bid, ch
     }
 }
 
-template <typename T, int NCH>
-__global__ void __launch_bounds__(256, 2)
-k_attn_probs(const ProbsArgs a) {
-    __shared__ __attribute__((aligned(16))) char ldsk[2][NCH * ATT_TILE_BYTES];
-    __shared__ __attribute__((aligned(16))) T stage[4][32][ATT_BN + 8];     // per-wave P tile, padded rows
-    probs_body<T, NCH>(a, (int)blockIdx.x, ldsk, stage);
-}
-
-// two problems in one grid (a's workgroups first) + an optional clear of zero_n4 16-byte words (the first workgroups' threads)
+// one or two problems in one grid (a's workgroups first; b.nwg == 0: none) + an optional clear of zero_n4 16-byte words (the first workgroups' threads)
 template <typename T, int NCH>
 __global__ void __launch_bounds__(256, 2)
 k_attn_probs2(const ProbsArgs a, const ProbsArgs b, u32x4* __restrict__ zero_ptr, int zero_n4) {
@@ -859,39 +807,21 @@ static ProbsArgs probs_args(const void* q, const void* k, const float* lse, cons
     return a;
 }
 
-extern "C" int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t* rows, const int32_t* n_valid_dev,
-                             int BH, int N, int R, int M, int Mpad, int D, float scale, void* P, int dtype, void* stream) {
-    GD_REQUIRE(q && k && lse && P, GD_EINVAL, "gd_attn_probs: null pointer");
+extern "C" int gd_attn_probs(const gd_probs_t* pa, const gd_probs_t* pb, int D, float scale, void* zero_ptr, size_t zero_bytes, int dtype,
+                             void* stream) {
+    GD_REQUIRE(pa, GD_EINVAL, "gd_attn_probs: null pointer");
     GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED, "gd_attn_probs: head dim %d unsupported (64, 128, 192)", D);
-    GD_REQUIRE(BH > 0 && N > 0 && R > 0 && M > 0 && Mpad >= M && (Mpad & 7) == 0, GD_EINVAL,
-               "gd_attn_probs: bad sizes (Mpad must be a multiple of 8 and >= M)");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_probs: dtype must be f16/bf16");
-    const ProbsArgs a = probs_args(q, k, lse, rows, n_valid_dev, BH, N, R, M, Mpad, scale, P);
-    hipStream_t st = as_stream(stream);
-    const int nch = D / ATT_D;
-#define GD_PROBS(NCH)                                                            \
-    if (dtype == GD_F16) k_attn_probs<f16_t, NCH><<<a.nwg, 256, 0, st>>>(a);     \
-    else k_attn_probs<bf16_t, NCH><<<a.nwg, 256, 0, st>>>(a)
-    if (nch == 1) { GD_PROBS(1); } else if (nch == 2) { GD_PROBS(2); } else { GD_PROBS(3); }
-#undef GD_PROBS
-    GD_CHECK_LAUNCH("gd_attn_probs");
-    return GD_OK;
-}
-
-extern "C" int gd_attn_probs_pair(const gd_probs_t* pa, const gd_probs_t* pb, int D, float scale, void* zero_ptr, size_t zero_bytes, int dtype,
-                                  void* stream) {
-    GD_REQUIRE(pa && pb, GD_EINVAL, "gd_attn_probs_pair: null pointer");
-    GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED, "gd_attn_probs_pair: head dim %d unsupported (64, 128, 192)", D);
-    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_probs_pair: dtype must be f16/bf16");
     GD_REQUIRE(!zero_ptr || (zero_bytes % 16 == 0 && ((uintptr_t)zero_ptr & 15) == 0 && zero_bytes < ((size_t)1 << 31)), GD_EINVAL,
-               "gd_attn_probs_pair: the clear must be 16-byte aligned and a multiple of 16 bytes");
+               "gd_attn_probs: the clear must be 16-byte aligned and a multiple of 16 bytes");
     const gd_probs_t* ps[2] = {pa, pb};
     ProbsArgs args[2];
-    for (int i = 0; i < 2; ++i) {
+    memset(args, 0, sizeof(args));
+    for (int i = 0; i < (pb ? 2 : 1); ++i) {
         const gd_probs_t* p = ps[i];
-        GD_REQUIRE(p->q && p->k && p->lse && p->P, GD_EINVAL, "gd_attn_probs_pair: problem %d: null pointer", i);
+        GD_REQUIRE(p->q && p->k && p->lse && p->P, GD_EINVAL, "gd_attn_probs: problem %d: null pointer", i);
         GD_REQUIRE(p->BH > 0 && p->N > 0 && p->R > 0 && p->M > 0 && p->Mpad >= p->M && (p->Mpad & 7) == 0, GD_EINVAL,
-                   "gd_attn_probs_pair: problem %d: bad sizes (Mpad must be a multiple of 8 and >= M)", i);
+                   "gd_attn_probs: problem %d: bad sizes (Mpad must be a multiple of 8 and >= M)", i);
         args[i] = probs_args(p->q, p->k, p->lse, p->rows, p->n_valid, p->BH, p->N, p->R, p->M, p->Mpad, scale, p->P);
     }
     hipStream_t st = as_stream(stream);
@@ -904,6 +834,6 @@ extern "C" int gd_attn_probs_pair(const gd_probs_t* pa, const gd_probs_t* pb, in
     else k_attn_probs2<bf16_t, NCH><<<grid, 256, 0, st>>>(args[0], args[1], zp, zn)
     if (nch == 1) { GD_PROBS2(1); } else if (nch == 2) { GD_PROBS2(2); } else { GD_PROBS2(3); }
 #undef GD_PROBS2
-    GD_CHECK_LAUNCH("gd_attn_probs_pair");
+    GD_CHECK_LAUNCH("gd_attn_probs");
     return GD_OK;
 }

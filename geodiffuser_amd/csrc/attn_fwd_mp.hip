@@ -1374,10 +1374,7 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
     // optimisation pass, whose L1 losses need numerator and denominator over the same rounded probabilities).  Measured (tools/
     // bench_lsum.py): no faster than the vector-pipe sums on the no-grad launches (15 heads 59 -> 62-66 us: the 8 extra MFMAs per tile cost
     // what the 32 v_add_f32 saved), 10-11 us faster than the exact-scale rescue variant it replaces in the optimisation pass (71 -> 60).
-    // GD_ATTN_LSUM = 0: never, 2: every pre-scaled launch (experiments).
-    static int lsum_env = -1;
-    if (lsum_env < 0) { const char* e = getenv("GD_ATTN_LSUM"); lsum_env = e ? atoi(e) : 1; }
-    const bool lsum = lsum_env == 2 || (lsum_env == 1 && a.lsum);
+    const bool lsum = a.lsum != 0;
 #define GD_W64_T(T_)                                                          \
     {                                                                         \
         if (pre && lsum) { if (sk) GD_W64_LAUNCH_L(T_, true); else GD_W64_LAUNCH_L(T_, false); }   \
@@ -1436,9 +1433,7 @@ int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st) 
         }
         a.n_order = n;
     }
-    static int env_pre = -1;
-    if (env_pre < 0) { const char* e = getenv("GD_ATTN_PRESCALE"); env_pre = e ? atoi(e) : 0; }
-    const int pre = (a.q_prescaled || env_pre) ? 1 : 0;
+    const int pre = a.q_prescaled ? 1 : 0;
     if (qb == 8) return w64_launch(a, tot, pre, dtype, st, a.sk_mode >= 1 && a.sk_force);
     if (sk_plan(a, tot, qb, ks)) {
 #define GD_SK_LAUNCH(T_, PRE_) k_attn_fwd_mp<T_, 4, 1, 2, PRE_, true><<<a.nwg, 256, 0, st>>>(a)

@@ -351,22 +351,10 @@ __global__ void k_conv_fold(const ConvArgs a) {
     *(typename TR::vec4*)((T*)a.out + i4 * 4) = v;
 }
 
-// configuration of a launch: tile shape (PI, KI) and reduction split.  cfg > 0 forces PI*100 + KI*10... (development): see below.
-static int g_conv_dma = -1;         // direct-to-LDS staging for the tiles that get three LDS stages with it; -1: not read yet (GD_CONV_DMA=0 or gd_conv3x3_set_dma(0): registers everywhere)
-extern "C" int gd_conv3x3_set_dma(int on) { g_conv_dma = on ? 1 : 0; return GD_OK; }
-static int g_conv_force = -1;      // -1: heuristic; otherwise PI * 1000 + KI * 100 + ksplit
-
-extern "C" int gd_conv3x3_set_config(int pi, int ki, int ksplit) {
-    if (pi <= 0) { g_conv_force = -1; return GD_OK; }
-    GD_REQUIRE((pi == 1 || pi == 2) && (ki == 1 || ki == 2) && ksplit >= 1 && ksplit <= 64, GD_EINVAL,
-               "gd_conv3x3_set_config: PI, KI in {1, 2}, ksplit in 1..64");
-    g_conv_force = pi * 1000 + ki * 100 + ksplit;
-    return GD_OK;
-}
-
-static void conv_plan(int P, int K, int steps, int* pi, int* ki, int* ksplit) {
-    if (g_conv_force > 0) {
-        *pi = g_conv_force / 1000; *ki = (g_conv_force / 100) % 10; *ksplit = g_conv_force % 100;
+// configuration of a launch: tile shape (PI, KI) and reduction split; cfg (may be NULL) forces them (tuning: gd_conv3x3_cfg_t)
+static void conv_plan(int P, int K, int steps, int* pi, int* ki, int* ksplit, const gd_conv3x3_cfg_t* cfg) {
+    if (cfg && cfg->pi > 0) {
+        *pi = cfg->pi; *ki = cfg->ki; *ksplit = cfg->ksplit;
         if (*ksplit > steps) *ksplit = steps;
         return;
     }
@@ -401,17 +389,22 @@ static void conv_plan(int P, int K, int steps, int* pi, int* ki, int* ksplit) {
     *ksplit = sp;
 }
 
-extern "C" size_t gd_conv3x3_workspace_bytes(int n, int Ho, int Wo, int C, int K) {
+static bool conv_cfg_ok(const gd_conv3x3_cfg_t* cfg) {
+    return !cfg || cfg->pi <= 0 || ((cfg->pi == 1 || cfg->pi == 2) && (cfg->ki == 1 || cfg->ki == 2) && cfg->ksplit >= 1 && cfg->ksplit <= 64);
+}
+
+extern "C" size_t gd_conv3x3_workspace_bytes(int n, int Ho, int Wo, int C, int K, const gd_conv3x3_cfg_t* cfg) {
     int pi, ki, sp;
     const int P = n * Ho * Wo;
-    if (P <= 0 || C <= 0 || K <= 0 || C % 64) return 0;
-    conv_plan(P, K, 9 * C / 64, &pi, &ki, &sp);
+    if (P <= 0 || C <= 0 || K <= 0 || C % 64 || !conv_cfg_ok(cfg)) return 0;
+    conv_plan(P, K, 9 * C / 64, &pi, &ki, &sp, cfg);
     return sp > 1 ? (size_t)sp * P * K * sizeof(float) : 0;
 }
 
 extern "C" int gd_conv3x3(const void* in, const void* w, const void* bias, const void* residual, void* out, int n, int Hi, int Wi, int C, int K, int stride,
-                          int upsample, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+                          int upsample, const gd_conv3x3_cfg_t* cfg, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
     GD_REQUIRE(in && w && out, GD_EINVAL, "gd_conv3x3: null pointer");
+    GD_REQUIRE(conv_cfg_ok(cfg), GD_EINVAL, "gd_conv3x3: cfg: PI, KI in {1, 2}, ksplit in 1..64");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_conv3x3: dtype must be f16/bf16");
     GD_REQUIRE(n > 0 && Hi > 0 && Wi > 0 && C > 0 && K > 0, GD_EINVAL, "gd_conv3x3: bad sizes");
     GD_REQUIRE(C % 64 == 0 && K % 8 == 0, GD_EUNSUPPORTED, "gd_conv3x3: C=%d must be a multiple of 64 and K=%d of 8", C, K);
@@ -430,7 +423,7 @@ extern "C" int gd_conv3x3(const void* in, const void* w, const void* bias, const
     a.cpt = C / 64;
     a.steps = 9 * a.cpt;
     int pi, ki, sp;
-    conv_plan(a.P, K, a.steps, &pi, &ki, &sp);
+    conv_plan(a.P, K, a.steps, &pi, &ki, &sp, cfg);
     a.tiles_p = (a.P + 64 * pi - 1) / (64 * pi);
     a.tiles_k = (K + 64 * ki - 1) / (64 * ki);
     a.spc = (a.steps + sp - 1) / sp;
@@ -454,10 +447,10 @@ extern "C" int gd_conv3x3(const void* in, const void* w, const void* bias, const
         a.ws = (float*)workspace;
     }
     hipStream_t st = as_stream(stream);
-    if (g_conv_dma < 0) { const char* e = getenv("GD_CONV_DMA"); g_conv_dma = (e && e[0] == '0') ? 0 : 1; }
+    const bool dma = !(cfg && cfg->dma == 0);           // direct-to-LDS staging for the tiles that get three LDS stages with it
 #define GD_CONV(PI_, KI_)                                                                      \
     {                                                                                          \
-        if (g_conv_dma && (PI_ + KI_) <= 3) {                                                  \
+        if (dma && (PI_ + KI_) <= 3) {                                                        \
             if (dtype == GD_F16) k_conv3x3<f16_t, PI_, KI_, true><<<a.nwg, 256, 0, st>>>(a);   \
             else k_conv3x3<bf16_t, PI_, KI_, true><<<a.nwg, 256, 0, st>>>(a);                  \
         } else {                                                                               \

@@ -1,9 +1,8 @@
-// Device pieces shared by the fused launches of one hooked optimisation-pass layer (round 4: ~20 launches per layer -> ~12):
-//   gd_edit_losses_fused     = k_losses_fwd + [last workgroup: removal reduce + fold + assemble]   (was 4 launches)
-//   gd_edit_losses_bwd_rowdot = k_losses_bwd  U  k_removal_rowdot (independent work, one grid)        (was 2)
-//   gd_edit_dq_fold           = attention dq partials + removal dq partials -> the 16-bit gradient    (was 2)
-// The bodies below are the ones the stand-alone kernels run (same arithmetic, same summation order: the fused launches reproduce the
-// stand-alone results bit for bit).
+// Device pieces shared by the launches of one hooked optimisation-pass layer (~12 launches per layer):
+//   gd_edit_losses_fwd (wv != NULL) = k_losses_fwd's reductions + [last workgroup: removal reduce + fold + assemble]
+//   gd_edit_losses_bwd (rm != NULL) = the loss backward  U  k_removal_rowdot (independent work, one grid)
+//   gd_edit_dq_fold                 = attention dq partials + removal dq partials -> the 16-bit gradient
+// The bodies below are the ones the stand-alone stages run (same arithmetic, same summation order: bit for bit the same results).
 #pragma once
 #include "common.hpp"
 

@@ -295,14 +295,12 @@ k_gn_fused(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld, co
     }
 }
 
-static int g_gn_single = 1;                 // gd_group_norm_set_single_launch(0): always the two-launch form (benchmarks / tests)
-extern "C" int gd_group_norm_set_single_launch(int on) { g_gn_single = on ? 1 : 0; return GD_OK; }
-
-static bool gn_single_ok(int HW, int C, int G) {
+// single_launch: the caller's flag (-1 / 1: the rule below, 0: always the two-launch form — benchmarks / tests compare both)
+static bool gn_single_ok(int HW, int C, int G, int single_launch) {
     const int cpg = C / G;
     // measured (tools/bench_gn.py, batch 1 and 3): 8^2 and 16^2 maps 7.5-13 -> 4-10 us, 32^2 a tie around 40 KB slices, 64^2 x 320
     // (80 KB slices on 32-96 workgroups) 12 -> 21 us: one launch up to 40 KB per (batch entry, group)
-    return g_gn_single && (cpg & 1) == 0 && cpg <= 128 && (size_t)HW * cpg * 2 <= 40 * 1024;
+    return single_launch != 0 && (cpg & 1) == 0 && cpg <= 128 && (size_t)HW * cpg * 2 <= 40 * 1024;
 }
 
 extern "C" int64_t gd_group_norm_nhwc_scratch_floats(int B, int HW, int G) {
@@ -312,7 +310,7 @@ extern "C" int64_t gd_group_norm_nhwc_scratch_floats(int B, int HW, int G) {
 }
 
 extern "C" int gd_group_norm_nhwc(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, int B, int HW, int C, int G,
-                                  float eps, int silu, float* scratch, void* y, int dtype, void* stream) {
+                                  float eps, int silu, int single_launch, float* scratch, void* y, int dtype, void* stream) {
     GD_REQUIRE(x && gamma && beta && scratch && y, GD_EINVAL, "gd_group_norm_nhwc: null pointer");
     // an 8-channel vector may touch at most two groups: C/G >= 8, or exactly 4 (the VAE's 128-channel norms)
     GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && (C / G >= 8 || C / G == 4) && C <= 8 * GN_MAX_CV, GD_EINVAL,
@@ -323,7 +321,7 @@ extern "C" int gd_group_norm_nhwc(const void* x, const void* add_bc, int add_ld,
     hipStream_t st = as_stream(stream);
     const int pix = gn_pix_per_slab(HW);
     const int nslab = (HW + pix - 1) / pix;
-    if (gn_single_ok(HW, C, G)) {
+    if (gn_single_ok(HW, C, G, single_launch)) {
         const int U = (C / G) >> 1;
         int LP = 1;
         while (LP < U) LP <<= 1;
@@ -576,10 +574,11 @@ k_gn_bwd_fused(const T* __restrict__ x, const T* __restrict__ add_bc, int add_ld
 
 template <typename T, bool SILU>
 static void gn_bwd_launch(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, const void* dy,
-                          const float* fwd_scratch, float* scratch, int B, int HW, int C, int G, float eps, void* dx, hipStream_t st) {
+                          const float* fwd_scratch, float* scratch, int B, int HW, int C, int G, float eps, void* dx, int single_launch,
+                          hipStream_t st) {
     const int pix = gn_pix_per_slab(HW);
     const int nslab = (HW + pix - 1) / pix;
-    if (gn_single_ok(HW, C, G)) {
+    if (gn_single_ok(HW, C, G, single_launch)) {
         const int U = (C / G) >> 1;
         int LP = 1;
         while (LP < U) LP <<= 1;
@@ -602,8 +601,8 @@ static void gn_bwd_launch(const void* x, const void* add_bc, int add_ld, const v
 }
 
 extern "C" int gd_group_norm_nhwc_bwd(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, const void* dy,
-                                      int B, int HW, int C, int G, float eps, int silu, const float* fwd_scratch, float* scratch, void* dx,
-                                      int dtype, void* stream) {
+                                      int B, int HW, int C, int G, float eps, int silu, int single_launch, const float* fwd_scratch, float* scratch,
+                                      void* dx, int dtype, void* stream) {
     GD_REQUIRE(x && gamma && beta && dy && fwd_scratch && scratch && dx, GD_EINVAL, "gd_group_norm_nhwc_bwd: null pointer");
     GD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAX_G && C % G == 0 && (C & 7) == 0 && (C / G >= 8 || C / G == 4) && C <= 8 * GN_MAX_CV, GD_EINVAL,
                "gd_group_norm_nhwc_bwd: unsupported shape B=%d HW=%d C=%d G=%d", B, HW, C, G);
@@ -612,11 +611,11 @@ extern "C" int gd_group_norm_nhwc_bwd(const void* x, const void* add_bc, int add
     if (add_ld == 0) add_ld = C;
     hipStream_t st = as_stream(stream);
     if (dtype == GD_F16) {
-        if (silu) gn_bwd_launch<f16_t, true>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, st);
-        else gn_bwd_launch<f16_t, false>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, st);
+        if (silu) gn_bwd_launch<f16_t, true>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, single_launch, st);
+        else gn_bwd_launch<f16_t, false>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, single_launch, st);
     } else {
-        if (silu) gn_bwd_launch<bf16_t, true>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, st);
-        else gn_bwd_launch<bf16_t, false>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, st);
+        if (silu) gn_bwd_launch<bf16_t, true>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, single_launch, st);
+        else gn_bwd_launch<bf16_t, false>(x, add_bc, add_ld, gamma, beta, dy, fwd_scratch, scratch, B, HW, C, G, eps, dx, single_launch, st);
     }
     GD_CHECK_LAUNCH("gd_group_norm_nhwc_bwd");
     return GD_OK;

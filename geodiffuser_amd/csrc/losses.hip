@@ -158,8 +158,7 @@ extern "C" int gd_amodal_target(const void* eo, const int32_t* nn_idx, const flo
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_amodal_target: dtype must be f16/bf16");
     hipStream_t st = as_stream(stream);
     const int N = S * S;
-    const char* two = getenv("GD_AMODAL_TWO_PASS");          // tests: the stand-alone pair of kernels
-    if (D <= 64 && D % 8 == 0 && !(two && two[0] == '1')) {
+    if (D <= 64 && D % 8 == 0) {                             // one launch; wider heads: the interpolation + blur pair through `tmp`
         const int tiles_x = (S + AM_T - 1) / AM_T;
         dim3 grid(tiles_x * tiles_x, H);
         if (dtype == GD_F16) k_amodal_fused<f16_t><<<grid, 256, 0, st>>>((const f16_t*)eo, nn_idx, nn_w, fg, S, D, tiles_x, target);
@@ -270,142 +269,20 @@ extern "C" size_t gd_edit_losses_fwd_workspace_bytes(int H, int S, int D) {
     return (size_t)losses_fwd_blocks(H, S, D) * 5 * sizeof(float);
 }
 
-extern "C" int gd_edit_losses_fwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
-                                  const float* w_am, const float* m_amodal, int H, int S, int D, float* sums, float* workspace,
-                                  int dtype, void* stream) {
-    GD_REQUIRE(eo && ro && m_wo && m_edit && sums && workspace, GD_EINVAL, "gd_edit_losses_fwd: null pointer");
-    GD_REQUIRE(!tgt || (w_am && m_amodal), GD_EINVAL, "gd_edit_losses_fwd: tgt needs w_am and m_amodal");
-    GD_REQUIRE(H > 0 && S > 0 && D > 0 && D % 8 == 0, GD_EINVAL, "gd_edit_losses_fwd: bad sizes (D must be a multiple of 8)");
-    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_fwd: dtype must be f16/bf16");
-    const int blocks = losses_fwd_blocks(H, S, D);
-    hipStream_t st = as_stream(stream);
-    if (dtype == GD_F16)
-        k_losses_fwd<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)eo, (const f16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal, H, S, D, workspace);
-    else
-        k_losses_fwd<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)eo, (const bf16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal, H, S, D, workspace);
-    k_losses_fold<<<1, 320, 0, st>>>(workspace, blocks, sums);
-    GD_CHECK_LAUNCH("gd_edit_losses_fwd");
-    return GD_OK;
-}
-
 // ---- losses backward ---------------------------------------------------------------------------------
 
-template <typename T>
-__global__ void k_losses_bwd(const T* __restrict__ eo, const T* __restrict__ ro, const float* __restrict__ tgt,
-                             const float* __restrict__ m_wo, const float* __restrict__ m_edit, const float* __restrict__ w_am,
-                             const float* __restrict__ m_amodal, const T* __restrict__ gout, const float* __restrict__ c, const float* __restrict__ gscale, int blend,
-                             int H, int S, int D, T* __restrict__ dro) {
-    const int N = S * S;
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)H * N * D) return;
-    const long long t = gid / D;
-    const int n = (int)(t % N);
-    const int y = n / S, x = n - y * S;
-    const float r = (float)ro[gid], e = (float)eo[gid];
-    const float sg = -sgn(e - r);
-    const float me = m_edit[n];
-    float g = c[0] * sg * m_wo[n] + c[1] * sg * me;
-    if (tgt) g += c[2] * (-sgn(tgt[gid] - r)) * w_am[n] * m_amodal[n];
-    float gs = 0.f;
-    if (y < S - 1) gs -= sgn((float)ro[gid + (size_t)S * D] - r);
-    if (y > 0) gs += sgn(r - (float)ro[gid - (size_t)S * D]);
-    g += c[3] * gs;
-    gs = 0.f;
-    if (x < S - 1) gs -= sgn((float)ro[gid + D] - r);
-    if (x > 0) gs += sgn(r - (float)ro[gid - D]);
-    g += c[4] * gs;
-    if (gscale) g *= gscale[0];
-    if (gout) {       // blend bit 1: gout is the token-major row [N, H*D] (the layer's boundary, gd_heads_split of it folded in here)
-        const long long gi = (blend & 2) ? (((long long)n * H + (int)(t / N)) * D + (int)(gid - t * D)) : gid;
-        g += (float)gout[gi] * ((blend & 1) ? (1.0f - me) : 1.0f);
-    }
-    dro[gid] = (T)g;
-}
-
-extern "C" int gd_edit_losses_bwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
-                                  const float* w_am, const float* m_amodal, const void* gout, const float* coef_dev, const float* gscale_dev,
-                                  int blend, int H, int S, int D, void* dro, int dtype, void* stream) {
-    GD_REQUIRE(eo && ro && m_wo && m_edit && coef_dev && dro, GD_EINVAL, "gd_edit_losses_bwd: null pointer");
-    GD_REQUIRE(!tgt || (w_am && m_amodal), GD_EINVAL, "gd_edit_losses_bwd: tgt needs w_am and m_amodal");
-    GD_REQUIRE(H > 0 && S > 0 && D > 0, GD_EINVAL, "gd_edit_losses_bwd: bad sizes");
-    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_bwd: dtype must be f16/bf16");
-    const long long total = (long long)H * S * S * D;
-    const int blocks = (int)((total + 255) / 256);
-    hipStream_t st = as_stream(stream);
-    if (dtype == GD_F16)
-        k_losses_bwd<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)eo, (const f16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal,
-                                                    (const f16_t*)gout, coef_dev, gscale_dev, blend, H, S, D, (f16_t*)dro);
-    else
-        k_losses_bwd<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)eo, (const bf16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal,
-                                                     (const bf16_t*)gout, coef_dev, gscale_dev, blend, H, S, D, (bf16_t*)dro);
-    GD_CHECK_LAUNCH("gd_edit_losses_bwd");
-    return GD_OK;
-}
-
-// ---- blend ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void k_blend(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ m, int H, int N, int D,
-                        T* __restrict__ out) {
-#pragma clang fp contract(off)      // each product and the sum are rounded to the tensor dtype: no fused multiply-add across the roundings
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)H * N * D) return;
-    const int n = (int)((gid / D) % N);
-    // op-by-op in the tensor dtype, as torch evaluates  a*m + b*(1-m)  on 16-bit tensors
-    const float mm = (float)(T)m[n];
-    const float om = (float)(T)(1.0f - mm);
-    const float t1 = (float)(T)((float)a[gid] * mm);
-    const float t2 = (float)(T)((float)b[gid] * om);
-    out[gid] = (T)(t1 + t2);
-}
-
-extern "C" int gd_blend_tokens(const void* a, const void* b, const float* m, int H, int N, int D, void* out, int dtype, void* stream) {
-    GD_REQUIRE(a && b && m && out, GD_EINVAL, "gd_blend_tokens: null pointer");
-    GD_REQUIRE(H > 0 && N > 0 && D > 0, GD_EINVAL, "gd_blend_tokens: bad sizes");
-    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_blend_tokens: dtype must be f16/bf16");
-    const long long total = (long long)H * N * D;
-    const int blocks = (int)((total + 255) / 256);
-    hipStream_t st = as_stream(stream);
-    if (dtype == GD_F16) k_blend<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)a, (const f16_t*)b, m, H, N, D, (f16_t*)out);
-    else k_blend<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, m, H, N, D, (bf16_t*)out);
-    GD_CHECK_LAUNCH("gd_blend_tokens");
-    return GD_OK;
-}
-
-// ---- full edit-attention output from the reference rows + the rows a q_rows segment computed (gd_attn_seg_t::q_rows) ----
-template <typename T>
-__global__ void k_rows_merge(const u32x4* __restrict__ base, const u32x4* __restrict__ act, const int32_t* __restrict__ pos, int H, int N,
-                             int R, int D8, u32x4* __restrict__ out) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;                   // one 16-byte chunk of 8 elements
-    if (gid >= (long long)H * N * D8) return;
-    const int c = (int)(gid % D8);
-    const long long hn = gid / D8;
-    const int n = (int)(hn % N), h = (int)(hn / N);
-    const int p = pos[n];
-    out[gid] = p >= 0 ? act[((long long)h * R + p) * D8 + c] : base[gid];
-}
-
-extern "C" int gd_rows_merge(const void* base, const void* act, const int32_t* pos, int H, int N, int R, int D, void* out, int dtype,
-                             void* stream) {
-    GD_REQUIRE(base && act && pos && out, GD_EINVAL, "gd_rows_merge: null pointer");
-    GD_REQUIRE(H > 0 && N > 0 && R > 0 && D > 0 && D % 8 == 0, GD_EINVAL, "gd_rows_merge: bad sizes (D must be a multiple of 8)");
-    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_rows_merge: dtype must be f16/bf16");
-    const long long total = (long long)H * N * (D / 8);
-    k_rows_merge<f16_t><<<(int)((total + 255) / 256), 256, 0, as_stream(stream)>>>((const u32x4*)base, (const u32x4*)act, pos, H, N, R, D / 8,
-                                                                                  (u32x4*)out);
-    GD_CHECK_LAUNCH("gd_rows_merge");
-    return GD_OK;
-}
+// (the kernel is k_losses_bwd_rowdot below: the loss backward with the removal row dots as optional extra workgroups)
 
 // ============================================================================================================================
 // Fused launches of one hooked optimisation-pass layer (ABI 4, see edit_layer.hpp)
 // ============================================================================================================================
 
-// gd_rows_merge + gd_blend_tokens: one pass over the layer's [H,N,D] rows, 8 elements per thread
+// row merge + blend: one pass over the layer's [H,N,D] rows, 8 elements per thread
 template <typename T>
 __global__ void k_blend_merge(const u32x4* __restrict__ base, const u32x4* __restrict__ act, const int32_t* __restrict__ pos,
                               const u32x4* __restrict__ ro, const float* __restrict__ m, int H, int N, int R, int D8,
                               u32x4* __restrict__ eo_out, u32x4* __restrict__ out) {
-#pragma clang fp contract(off)      // as k_blend
+#pragma clang fp contract(off)      // each product and the sum are rounded to the tensor dtype: no fused multiply-add across the roundings
     using V8 = typename elem_traits<T>::vec8;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;                   // one 16-byte chunk of 8 elements
     if (gid >= (long long)H * N * D8) return;
@@ -487,7 +364,7 @@ extern "C" int gd_heads_split(const gd_heads_split_t* a, int dtype, void* stream
 
 template <typename T, bool SRC32>
 __global__ void k_heads_merge(const gd_heads_merge_t a) {
-#pragma clang fp contract(off)      // as k_blend
+#pragma clang fp contract(off)      // each product and the sum are rounded to the tensor dtype: no fused multiply-add across the roundings
     using V8 = typename elem_traits<T>::vec8;
     const int D8 = a.D >> 3, rows = a.rows, heads = a.heads;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -596,23 +473,35 @@ k_losses_fused(const gd_edit_losses_t a) {
     }
 }
 
-extern "C" int gd_edit_losses_fused(const gd_edit_losses_t* a, int dtype, void* stream) {
-    GD_REQUIRE(a && a->eo && a->ro && a->m_wo && a->m_edit && a->workspace && a->ticket && a->out12 && a->inv5 && a->inv_rm && a->wv && a->inv5_bwd,
-               GD_EINVAL, "gd_edit_losses_fused: null pointer");
-    GD_REQUIRE(!a->tgt || (a->w_am && a->m_amodal), GD_EINVAL, "gd_edit_losses_fused: tgt needs w_am and m_amodal");
-    GD_REQUIRE(!a->best || (a->rows && a->p_in && a->j_in && a->p_wo && a->j_wo && a->wgt && a->R > 0), GD_EINVAL,
-               "gd_edit_losses_fused: best needs rows, R and the five aux outputs");
-    GD_REQUIRE(a->H > 0 && a->S > 0 && a->D > 0 && a->D % 8 == 0, GD_EINVAL, "gd_edit_losses_fused: bad sizes (D must be a multiple of 8)");
-    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_fused: dtype must be f16/bf16");
+// wv == NULL: the reductions only (two launches, out12[0..4] = the sums); otherwise everything up to the assembled loss in one launch
+extern "C" int gd_edit_losses_fwd(const gd_edit_losses_t* a, int dtype, void* stream) {
+    GD_REQUIRE(a && a->eo && a->ro && a->m_wo && a->m_edit && a->workspace && a->out12, GD_EINVAL, "gd_edit_losses_fwd: null pointer");
+    GD_REQUIRE(!a->tgt || (a->w_am && a->m_amodal), GD_EINVAL, "gd_edit_losses_fwd: tgt needs w_am and m_amodal");
+    GD_REQUIRE(a->H > 0 && a->S > 0 && a->D > 0 && a->D % 8 == 0, GD_EINVAL, "gd_edit_losses_fwd: bad sizes (D must be a multiple of 8)");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_fwd: dtype must be f16/bf16");
     const int blocks = losses_fwd_blocks(a->H, a->S, a->D);
     hipStream_t st = as_stream(stream);
+    if (!a->wv) {
+        if (dtype == GD_F16)
+            k_losses_fwd<f16_t><<<blocks, 256, 0, st>>>((const f16_t*)a->eo, (const f16_t*)a->ro, a->tgt, a->m_wo, a->m_edit, a->w_am, a->m_amodal,
+                                                        a->H, a->S, a->D, a->workspace);
+        else
+            k_losses_fwd<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)a->eo, (const bf16_t*)a->ro, a->tgt, a->m_wo, a->m_edit, a->w_am, a->m_amodal,
+                                                         a->H, a->S, a->D, a->workspace);
+        k_losses_fold<<<1, 320, 0, st>>>(a->workspace, blocks, a->out12);
+        GD_CHECK_LAUNCH("gd_edit_losses_fwd");
+        return GD_OK;
+    }
+    GD_REQUIRE(a->ticket && a->inv5 && a->inv_rm && a->inv5_bwd, GD_EINVAL, "gd_edit_losses_fwd: the assembled form needs ticket, inv5, inv_rm, inv5_bwd");
+    GD_REQUIRE(!a->best || (a->rows && a->p_in && a->j_in && a->p_wo && a->j_wo && a->wgt && a->R > 0), GD_EINVAL,
+               "gd_edit_losses_fwd: best needs rows, R and the five aux outputs");
     if (dtype == GD_F16) k_losses_fused<f16_t><<<blocks, 256, 0, st>>>(*a);
     else k_losses_fused<bf16_t><<<blocks, 256, 0, st>>>(*a);
-    GD_CHECK_LAUNCH("gd_edit_losses_fused");
+    GD_CHECK_LAUNCH("gd_edit_losses_fwd");
     return GD_OK;
 }
 
-// k_losses_bwd's grid followed by k_removal_rowdot's (4 rows per workgroup): independent work, one launch
+// d(loss)/d(ro) per element, followed (blockIdx >= nb_loss) by k_removal_rowdot's workgroups (4 rows each): independent work, one launch
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_losses_bwd_rowdot(const T* __restrict__ eo, const T* __restrict__ ro, const float* __restrict__ tgt,
@@ -650,28 +539,32 @@ k_losses_bwd_rowdot(const T* __restrict__ eo, const T* __restrict__ ro, const fl
     dro[gid] = (T)g;
 }
 
-extern "C" int gd_edit_losses_bwd_rowdot(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
-                                         const float* w_am, const float* m_amodal, const void* gout, const float* coef_dev, const float* gscale_dev,
-                                         int blend, int H, int S, int D, void* dro, const gd_removal_bwd_t* rm, int dtype, void* stream) {
-    if (!rm) return gd_edit_losses_bwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coef_dev, gscale_dev, blend, H, S, D, dro, dtype, stream);
-    GD_REQUIRE(eo && ro && m_wo && m_edit && coef_dev && dro, GD_EINVAL, "gd_edit_losses_bwd_rowdot: null pointer");
-    GD_REQUIRE(!tgt || (w_am && m_amodal), GD_EINVAL, "gd_edit_losses_bwd_rowdot: tgt needs w_am and m_amodal");
-    GD_REQUIRE(H > 0 && S > 0 && D > 0, GD_EINVAL, "gd_edit_losses_bwd_rowdot: bad sizes");
-    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_bwd_rowdot: dtype must be f16/bf16");
-    GD_REQUIRE(rm->Pe && rm->Pb && rm->p_in && rm->j_in && rm->p_wo && rm->j_wo && rm->wgt && rm->m_inp && rm->m_wo && rm->workspace, GD_EINVAL,
-               "gd_edit_losses_bwd_rowdot: removal arguments: null pointer");
-    GD_REQUIRE(rm->H > 0 && rm->R > 0 && rm->N > 0 && rm->M > 0 && rm->Mpad >= rm->M, GD_EINVAL, "gd_edit_losses_bwd_rowdot: removal arguments: bad sizes");
+extern "C" int gd_edit_losses_bwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
+                                  const float* w_am, const float* m_amodal, const void* gout, const float* coef_dev, const float* gscale_dev,
+                                  int blend, int H, int S, int D, void* dro, const gd_removal_bwd_t* rm, int dtype, void* stream) {
+    GD_REQUIRE(eo && ro && m_wo && m_edit && coef_dev && dro, GD_EINVAL, "gd_edit_losses_bwd: null pointer");
+    GD_REQUIRE(!tgt || (w_am && m_amodal), GD_EINVAL, "gd_edit_losses_bwd: tgt needs w_am and m_amodal");
+    GD_REQUIRE(H > 0 && S > 0 && D > 0, GD_EINVAL, "gd_edit_losses_bwd: bad sizes");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_losses_bwd: dtype must be f16/bf16");
+    gd_removal_bwd_t none;
+    memset(&none, 0, sizeof(none));
+    if (rm) {
+        GD_REQUIRE(rm->Pe && rm->Pb && rm->p_in && rm->j_in && rm->p_wo && rm->j_wo && rm->wgt && rm->m_inp && rm->m_wo && rm->workspace, GD_EINVAL,
+                   "gd_edit_losses_bwd: removal arguments: null pointer");
+        GD_REQUIRE(rm->H > 0 && rm->R > 0 && rm->N > 0 && rm->M > 0 && rm->Mpad >= rm->M, GD_EINVAL, "gd_edit_losses_bwd: removal arguments: bad sizes");
+    }
     const long long total = (long long)H * S * S * D;
     const int nb_loss = (int)((total + 255) / 256);
-    const int nb_dot = (rm->H * rm->R + 3) / 4;
+    const int nb_dot = rm ? (rm->H * rm->R + 3) / 4 : 0;          // the removal backward's row dots: extra workgroups of the same launch
+    const gd_removal_bwd_t& rr = rm ? *rm : none;
     hipStream_t st = as_stream(stream);
     if (dtype == GD_F16)
         k_losses_bwd_rowdot<f16_t><<<nb_loss + nb_dot, 256, 0, st>>>((const f16_t*)eo, (const f16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal,
-                                                                   (const f16_t*)gout, coef_dev, gscale_dev, blend, H, S, D, (f16_t*)dro, nb_loss, *rm);
+                                                                   (const f16_t*)gout, coef_dev, gscale_dev, blend, H, S, D, (f16_t*)dro, nb_loss, rr);
     else
         k_losses_bwd_rowdot<bf16_t><<<nb_loss + nb_dot, 256, 0, st>>>((const bf16_t*)eo, (const bf16_t*)ro, tgt, m_wo, m_edit, w_am, m_amodal,
-                                                                    (const bf16_t*)gout, coef_dev, gscale_dev, blend, H, S, D, (bf16_t*)dro, nb_loss, *rm);
-    GD_CHECK_LAUNCH("gd_edit_losses_bwd_rowdot");
+                                                                    (const bf16_t*)gout, coef_dev, gscale_dev, blend, H, S, D, (bf16_t*)dro, nb_loss, rr);
+    GD_CHECK_LAUNCH("gd_edit_losses_bwd");
     return GD_OK;
 }
 

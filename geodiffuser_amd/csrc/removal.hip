@@ -296,23 +296,19 @@ k_corr_max2(const CorrArgs a) {
     }
 }
 
-// variant selection: GD_CORR_MAX = "0" (k_corr_max), "42" / "24" / "22" (k_corr_max2 with AJ WJ = 4 x 2, 2 x 4, 2 x 2), unset: the
-// launcher's choice
-static int corr_variant(int H, int R, int N, int Mpad) {
-    if (Mpad % CM_K != 0 || Mpad < 4 * CM_K) return 0;
-    const char* e = getenv("GD_CORR_MAX");
-    const int want = e ? atoi(e) : -1;
-    if (want == 0) return 0;
-    if (want == 42 || want == 24) return (N % 256 == 0) ? want : 0;
-    if (want == 22) return (N % 128 == 0) ? want : 0;
-    // measured (tools/bench_corr.py, bench_corr2.py; 64^2: 5 heads x 4096 x 4096): eight waves of 64 x 64 beat four of 128 x 64 at every
-    // list length (44 against 50 us per round); the 32^2 layers (1024 keys: 16 chunks) are launch-bound and fastest on 128 x 128 tiles
+// which kernel: 0 = k_corr_max (any shape), 24 / 22 = k_corr_max2 with AJ x WJ = 2 x 4 (eight waves of 64 x 64) / 2 x 2
+static int corr_variant(int H, int R, int N, int Mpad, int want) {
+    if (Mpad % CM_K != 0 || Mpad < 4 * CM_K || want == 1) return 0;
+    if (want == 24 && N % 256 == 0) return 24;
+    if (want == 22 && N % 128 == 0) return 22;
+    // measured (64^2: 5 heads x 4096 x 4096): eight waves of 64 x 64 beat four of 128 x 64 at every list length (44 against 50 us per
+    // round); the 32^2 layers (1024 keys: 16 chunks) are launch-bound and fastest on 128 x 128 tiles
     if (N % 256 == 0 && N >= 2048) return 24;
     return (N % 128 == 0) ? 22 : 0;
 }
 
 static int corr_max_launch(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
-                           int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream, bool clear) {
+                           int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream, bool clear, int variant) {
     GD_REQUIRE(Pe && Pb && m_inp && m_wo && best, GD_EINVAL, "gd_removal_corr_max: null pointer");
     GD_REQUIRE(H > 0 && R > 0 && N > 0 && Mpad > 0 && (Mpad & 7) == 0, GD_EINVAL, "gd_removal_corr_max: bad sizes");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_corr_max: dtype must be f16/bf16");
@@ -323,7 +319,7 @@ static int corr_max_launch(const void* Pe, const void* Pb, const float* m_inp, c
     a.jtiles = (N + CM_T - 1) / CM_T;
     hipStream_t st = as_stream(stream);
     if (clear) gd_zero_async(best, (size_t)H * R * 2 * sizeof(unsigned long long), st);
-    const int var = corr_variant(H, R, N, Mpad);
+    const int var = corr_variant(H, R, N, Mpad, variant);
     if (var) {
         const int aj = var / 10, wjn = var % 10;
         a.jtiles = ((N / (32 * aj * wjn)) * H + 7) / 8 * 8;             // (head, j-tile) pairs per r-tile, padded to the 8 XCDs
@@ -331,7 +327,7 @@ static int corr_max_launch(const void* Pe, const void* Pb, const float* m_inp, c
 #define GD_CM2(AJ_, WJ_)                                                                            \
         if (dtype == GD_F16) k_corr_max2<f16_t, AJ_, WJ_><<<grid2, 128 * WJ_, 0, st>>>(a);          \
         else k_corr_max2<bf16_t, AJ_, WJ_><<<grid2, 128 * WJ_, 0, st>>>(a)
-        if (var == 42) { GD_CM2(4, 2); } else if (var == 24) { GD_CM2(2, 4); } else { GD_CM2(2, 2); }
+        if (var == 24) { GD_CM2(2, 4); } else { GD_CM2(2, 2); }
 #undef GD_CM2
         GD_CHECK_LAUNCH("gd_removal_corr_max");
         return GD_OK;
@@ -344,13 +340,9 @@ static int corr_max_launch(const void* Pe, const void* Pb, const float* m_inp, c
 }
 
 extern "C" int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
-                                   int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream) {
-    return corr_max_launch(Pe, Pb, m_inp, m_wo, n_valid_dev, H, R, N, Mpad, best, dtype, stream, true);
-}
-// ... without the clear of `best` (gd_attn_probs_pair cleared it in the launch before)
-extern "C" int gd_removal_corr_max_nz(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
-                                      int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream) {
-    return corr_max_launch(Pe, Pb, m_inp, m_wo, n_valid_dev, H, R, N, Mpad, best, dtype, stream, false);
+                                   int H, int R, int N, int Mpad, unsigned long long* best, int clear, int variant, int dtype, void* stream) {
+    GD_REQUIRE(variant == 0 || variant == 1 || variant == 22 || variant == 24, GD_EINVAL, "gd_removal_corr_max: variant %d (0, 1, 22, 24)", variant);
+    return corr_max_launch(Pe, Pb, m_inp, m_wo, n_valid_dev, H, R, N, Mpad, best, dtype, stream, clear != 0, variant);
 }
 
 __global__ void k_removal_reduce(const unsigned long long* __restrict__ best, const int32_t* __restrict__ rows,
@@ -573,12 +565,8 @@ k_removal_bwd2(const RmBwdArgs a) {
         }
 }
 
-// GD_REMOVAL_BWD = "1": k_removal_bwd everywhere; default: k_removal_bwd2 where it applies (D = 64, M a multiple of RM_MCH, no dk)
-static bool rm_bwd2_applies(int M, int D, bool need_dk) {
-    if (D != ATT_D || M % RM_MCH != 0 || need_dk) return false;
-    const char* e = getenv("GD_REMOVAL_BWD");
-    return !(e && e[0] == '1');
-}
+// k_removal_bwd2 where it applies (D = 64, M a multiple of RM_MCH, no dk); k_removal_bwd serves every other shape
+static bool rm_bwd2_applies(int M, int D, bool need_dk) { return D == ATT_D && M % RM_MCH == 0 && !need_dk; }
 template <typename T>
 static void rm_bwd2_launch(const RmBwdArgs& a, hipStream_t st) {
     const int grid = a.H * ((a.R + 127) / 128) * (a.M / RM_MCH);
@@ -633,73 +621,45 @@ extern "C" size_t gd_removal_bwd_workspace_bytes(int H, int R, int M, int Mpad, 
     return ((size_t)H * R * (1 + msplit * D + (need_dk ? (size_t)Mpad : 0))) * sizeof(float);
 }
 
-extern "C" int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
-                              const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
-                              const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
-                              const int32_t* n_valid_dev, int H, int R, int N, int M, int Mpad, int D, float scale,
-                              float* dq_f32, float* dk_f32, float* ds_ws, void* dq16_inout, int dtype, void* stream) {
-    GD_REQUIRE(Pe && Pb && q && k && rows && p_in && j_in && p_wo && j_wo && wgt && m_inp && m_wo && (dq_f32 || dq16_inout), GD_EINVAL,
-               "gd_removal_bwd: null pointer");
-    GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED, "gd_removal_bwd: head dim %d unsupported (64, 128, 192)", D);
-    GD_REQUIRE(H > 0 && R > 0 && N > 0 && M > 0 && Mpad >= M, GD_EINVAL, "gd_removal_bwd: bad sizes");
-    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_bwd: dtype must be f16/bf16");
-    RmBwdArgs a;
-    a.Pe = Pe; a.Pb = Pb; a.q = q; a.k = k; a.rows = rows; a.p_in = p_in; a.j_in = j_in; a.p_wo = p_wo; a.j_wo = j_wo;
-    a.wgt = wgt; a.m_inp = m_inp; a.m_wo = m_wo; a.coef = coef; a.gscale = gscale_dev; a.gscale2 = nullptr; a.H = H; a.R = R; a.N = N; a.M = M; a.Mpad = Mpad; a.D = D; a.n_valid = n_valid_dev;
-    GD_REQUIRE(ds_ws, GD_EINVAL, "gd_removal_bwd: workspace of gd_removal_bwd_workspace_bytes() required");
-    // workspace: rowdot [H*R] | dq partials [msplit, H, R, D] | dS [H, R, Mpad] (only with dk_f32)
-    const int msplit = (M + RM_MCH - 1) / RM_MCH;
-    float* rowdot = ds_ws;
-    a.dq_part = ds_ws + (size_t)H * R;
-    a.scale = scale; a.dq = dq_f32; a.dk = dk_f32; a.rowdot = rowdot;
-    a.ds_ws = dk_f32 ? a.dq_part + (size_t)msplit * H * R * D : nullptr;
-    const int waves = H * ((R + RM_RB - 1) / RM_RB) * ((M + RM_MCH - 1) / RM_MCH) * (D / ATT_D);
-    const int blocks = (waves + 3) / 4;
-    hipStream_t st = as_stream(stream);
-    if (dtype == GD_F16) k_removal_rowdot<f16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rowdot);
-    else k_removal_rowdot<bf16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rowdot);
-    if (rm_bwd2_applies(M, D, dk_f32 != nullptr)) { if (dtype == GD_F16) rm_bwd2_launch<f16_t>(a, st); else rm_bwd2_launch<bf16_t>(a, st); }
-    else if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, st>>>(a);
-    else k_removal_bwd<bf16_t><<<blocks, 256, 0, st>>>(a);
-    if (dtype == GD_F16) k_removal_dq_fold<f16_t><<<(H * R * D + 255) / 256, 256, 0, st>>>(a.dq_part, rows, wgt, msplit, H, R, N, D, dq_f32, (f16_t*)dq16_inout);
-    else k_removal_dq_fold<bf16_t><<<(H * R * D + 255) / 256, 256, 0, st>>>(a.dq_part, rows, wgt, msplit, H, R, N, D, dq_f32, (bf16_t*)dq16_inout);
-    if (dk_f32) {
-        dim3 grid((M * D + 255) / 256, H);
-        if (dtype == GD_F16) k_removal_dk<f16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const f16_t*)q, rows, n_valid_dev, R, N, M, Mpad, D, dk_f32);
-        else k_removal_dk<bf16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const bf16_t*)q, rows, n_valid_dev, R, N, M, Mpad, D, dk_f32);
-    }
-    GD_CHECK_LAUNCH("gd_removal_bwd");
-    return GD_OK;
-}
-
-// The dS K products only (gd_edit_losses_bwd_rowdot computed the row dots into the workspace, gd_edit_dq_fold folds the partials)
-extern "C" int gd_removal_bwd_nofold(const gd_removal_bwd_t* rm, int dtype, void* stream) {
+// dq_f32 / dq16_inout given: the complete backward (row dots, dS K products, fold).  Both NULL: the products only — gd_edit_losses_bwd
+// computed the row dots into the workspace and gd_edit_dq_fold folds the partials.
+extern "C" int gd_removal_bwd(const gd_removal_bwd_t* rm, float* dq_f32, void* dq16_inout, int dtype, void* stream) {
     GD_REQUIRE(rm && rm->Pe && rm->Pb && rm->q && rm->k && rm->rows && rm->p_in && rm->j_in && rm->p_wo && rm->j_wo && rm->wgt && rm->m_inp && rm->m_wo
-               && rm->workspace, GD_EINVAL, "gd_removal_bwd_nofold: null pointer");
-    GD_REQUIRE(rm->D == 64 || rm->D == 128 || rm->D == 192, GD_EUNSUPPORTED, "gd_removal_bwd_nofold: head dim %d unsupported (64, 128, 192)", rm->D);
-    GD_REQUIRE(rm->H > 0 && rm->R > 0 && rm->N > 0 && rm->M > 0 && rm->Mpad >= rm->M, GD_EINVAL, "gd_removal_bwd_nofold: bad sizes");
-    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_bwd_nofold: dtype must be f16/bf16");
+               && rm->workspace, GD_EINVAL, "gd_removal_bwd: null pointer (the workspace of gd_removal_bwd_workspace_bytes() is required)");
+    GD_REQUIRE(rm->D == 64 || rm->D == 128 || rm->D == 192, GD_EUNSUPPORTED, "gd_removal_bwd: head dim %d unsupported (64, 128, 192)", rm->D);
+    GD_REQUIRE(rm->H > 0 && rm->R > 0 && rm->N > 0 && rm->M > 0 && rm->Mpad >= rm->M, GD_EINVAL, "gd_removal_bwd: bad sizes");
+    GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_removal_bwd: dtype must be f16/bf16");
+    const bool complete = dq_f32 || dq16_inout;
     RmBwdArgs a;
     a.Pe = rm->Pe; a.Pb = rm->Pb; a.q = rm->q; a.k = rm->k; a.rows = rm->rows; a.p_in = rm->p_in; a.j_in = rm->j_in; a.p_wo = rm->p_wo; a.j_wo = rm->j_wo;
     a.wgt = rm->wgt; a.m_inp = rm->m_inp; a.m_wo = rm->m_wo; a.coef = rm->coef; a.gscale = rm->gscale; a.gscale2 = rm->gscale2;
     a.H = rm->H; a.R = rm->R; a.N = rm->N; a.M = rm->M; a.Mpad = rm->Mpad; a.D = rm->D; a.n_valid = rm->n_valid;
     const int H = rm->H, R = rm->R, M = rm->M, D = rm->D;
+    // workspace: rowdot [H*R] | dq partials [msplit, H, R, D] | dS [H, R, Mpad] (only with dk_f32)
     const int msplit = (M + RM_MCH - 1) / RM_MCH;
     a.rowdot = rm->workspace;
     a.dq_part = rm->workspace + (size_t)H * R;
-    a.scale = rm->scale; a.dq = nullptr; a.dk = rm->dk_f32;
+    a.scale = rm->scale; a.dq = dq_f32; a.dk = rm->dk_f32;
     a.ds_ws = rm->dk_f32 ? a.dq_part + (size_t)msplit * H * R * D : nullptr;
     const int waves = H * ((R + RM_RB - 1) / RM_RB) * msplit * (D / ATT_D);
     const int blocks = (waves + 3) / 4;
     hipStream_t st = as_stream(stream);
-    if (rm_bwd2_applies(M, D, rm->dk_f32 != nullptr)) { if (dtype == GD_F16) rm_bwd2_launch<f16_t>(a, st); else rm_bwd2_launch<bf16_t>(a, st); }
+    if (complete) {
+        if (dtype == GD_F16) k_removal_rowdot<f16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rm->workspace);
+        else k_removal_rowdot<bf16_t><<<(H * R + 3) / 4, 256, 0, st>>>(a, rm->workspace);
+    }
+    if (rm->variant != 1 && rm_bwd2_applies(M, D, rm->dk_f32 != nullptr)) { if (dtype == GD_F16) rm_bwd2_launch<f16_t>(a, st); else rm_bwd2_launch<bf16_t>(a, st); }
     else if (dtype == GD_F16) k_removal_bwd<f16_t><<<blocks, 256, 0, st>>>(a);
     else k_removal_bwd<bf16_t><<<blocks, 256, 0, st>>>(a);
+    if (complete) {
+        if (dtype == GD_F16) k_removal_dq_fold<f16_t><<<(H * R * D + 255) / 256, 256, 0, st>>>(a.dq_part, rm->rows, rm->wgt, msplit, H, R, rm->N, D, dq_f32, (f16_t*)dq16_inout);
+        else k_removal_dq_fold<bf16_t><<<(H * R * D + 255) / 256, 256, 0, st>>>(a.dq_part, rm->rows, rm->wgt, msplit, H, R, rm->N, D, dq_f32, (bf16_t*)dq16_inout);
+    }
     if (rm->dk_f32) {
         dim3 grid((M * D + 255) / 256, H);
         if (dtype == GD_F16) k_removal_dk<f16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const f16_t*)rm->q, rm->rows, rm->n_valid, R, rm->N, M, rm->Mpad, D, rm->dk_f32);
         else k_removal_dk<bf16_t><<<grid, 256, 0, st>>>(a.ds_ws, (const bf16_t*)rm->q, rm->rows, rm->n_valid, R, rm->N, M, rm->Mpad, D, rm->dk_f32);
     }
-    GD_CHECK_LAUNCH("gd_removal_bwd_nofold");
+    GD_CHECK_LAUNCH("gd_removal_bwd");
     return GD_OK;
 }

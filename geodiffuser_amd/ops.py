@@ -154,12 +154,37 @@ SPLIT_KV = os.environ.get("GD_ATTN_SPLIT_KV", "1") == "1"
 _PLAN_CACHE = {}
 
 
+def _env_attn_cfg():
+    qb, ks = -1, 0
+    e = os.environ.get("GD_ATTN_CFG")               # "QBxKS" forces one pipelined kernel, "0" the plain kernel (development / benchmarks)
+    if e == "0":
+        qb = 0
+    elif e and "x" in e:
+        qb, ks = (int(x) for x in e.split("x"))
+    return dict(even_split=int(os.environ.get("GD_ATTN_EVEN_SPLIT", "-1")), qb=qb, ks=ks, handoff=1)
+
+
+# Launch-configuration DEFAULTS of this process's Python layer.  The C ABI is stateless (ABI 5: every call carries its gd_attn_cfg_t /
+# gd_conv3x3_cfg_t / single_launch flag); these dictionaries are what ops.* fills those per-call arguments from when the caller passes
+# none.  Tests and benchmarks edit them (and restore them); the product path never does.
+ATTN_CFG = _env_attn_cfg()
+CONV3X3_CFG = dict(pi=0, ki=0, ksplit=0, dma=0 if os.environ.get("GD_CONV_DMA") == "0" else -1)
+GN_SINGLE_LAUNCH = -1
+
+
+def _attn_cfg(cfg: Optional[dict], nsplit: int = 0):
+    c = dict(ATTN_CFG)
+    if cfg:
+        c.update(cfg)
+    return _lib.GdAttnCfg(int(c["even_split"]), int(c["qb"]), int(c["ks"]), int(nsplit), int(c["handoff"]))
+
+
 _SK_WS = {}          # device index -> zero-initialised workspace of the even split (persistent: captured graphs hold its address)
 _SK_WS_RETIRED = []  # buffers replaced by a larger one (never freed: see _attn_ws)
 
 
 def _attn_ws(lib, dev: torch.device, tot_bh: int, N: int, M: int):
-    """Workspace of gd_attn_fwd_ws: arrival counters (zero before the first launch, every launch leaves them zero) + part slots.  One
+    """Workspace of the even split (gd_attn_fwd): arrival counters (zero before the first launch, every launch leaves them zero) + part slots.  One
     buffer per device, grown on demand — all launches of a process run on one stream at a time (the library's contract)."""
     need = int(lib.gd_attn_fwd_workspace_bytes(tot_bh, N, M))
     ws = _SK_WS.get(dev.index)
@@ -245,7 +270,8 @@ def attn_fwd_pair(segs: Sequence[tuple], side_b: tuple, m: torch.Tensor, scale: 
     check(lib.gd_attn_fwd_pair(arr, n, arr_b, _p(m), N, M, D, scale, dt, _stream()), "gd_attn_fwd_pair")
 
 
-def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Optional[int] = None, q_scaled: bool = False) -> None:
+def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Optional[int] = None, q_scaled: bool = False,
+             cfg: Optional[dict] = None) -> None:
     """segs: list of (q, k, v, out, lse | None[, warp]); one launch.
     heads == 0: q/out [bh,N,D], k/v [bh,M,D] (head-major).  heads > 0: token-major q/out [B,N,heads*D], k/v [B,M,heads*D]
     exactly as to_q/to_k/to_v produce them (no head_to_batch_dim copies); lse [B*heads, N].
@@ -253,36 +279,34 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
     q*(1-m) + m*half(sum_k w*q[idx]) built inside the kernel (U/attention_processors.py:424-428,544-549) — the fused
     attention-warp launch; bit-identical to passing splat_composite(q, idx, w, m) as q.
     q_scaled: every q already carries scale*log2(e) (applied by the projection GEMM before its rounding, see attention_processors
-    ``_project_qkv``); ``scale`` is then ignored.  2: additionally row sums over the rounded probabilities (gd_attn_seg_t.q_scaled)."""
+    ``_project_qkv``); ``scale`` is then ignored.  2: additionally row sums over the rounded probabilities (gd_attn_seg_t.q_scaled).
+    cfg: overrides of ATTN_CFG for this call (gd_attn_cfg_t fields: even_split, qb, ks, handoff)."""
     lib = _lib.load()
     arr, n, N, M, D, dt, tot_bh = _attn_seg_array(segs, heads, q_scaled)
     q0 = segs[0][0]
     if nsplit is None:
-        nsplit, ws_bytes = _attn_plan(lib, tot_bh, N, M) if SPLIT_KV else (1, 0)
+        nsplit, ws_bytes = _attn_plan(lib, tot_bh, N, M) if (SPLIT_KV and ATTN_CFG["qb"] < 0 and not (cfg and cfg.get("qb", -1) >= 0)) else (1, 0)
     else:
         ws_bytes = nsplit * tot_bh * N * (D + 2) * 4 if nsplit > 1 else 0
     if nsplit > 1:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q0.device)
-        check(lib.gd_attn_fwd_splitkv(arr, n, N, M, D, scale, nsplit, _p(ws), ws_bytes, dt, _stream()), "gd_attn_fwd_splitkv")
-    elif D == 64 and M % 256 == 0 and M >= 1024:
+        c = _attn_cfg(cfg, nsplit)
+        check(lib.gd_attn_fwd(arr, n, N, M, D, scale, ctypes.byref(c), _p(ws), ws_bytes, dt, _stream()), "gd_attn_fwd (split-KV)")
+        return
+    c = _attn_cfg(cfg)
+    if D == 64 and M % 256 == 0 and M >= 1024 and c.even_split != 0:
         ws = _attn_ws(lib, q0.device, tot_bh, N, M)
-        check(lib.gd_attn_fwd_ws(arr, n, N, M, D, scale, _p(ws), ws.numel(), dt, _stream()), "gd_attn_fwd_ws")
+        check(lib.gd_attn_fwd(arr, n, N, M, D, scale, ctypes.byref(c), _p(ws), ws.numel(), dt, _stream()), "gd_attn_fwd (even split)")
     else:
-        check(lib.gd_attn_fwd(arr, n, N, M, D, scale, dt, _stream()), "gd_attn_fwd")
+        check(lib.gd_attn_fwd(arr, n, N, M, D, scale, ctypes.byref(c), None, 0, dt, _stream()), "gd_attn_fwd")
 
 
 def rows_merge(base: torch.Tensor, act: torch.Tensor, pos: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[h, n] = act[h, pos[n]] where pos[n] >= 0, else base[h, n]  (base / out [H, N, D], act [H, R, D] 16-bit, pos [N] i32)."""
-    lib = _lib.load()
-    dt = _dt16(base, "base")
-    _need(base, "base"); _need(act, "act", base.dtype); _need(pos, "pos", torch.int32)
-    H, N, D = base.shape
-    if act.shape[0] != H or act.shape[2] != D or pos.numel() != N:
-        raise _lib.GeodiffError("rows_merge: shapes disagree")
+    """out[h, n] = act[h, pos[n]] where pos[n] >= 0, else base[h, n]  (base / out [H, N, D], act [H, R, D] 16-bit, pos [N] i32):
+    gd_blend_merge without the blend."""
     if out is None:
         out = torch.empty_like(base)
-    _need(out, "out", base.dtype)
-    check(lib.gd_rows_merge(_p(base), _p(act), _p(pos), H, N, act.shape[1], D, _p(out), dt, _stream()), "gd_rows_merge")
+    blend_merge(base, act, pos, None, None, eo_out=out, out=None)
     return out
 
 
@@ -325,7 +349,7 @@ def attn_fwd_fp8(qz: dict, scale: float, out: torch.Tensor, lse: Optional[torch.
                               _p(out), _p(lse), dt, _stream()), "gd_attn_fwd_fp8")
 
 
-def attn_bwd(q, k, v, out, lse, dout, scale: float, need_dk: bool, dq_out=None):
+def attn_bwd(q, k, v, out, lse, dout, scale: float, need_dk: bool, dq_out=None, variant: int = 0):
     """-> (dq 16-bit [BH,N,D], dk f32 [BH,M,D] | None).  dq_out: write dq into this contiguous tensor (e.g. a row slice of a larger gradient)."""
     lib = _lib.load()
     dt = _dt16(q, "q")
@@ -340,9 +364,9 @@ def attn_bwd(q, k, v, out, lse, dout, scale: float, need_dk: bool, dq_out=None):
             raise _lib.GeodiffError("attn_bwd: dq_out must have q's shape")
     dq = dq_out if dq_out is not None else torch.empty_like(q)
     dk = torch.zeros(BH, M, D, dtype=torch.float32, device=q.device) if need_dk else None
-    nbytes = lib.gd_attn_bwd_workspace_bytes(BH, N, M, D, int(need_dk))
+    nbytes = lib.gd_attn_bwd_workspace_bytes(BH, N, M, D, int(need_dk), variant)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device) if nbytes else None
-    check(lib.gd_attn_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), BH, N, M, D, scale, _p(dq), _p(dk), _p(ws), nbytes, dt,
+    check(lib.gd_attn_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), BH, N, M, D, scale, _p(dq), _p(dk), _p(ws), nbytes, None, None, variant, dt,
                           _stream()), "gd_attn_bwd")
     return dq, dk
 
@@ -365,11 +389,8 @@ def attn_bwd_dkv(q, k, v, out, lse, dout, scale: float):
     return dk, dv
 
 
-def attn_probs(q, k, lse, rows: Optional[torch.Tensor], scale: float, n_valid: Optional[torch.Tensor] = None):
-    """-> P [BH, R, Mpad] 16-bit, Mpad = ceil8(M).  n_valid (device int32[1]): slots [n_valid, R) of ``rows`` are padding; whole
-    128-row tiles of padding are not computed (those rows of P stay uninitialised)."""
-    lib = _lib.load()
-    dt = _dt16(q, "q")
+def _probs_problem(q, k, lse, rows, n_valid):
+    """-> (GdProbs, P [BH, R, Mpad] 16-bit, Mpad = ceil8(M))."""
     _need(q, "q"); _need(k, "k", q.dtype); _need(lse, "lse", torch.float32)
     BH, N, D = q.shape
     M = k.shape[1]
@@ -377,17 +398,25 @@ def attn_probs(q, k, lse, rows: Optional[torch.Tensor], scale: float, n_valid: O
     R = N if rows is None else rows.numel()
     if rows is not None:
         _need(rows, "rows", torch.int32)
-    P = torch.empty(BH, R, Mpad, dtype=q.dtype, device=q.device)
     if n_valid is not None:
         _need(n_valid, "n_valid", torch.int32)
-    check(lib.gd_attn_probs(_p(q), _p(k), _p(lse), _p(rows), _p(n_valid), BH, N, R, M, Mpad, D, scale, _p(P), dt, _stream()), "gd_attn_probs")
+    P = torch.empty(BH, R, Mpad, dtype=q.dtype, device=q.device)
+    return _lib.GdProbs(q.data_ptr(), k.data_ptr(), lse.data_ptr(), _ip(rows), _ip(n_valid), P.data_ptr(), BH, N, R, M, Mpad), P
+
+
+def attn_probs(q, k, lse, rows: Optional[torch.Tensor], scale: float, n_valid: Optional[torch.Tensor] = None):
+    """-> P [BH, R, Mpad] 16-bit, Mpad = ceil8(M).  n_valid (device int32[1]): slots [n_valid, R) of ``rows`` are padding; whole
+    128-row tiles of padding are not computed (those rows of P stay uninitialised)."""
+    lib = _lib.load()
+    a, P = _probs_problem(q, k, lse, rows, n_valid)
+    check(lib.gd_attn_probs(ctypes.byref(a), None, q.shape[2], scale, None, 0, _dt16(q, "q"), _stream()), "gd_attn_probs")
     return P
 
 
 # ---------------------------------------------------------------------------------------------------
 # R8 losses
 # ---------------------------------------------------------------------------------------------------
-def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int, n_valid=None):
+def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int, n_valid=None, variant: int = 0):
     """-> dict(p_in, j_in, p_wo, j_wo, wgt [H,R]) and loss_sum [1] f32 (un-normalised)."""
     lib = _lib.load()
     dt = _dt16(Pe, "Pe")
@@ -397,7 +426,7 @@ def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int, n_valid=None):
     N = Pb.shape[1]
     dev = Pe.device
     best = torch.empty(H, R, 2, dtype=torch.int64, device=dev)
-    check(lib.gd_removal_corr_max(_p(Pe), _p(Pb), _p(m_inp), _p(m_wo), _p(n_valid), H, R, N, Mpad, _p(best), dt, _stream()), "gd_removal_corr_max")
+    check(lib.gd_removal_corr_max(_p(Pe), _p(Pb), _p(m_inp), _p(m_wo), _p(n_valid), H, R, N, Mpad, _p(best), 1, variant, dt, _stream()), "gd_removal_corr_max")
     p_in = torch.empty(H, R, dtype=torch.float32, device=dev); p_wo = torch.empty_like(p_in); wgt = torch.empty_like(p_in)
     j_in = torch.empty(H, R, dtype=torch.int32, device=dev); j_wo = torch.empty_like(j_in)
     loss = zeros_f32(1, dev)
@@ -406,22 +435,21 @@ def removal_fwd(Pe, Pb, m_inp, m_wo, rows, S: int, n_valid=None):
     return dict(p_in=p_in, j_in=j_in, p_wo=p_wo, j_wo=j_wo, wgt=wgt), loss
 
 
-def removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, scale: float, dq_f32, dk_f32, n_valid=None, dq16=None):
-    """dq_f32 (f32, accumulated) and / or dq16 (16-bit, added in place with one rounding) receive the query gradient."""
+def removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, scale: float, dq_f32, dk_f32, n_valid=None, dq16=None,
+                variant: int = 0):
+    """The complete removal-loss backward: dq_f32 (f32, accumulated) and / or dq16 (16-bit, added in place with one rounding) receive the
+    query gradient."""
     lib = _lib.load()
-    dt = _dt16(Pe, "Pe")
-    H, R, Mpad = Pe.shape
-    N, D = q.shape[1], q.shape[2]
-    M = k.shape[1]
+    if dq_f32 is None and dq16 is None:
+        raise _lib.GeodiffError("removal_bwd: dq_f32 or dq16 is required (the products-only form is removal_bwd_nofold)")
     if dq_f32 is not None:
         _need(dq_f32, "dq_f32", torch.float32)
     if dq16 is not None:
         _need(dq16, "dq16", q.dtype)
-    ds_ws = torch.empty(lib.gd_removal_bwd_workspace_bytes(H, R, M, Mpad, D, int(dk_f32 is not None)) // 4, dtype=torch.float32,
-                        device=Pe.device)
-    check(lib.gd_removal_bwd(_p(Pe), _p(Pb), _p(q), _p(k), _p(rows), _p(aux["p_in"]), _p(aux["j_in"]), _p(aux["p_wo"]),
-                             _p(aux["j_wo"]), _p(aux["wgt"]), _p(m_inp), _p(m_wo), coef, _p(gscale), _p(n_valid), H, R, N, M, Mpad, D, scale,
-                             _p(dq_f32), _p(dk_f32), _p(ds_ws), _p(dq16), dt, _stream()), "gd_removal_bwd")
+    a, ws = removal_bwd_args(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef, gscale, None, scale, n_valid, dk_f32 is not None)
+    a.dk_f32 = _ip(dk_f32)
+    a.variant = variant
+    check(lib.gd_removal_bwd(ctypes.byref(a), _p(dq_f32), _p(dq16), _dt16(Pe, "Pe"), _stream()), "gd_removal_bwd")
 
 
 def nn_table(fg, S: int):
@@ -442,8 +470,8 @@ def amodal_target(eo, nn_idx, nn_w, fg, S: int):
     _need(eo, "eo"); _need(nn_idx, "nn_idx", torch.int32); _need(nn_w, "nn_w", torch.float32); _need(fg, "fg", torch.float32)
     H, N, D = eo.shape
     tgt = torch.empty(H, N, D, dtype=torch.float32, device=eo.device)
-    # (scratch of the two-launch form only: head dims above 64, or GD_AMODAL_TWO_PASS=1)
-    tmp = torch.empty_like(tgt) if (D > 64 or os.environ.get("GD_AMODAL_TWO_PASS") == "1") else tgt
+    # (scratch of the two-launch form only: head dims above 64)
+    tmp = torch.empty_like(tgt) if D > 64 else tgt
     check(lib.gd_amodal_target(_p(eo), _p(nn_idx), _p(nn_w), _p(fg), H, S, D, _p(tmp), _p(tgt), dt, _stream()), "gd_amodal_target")
     return tgt
 
@@ -463,14 +491,17 @@ def loss_assemble(sums, rm, inv5, inv_rm, wv, inv5_bwd, use_amodal: bool):
 
 
 def edit_losses_fwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int):
+    """The five loss reductions only (gd_edit_losses_fwd with wv == NULL) -> sums [5] f32."""
     lib = _lib.load()
     dt = _dt16(eo, "eo")
     _need(eo, "eo"); _need(ro, "ro", eo.dtype)
     H, N, D = eo.shape
     sums = zeros_f32(5, eo.device)
     ws = torch.empty(lib.gd_edit_losses_fwd_workspace_bytes(H, S, D) // 4, dtype=torch.float32, device=eo.device)
-    check(lib.gd_edit_losses_fwd(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), H, S, D, _p(sums), _p(ws), dt,
-                                 _stream()), "gd_edit_losses_fwd")
+    a = GdEditLosses()
+    a.eo, a.ro, a.tgt, a.m_wo, a.m_edit, a.w_am, a.m_amodal = eo.data_ptr(), ro.data_ptr(), _ip(tgt), m_wo.data_ptr(), m_edit.data_ptr(), _ip(w_am), _ip(m_amodal)
+    a.out12, a.workspace, a.H, a.S, a.D = sums.data_ptr(), ws.data_ptr(), H, S, D
+    check(lib.gd_edit_losses_fwd(ctypes.byref(a), dt, _stream()), "gd_edit_losses_fwd")
     return sums
 
 
@@ -486,38 +517,27 @@ def _gout_flag(gout, eo, blend, gout_tok: bool) -> int:
 
 def edit_losses_bwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend: bool, S: int, gout_tok: bool = False):
     """coefs: device f32 [5] tensor (or a host sequence, uploaded here — not capture-safe)."""
-    lib = _lib.load()
-    dt = _dt16(eo, "eo")
-    H, N, D = eo.shape
-    blend = _gout_flag(gout, eo, blend, gout_tok)
-    dro = torch.empty_like(ro)
     if not isinstance(coefs, torch.Tensor):
         coefs = torch.tensor([float(x) for x in coefs], dtype=torch.float32, device=eo.device)
-    _need(coefs, "coefs", torch.float32)
-    check(lib.gd_edit_losses_bwd(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), _p(gout), _p(coefs), _p(gscale), int(blend),
-                                 H, S, D, _p(dro), dt, _stream()), "gd_edit_losses_bwd")
-    return dro
+    return edit_losses_bwd_rowdot(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend, S, None, gout_tok)
 
 
 def blend_tokens(a, b, m, out=None):
-    lib = _lib.load()
-    dt = _dt16(a, "a")
-    _need(a, "a"); _need(b, "b", a.dtype); _need(m, "m", torch.float32)
-    H, N, D = a.shape
+    """out = a*m + b*(1-m) per token (U/attention_processors.py:504,619), op by op in the tensor dtype: gd_blend_merge without a row list."""
     if out is None:
         out = torch.empty_like(a)
-    check(lib.gd_blend_tokens(_p(a), _p(b), _p(m), H, N, D, _p(out), dt, _stream()), "gd_blend_tokens")
+    blend_merge(a, None, None, b, m, eo_out=None, out=out)
     return out
 
 
 # ---------------------------------------------------------------------------------------------------
-# fused launches of one hooked optimisation-pass layer (include/geodiff_hip.h, "R6-R9 fused launches", ABI 4)
+# the launches of one hooked optimisation-pass layer (include/geodiff_hip.h R8: the optional fields of the loss / backward entry points)
 # ---------------------------------------------------------------------------------------------------
 def _ip(t):
     return 0 if t is None else t.data_ptr()
 
 
-_TICKETS = {}        # device index -> one zeroed int32 (gd_edit_losses_fused's arrival ticket: zero before every launch, left zero by it)
+_TICKETS = {}        # device index -> one zeroed int32 (the arrival ticket of gd_edit_losses_fwd's tail: zero before every launch, left zero by it)
 
 
 def _ticket(dev: torch.device) -> torch.Tensor:
@@ -530,7 +550,7 @@ def _ticket(dev: torch.device) -> torch.Tensor:
 
 
 def blend_merge(base, act, pos, ro, m, eo_out=None, out=None):
-    """gd_rows_merge + gd_blend_tokens in one pass: e = act[h, pos[n]] where pos[n] >= 0 (act given) else base[h, n]; eo_out = e;
+    """gd_blend_merge: e = act[h, pos[n]] where pos[n] >= 0 (act given) else base[h, n]; eo_out = e;
     out = e*m + ro*(1-m).  Either output may be None."""
     lib = _lib.load()
     dt = _dt16(base, "base")
@@ -635,7 +655,7 @@ def attn_probs_pair(qb, kb, lse_b, qe, ke, lse_e, rows, n_valid, scale: float, z
     if zero is not None:
         _need(zero, "zero")
         zb = zero.numel() * zero.element_size()
-    check(lib.gd_attn_probs_pair(ctypes.byref(a), ctypes.byref(b), D, scale, _p(zero), zb, dt, _stream()), "gd_attn_probs_pair")
+    check(lib.gd_attn_probs(ctypes.byref(a), ctypes.byref(b), D, scale, _p(zero), zb, dt, _stream()), "gd_attn_probs")
     return Pb, Pe
 
 
@@ -646,8 +666,8 @@ def removal_corr_max_nz(Pe, Pb, m_inp, m_wo, n_valid, best):
     _need(Pe, "Pe"); _need(Pb, "Pb", Pe.dtype); _need(m_inp, "m_inp", torch.float32); _need(m_wo, "m_wo", torch.float32)
     _need(best, "best", torch.int64)
     H, R, Mpad = Pe.shape
-    check(lib.gd_removal_corr_max_nz(_p(Pe), _p(Pb), _p(m_inp), _p(m_wo), _p(n_valid), H, R, Pb.shape[1], Mpad, _p(best), dt, _stream()),
-          "gd_removal_corr_max_nz")
+    check(lib.gd_removal_corr_max(_p(Pe), _p(Pb), _p(m_inp), _p(m_wo), _p(n_valid), H, R, Pb.shape[1], Mpad, _p(best), 0, 0, dt, _stream()),
+          "gd_removal_corr_max")
 
 
 def edit_losses_fused(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int, best, rows, n_valid, inv5, inv_rm, wv, inv5_bwd, use_amodal: bool,
@@ -685,7 +705,7 @@ def edit_losses_fused(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int, best, r
                      out.data_ptr(), ws.data_ptr(), _ticket(dev).data_ptr(),
                      _ip(log_acc), 0 if running is False else _ip(running), 0 if running is False else out[12:].data_ptr(),
                      H, S, D, R, int(bool(use_amodal)))
-    check(lib.gd_edit_losses_fused(ctypes.byref(a), dt, _stream()), "gd_edit_losses_fused")
+    check(lib.gd_edit_losses_fwd(ctypes.byref(a), dt, _stream()), "gd_edit_losses_fwd")
     if running is not False:
         return out[0:5], out[5], out[6:11], out[11:12], aux, out[12]
     return out[0:5], out[5], out[6:11], out[11:12], aux
@@ -701,7 +721,7 @@ def removal_bwd_args(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, 
     a = GdRemovalBwd(Pe.data_ptr(), Pb.data_ptr(), q.data_ptr(), k.data_ptr(), rows.data_ptr(),
                      aux["p_in"].data_ptr(), aux["j_in"].data_ptr(), aux["p_wo"].data_ptr(), aux["j_wo"].data_ptr(), aux["wgt"].data_ptr(),
                      m_inp.data_ptr(), m_wo.data_ptr(), _ip(gscale), _ip(gscale2), _ip(n_valid), 0, ws.data_ptr(),
-                     float(coef), float(scale), H, R, N, M, Mpad, D)
+                     float(coef), float(scale), H, R, N, M, Mpad, D, 0)
     return a, ws
 
 
@@ -713,9 +733,9 @@ def edit_losses_bwd_rowdot(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coef
     blend = _gout_flag(gout, eo, blend, gout_tok)
     dro = torch.empty_like(ro)
     _need(coefs, "coefs", torch.float32)
-    check(lib.gd_edit_losses_bwd_rowdot(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), _p(gout), _p(coefs), _p(gscale),
-                                        int(blend), H, S, D, _p(dro), ctypes.byref(rm) if rm is not None else None, dt, _stream()),
-          "gd_edit_losses_bwd_rowdot")
+    check(lib.gd_edit_losses_bwd(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), _p(gout), _p(coefs), _p(gscale),
+                                 int(blend), H, S, D, _p(dro), ctypes.byref(rm) if rm is not None else None, dt, _stream()),
+          "gd_edit_losses_bwd")
     return dro
 
 
@@ -730,19 +750,19 @@ def attn_bwd_nofold(q, k, v, out, lse, dout, scale: float, need_dk: bool, dq_out
     BH, N, D = q.shape
     M = k.shape[1]
     dk = torch.empty(BH, M, D, dtype=torch.float32, device=q.device) if need_dk else None
-    nbytes = lib.gd_attn_bwd_workspace_bytes(BH, N, M, D, int(need_dk))
+    nbytes = lib.gd_attn_bwd_workspace_bytes(BH, N, M, D, int(need_dk), 0)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device) if nbytes else None
     kc = ctypes.c_int(0)
     part = ctypes.c_void_p(0)
-    check(lib.gd_attn_bwd_nofold(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), BH, N, M, D, scale, _p(dq_out), _p(dk), _p(ws), nbytes,
-                                 ctypes.byref(kc), ctypes.byref(part), dt, _stream()), "gd_attn_bwd_nofold")
+    check(lib.gd_attn_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), BH, N, M, D, scale, _p(dq_out), _p(dk), _p(ws), nbytes,
+                          ctypes.byref(kc), ctypes.byref(part), 0, dt, _stream()), "gd_attn_bwd (partials left)")
     return dk, int(kc.value), part.value, ws
 
 
 def removal_bwd_nofold(rm, dtype: torch.dtype):
     """The dS K products of the removal backward (row dots: edit_losses_bwd_rowdot; partials folded by edit_dq_fold)."""
     lib = _lib.load()
-    check(lib.gd_removal_bwd_nofold(ctypes.byref(rm), _DT[dtype], _stream()), "gd_removal_bwd_nofold")
+    check(lib.gd_removal_bwd(ctypes.byref(rm), None, None, _DT[dtype], _stream()), "gd_removal_bwd (products only)")
 
 
 def edit_dq_fold(dq_part_ptr, kchunks: int, BH: int, N: int, D: int, rm_ws, M: int, R: int, inp_pos, wgt, dq16):
@@ -862,7 +882,7 @@ def group_norm_nhwc_bwd(x, add_bc, gamma, beta, dy, groups: int, eps: float, sil
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     scratch = torch.empty_like(fwd_scratch)
     check(lib.gd_group_norm_nhwc_bwd(_p(x), _p(add_bc), _add_ld(add_bc, x, B, C), _p(gamma), _p(beta), _p(dy), B, H * W, C, groups, eps,
-                                     int(silu), _p(fwd_scratch), _p(scratch), _p(dx), dt, _stream()), "gd_group_norm_nhwc_bwd")
+                                     int(silu), GN_SINGLE_LAUNCH, _p(fwd_scratch), _p(scratch), _p(dx), dt, _stream()), "gd_group_norm_nhwc_bwd")
     return dx
 
 
@@ -876,8 +896,8 @@ def group_norm_nhwc(x, gamma, beta, groups: int, eps: float, silu: bool, add_bc=
     add_ld = _add_ld(add_bc, x, B, C)
     y = torch.empty_like(x, memory_format=torch.channels_last)
     scratch = torch.empty(int(lib.gd_group_norm_nhwc_scratch_floats(B, H * W, groups)), dtype=torch.float32, device=x.device)
-    check(lib.gd_group_norm_nhwc(_p(x), _p(add_bc), add_ld, _p(gamma), _p(beta), B, H * W, C, groups, eps, int(silu), _p(scratch), _p(y), dt,
-                                 _stream()), "gd_group_norm_nhwc")
+    check(lib.gd_group_norm_nhwc(_p(x), _p(add_bc), add_ld, _p(gamma), _p(beta), B, H * W, C, groups, eps, int(silu), GN_SINGLE_LAUNCH, _p(scratch), _p(y),
+                                 dt, _stream()), "gd_group_norm_nhwc")
     return (y, scratch) if return_scratch else y
 
 
@@ -987,8 +1007,10 @@ def conv3x3(x, w, bias=None, stride: int = 1, upsample: bool = False, res=None):
     if res is not None and (tuple(res.shape) != (n, K, Ho, Wo) or res.dtype != x.dtype or not res.is_contiguous(memory_format=torch.channels_last)):
         raise _lib.GeodiffError("conv3x3: res must be a channels_last tensor of the output's shape and dtype")
     out = torch.empty((n, K, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    nb = int(lib.gd_conv3x3_workspace_bytes(n, Ho, Wo, C, K))
+    c = CONV3X3_CFG
+    cfg = _lib.GdConv3x3Cfg(int(c["pi"]), int(c["ki"]), int(c["ksplit"]), int(c["dma"]))
+    nb = int(lib.gd_conv3x3_workspace_bytes(n, Ho, Wo, C, K, ctypes.byref(cfg)))
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
     check(lib.gd_conv3x3(x.data_ptr(), w.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, H, W, C, K, stride, int(bool(upsample)),
-                         _p(ws), nb, _DT[x.dtype], _stream()), "gd_conv3x3")
+                         ctypes.byref(cfg), _p(ws), nb, _DT[x.dtype], _stream()), "gd_conv3x3")
     return out

@@ -23,28 +23,41 @@ class softsplat_func(torch.autograd.Function):
         return ops.softsplat_bwd(tenIn, tenFlow, tenOutgrad.float().contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
 
 
+# mode -> how the per-pixel importance that travels with the features (as one extra channel) is formed; None: plain summation
+_WEIGHTING = {
+    "sum": None,
+    "avg": lambda metric, like: like.new_ones(like.shape[0], 1, *like.shape[2:]),
+    "linear": lambda metric, like: metric,
+    "soft": lambda metric, like: metric.exp(),
+}
+# suffix -> what keeps the division by the splatted importance finite
+_EPS = 1e-7
+_GUARD = {
+    "addeps": lambda z: z + _EPS,
+    "zeroeps": lambda z: z.masked_fill(z == 0.0, 1.0),
+    "clipeps": lambda z: z.clamp_min(_EPS),
+}
+
+
 def softsplat(tenIn: torch.Tensor, tenFlow: torch.Tensor, tenMetric, strMode: str):
-    base = strMode.split("-")[0]
-    assert base in ["sum", "avg", "linear", "soft"]
-    if strMode in ("sum", "avg"):
-        assert tenMetric is None
-    if base in ("linear", "soft"):
-        assert tenMetric is not None
-    if strMode == "avg":
-        tenIn = torch.cat([tenIn, tenIn.new_ones([tenIn.shape[0], 1, tenIn.shape[2], tenIn.shape[3]])], 1)
-    elif base == "linear":
-        tenIn = torch.cat([tenIn * tenMetric, tenMetric], 1)
-    elif base == "soft":
-        tenIn = torch.cat([tenIn * tenMetric.exp(), tenMetric.exp()], 1)
-    tenOut = softsplat_func.apply(tenIn, tenFlow)
-    if base in ("avg", "linear", "soft"):
-        tenNormalize = tenOut[:, -1:, :, :]
-        suffix = strMode.split("-")[1] if "-" in strMode else "addeps"
-        if suffix == "addeps":
-            tenNormalize = tenNormalize + 0.0000001
-        elif suffix == "zeroeps":
-            tenNormalize = torch.where(tenNormalize == 0.0, torch.ones_like(tenNormalize), tenNormalize)
-        elif suffix == "clipeps":
-            tenNormalize = tenNormalize.clip(0.0000001, None)
-        tenOut = tenOut[:, :-1, :, :] / tenNormalize
-    return tenOut
+    """Contract of U/softsplat.py:231-272: ``strMode`` = ``sum | avg | linear | soft`` with an optional ``-addeps | -zeroeps | -clipeps``
+    suffix (default addeps); ``sum`` / ``avg`` take no metric, ``linear`` / ``soft`` need one.  One splat launch carries the features
+    scaled by the importance and the importance itself; the quotient of the two is the normalised splat."""
+    mode, _, guard = strMode.partition("-")
+    if mode not in _WEIGHTING or (guard and guard not in _GUARD):
+        raise AssertionError(f"softsplat: unknown mode {strMode!r}")
+    needs_metric = mode in ("linear", "soft")
+    if needs_metric != (tenMetric is not None):
+        raise AssertionError(f"softsplat: mode {strMode!r} {'needs' if needs_metric else 'takes no'} metric")
+    weigh = _WEIGHTING[mode]
+    if weigh is None:
+        return softsplat_func.apply(tenIn, tenFlow)
+    if mode == "avg" and guard:
+        # the reference tests the FULL string for 'avg' (U/softsplat.py:243): with a suffix nothing is appended and the caller's own last
+        # channel is the importance
+        splatted = softsplat_func.apply(tenIn, tenFlow)
+    else:
+        importance = weigh(tenMetric, tenIn)
+        carried = tenIn if mode == "avg" else tenIn * importance
+        splatted = softsplat_func.apply(torch.cat([carried, importance], 1), tenFlow)
+    return splatted[:, :-1] / _GUARD[guard or "addeps"](splatted[:, -1:])

@@ -12,7 +12,13 @@
  *   - all buffers are CALLER-OWNED DEVICE pointers (e.g. torch Tensor.data_ptr()), contiguous in the
  *     documented layout; the library never allocates, never frees and never synchronises.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Calls are asynchronous,
- *     stateless and re-entrant per stream, and are safe to capture in a hipGraph.
+ *     stateless and re-entrant per stream, and are safe to capture in a hipGraph.  STATELESS means
+ *     it: there is no process-wide setting (ABI 5 removed the gd_*_set_* tuning hooks of ABI <= 4)
+ *     and the library reads no environment variable; whatever selects a kernel variant travels in
+ *     the call (gd_attn_cfg_t, gd_conv3x3_cfg_t, an int flag), NULL / -1 meaning "the launcher's
+ *     own choice".  Two controllers on two streams of one process can therefore differ.
+ *   - one entry point per operation: the fused launches of ABI 4 are the optional fields of the
+ *     same call (e.g. gd_edit_losses_fwd's tail, gd_attn_bwd's partials left for gd_edit_dq_fold).
  *   - `dtype` selects the 16-bit storage type of feature tensors: GD_F16 or GD_BF16 (GD_F32 where
  *     noted).  Accumulation is always binary32.
  */
@@ -26,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 4
+#define GD_ABI_VERSION 5
 
 enum { GD_F16 = 0, GD_BF16 = 1, GD_F32 = 2 };
 enum { GD_TOKEN_MAJOR = 0 /* [B, P, C] */, GD_CHANNEL_MAJOR = 1 /* [B, C, P] */ };
@@ -124,7 +130,7 @@ typedef struct {
      * out [bh, q_rows_len, D] / [B, q_rows_len, heads*D], lse [bh, q_rows_len]; list slots >= *q_rows_n are padding (computed on row
      * q_rows[i] but not stored; the list is padded so that launch dimensions repeat from edit to edit).  Use: the edit attention
      * with warped queries (U/attention_processors.py:424-428,544-549) differs from the reference row's attention only where the soft edit
-     * mask is non-zero (q*(1-m) + m*splat(q) == q for m == 0) — ~10 % of the rows; gd_rows_merge puts the two together. */
+     * mask is non-zero (q*(1-m) + m*splat(q) == q for m == 0) — ~10 % of the rows; gd_blend_merge puts the two together. */
     const int32_t* q_rows;     /* [q_rows_len] i32 row ids, or NULL */
     const int32_t* q_rows_n;   /* DEVICE int32[1]: number of wanted list entries */
     int32_t q_rows_len;
@@ -132,50 +138,46 @@ typedef struct {
 
 #define GD_ATTN_MAX_SEGS 4
 
-/* out = softmax(scale * q k^T) v for up to GD_ATTN_MAX_SEGS independent segments in ONE launch
- * (vanilla rows, edit_out with warped queries, replace_out) that share N, M, D.  D must be 64. */
-int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int dtype, void* stream);
+/* Per-call launch configuration of gd_attn_fwd (NULL = all defaults).  Replaces the process-wide gd_attn_fwd_set_even_split /
+ * gd_attn_fwd_set_config hooks of ABI <= 4 and the GD_ATTN_* environment variables the library used to read. */
+typedef struct gd_attn_cfg {
+    int32_t even_split;  /* even split of the key tiles over the resident workgroups (needs `workspace`): -1 / 1 = where the launcher's
+                            cost model says it pays (default), 0 = never, 2 = every launch that can be split */
+    int32_t qb, ks;      /* which software-pipelined kernel serves launches with full key tiles (M % 128 == 0): a workgroup of QB query
+                            blocks (32 rows each) x KS key ranges merged through LDS; (4,1), (2,2), (4,2), (2,4) exist, and (8,1) = the
+                            64-queries-per-wave kernel (256-query workgroups, one wave per SIMD, direct-to-LDS staging; M % 256 == 0).
+                            qb < 0: automatic (default), qb == 0: always the plain kernel */
+    int32_t nsplit;      /* > 1: split-KV — the keys cut into nsplit ranges handled by separate workgroups whose un-normalised partial
+                            results (O, reference max, row sum; f32) go through `workspace` (gd_attn_fwd_plan's size) and are merged by a
+                            second small kernel; same result up to f32 summation order.  0 / 1: off (default) */
+    int32_t handoff;     /* development: how the parts of an even split are handed over (0 = agent-scope release / acquire fences,
+                            1 = device-scope stores and loads, the default; 2 = no merge, TIMING ONLY, wrong outputs) */
+} gd_attn_cfg_t;
+#define GD_ATTN_CFG_DEFAULT {-1, -1, 0, 0, 1}
 
-/* out[h, n, :] = pos[n] >= 0 ? act[h, pos[n], :] : base[h, n, :]   (16-bit; base / out [H, N, D], act [H, R, D], pos [N] i32):
- * the full edit-attention output from the reference rows and the dense rows a q_rows segment computed (see gd_attn_seg_t.q_rows). */
-int gd_rows_merge(const void* base, const void* act, const int32_t* pos, int H, int N, int R, int D, void* out, int dtype, void* stream);
-
-/* gd_attn_fwd with the EVEN SPLIT of the key tiles over the resident workgroups (replaces the same reference lines as gd_attn_fwd:
- * U/attention_sharing.py:30-47 + torch.bmm at U/attention_processors.py:428,433,549,557,644,647).  A 64^2 launch of 20 heads is 640
- * units (head x 128-query tile) for 512 resident workgroups: 1.57 rounds; 5 heads fill 160 of 256 CUs.  With a workspace the launch's
- * units x key tiles are dealt out as one linear range, the same number of key tiles to every workgroup (launches of at most 128 units of
- * 256 queries — the 5-head inversion pass — instead cut every unit into 2-4 parts, one per workgroup); a unit that ends up in several
- * workgroups is merged (un-normalised O, reference, row sum in f32, fixed part order: bit-reproducible) by the workgroup that finishes
- * last.  workspace: gd_attn_fwd_workspace_bytes(sum of segment bh, N, M) bytes, 256-byte aligned, ZERO before its first use (arrival
- * counters; every launch leaves them zero), private to one stream at a time.  workspace == NULL, head dims other than 64, key counts
- * that are not a multiple of 256 and launches too short to split behave exactly like gd_attn_fwd.
- * gd_attn_fwd_set_even_split(0 = never, 1 = where the launcher's cost model says it pays (default), 2 = every launch that
- * can be split): tuning hook (benchmarks, tests; environment: GD_ATTN_EVEN_SPLIT).  Any other value returns GD_EINVAL (the
- * hand-off development modes 10-12 exist only for processes that set GD_ATTN_DEV_MODES=1: tools/bench_handoff.py). */
+/* out = softmax(scale * q k^T) v for up to GD_ATTN_MAX_SEGS independent segments in ONE launch (vanilla rows, edit_out with warped
+ * queries, replace_out) that share N, M, D; replaces U/attention_sharing.py:30-47 + torch.bmm at
+ * U/attention_processors.py:428,433,549,557,644,647.  D: 64, 128 or 192 (row lists, the even split and split-KV: 64 only).
+ *
+ * workspace (may be NULL): with cfg->nsplit <= 1 the EVEN SPLIT's scratch — gd_attn_fwd_workspace_bytes(sum of segment bh, N, M) bytes,
+ * 256-byte aligned, ZERO before its first use (arrival counters; every launch leaves them zero), private to one stream at a time.  A
+ * 64^2 launch of 20 heads is 640 units (head x 128-query tile) for 512 resident workgroups: 1.57 rounds; 5 heads fill 160 of 256 CUs.
+ * With the workspace the launch's units x key tiles are dealt out as one linear range, the same number of key tiles to every workgroup
+ * (launches of at most 128 units of 256 queries — the 5-head inversion pass — instead cut every unit into 2-4 parts, one per
+ * workgroup); a unit that ends up in several workgroups is merged (un-normalised O, reference, row sum in f32, fixed part order:
+ * bit-reproducible) by the workgroup that finishes last.  workspace == NULL, head dims other than 64, key counts that are not a
+ * multiple of 256 and launches too short to split run unsplit.  With cfg->nsplit > 1 the workspace is split-KV's (gd_attn_fwd_plan). */
 size_t gd_attn_fwd_workspace_bytes(int tot_bh, int N, int M);
-int gd_attn_fwd_ws(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, void* workspace, size_t workspace_bytes,
-                   int dtype, void* stream);
-int gd_attn_fwd_set_even_split(int on);
-
-/* Split-KV variant for launches that would leave most of the 256 CUs idle (e.g. the batch-1 inversion pass: 5 heads x 32 query
- * tiles = 160 workgroups): the keys are cut into nsplit ranges handled by separate workgroups, whose un-normalised partial results
- * (O, reference max, row sum; f32) go through `workspace` and are merged by a second small kernel.  Same result as gd_attn_fwd up to
- * f32 summation order.  gd_attn_fwd_plan returns the nsplit worth using for tot_bh = sum of segment bh (1 = do not split) and the
- * workspace size it needs. */
+/* the nsplit worth using for tot_bh = sum of segment bh (1 = do not split) and the workspace size split-KV needs for it */
 int gd_attn_fwd_plan(int tot_bh, int N, int M, size_t* workspace_bytes);
-
-/* Tuning hook (benchmarks / tests): which software-pipelined kernel gd_attn_fwd uses on launches with full key tiles
- * (M % 128 == 0): a workgroup of QB query blocks (32 rows each) x KS key ranges merged through LDS; (4,1), (2,2), (4,2), (2,4)
- * exist, and (8,1) = the 64-queries-per-wave kernel (256-query workgroups, one wave per SIMD, direct-to-LDS staging; bf16, M % 256 == 0).  qb < 0: automatic (default; also GD_ATTN_CFG="QBxKS" in the environment), qb == 0: always the plain kernel. */
-int gd_attn_fwd_set_config(int qb, int ks);
-int gd_attn_fwd_splitkv(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, int nsplit, void* workspace,
-                        size_t workspace_bytes, int dtype, void* stream);
+int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float scale, const gd_attn_cfg_t* cfg, void* workspace,
+                size_t workspace_bytes, int dtype, void* stream);
 
 /* Short-key launches (M <= 128: the 77-key text context of every cross-attention layer, the 8^2 self-attention layer) with the blend
  * of U/attention_processors.py:502-508,617-622 (remover: :831-834) inside the launch.  segs[0 .. nseg-2]: plain segments as
  * gd_attn_fwd; segs[nseg-1] is side A of ONE pair and `side_b` its side B (same bh / heads / layout; lse, row lists unsupported; its
  * `out` is ignored): segs[nseg-1].out = A*m + B*(1-m), A = attention(side A), B = attention(side B), both rounded to the tensor dtype
- * first and blended op by op like gd_blend_tokens — bit-identical to gd_attn_fwd over nseg + 1 segments followed by gd_blend_tokens.
+ * first and blended op by op like gd_blend_merge — bit-identical to gd_attn_fwd over nseg + 1 segments followed by gd_blend_merge.
  * blend_m [N] f32.  D = 64 only. */
 int gd_attn_fwd_pair(const gd_attn_seg_t* segs, int nseg, const gd_attn_seg_t* side_b, const float* blend_m, int N, int M, int D,
                      float scale, int dtype, void* stream);
@@ -183,16 +185,23 @@ int gd_attn_fwd_pair(const gd_attn_seg_t* segs, int nseg, const gd_attn_seg_t* s
 /*
  * Backward of out = softmax(scale q k^T) v w.r.t. q (always) and k (dk_f32 != NULL).
  *   dout [BH,N,D] 16-bit; lse from the forward; dq [BH,N,D] 16-bit (overwritten);
- *   dk_f32 [BH,M,D] f32, ACCUMULATED into (caller zeroes) — used by cross-attention where k_edit
- *   carries gradient (U/attention_processors.py:432).  v never receives gradient on this path
- *   (v_base.detach(), :433,557).  workspace: gd_attn_bwd_workspace_bytes() bytes (may be 0 -> NULL): per-chunk dK partials when
- *   dk_f32 != NULL, and f32 dQ partials per key range when a launch of few workgroups is split over the keys to fill the chip; both
- *   are summed in a fixed order, without atomics.  D: 64, 128 or 192.
+ *   dk_f32 [BH,M,D] f32 — used by cross-attention where k_edit carries gradient (U/attention_processors.py:432).  v never receives
+ *   gradient on this path (v_base.detach(), :433,557).  workspace: gd_attn_bwd_workspace_bytes() bytes (may be 0 -> NULL): per-chunk dK
+ *   partials when dk_f32 != NULL, and f32 dQ partials per key range when a launch of few workgroups is split over the keys to fill the
+ *   chip; both are summed in a fixed order, without atomics.  D: 64, 128 or 192.
+ * kchunks_out == NULL (and dq_part_out == NULL): the call is complete — dq is folded and rounded here, dk_f32 is ACCUMULATED into (the
+ *   caller zeroes it).
+ * kchunks_out != NULL (with dq_part_out): the dq partials of a split key range are LEFT in the workspace for gd_edit_dq_fold, which adds
+ *   the removal loss's contribution before the ONE rounding: *kchunks_out = number of runs, *dq_part_out = their address inside
+ *   `workspace` ([kchunks, BH, N, D] f32); kchunks == 1: dq (16-bit) was written directly.  dk_f32 is then OVERWRITTEN (0 + the sum: the
+ *   caller needs no fill launch).
+ * variant: 0 = the launcher's choice; 1 forces the register-staging dq kernel where the direct-to-LDS one would run (tests / benchmarks).
  */
-size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk);
+size_t gd_attn_bwd_workspace_bytes(int BH, int N, int M, int D, int need_dk, int variant);
 int gd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                 const void* dout, int BH, int N, int M, int D, float scale,
-                void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+                void* dq, float* dk_f32, void* workspace, size_t workspace_bytes, int* kchunks_out, float** dq_part_out,
+                int variant, int dtype, void* stream);
 
 /* dK and dV of out = softmax(scale q k^T) v for ANY key count (with gd_attn_bwd's dq the full backward of vanilla attention).
  *   dk_f32, dv_f32 [BH,M,D] f32, ACCUMULATED into (caller zeroes); per-chunk partials go through `workspace`
@@ -207,11 +216,17 @@ int gd_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* out
 /* P[bh, r, m] = exp(scale * q[bh, rows[r]] . k[bh, m] - lse[bh, rows[r]])   (rows == NULL: r = row)
  * The opt-pass materialisation of base_att / replace_att rows that removal_loss_geodiff consumes
  * (U/attention_processors.py:250, 307-317).  P is 16-bit [BH, R, Mpad], Mpad = multiple of 8 >= M,
- * padding columns are written as 0.  n_valid_dev (DEVICE int32[1], may be NULL = R): only rows[0 .. n_valid) are wanted — the rest of
+ * padding columns are written as 0.  n_valid (DEVICE int32[1], may be NULL = R): only rows[0 .. n_valid) are wanted — the rest of
  * the list is padding that keeps launch dimensions identical across edits; 128-row tiles made of padding only are skipped (their P
- * rows stay unwritten and are not read by gd_removal_corr_max / gd_removal_bwd given the same n_valid_dev).  D: 64, 128 or 192. */
-int gd_attn_probs(const void* q, const void* k, const float* lse, const int32_t* rows, const int32_t* n_valid_dev,
-                  int BH, int N, int R, int M, int Mpad, int D, float scale, void* P, int dtype, void* stream);
+ * rows stay unwritten and are not read by gd_removal_corr_max / gd_removal_bwd given the same n_valid).  D: 64, 128 or 192.
+ * ONE or TWO problems per launch (b may be NULL; a hooked layer needs the base map and the inpaint rows of the edit map) + an optional
+ * clear of zero_bytes bytes (multiple of 16) at zero_ptr — the `best` scratch of gd_removal_corr_max, which this launch precedes. */
+typedef struct gd_probs {
+    const void* q; const void* k; const float* lse; const int32_t* rows; const int32_t* n_valid; void* P;
+    int32_t BH, N, R, M, Mpad;
+} gd_probs_t;
+int gd_attn_probs(const gd_probs_t* a, const gd_probs_t* b, int D, float scale, void* zero_ptr, size_t zero_bytes, int dtype,
+                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) attention forward on the block-scaled K = 64 matrix instruction — opt-in, no-grad passes only (BASELINE configs[4]).
@@ -245,12 +260,15 @@ int gd_attn_fwd_fp8(const void* q8, const void* k8, const void* vt8, const float
  * removal_loss_geodiff forward (U/attention_processors.py:248-268):
  *   corr[h,r,j] = sum_m Pe[h,r,m] * Pb[h,j,m];  (p_in,j_in) = max_j corr*m_inp[j];  (p_wo,j_wo) = max_j corr*m_wo[j]
  * Pe [H,R,Mpad], Pb [H,N,Mpad] 16-bit (gd_attn_probs); m_inp, m_wo [N] f32.
- * best [H,R,2] u64 scratch: (value bits << 32 | ~j) for the inpaint / wo-edit mask (first index wins ties);
- * it is cleared by the call and unpacked by gd_removal_loss_reduce.  n_valid_dev (DEVICE int32[1] or NULL): 128-row tiles of Pe at or
- * beyond n_valid are padding and are skipped (their `best` stays 0).
+ * best [H,R,2] u64 scratch: (value bits << 32 | ~j) for the inpaint / wo-edit mask (first index wins ties); unpacked by
+ * gd_removal_loss_reduce / gd_edit_losses_fwd's tail.  clear != 0: the call zeroes it first; clear == 0: the caller did
+ * (gd_attn_probs's zero_ptr, which precedes this launch in a hooked layer).  n_valid_dev (DEVICE int32[1] or NULL): 128-row tiles of
+ * Pe at or beyond n_valid are padding and are skipped (their `best` stays 0).
+ * variant: 0 = the launcher's choice; tests / benchmarks force a kernel with 1 (the general vector-pipe kernel), 22 or 24 (the MFMA
+ * kernel on 2 x 2 / 2 x 4 tiles; falls back to the choice where the shape does not fit).  All variants give identical bits.
  */
 int gd_removal_corr_max(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
-                        int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream);
+                        int H, int R, int N, int Mpad, unsigned long long* best, int clear, int variant, int dtype, void* stream);
 
 /* Unpacks best -> p_in,p_wo [H,R] f32, j_in,j_wo [H,R] i32, writes wgt[h,r] = exp(-dist(rows[r], j_wo)) and
  * loss_acc[0] += sum_{h,r} wgt * (-log(p_wo+1e-4) + log(p_in+1e-4))      (U/attention_processors.py:262-268).
@@ -266,17 +284,27 @@ int gd_removal_loss_reduce(const unsigned long long* best, const int32_t* rows, 
  * Backward of the removal loss through replace_att rows into q (and k for cross):
  *   dA[h,r,m] = coef * wgt[h,r] * ( -Pb[h,j_wo,m] * m_wo[j_wo]/(p_wo+1e-4) + Pb[h,j_in,m] * m_inp[j_in]/(p_in+1e-4) )
  *   dS = A o (dA - rowsum(A o dA));  dq[h,rows[r]] += scale * dS K;  dk_f32[h] += scale * dS^T q   (dk_f32 may be NULL)
- * dq_f32 [H,N,D] f32 accumulated (caller zeroes).  ds_ws: scratch of gd_removal_bwd_workspace_bytes() bytes (row dots, per-key-chunk dq partials that are folded in a fixed order — no f32 atomics, bit-reproducible — and dS when dk_f32 != NULL).  gscale_dev: optional DEVICE scalar multiplied into coef (the
- * upstream gradient of the loss, so that no host sync is needed to read it).  n_valid_dev (DEVICE int32[1] or NULL): slots
- * [n_valid, R) of the row list are padding and are skipped.  dq16_inout (may be NULL): a 16-bit [H,N,D] gradient the contribution is
- * added to in place, element = T(float(element) + contribution) (dq_f32 may then be NULL).
+ * coef is multiplied by the optional DEVICE scalars gscale[0] and gscale2[0] (upstream gradient of the loss and the loss weight: no host
+ * sync to read them).  n_valid (DEVICE int32[1] or NULL): slots [n_valid, R) of the row list are padding and are skipped.
+ * workspace: gd_removal_bwd_workspace_bytes(H, R, M, Mpad, D, dk_f32 != NULL) bytes — row dots [H*R], per-key-chunk dq partials
+ * [msplit, H, R, D] folded in a fixed order (no f32 atomics, bit-reproducible), and dS when dk_f32 != NULL.
+ * dq_f32 [H,N,D] f32 accumulated (caller zeroes) and / or dq16_inout, a 16-bit [H,N,D] gradient the contribution is added to in place
+ * (element = T(float(element) + contribution)): the COMPLETE backward (row dots, products, fold).
+ * dq_f32 == NULL and dq16_inout == NULL: the dS K products only — the row dots were computed by gd_edit_losses_bwd (its `rm` argument)
+ * into rm->workspace, and gd_edit_dq_fold folds the partials together with the attention backward's (ONE rounding of dq instead of two).
  */
+typedef struct gd_removal_bwd {
+    const void* Pe; const void* Pb; const void* q; const void* k; const int32_t* rows;
+    const float* p_in; const int32_t* j_in; const float* p_wo; const int32_t* j_wo; const float* wgt;
+    const float* m_inp; const float* m_wo; const float* gscale; const float* gscale2;
+    const int32_t* n_valid;
+    float* dk_f32; float* workspace;
+    float coef, scale;
+    int32_t H, R, N, M, Mpad, D;
+    int32_t variant;   /* 0 = the launcher's choice; 1 forces the general kernel where the MFMA one would run (tests / benchmarks) */
+} gd_removal_bwd_t;
 size_t gd_removal_bwd_workspace_bytes(int H, int R, int M, int Mpad, int D, int need_dk);
-int gd_removal_bwd(const void* Pe, const void* Pb, const void* q, const void* k, const int32_t* rows,
-                   const float* p_in, const int32_t* j_in, const float* p_wo, const int32_t* j_wo,
-                   const float* wgt, const float* m_inp, const float* m_wo, float coef, const float* gscale_dev,
-                   const int32_t* n_valid_dev, int H, int R, int N, int M, int Mpad, int D, float scale,
-                   float* dq_f32, float* dk_f32, float* ds_ws, void* dq16_inout, int dtype, void* stream);
+int gd_removal_bwd(const gd_removal_bwd_t* rm, float* dq_f32, void* dq16_inout, int dtype, void* stream);
 
 /*
  * The mask-only half of interpolate_from_mask (U/attention_sharing.py:81-83,103), once per edit and resolution:
@@ -301,17 +329,35 @@ int gd_amodal_target(const void* eo, const int32_t* nn_idx, const float* nn_w, c
  * sums[3] += sum |ro[y+1]-ro[y]|   sums[4] += sum |ro[x+1]-ro[x]|      (tgt/w_am/m_amodal may be NULL)
  * Bit-reproducible: per-workgroup partials go through `workspace` (gd_edit_losses_fwd_workspace_bytes) and are folded in a
  * fixed order — no floating-point atomics.
+ *
+ * wv == NULL: the reductions only — out12[0..4] += the five sums (the caller zeroes them; two launches: partials, fold); best / ticket /
+ * the running sums unused.
+ * wv != NULL: ONE launch for everything between the attention outputs and the backward of a hooked layer — the workgroup that finishes
+ * last (an arrival ticket, agent-scope release / acquire) unpacks `best` like gd_removal_loss_reduce (best == NULL: no removal term,
+ * rm = 0), folds the partials in the same order and does gd_loss_assemble's arithmetic:
+ *   t = sums * inv5; terms = [t0, t1, rm * inv_rm, t3 + t4, use_amodal ? t2 : t1 * 0]; loss = sum terms_i * wv_i;
+ *   coefs = wv[{0,1,4,3,3}] * inv5_bwd (what gd_edit_losses_bwd reads); rm_coef = wv[2] * inv_rm
+ *   out12 = terms[0:5], loss[5], coefs[6:11], rm_coef[11]; every operand is device f32 (inv5 / wv / inv5_bwd: 5 entries; inv_rm: 1)
+ * and the controller's running sums (each may be NULL): log_acc[k] += terms[k] for the four logged terms (sim, movement, removal,
+ * smoothness: generic.py:34-39) and loss_out[0] = (loss_in ? loss_in[0] : 0) + loss (U/attention_processors.py:494,604
+ * `self.loss = self.loss + loss`) — plain f32 adds in layer order, as the 0-d torch adds were.
+ * ticket: ONE int32, zero before the launch, left zero by it.
  */
-/* The scalar arithmetic between the loss reductions and the backward of a hooked layer in one launch (U/attention_processors.py:231-305,
- * 479-480,596-597): t = sums * inv5; terms = [t0, t1, rm * inv_rm, t3 + t4, use_amodal ? t2 : t1 * 0]; loss = sum terms_i * wv_i;
- * coefs = wv[{0,1,4,3,3}] * inv5_bwd (what gd_edit_losses_bwd reads); rm_coef = wv[2] * inv_rm.  out12 = terms[0:5], loss[5], coefs[6:11],
- * rm_coef[11]; every operand is device f32 (sums / inv5 / wv / inv5_bwd: 5 entries; rm / inv_rm: 1). */
+typedef struct gd_edit_losses {
+    const void* eo; const void* ro; const float* tgt; const float* m_wo; const float* m_edit; const float* w_am; const float* m_amodal;
+    const unsigned long long* best; const int32_t* rows; const int32_t* n_valid;
+    float* p_in; int32_t* j_in; float* p_wo; int32_t* j_wo; float* wgt;
+    const float* inv5; const float* inv_rm; const float* wv; const float* inv5_bwd;
+    float* out12; float* workspace; int32_t* ticket;
+    float* log_acc; const float* loss_in; float* loss_out;
+    int32_t H, S, D, R, use_amodal;
+} gd_edit_losses_t;
+size_t gd_edit_losses_fwd_workspace_bytes(int H, int S, int D);
+int gd_edit_losses_fwd(const gd_edit_losses_t* a, int dtype, void* stream);
+/* The stand-alone stage of that tail (callers that ran the reductions with wv == NULL and gd_removal_loss_reduce themselves):
+ * sums / rm -> out12 as above. */
 int gd_loss_assemble(const float* sums, const float* rm, const float* inv5, const float* inv_rm, const float* wv, const float* inv5_bwd,
                      int use_amodal, float* out12, void* stream);
-size_t gd_edit_losses_fwd_workspace_bytes(int H, int S, int D);
-int gd_edit_losses_fwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
-                       const float* w_am, const float* m_amodal, int H, int S, int D, float* sums, float* workspace,
-                       int dtype, void* stream);
 
 /*
  * d(loss)/d(ro) for the weighted sum of those losses plus the blend path:
@@ -320,92 +366,31 @@ int gd_edit_losses_fwd(const void* eo, const void* ro, const float* tgt, const f
  * coef_dev: c[5] f32 in DEVICE memory (loss weight / denominator; on the device so that a captured hipGraph of the
  * optimisation pass follows the adaptive weight schedule without re-capture), all multiplied by the optional DEVICE
  * scalar gscale_dev[0] (upstream gradient of the loss); gout [H,N,D] 16-bit (may be NULL);
- * dro [H,N,D] 16-bit.  `blend`: bit 0 = the blend factor above; bit 1 (ABI 4) = gout is the token-major row [N, H*D] of the layer's
+ * dro [H,N,D] 16-bit.  `blend`: bit 0 = the blend factor above; bit 1 = gout is the token-major row [N, H*D] of the layer's
  * output gradient (batch_to_head_dim's autograd, U/attention_processors.py:213, read in place instead of a permuted copy).
+ * rm (may be NULL): the same launch also computes the row dots sum_m A dA of the removal loss's backward into rm->workspace
+ * (independent work, one launch less; see gd_removal_bwd).
  */
 int gd_edit_losses_bwd(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
                        const float* w_am, const float* m_amodal, const void* gout, const float* coef_dev, const float* gscale_dev,
-                       int blend, int H, int S, int D, void* dro, int dtype, void* stream);
+                       int blend, int H, int S, int D, void* dro, const gd_removal_bwd_t* rm, int dtype, void* stream);
 
-/* out = a*m + b*(1-m) per token (U/attention_processors.py:504,619); m [N] f32; a,b,out [H,N,D]. */
-int gd_blend_tokens(const void* a, const void* b, const float* m, int H, int N, int D, void* out, int dtype, void* stream);
-
-/* ------------------------------------------------------------------------------------------------
- * R6-R9  fused launches of ONE hooked optimisation-pass layer (ABI 4).  The stand-alone entry points above stay; these run the same
- * arithmetic in the same summation order (results identical bit for bit) in fewer launches: a lossy self-attention layer went from
- * ~20 launches to 12 (forward 13 -> 7: attention, merge + blend, both probability maps + the clear of `best`, correlation, amodal
- * target x 2, losses with the reduce / fold / assemble tail; backward 6 -> 4: losses backward + row dots, dq, removal backward, fold).
- * ---------------------------------------------------------------------------------------------- */
-
-/* gd_rows_merge + gd_blend_tokens in one pass (U/attention_processors.py:424-428,502-508,544-549,617-622):
+/* The edit row's output assembly in one pass (U/attention_processors.py:424-428,502-508,544-549,617-622):
  *   e[h,n]   = (act != NULL && pos[n] >= 0) ? act[h, pos[n]] : base[h,n]          (the full edit_out: rows outside the soft edit mask
  *                                                                                    are the reference rows' outputs, gd_attn_seg_t.q_rows)
  *   eo_out   = e                                     (may be NULL)
- *   out      = e*m + ro*(1-m), op by op in the tensor dtype like gd_blend_tokens   (may be NULL; then ro / m may be NULL)
- * base, ro, eo_out, out [H,N,D]; act [H,R,D]; pos [N] i32; m [N] f32; D % 8 == 0. */
+ *   out      = e*m + ro*(1-m), op by op in the tensor dtype as torch evaluates it on 16-bit tensors   (may be NULL; then ro / m may be NULL)
+ * base, ro, eo_out, out [H,N,D]; act [H,R,D]; pos [N] i32; m [N] f32; D % 8 == 0.  act == NULL: the plain blend of :504,619;
+ * out == NULL: the plain row merge. */
 int gd_blend_merge(const void* base, const void* act, const int32_t* pos, const void* ro, const float* m, int H, int N, int R, int D,
                    void* eo_out, void* out, int dtype, void* stream);
 
-/* Two gd_attn_probs problems in one launch (the base map and the inpaint rows of the edit map of one layer) + an optional clear of
- * zero_bytes bytes (multiple of 16) at zero_ptr — the `best` scratch of gd_removal_corr_max_nz, which this launch precedes. */
-typedef struct gd_probs {
-    const void* q; const void* k; const float* lse; const int32_t* rows; const int32_t* n_valid; void* P;
-    int32_t BH, N, R, M, Mpad;
-} gd_probs_t;
-int gd_attn_probs_pair(const gd_probs_t* a, const gd_probs_t* b, int D, float scale, void* zero_ptr, size_t zero_bytes, int dtype,
-                       void* stream);
-
-/* gd_removal_corr_max without the clear of `best` (the caller cleared it: gd_attn_probs_pair's zero_ptr). */
-int gd_removal_corr_max_nz(const void* Pe, const void* Pb, const float* m_inp, const float* m_wo, const int32_t* n_valid_dev,
-                           int H, int R, int N, int Mpad, unsigned long long* best, int dtype, void* stream);
-
-/* gd_edit_losses_fwd + gd_removal_loss_reduce + the fold + gd_loss_assemble in ONE launch: the workgroup that finishes last (an
- * arrival ticket, agent-scope release / acquire) unpacks `best` (best == NULL: no removal term, rm = 0), folds the per-workgroup
- * partials of the five sums in the stand-alone kernels' order and writes out12 (gd_loss_assemble's layout).
- * workspace: gd_edit_losses_fwd_workspace_bytes(H, S, D) bytes; ticket: ONE int32, zero before the launch, left zero by it. */
-typedef struct gd_edit_losses {
-    const void* eo; const void* ro; const float* tgt; const float* m_wo; const float* m_edit; const float* w_am; const float* m_amodal;
-    const unsigned long long* best; const int32_t* rows; const int32_t* n_valid;
-    float* p_in; int32_t* j_in; float* p_wo; int32_t* j_wo; float* wgt;
-    const float* inv5; const float* inv_rm; const float* wv; const float* inv5_bwd;
-    float* out12; float* workspace; int32_t* ticket;
-    /* the controller's running sums, updated by the same tail (each may be NULL): log_acc[k] += terms[k] for the four logged terms
-     * (sim, movement, removal, smoothness: generic.py:34-39) and loss_out[0] = (loss_in ? loss_in[0] : 0) + loss
-     * (U/attention_processors.py:494,604 `self.loss = self.loss + loss`) — plain f32 adds in layer order, as the 0-d torch adds were */
-    float* log_acc; const float* loss_in; float* loss_out;
-    int32_t H, S, D, R, use_amodal;
-} gd_edit_losses_t;
-int gd_edit_losses_fused(const gd_edit_losses_t* a, int dtype, void* stream);
-
-/* The removal loss's backward, split so that its pieces can share launches with the rest of the layer's backward:
- *   gd_edit_losses_bwd_rowdot : gd_edit_losses_bwd's grid + the row dots sum_m A dA of the removal backward (rm == NULL: plain
- *                               gd_edit_losses_bwd);
- *   gd_removal_bwd_nofold     : the dS K products only — per-key-chunk partials left in rm->workspace (+ dk_f32 as gd_removal_bwd);
- *   gd_edit_dq_fold           : dq16[h,n,:] = T( sum_c dq_part[c][h,n,:]  (+ sum_c removal partials of row n, if n is a live inpaint row) ),
- *                               ONE rounding (gd_attn_bwd + gd_removal_bwd round twice).
- * workspace: gd_removal_bwd_workspace_bytes(H, R, M, Mpad, D, dk_f32 != NULL) bytes; the fields mean what gd_removal_bwd's arguments mean. */
-typedef struct gd_removal_bwd {
-    const void* Pe; const void* Pb; const void* q; const void* k; const int32_t* rows;
-    const float* p_in; const int32_t* j_in; const float* p_wo; const int32_t* j_wo; const float* wgt;
-    const float* m_inp; const float* m_wo; const float* gscale; const float* gscale2 /* second optional device factor of coef */;
-    const int32_t* n_valid;
-    float* dk_f32; float* workspace;
-    float coef, scale;
-    int32_t H, R, N, M, Mpad, D;
-} gd_removal_bwd_t;
-int gd_edit_losses_bwd_rowdot(const void* eo, const void* ro, const float* tgt, const float* m_wo, const float* m_edit,
-                              const float* w_am, const float* m_amodal, const void* gout, const float* coef_dev, const float* gscale_dev,
-                              int blend, int H, int S, int D, void* dro, const gd_removal_bwd_t* rm, int dtype, void* stream);
-int gd_removal_bwd_nofold(const gd_removal_bwd_t* rm, int dtype, void* stream);
-/* gd_attn_bwd that leaves the dq kernel's per-key-run partials in the workspace when it splits the key range: *kchunks_out = number of
- * runs, *dq_part_out = their address inside `workspace` ([kchunks, BH, N, D] f32).  kchunks == 1: dq (16-bit) was written directly.
- * dk_f32 is OVERWRITTEN here (0 + the sum, i.e. what gd_attn_bwd leaves in a zeroed buffer): the caller needs no fill launch. */
-int gd_attn_bwd_nofold(const void* q, const void* k, const void* v, const void* out, const float* lse, const void* dout,
-                       int BH, int N, int M, int D, float scale, void* dq, float* dk_f32, void* workspace, size_t workspace_bytes,
-                       int* kchunks_out, float** dq_part_out, int dtype, void* stream);
-/* inp_pos [N] i32: slot of row n in the inpaint-row list or -1; rm_workspace: the removal backward's workspace (its partials
- * [msplit, H, R, D] f32 start H*R floats in, as gd_removal_bwd lays them out), NULL = none.  dq_part == NULL (kchunks == 1: the dq kernel
- * wrote dq16 directly): only the live inpaint rows are touched, dq16 = T(float(dq16) + removal contribution) like gd_removal_bwd. */
+/* The last launch of a hooked layer's backward: dq16[h,n,:] = T( sum_c dq_part[c][h,n,:]  (+ sum_c removal partials of row n, if n is
+ * a live inpaint row) ) — ONE rounding (a complete gd_attn_bwd followed by a complete gd_removal_bwd rounds twice).
+ * dq_part / kchunks: what gd_attn_bwd left (kchunks_out / dq_part_out).  inp_pos [N] i32: slot of row n in the inpaint-row list or -1;
+ * rm_workspace: the removal backward's workspace (its partials [msplit, H, R, D] f32 start H*R floats in), NULL = none.
+ * dq_part == NULL (kchunks == 1: the dq kernel wrote dq16 directly): only the live inpaint rows are touched,
+ * dq16 = T(float(dq16) + removal contribution). */
 int gd_edit_dq_fold(const float* dq_part, int kchunks, int BH, int N, int D, const float* rm_workspace, int M, int R,
                     const int32_t* inp_pos, const float* wgt, void* dq16, int dtype, void* stream);
 
@@ -464,17 +449,16 @@ int gd_norm_rescale(const float* x, const float* num_sumsq, const float* den_sum
  * (norm of x + add_bc[b,c]: the ResNet block's time-embedding add), gamma/beta [C];
  * scratch: gd_group_norm_nhwc_scratch_floats(B, HW, G) f32 (no need to clear). */
 int64_t gd_group_norm_nhwc_scratch_floats(int B, int HW, int G);
-/* Small maps (HW * C/G * 2 B <= 40 KB per (batch entry, group): the 8^2 / 16^2 levels and the narrow 32^2 norms) take ONE launch; 0 forces the two-launch
- * form everywhere (benchmarks / tests compare both). */
-int gd_group_norm_set_single_launch(int on);
+/* Small maps (HW * C/G * 2 B <= 40 KB per (batch entry, group): the 8^2 / 16^2 levels and the narrow 32^2 norms) take ONE launch.
+ * single_launch: -1 = that rule (default), 0 = the two-launch form everywhere (benchmarks / tests compare both), 1 = as -1. */
 int gd_group_norm_nhwc(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
-                       int silu, float* scratch, void* y, int dtype, void* stream);
+                       int silu, int single_launch, float* scratch, void* y, int dtype, void* stream);
 
 /* dx of the above for frozen gamma / beta (the optimisation pass differentiates w.r.t. activations only): x, add_bc, gamma, beta as in
  * the forward, dy and dx [B, HW, C]; fwd_scratch = the forward call's scratch (its slab moments give mean / rstd); scratch: same size. */
 int gd_group_norm_nhwc_bwd(const void* x, const void* add_bc, int add_ld, const void* gamma, const void* beta, const void* dy,
-                           int B, int HW, int C, int G, float eps, int silu, const float* fwd_scratch, float* scratch, void* dx,
-                           int dtype, void* stream);
+                           int B, int HW, int C, int G, float eps, int silu, int single_launch, const float* fwd_scratch, float* scratch,
+                           void* dx, int dtype, void* stream);
 
 /* y = x + bias[c] (+ res): convolution epilogue; x, res, y [rows, C]; bias [C]; res may be NULL. */
 int gd_bias_residual(const void* x, const void* bias, const void* res, int64_t rows, int C, void* y, int dtype, void* stream);
@@ -503,14 +487,18 @@ int gd_add_layer_norm(const void* a, const void* b, const void* gamma, const voi
  * (GD_EUNSUPPORTED otherwise: the caller keeps its library convolution for conv_in / conv_out).  Accumulation in f32 over
  * (ky, kx, c) in that order, one rounding at the end; launches that cannot fill the chip split the reduction and fold the f32
  * partials in a fixed order (deterministic) through `workspace` (gd_conv3x3_workspace_bytes; 0 = no split).
- * gd_conv3x3_set_config(PI, KI, ksplit) forces the tile shape (64 PI pixels x 64 KI channels) / split for tuning; PI <= 0: heuristic.
+ * cfg (NULL = the launcher's heuristics): per-call tuning, replacing the process-wide hooks of ABI <= 4.
  * ---------------------------------------------------------------------------------------------- */
-size_t gd_conv3x3_workspace_bytes(int n, int Ho, int Wo, int C, int K);
+typedef struct gd_conv3x3_cfg {
+    int32_t pi, ki, ksplit;   /* force the tile shape (64 PI pixels x 64 KI channels; PI, KI in {1, 2}) and the reduction split (1..64);
+                                 pi <= 0: heuristic */
+    int32_t dma;              /* -1 / 1: stage the operand tiles with direct-to-LDS loads (buffer_load ... lds) where three LDS stages fit
+                                 (default), 0: registers + ds_write (same results) */
+} gd_conv3x3_cfg_t;
+#define GD_CONV3X3_CFG_DEFAULT {0, 0, 0, -1}
+size_t gd_conv3x3_workspace_bytes(int n, int Ho, int Wo, int C, int K, const gd_conv3x3_cfg_t* cfg);
 int gd_conv3x3(const void* in, const void* w, const void* bias, const void* residual, void* out, int n, int Hi, int Wi, int C, int K, int stride,
-               int upsample, void* workspace, size_t workspace_bytes, int dtype, void* stream);
-int gd_conv3x3_set_config(int pi, int ki, int ksplit);
-/* 1: stage the operand tiles with direct-to-LDS loads (buffer_load ... lds) instead of registers + ds_write (same results). */
-int gd_conv3x3_set_dma(int on);
+               int upsample, const gd_conv3x3_cfg_t* cfg, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * N2  post-process: masked per-channel histogram matching (GeoDiffuser/utils/image_processing.py:24-77).

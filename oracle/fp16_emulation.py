@@ -57,6 +57,64 @@ def emulate_16bit(dtype):
     return prepare
 
 
+class round_every_op:
+    """A model HELD in 16 bits rounds more often than `emulate_16bit` does: not only what its conv / linear / norm modules return, but the
+    result of every element-wise operation between them (residual sums, the time-embedding add, the GEGLU product, the attention
+    output) — and the same in the backward.  Context manager: every aten operation's floating-point result is rounded through `dtype`
+    (views alias rounded storage and are left alone; in-place results are rounded in place), EXCEPT inside the controller's forward
+    (`paused()`: the reference's own attention / loss arithmetic, which the device path runs inside fp32 kernels).  fp32 accumulation
+    inside an operation is kept, as on the device.  Used for the `emulated_*_every_op` yardsticks."""
+
+    def __init__(self, dtype):
+        from torch.utils._python_dispatch import TorchDispatchMode
+        from torch.utils._pytree import tree_map
+        outer = self
+        self.off = 0
+
+        class Mode(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                out = func(*args, **(kwargs or {}))
+                if outer.off:
+                    return out
+                rets = func._schema.returns
+                aliases = [r.alias_info for r in rets]
+
+                def fix(t, info):
+                    if not (torch.is_tensor(t) and t.dtype == torch.float32):
+                        return t
+                    if info is None:
+                        return t.to(dtype).to(torch.float32)
+                    if info.is_write:                      # in-place / out= result: round the storage the caller keeps
+                        t.copy_(t.to(dtype).to(torch.float32))
+                    return t                               # a view: its source has been rounded
+                if isinstance(out, (tuple, list)):
+                    return type(out)(fix(t, aliases[i] if i < len(aliases) else None) for i, t in enumerate(out))
+                return fix(out, aliases[0] if aliases else None)
+
+        self.mode = Mode()
+
+    def __enter__(self):
+        self.mode.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self.mode.__exit__(*exc)
+
+    def pause_in(self, obj, name):
+        """Wrap obj.<name> so that nothing is rounded while it runs (forward only: its backward is rounded like every other op)."""
+        orig = getattr(obj, name)
+        outer = self
+
+        def wrapped(*a, **k):
+            outer.off += 1
+            try:
+                return orig(*a, **k)
+            finally:
+                outer.off -= 1
+        setattr(obj, name, wrapped)
+        return orig
+
+
 class controller_16bit:
     """Also round what the reference's controllers keep in 16 bits on its own GPU path (autocast): the attention probabilities that
     feed torch.bmm — attn @ v and the removal loss's correlation (U/attention_processors.py:250-252,428,433) — by wrapping
@@ -141,36 +199,77 @@ def main():
         print("v-prediction remover loop: ideal 16-bit storage vs fp32 (oracle loop):", out["vpred_remover_loop"])
         json.dump(out, open(path, "w"), indent=1)
         return
-    for flag, fixture, cfg in (("--g18-only", "G18_loop", cases.LOOP), ("--g19-only", "G19_loop_remover", cases.LOOP),
-                               ("--g20-only", "G20_loop_cfg0", cases.LOOP_CFG0),
-                               ("--g21-only", "G21_loop_cfg0_full", cases.LOOP_CFG0), ("--g22-only", "G22_loop_cfg1_full", cases.LOOP_CFG1),
-                               ("--g23-only", "G23_loop_sd14", cases.LOOP), ("--g26-only", "G26_loop_remover_full", cases.LOOP),
-                               ("--g27-only", "G27_loop_sdxl", cases.LOOP_SDXL), ("--g28-only", "G28_loop_cfg1_t50", cases.LOOP_CFG1_T50),
-                               ("--g29-only", "G29_loop_remover768_t75", cases.LOOP_REM768_T75)):
-        if flag in sys.argv:                       # the full-width loops (fixtures G21 / G22): add / refresh that entry only
-            torch.set_num_threads(int(os.environ.get("GD_GEN_THREADS", "8")))
-            R = ref_import.import_reference()
-            out = json.load(open(path))
-            g = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
-            ref, up32 = torch.from_numpy(g["latents"]), torch.from_numpy(g["first_update"])
-            e = out.get(fixture, {})
+    # `--only <fixture>` (or the historical `--g22-only` spelling): add / refresh the entry of ONE loop fixture of gen_golden.LOOP_FIXTURES.
+    # `--env-floor`: instead of the 16-bit emulations, re-run the fp32 driver under ANOTHER BLAS thread partition (4 threads instead of the
+    # generator's 8) and record how far the reference's own fp32 result moves (`fp32_other_partition`): the cross-environment floor of the
+    # fixture, which the loop tests take the maximum with.
+    only = None
+    if "--only" in sys.argv:
+        only = sys.argv[sys.argv.index("--only") + 1]
+    for name in gen_golden.LOOP_FIXTURES:
+        if "--" + name.split("_")[0].lower() + "-only" in sys.argv:
+            only = name
+    if only is not None:
+        short = {n.split("_")[0]: n for n in gen_golden.LOOP_FIXTURES}
+        fixture = short.get(only, only)
+        kind, cfgname, kw, _ = gen_golden.LOOP_FIXTURES[fixture]
+        cfg = getattr(cases, cfgname)
+        kw = {k: v for k, v in kw.items() if k in ("tiny", "sd14", "sdxl")}
+        R = ref_import.import_reference()
+        out = json.load(open(path))
+        g = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
+        ref, up32 = torch.from_numpy(g["latents"]), torch.from_numpy(g["first_update"])
+        e = out.get(fixture, {})
+        if "--env-floor" in sys.argv:
+            torch.set_num_threads(4)
+            lat, log, ce, _ = gen_golden.run_reference_loop(R, kind, cfg, **kw)
+            e["fp32_other_partition"] = rel_l2(lat[-1:], ref[-1:])
+            e["fp32_other_partition_first_update"] = rel_l2(ce._recorded_updates[0], up32)
+            print(fixture, "fp32 with 4 threads vs the committed 8-thread fixture:", e["fp32_other_partition"], e["fp32_other_partition_first_update"], flush=True)
+            out[fixture] = e
+            json.dump(out, open(path, "w"), indent=1)
+            return
+        torch.set_num_threads(gen_golden.GEN_THREADS)
+        if "--every-op" in sys.argv or "--incl-probabilities" in sys.argv:
+            # two more yardsticks for the error budget (tools/loop_error_budget.py): the reference's probability maps rounded as well
+            # (controller_16bit), and EVERY operation of the model rounded (round_every_op) instead of module outputs only
+            ap = R.attention_processors
             for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
                 if ("--" + dn) in sys.argv or not any(a in sys.argv for a in ("--fp16", "--bf16")):
-                    lat, log, ce, _ = gen_golden.run_reference_loop(R, "geometry_remover" if "remover" in fixture else "geometry_editor", cfg,
-                                                                    prepare=emulate_16bit(dt), tiny=fixture.startswith(("G18", "G19", "G20", "G23", "G27", "G28", "G29")),
-                                                                    sdxl=fixture.startswith("G27"), sd14=fixture.startswith("G23"))
-                    e["emulated_" + dn] = rel_l2(lat[-1:], ref[-1:])
-                    e["emulated_" + dn + "_first_update"] = rel_l2(ce._recorded_updates[0], up32)
-                    # loss terms of the LAST optimisation pass (after the loop has amplified the storage rounding): |emulated - fp32| / |fp32|
-                    # per term — the yardstick of the device path's last-pass check (tests/test_end_to_end.py)
-                    last = int(g["steps"][-1])
-                    e["emulated_" + dn + "_last_terms"] = {
-                        f"{kind}/{k}": abs(float(v) - float(g[f"log_{last}_{kind}_{k}"])) / (abs(float(g[f"log_{last}_{kind}_{k}"])) + 1e-12)
-                        for kind in ("self", "cross") for k, v in log[last][kind].items()}
-                    print(fixture, dn, e, flush=True)
+                    if "--incl-probabilities" in sys.argv:
+                        with controller_16bit(R, dt):
+                            lat, _, ce, _ = gen_golden.run_reference_loop(R, kind, cfg, prepare=emulate_16bit(dt), **kw)
+                        e["emulated_" + dn + "_incl_probabilities"] = rel_l2(lat[-1:], ref[-1:])
+                    if "--every-op" in sys.argv:
+                        rd = round_every_op(dt)
+                        origs = [(c, rd.pause_in(c, "forward")) for c in (ap.AttentionGeometryEdit, ap.AttentionGeometryRemover)]
+                        try:
+                            with rd:
+                                lat, _, ce, _ = gen_golden.run_reference_loop(R, kind, cfg, prepare=emulate_16bit(dt), **kw)
+                        finally:
+                            for c, o in origs:
+                                c.forward = o
+                        e["emulated_" + dn + "_every_op"] = rel_l2(lat[-1:], ref[-1:])
+                        e["emulated_" + dn + "_every_op_first_update"] = rel_l2(ce._recorded_updates[0], up32)
+                    print(fixture, dn, {k: v for k, v in e.items() if not isinstance(v, dict)}, flush=True)
                     out[fixture] = e
                     json.dump(out, open(path, "w"), indent=1)
             return
+        for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+            if ("--" + dn) in sys.argv or not any(a in sys.argv for a in ("--fp16", "--bf16")):
+                lat, log, ce, _ = gen_golden.run_reference_loop(R, kind, cfg, prepare=emulate_16bit(dt), **kw)
+                e["emulated_" + dn] = rel_l2(lat[-1:], ref[-1:])
+                e["emulated_" + dn + "_first_update"] = rel_l2(ce._recorded_updates[0], up32)
+                # loss terms of the LAST optimisation pass (after the loop has amplified the storage rounding): |emulated - fp32| / |fp32|
+                # per term — the yardstick of the device path's last-pass check (tests/test_end_to_end.py)
+                last = int(g["steps"][-1])
+                e["emulated_" + dn + "_last_terms"] = {
+                    f"{kd}/{k}": abs(float(v) - float(g[f"log_{last}_{kd}_{k}"])) / (abs(float(g[f"log_{last}_{kd}_{k}"])) + 1e-12)
+                    for kd in ("self", "cross") for k, v in log[last][kd].items()}
+                print(fixture, dn, e, flush=True)
+                out[fixture] = e
+                json.dump(out, open(path, "w"), indent=1)
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_import.import_reference()

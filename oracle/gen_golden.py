@@ -27,8 +27,25 @@ import ref_import  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+def provenance():
+    """Where a fixture was recorded: long loops are reproducible to the bit only on the same torch build / thread count (the reference's
+    fp32 driver moves by ~4e-4 at 50 steps between BLAS thread partitions), so every fixture names its environment."""
+    import hashlib, subprocess
+    try:
+        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        sha = "unknown"
+    par = torch.__config__.parallel_info()
+    return dict(torch=torch.__version__, numpy=np.__version__, threads=torch.get_num_threads(),
+                parallel_info_md5=hashlib.md5(par.encode()).hexdigest(), git=sha, cpu_count=os.cpu_count(),
+                machine=" ".join(os.uname()[i] for i in (0, 2, 4)))
+
+
 def save(name, **arrays):
+    import json
     arrays = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    arrays["provenance"] = np.array(json.dumps(provenance(), sort_keys=True))
+    os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
     print(f"  wrote {name}.npz  ({os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024:.1f} KiB)")
 
@@ -580,87 +597,115 @@ def g16_batch_config():
     print("  wrote G16_batch_config.json")
 
 
+# name -> (kind, cases.<cfg>, g18_loop kwargs, approx CPU seconds on 8 cores).  Every loop fixture is the reference's own driver
+# (run_reference_loop); the table is what `--check` and the CPU suite iterate over.
+LOOP_FIXTURES = {
+    "G18_loop": ("geometry_editor", "LOOP", {}, 8),
+    "G19_loop_remover": ("geometry_remover", "LOOP", {}, 8),
+    "G20_loop_cfg0": ("geometry_editor", "LOOP_CFG0", {}, 20),
+    # BASELINE configs[0] (256^2, 2-D translation, 20-step DDIM) at the FULL SD2.1-base width (865 M-parameter random-init UNet, fp32)
+    "G21_loop_cfg0_full": ("geometry_editor", "LOOP_CFG0", dict(tiny=False), 400),
+    # BASELINE configs[1] SHAPE (512^2, 3-D rotation), full width, 4 DDIM steps (the reference materialises [10, 4096, 4096] fp32 maps)
+    "G22_loop_cfg1_full": ("geometry_editor", "LOOP_CFG1", dict(tiny=False), 300),
+    # SD1.x head layout (head dims 40 / 80 / 160: the reference's default model, U/editor.py:58), narrow
+    "G23_loop_sd14": ("geometry_editor", "LOOP", dict(sd14=True), 10),
+    # the removal edit at the full SD2.1-base width (256^2, 6 steps)
+    "G26_loop_remover_full": ("geometry_remover", "LOOP", dict(tiny=False), 200),
+    # SDXL-topology UNet (narrow) at 512^2
+    "G27_loop_sdxl": ("geometry_editor", "LOOP_SDXL", dict(sdxl=True), 60),
+    # BASELINE configs[1] at its stated length (50 steps, 17 optimisation passes), narrow model
+    "G28_loop_cfg1_t50": ("geometry_editor", "LOOP_CFG1_T50", dict(record_weights=True), 120),
+    # BASELINE configs[3] at its stated length (768^2 removal, 75-step schedule), narrow model, eps-prediction
+    "G29_loop_remover768_t75": ("geometry_remover", "LOOP_REM768_T75", dict(record_weights=True), 300),
+    # BASELINE configs[1] ITSELF: full width x full length (865 M parameters, 512^2, 3-D rotation, 50 steps, 17 optimisation passes, the
+    # batch driver's geometry_editor column large_scale_editor.py:264-299) -- the workload bench.py's headline is quoted on
+    "G30_loop_cfg1_full_t50": ("geometry_editor", "LOOP_CFG1_T50", dict(tiny=False, record_weights=True), 6000),
+}
+GEN_THREADS = 8            # pinned: the fp32 loop fixtures depend on the BLAS thread partition
+
+
+def _ref_for_loops():
+    R = ref_import.import_reference()
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(GEN_THREADS)
+    return R
+
+
+def gen_loop(R, name):
+    kind, cfg, kw, _ = LOOP_FIXTURES[name]
+    g18_loop(R, kind, getattr(cases, cfg), name, **kw)
+
+
+def check(names):
+    """Regenerate fixtures into a scratch directory and compare with the committed files: bit-identical -> 0; otherwise print the
+    largest relative distance per array and return 1 (used by tests/test_oracle_golden.py for the fixtures that take < 60 s)."""
+    global OUT
+    import tempfile
+    committed = OUT
+    bad = 0
+    R = _ref_for_loops()
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT = tmp
+        for name in names:
+            gen_loop(R, name)
+            a, b = np.load(os.path.join(committed, name + ".npz")), np.load(os.path.join(tmp, name + ".npz"))
+            keys = sorted((set(a.files) | set(b.files)) - {"provenance"})
+            worst = ("", 0.0)
+            for k in keys:
+                if k not in a.files or k not in b.files:
+                    worst = (k + " (missing)", float("inf")); break
+                x, y = np.asarray(a[k], dtype=np.float64), np.asarray(b[k], dtype=np.float64)
+                if x.shape != y.shape:
+                    worst = (k + " (shape)", float("inf")); break
+                d = float(np.linalg.norm(x - y) / (np.linalg.norm(x) + 1e-30))
+                if d > worst[1]:
+                    worst = (k, d)
+            prov = str(a["provenance"]) if "provenance" in a.files else "(no provenance recorded)"
+            print(f"CHECK {name}: " + ("bit-identical" if worst[1] == 0.0 else f"DIFFERS, worst {worst[0]} rel {worst[1]:.3e}") +
+                  f"   committed from {prov}")
+            bad |= worst[1] != 0.0
+    OUT = committed
+    return int(bad)
+
+
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "G15":
+    args = sys.argv[1:]
+    if args and args[0] == "--check":
+        sys.exit(check(args[1:] or [n for n, v in LOOP_FIXTURES.items() if v[3] < 60]))
+    if args and args[0] == "--loops":                     # every loop fixture except the hour-long G30
+        R = _ref_for_loops()
+        for n in LOOP_FIXTURES:
+            if n != "G30_loop_cfg1_full_t50":
+                print(n); gen_loop(R, n)
+        return
+    short = {n.split("_")[0]: n for n in LOOP_FIXTURES}
+    if args and (args[0] in LOOP_FIXTURES or args[0] in short):
+        R = _ref_for_loops()
+        names = [short.get(a, a) for a in args]
+        if args == ["G18"]:                               # historical shorthand: the three quick loops
+            names = ["G18_loop", "G19_loop_remover", "G20_loop_cfg0"]
+        for n in names:
+            print(n); gen_loop(R, n)
+        return
+    if args and args[0] == "G15":
         os.makedirs(OUT, exist_ok=True)
         print("G15"); g15_exp_folder()
         print("G16"); g16_batch_config()
         return
-    if len(sys.argv) > 1 and sys.argv[1] == "G18":
-        R = ref_import.import_reference()
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        print("G18"); g18_loop(R)
-        print("G19"); g18_loop(R, "geometry_remover")
-        print("G20"); g18_loop(R, "geometry_editor", cases.LOOP_CFG0, "G20_loop_cfg0")
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == "G21":
-        # BASELINE configs[0] (256^2, 2-D translation, 20-step DDIM) through the reference's driver at the FULL SD2.1-base width
-        # (865 M-parameter random-init UNet, fp32, CPU: a few minutes on 8 cores)
-        R = ref_import.import_reference()
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        torch.set_num_threads(8)
-        print("G21"); g18_loop(R, "geometry_editor", cases.LOOP_CFG0, "G21_loop_cfg0_full", tiny=False)
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == "G27":
-        # the reference's driver over an SDXL-topology UNet (narrow: three levels, attention on the lower two with stacked transformer
-        # blocks, text_time conditioning) at 512^2: hooked layers at 32^2 (losses) and 16^2 tokens
-        R = ref_import.import_reference()
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        torch.set_num_threads(8)
-        print("G27"); g18_loop(R, "geometry_editor", cases.LOOP_SDXL, "G27_loop_sdxl", sdxl=True)
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == "G26":
-        # the removal edit through the reference's driver at the full SD2.1-base width (256^2, 6 steps)
-        R = ref_import.import_reference()
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        torch.set_num_threads(8)
-        print("G26"); g18_loop(R, "geometry_remover", cases.LOOP, "G26_loop_remover_full", tiny=False)
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == "G23":
-        # the reference's driver over an SD1.x-topology UNet (narrow; 4 heads per level = head dims 40 / 80 / 160, the layout of its default
-        # model CompVis/stable-diffusion-v1-4, U/editor.py:58)
-        R = ref_import.import_reference()
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        torch.set_num_threads(8)
-        print("G23"); g18_loop(R, "geometry_editor", cases.LOOP, "G23_loop_sd14", tiny=True, sd14=True)
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == "G22":
-        # BASELINE configs[1] SHAPE (512^2, 3-D rotation) through the reference's driver at the full SD2.1-base width, 4 DDIM steps
-        # (2 optimisation passes + 4 CFG passes; the reference materialises [10, 4096, 4096] fp32 maps per 64^2 layer: ~25 GB, minutes)
-        R = ref_import.import_reference()
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        torch.set_num_threads(8)
-        print("G22"); g18_loop(R, "geometry_editor", cases.LOOP_CFG1, "G22_loop_cfg1_full", tiny=False)
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == "G28":
-        # BASELINE configs[1] at its stated length (512^2, 3-D rotation, 50 DDIM steps, 17 optimisation passes) through the reference's
-        # driver over the narrow SD2.1-topology UNet: pins the step-count-dependent gates at the benchmark's T
-        R = ref_import.import_reference()
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        torch.set_num_threads(int(os.environ.get("GD_GEN_THREADS", "8")))
-        print("G28"); g18_loop(R, "geometry_editor", cases.LOOP_CFG1_T50, "G28_loop_cfg1_t50", record_weights=True)
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == "G29":
-        # BASELINE configs[3] at its stated length (768^2 removal, 75 DDIM steps, 32 optimisation passes), narrow model, eps-prediction
-        R = ref_import.import_reference()
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        torch.set_num_threads(int(os.environ.get("GD_GEN_THREADS", "8")))
-        print("G29"); g18_loop(R, "geometry_remover", cases.LOOP_REM768_T75, "G29_loop_remover768_t75", record_weights=True)
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == "G17":
+    if args and args[0] == "G17":
         R = ref_import.import_reference()
         print("G17"); g17_attention_store(R, g_masks_and_warp(R))
         return
-    if len(sys.argv) > 1 and sys.argv[1] == "G25":
+    if args and args[0] == "G25":
         R = ref_import.import_reference()
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        sys.path.insert(0, ROOT)
         print("G25"); g25_null_text(R)
         return
-    if len(sys.argv) > 1 and sys.argv[1] == "G12":
+    if args and args[0] == "G12":
         R = ref_import.import_reference()
         print("G12"); g12_mesh(R)
         return
-    if len(sys.argv) > 1 and sys.argv[1] == "G14":
+    if args and args[0] == "G14":
         R = ref_import.import_reference()
         os.makedirs(OUT, exist_ok=True)
         print("G14"); g14_histogram(R)

@@ -15,6 +15,16 @@ def load(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
 
+def fixture_mismatch(why: str):
+    """A loop fixture does not apply on this machine (its seeded weights come out differently: another torch build).  That silently
+    removes the whole loop-parity class, so it FAILS unless the caller says it is expected (GD_ALLOW_FIXTURE_SKIP=1)."""
+    import pytest
+    if os.environ.get("GD_ALLOW_FIXTURE_SKIP", "0") == "1":
+        pytest.skip(why)
+    pytest.fail(why + " -- regenerate the loop fixtures on this torch build (python oracle/gen_golden.py --loops) or set "
+                "GD_ALLOW_FIXTURE_SKIP=1 to skip", pytrace=False)
+
+
 def warped_mask(kind: str) -> torch.Tensor:
     """[2,1,512,512] binarised 512^2 warp of the object mask (bit-packed in G0)."""
     bits = load("G0_warped_mask_512")[kind]
@@ -70,3 +80,36 @@ def removal_consistency(h_aux, o_aux, S: int, f: int, m_inp_sum: float, tie_tol:
     w = torch.exp(-dist[o_aux["rows"][None, :].expand_as(j_wo), j_wo])
     expected = float((w * (-torch.log(v_wo + 1e-4) + torch.log(v_in + 1e-4))).sum() / (m_inp_sum * f + 1e-8))
     return same, expected
+
+
+class Tune:
+    """Per-call launch configuration for the kernel tests.  ABI 5 has no process-wide tuning hooks: every call carries its gd_attn_cfg_t /
+    gd_conv3x3_cfg_t / single_launch flag, which geodiffuser_amd.ops fills from its module-level DEFAULTS (ops.ATTN_CFG, ops.CONV3X3_CFG,
+    ops.GN_SINGLE_LAUNCH).  The tests select kernel variants by editing those defaults through this object (same verbs as the removed
+    gd_*_set_* functions) and restore them in their `finally` blocks."""
+
+    def gd_attn_fwd_set_config(self, qb, ks):
+        from geodiffuser_amd import ops
+        ops.ATTN_CFG.update(qb=-1 if qb < 0 else qb, ks=ks if qb > 0 else 0)
+        return 0
+
+    def gd_attn_fwd_set_even_split(self, on):
+        # 0 = never, 1 = where it pays, 2 = every launch that can be split; 10 / 11 / 12 = as 2 with the hand-off mode 0 / 1 / 2
+        from geodiffuser_amd import ops
+        ops.ATTN_CFG.update(even_split=2 if on >= 10 else on, handoff=on - 10 if on >= 10 else 1)
+        return 0
+
+    def gd_conv3x3_set_config(self, pi, ki, ksplit):
+        from geodiffuser_amd import ops
+        ops.CONV3X3_CFG.update(pi=pi, ki=ki, ksplit=ksplit)
+        return 0
+
+    def gd_conv3x3_set_dma(self, on):
+        from geodiffuser_amd import ops
+        ops.CONV3X3_CFG.update(dma=1 if on else 0)
+        return 0
+
+    def gd_group_norm_set_single_launch(self, on):
+        from geodiffuser_amd import ops
+        ops.GN_SINGLE_LAUNCH = 1 if on else 0
+        return 0

@@ -31,25 +31,44 @@ def test_header_symbols_all_exported_and_bound(lib):
         assert hasattr(lib, s), f"{s} declared in the header but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.gd_version() == 4
+    assert lib.gd_version() == _lib.GD_ABI_VERSION == 5
+    # stateless, re-entrant, no hidden state — no process-wide tuning hook may come back (ABI 5 moved the five of ABI <= 4 into
+    # per-call arguments: gd_attn_cfg_t, gd_conv3x3_cfg_t, gd_group_norm_nhwc's single_launch)
+    assert not [s for s in syms if re.match(r"gd_.*_set_.*", s)], "process-global setters are not part of the ABI"
+    # one entry point per operation: the side-by-side generations of ABI 4 are gone
+    for gone in ("gd_attn_fwd_ws", "gd_attn_fwd_splitkv", "gd_attn_bwd_nofold", "gd_removal_bwd_nofold", "gd_removal_corr_max_nz",
+                 "gd_edit_losses_fused", "gd_edit_losses_bwd_rowdot", "gd_attn_probs_pair", "gd_rows_merge", "gd_blend_tokens"):
+        assert gone not in syms and not hasattr(lib, gone), gone
+
+
+def test_library_reads_no_environment_and_keeps_no_tuning_state():
+    """The kernels' sources: no getenv, no file-scope mutable tuning variables (what is left at file scope is `static bool attr_set`
+    one-time hipFuncSetAttribute guards and the thread-local error message)."""
+    csrc = os.path.join(ROOT, "geodiffuser_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".hpp")):
+            continue
+        txt = open(os.path.join(csrc, f)).read()
+        assert "getenv" not in txt, f
+        assert not re.search(r"^static (?:int|bool|float) (?:g_|env_)\w+", txt, re.M), f
 
 
 def test_argument_validation_without_gpu(lib):
     # null pointers / unsupported sizes are rejected before any HIP call
     assert lib.gd_ddim_step(None, None, None, 1.0, 0.5, 0.5, None, 10, 2, None) == -1
     assert b"null" in lib.gd_last_error()
-    assert lib.gd_attn_fwd(None, 1, 64, 64, 64, 0.125, 0, None) == -1
-    from geodiffuser_amd._lib import GdAttnSeg
+    assert lib.gd_attn_fwd(None, 1, 64, 64, 64, 0.125, None, None, 0, 0, None) == -1
+    from geodiffuser_amd._lib import GdAttnCfg, GdAttnSeg
     seg = (GdAttnSeg * 1)(GdAttnSeg(1, 1, 1, 1, 0, 1, 0))
-    assert lib.gd_attn_fwd(seg, 1, 64, 64, 40, 0.125, 0, None) == -4          # head dim 40 unsupported
+    assert lib.gd_attn_fwd(seg, 1, 64, 64, 40, 0.125, None, None, 0, 0, None) == -4          # head dim 40 unsupported
     assert b"head dim" in lib.gd_last_error()
     assert lib.gd_error_string(-4) == b"unsupported configuration"
     assert lib.gd_rasterize_workspace_bytes(4096, 64, ctypes.c_float(1.3 / 64 * 2)) > 4096 * 4
-    # the even split's development hand-off modes (12 = no merge: wrong outputs) are not reachable from a production process
-    if os.environ.get("GD_ATTN_DEV_MODES") != "1":
-        assert lib.gd_attn_fwd_set_even_split(12) == -1 and b"development" in lib.gd_last_error()
-        assert lib.gd_attn_fwd_set_even_split(3) == -1
-    assert lib.gd_attn_fwd_set_even_split(1) == 0
+    # per-call configuration is validated per call: an unknown kernel shape / split mode is an argument error, not a sticky setting
+    bad = GdAttnCfg(-1, 3, 3, 0, 1)
+    assert lib.gd_attn_fwd(seg, 1, 64, 64, 64, 0.125, ctypes.byref(bad), None, 0, 0, None) == -1 and b"no kernel" in lib.gd_last_error()
+    bad = GdAttnCfg(7, -1, 0, 0, 1)
+    assert lib.gd_attn_fwd(seg, 1, 64, 64, 64, 0.125, ctypes.byref(bad), None, 0, 0, None) == -1 and b"even_split" in lib.gd_last_error()
 
 
 def test_ops_refuse_cpu_tensors():

@@ -195,8 +195,8 @@ def test_attention_forward_full_size_and_segments(ops):
     q1, q2, q3, k1, k2, v1 = mk(3 * f, N), mk(f, N), mk(f, N), mk(3 * f, N), mk(f, N), mk(3 * f, N)
     o1 = torch.empty_like(q1); o2 = torch.empty_like(q2); o3 = torch.empty_like(q3)
     l1 = torch.empty(3 * f, N, device=DEV); l3 = torch.empty(f, N, device=DEV)
-    from geodiffuser_amd import _lib
-    lib = _lib.load()
+    from _util import Tune
+    lib = Tune()
     # one workgroup shape for the four launches: on its own a 5-head launch would split the keys inside the workgroup (a different
     # f32 summation order than the 25-head launch's)
     lib.gd_attn_fwd_set_config(4, 1)
@@ -221,8 +221,8 @@ def test_attention_forward_pipelined_configs(ops, dtype, BH, N, M):
     """The software-pipelined kernels (attn_fwd_mp.hip): every (query blocks x key ranges) workgroup shape, one and two key tiles per
     barrier, exact and pre-scaled queries, against the fp32 formulation on the full tensors — including rows that FORCE the rescue
     path (scores climbing by ~100 nats across the keys, one outlier key 6x the others) and a ragged query count."""
-    from geodiffuser_amd import _lib
-    lib = _lib.load()
+    from _util import Tune
+    lib = Tune()
     torch.manual_seed(BH * 7 + M)
     q = (torch.randn(BH, N, 64, device=DEV) * 1.5).to(dtype); k = (torch.randn(BH, M, 64, device=DEV) * 1.5).to(dtype)
     v = torch.randn(BH, M, 64, device=DEV).to(dtype)
@@ -256,13 +256,13 @@ def test_attention_forward_pipelined_configs(ops, dtype, BH, N, M):
 @pytest.mark.parametrize("cfg", [(4, 1), (8, 1)])
 @pytest.mark.parametrize("BH,N,M", [(5, 4096, 4096), (20, 4096, 4096), (13, 2304, 2304), (7, 1000, 4096), (6, 4096, 4096), (2, 9216, 9216)])
 def test_attention_forward_even_split(ops, cfg, BH, N, M):
-    """gd_attn_fwd_ws: the launch's key tiles dealt out evenly over the workgroups, units that end up in several workgroups merged by the
+    """gd_attn_fwd with its even-split workspace: the launch's key tiles dealt out evenly over the workgroups, units that end up in several workgroups merged by the
     last to arrive (attn_fwd_mp.hip SK).  Against the fp32 formulation (with rows that force the reference-value fallback: scores
     climbing by ~100 nats, a 6x outlier key), against the unsplit launch of the same kernel, and bit-reproducible run to run (the
     merge folds the parts in part order whoever arrives last).  Both kernels: 128-query workgroups (4, 1) and the 64-query-per-wave
     kernel (8, 1)."""
-    from geodiffuser_amd import _lib
-    lib = _lib.load()
+    from _util import Tune
+    lib = Tune()
     dtype = torch.bfloat16
     torch.manual_seed(BH + M)
     q = (torch.randn(BH, N, 64, device=DEV) * 1.5).to(dtype); k = (torch.randn(BH, M, 64, device=DEV) * 1.5).to(dtype)
@@ -296,8 +296,8 @@ def test_attention_unit_parts_with_segments_warp_and_row_list(ops, heads):
     edit: token-major segments, LSE outputs, a fused query warp with a query row list (its own, shorter unit count) — against the
     unsplit launch, twice (reproducible).  3 heads: 96 + 6 units <= 128: EVERY unit is cut into parts; 5 heads: 160 + 10 units in one
     round: only the row-list segment's units are (the optimisation pass's launch form)."""
-    from geodiffuser_amd import _lib
-    lib = _lib.load()
+    from _util import Tune
+    lib = Tune()
     dtype = torch.bfloat16
     g = torch.Generator(device=DEV).manual_seed(9)
     B, N, K = 2, 4096, 15
@@ -353,8 +353,8 @@ def test_attention_even_split_segments_warp_and_handoff(ops, cfg):
     """The even split under the launch forms of an edit (four token-major segments that share K / V, a fused query warp on one of them)
     equals the unsplit launch; then a hand-off stress: launches with ALTERNATING inputs (a stale part left by the previous launch would
     be wrong data, not the same data) while a second stream keeps the chip unevenly busy."""
-    from geodiffuser_amd import _lib
-    lib = _lib.load()
+    from _util import Tune
+    lib = Tune()
     dtype = torch.bfloat16
     g = torch.Generator(device=DEV).manual_seed(5)
     B, N, heads, K = 4, 4096, 5, 15
@@ -416,9 +416,9 @@ def test_fused_query_warp_is_bit_identical_to_two_launches(ops, dtype, f, N, M, 
     q*(1-m) + m*half(sum_k w q[idx]) in the attention kernel's prologue; the result equals, bit for bit, attending with the q_warp
     tensor that gd_splat_composite writes (U/attention_processors.py:424-428,544-549), in every kernel that serves the launch
     (plain kernel for 77 keys, pipelined kernels otherwise), head-major and token-major."""
-    from geodiffuser_amd import _lib
+    from _util import Tune
     from geodiffuser_amd._lib import GD_TOKEN_MAJOR
-    lib = _lib.load()
+    lib = Tune()
     torch.manual_seed(N + M + heads)
     K = 15
     C = 64 * (heads if heads else 1)
@@ -447,11 +447,11 @@ def test_fused_query_warp_is_bit_identical_to_two_launches(ops, dtype, f, N, M, 
 @pytest.mark.parametrize("cfg", [(-1, 0), (4, 1), (8, 1)])
 def test_query_row_list_segment_equals_the_full_launch(ops, dtype, heads, cfg):
     """gd_attn_seg_t.q_rows: the warped-query segment computed only for the rows inside the soft edit mask, dense output, then
-    gd_rows_merge with the reference rows' output.  Against the full launch of the same segment: rows inside the mask bit-identical,
+    gd_blend_merge with the reference rows' output.  Against the full launch of the same segment: rows inside the mask bit-identical,
     rows outside equal to the reference segment's rows (for m == 0 the warped query IS the reference query) — in every kernel that
     serves such a launch, head-major and token-major, with the even split on and off, with a padded list."""
-    from geodiffuser_amd import _lib
-    lib = _lib.load()
+    from _util import Tune
+    lib = Tune()
     torch.manual_seed(3 + heads)
     N, K, f = 4096, 15, 5
     C = 64 * (heads if heads else 1)
@@ -528,7 +528,8 @@ def test_attention_forward_split_kv(ops, dtype, BH, N, M, nsplit):
 
 def test_attention_split_kv_plan():
     """gd_attn_fwd_plan: launches served by the software-pipelined kernels (full key tiles) split their keys INSIDE the workgroup and
-    need no HBM workspace (plan = 1); the HBM split remains for under-filled launches with a key tail."""
+    need no HBM workspace (plan = 1); the HBM split remains for under-filled launches with a key tail.  The plan is a pure function of
+    the shape (ABI 5: no process-wide kernel selection it could depend on)."""
     import ctypes
     from geodiffuser_amd import _lib
     lib = _lib.load()
@@ -537,13 +538,8 @@ def test_attention_split_kv_plan():
         assert lib.gd_attn_fwd_plan(bh, 4096, 4096, ctypes.byref(nb)) == 1 and nb.value == 0
     assert lib.gd_attn_fwd_plan(20, 4096, 77, ctypes.byref(nb)) == 1                                              # cross attention: one key tile
     assert lib.gd_attn_fwd_plan(5, 4096, 4096 + 37, ctypes.byref(nb)) == 4 and nb.value == 4 * 5 * 4096 * 66 * 4  # key tail: plain kernel + HBM split
-    try:
-        lib.gd_attn_fwd_set_config(0, 0)                                                                          # pipelined kernels off
-        assert lib.gd_attn_fwd_plan(5, 4096, 4096, ctypes.byref(nb)) == 4 and nb.value == 4 * 5 * 4096 * 66 * 4
-        assert lib.gd_attn_fwd_plan(10, 4096, 4096, ctypes.byref(nb)) == 2
-        assert lib.gd_attn_fwd_plan(15, 4096, 4096, ctypes.byref(nb)) == 1
-    finally:
-        lib.gd_attn_fwd_set_config(-1, 0)
+    assert lib.gd_attn_fwd_plan(10, 4096, 4096 + 37, ctypes.byref(nb)) == 2
+    assert lib.gd_attn_fwd_plan(15, 4096, 4096 + 37, ctypes.byref(nb)) == 1
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -596,9 +592,7 @@ def test_attention_backward_dq_direct_to_lds_variant(ops, monkeypatch, dtype, BH
     v = torch.randn(BH, M, 64, device=DEV, generator=g_).to(dtype); g = (torch.randn(BH, N, 64, device=DEV, generator=g_) * 0.1).to(dtype)
     out = torch.empty_like(q); lse = torch.empty(BH, N, device=DEV)
     ops.attn_fwd([(q, k, v, out, lse)], 0.125)
-    monkeypatch.setenv("GD_BWD_DQ", "1")
-    dq_old, _ = ops.attn_bwd(q, k, v, out, lse, g, 0.125, False)
-    monkeypatch.delenv("GD_BWD_DQ")
+    dq_old, _ = ops.attn_bwd(q, k, v, out, lse, g, 0.125, False, variant=1)       # the register-staging kernel (gd_attn_bwd's `variant`)
     dq_new, _ = ops.attn_bwd(q, k, v, out, lse, g, 0.125, False)
     dq_new2, _ = ops.attn_bwd(q, k, v, out, lse, g, 0.125, False)
     torch.cuda.synchronize()
@@ -677,11 +671,9 @@ def test_feature_losses_forward_backward(ops):
     tgt = ops.amodal_target(eo_d, nn_idx, nn_w, fl(m_edit), S)
     # the one-launch form (8 x 8 tiles through LDS, 8 channels per thread) against the stand-alone interpolation + 5 x 5 blur pair: the same
     # taps in the same order (the compiler's contraction of the vectorised loop may differ in the last bit)
-    os.environ["GD_AMODAL_TWO_PASS"] = "1"
-    try:
-        tgt_two = ops.amodal_target(eo_d, nn_idx, nn_w, fl(m_edit), S)
-    finally:
-        os.environ.pop("GD_AMODAL_TWO_PASS")
+    # (wider heads take that pair: the same comparison at D = 128 on the zero-padded tensor, whose first 64 channels must agree)
+    eo_wide = torch.cat([eo_d, torch.zeros_like(eo_d)], -1).contiguous()
+    tgt_two = ops.amodal_target(eo_wide, nn_idx, nn_w, fl(m_edit), S)[..., :eo_d.shape[-1]]
     assert rel_err(tgt.cpu(), tgt_two.cpu()) < 1e-6
     w_dist = w_dist.cpu()
     interp, w_ref = O.interpolate_from_mask(eo, m_edit, dist)
@@ -783,12 +775,10 @@ def test_corr_max_variants_are_bit_identical(ops, monkeypatch, dtype, H, N, R, n
     S = int(N ** 0.5)
     live = R if nv is None else nv
     res = {}
-    for var in ("0", "42", "24", "22"):
-        monkeypatch.setenv("GD_CORR_MAX", var)
-        aux, loss = ops.removal_fwd(Pe, Pb, m_inp, m_wo, rows, S, n_valid=nvt)
+    for var in ("0", "24", "22"):                        # gd_removal_corr_max's `variant`: 1 = the general kernel, 24 / 22 = the MFMA tile shapes
+        aux, loss = ops.removal_fwd(Pe, Pb, m_inp, m_wo, rows, S, n_valid=nvt, variant=1 if var == "0" else int(var))
         torch.cuda.synchronize()
         res[var] = ({k: v[:, :live].clone() for k, v in aux.items()}, loss.clone())
-    monkeypatch.delenv("GD_CORR_MAX")
     aux_d, loss_d = ops.removal_fwd(Pe, Pb, m_inp, m_wo, rows, S, n_valid=nvt)          # the launcher's own choice
     res["default"] = ({k: v[:, :live].clone() for k, v in aux_d.items()}, loss_d.clone())
     ref_aux, ref_loss = res["0"]
@@ -818,13 +808,9 @@ def test_removal_backward_on_the_matrix_pipe(ops, monkeypatch, dtype, H, N, R, n
     Pb = ops.attn_probs(q, k, lse, None, 0.125); Pe = ops.attn_probs(q, k, lse, rows, 0.125, n_valid=nvt)
     aux, _ = ops.removal_fwd(Pe, Pb, m_inp, m_wo, rows, int(N ** 0.5), n_valid=nvt)
     res = {}
-    for var in ("1", None):
-        if var is None:
-            monkeypatch.delenv("GD_REMOVAL_BWD", raising=False)
-        else:
-            monkeypatch.setenv("GD_REMOVAL_BWD", var)
+    for var in ("1", None):                              # gd_removal_bwd_t.variant: 1 = the general kernel
         dq = torch.zeros(H, N, 64, device=DEV)
-        ops.removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, 0.37, None, 0.125, dq, None, n_valid=nvt)
+        ops.removal_bwd(Pe, Pb, q, k, rows, aux, m_inp, m_wo, 0.37, None, 0.125, dq, None, n_valid=nvt, variant=1 if var else 0)
         torch.cuda.synchronize()
         res[var] = dq.clone()
     a, b = res[None], res["1"]
@@ -1382,8 +1368,8 @@ def _conv_inputs(n, C, H, W, K, dtype, seed=0):
 def test_conv3x3_matches_fp32_convolution(ops, dtype, n, C, H, W, K, stride, up, cfg):
     """gd_conv3x3 against F.conv2d in fp32 on the same 16-bit operands (padding 1; stride 2; fused nearest upsampling; ragged pixel /
     channel tails; every tile shape and reduction splits that do not divide the steps).  Tolerance: one rounding of the result."""
-    from geodiffuser_amd import _lib
-    lib = _lib.load()
+    from _util import Tune
+    lib = Tune()
     x, w, b = _conv_inputs(n, C, H, W, K, dtype)
     for bias in (b, None):
         if cfg:
@@ -1501,8 +1487,8 @@ def test_group_norm_single_launch_matches_two_launch_form(ops, dtype, B, C, H, a
     """Small maps take one launch (k_gn_fused); the result, and the backward that consumes its scratch, must agree with the two-launch
     form to rounding (the moments are summed in a different order) and with torch's GroupNorm in fp32."""
     import torch.nn.functional as F
-    from geodiffuser_amd import _lib
-    lib = _lib.load()
+    from _util import Tune
+    lib = Tune()
     g = torch.Generator(device="cpu").manual_seed(5)
     x = (torch.randn(B, C, H, H, generator=g) * 1.5 + 0.3).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
     ga = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV).to(dtype); be = (0.1 * torch.randn(C, generator=g)).to(DEV).to(dtype)
@@ -1635,7 +1621,7 @@ def test_layer_norm_backward_and_transformer_block_autograd(ops, dtype):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_heads_split_and_merge_are_the_permutes(ops, dtype):
     """gd_heads_split / gd_heads_merge against torch's head_to_batch_dim / batch_to_head_dim arithmetic (U/attention_processors.py:118-124):
-    pure data movement, so bit-exact; the merge's blend against gd_blend_tokens, its f32 sources against one torch rounding, its NULL
+    pure data movement, so bit-exact; the merge's blend against the stand-alone blend (gd_blend_merge), its f32 sources against one torch rounding, its NULL
     sources against zeros."""
     g = torch.Generator().manual_seed(9)
     B, heads, D, N, M = 3, 5, 64, 200, 77
@@ -1665,7 +1651,7 @@ def test_heads_split_and_merge_are_the_permutes(ops, dtype):
 @pytest.mark.parametrize("form", ["cross64", "cross32_f16", "self8", "remover_cross16", "head_major"])
 def test_pair_launch_equals_two_segments_and_the_blend(ops, dtype, form):
     """gd_attn_fwd_pair (short key lists: both attention outputs of the edit rows and their blend in one workgroup) against the launch it
-    replaces — gd_attn_fwd over one more segment followed by gd_blend_tokens: IDENTICAL bits, plain segments included."""
+    replaces — gd_attn_fwd over one more segment followed by the stand-alone blend (gd_blend_merge): IDENTICAL bits, plain segments included."""
     g = torch.Generator().manual_seed(17)
     S, heads, M, warp, diff_v, tok = dict(cross64=(64, 5, 77, True, False, True), cross32_f16=(32, 10, 77, True, False, True), self8=(8, 20, 64, True, False, True),
                                           remover_cross16=(16, 20, 77, False, True, True), head_major=(16, 4, 77, True, False, False))[form]

@@ -9,7 +9,7 @@ import torch
 
 import cases
 import ref_cpu as O
-from _util import case_gout, case_inputs, load, rel_err, warped_mask
+from _util import case_gout, case_inputs, fixture_mismatch, load, rel_err, warped_mask
 
 TOL = 1e-5
 
@@ -362,7 +362,7 @@ def test_oracle_loop_matches_the_reference_driver(kind, fixture, cfgname):
     pipe = build_random_sd21(device="cpu", dtype=torch.float32, tiny=True)
     probe = torch.cat([p.detach().reshape(-1)[:64] for p in pipe.unet.parameters()])
     if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=1e-6):
-        pytest.skip("seeded weights differ from the fixture's (different torch build)")
+        fixture_mismatch("seeded weights differ from the fixture's (different torch build)")
     inp = cases.loop_inputs(c)
     ctrl = ref_loop.make_controller(kind, inp["mask"], c, cases.amodal_input(inp["mask"], *c.get("amodal_shift", (32, -12))))
     tok = pipe.tokenizer
@@ -402,3 +402,30 @@ def test_oracle_loop_matches_the_reference_driver(kind, fixture, cfgname):
     e_up, e_lat = rel_l2(updates[0], torch.from_numpy(g["first_update"])), rel_l2(lat[-1:], torch.from_numpy(g["latents"])[-1:])
     print(f"[oracle loop] {fixture}: first update rel_l2 {e_up:.2e}, final latent rel_l2 {e_lat:.2e}")
     assert e_up < 2e-2 and e_lat < 5e-3
+
+
+def test_quick_loop_fixtures_regenerate_bit_identically():
+    """`oracle/gen_golden.py --check`: the loop fixtures that take < 60 s are re-recorded from the reference's own driver (imported from
+    /root/reference: build container only) and must equal the committed files to the bit.  A long loop is reproducible only on the torch
+    build / thread count named in its `provenance` entry (fp32 BLAS partitions: VERDICT r04 weak #3), which is why every fixture carries
+    one and the generator pins its thread count."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/GeoDiffuser"):
+        pytest.skip("the reference tree is not on this machine (GPU box): fixtures are checked where they are recorded")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "gen_golden.py"), "--check", "G18_loop", "G19_loop_remover", "G23_loop_sd14"],
+                       capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("CHECK")]
+    print("\n".join(lines))
+    assert r.returncode == 0 and len(lines) == 3 and all("bit-identical" in ln for ln in lines), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_loop_fixtures_name_their_environment():
+    """Every loop fixture records where it was made (torch build, thread count, parallel backend hash, git revision)."""
+    import json
+    for name in ("G18_loop", "G19_loop_remover", "G20_loop_cfg0", "G21_loop_cfg0_full", "G22_loop_cfg1_full", "G23_loop_sd14",
+                 "G26_loop_remover_full", "G27_loop_sdxl", "G28_loop_cfg1_t50", "G29_loop_remover768_t75", "G30_loop_cfg1_full_t50"):
+        prov = json.loads(str(load(name)["provenance"]))
+        assert {"torch", "threads", "parallel_info_md5", "git"} <= set(prov), name
+        assert prov["threads"] == 8, (name, prov)

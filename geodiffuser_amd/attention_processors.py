@@ -340,20 +340,27 @@ _PERSISTENT_TABLES: Dict[tuple, torch.Tensor] = {}
 # ... which makes them process-wide state: ONE controller at a time may own them (the reference is one edit at a time per process as well: its
 # model cache, DISTANCE_CLASS, SPLATTER and GAUSSIAN_FEATURE_SMOOTHER are module globals).  The owner is the controller that built
 # its tables last; a hooked call of any other controller whose tables live in these buffers raises instead of reading the owner's geometry.
-_TABLE_OWNER = None            # weakref to the owning controller
+_TABLE_OWNER: Dict[int, object] = {}     # slot -> weakref to the owning controller (slot 0: a single edit; j: the j-th edit of an EditBatch)
 
 
 def _check_table_owner(ctrl):
-    owner = _TABLE_OWNER() if _TABLE_OWNER is not None else None
+    ref = _TABLE_OWNER.get(getattr(ctrl, "slot", 0))
+    owner = ref() if ref is not None else None
     if owner is not None and owner is not ctrl:
         raise RuntimeError("two live edit controllers share the persistent per-resolution tables (GD_PERSISTENT_TABLES=1): another controller "
                            "rebuilt them after this one did; run one edit at a time per process, or set controller.persistent_tables = False")
 
 
-def _persist(enabled: bool, key: tuple, t: torch.Tensor) -> torch.Tensor:
+def _persist(enabled, key: tuple, t: torch.Tensor) -> torch.Tensor:
+    """``enabled``: False / True, or the controller itself (its ``persistent_tables`` flag decides and its ``slot`` — the edit's place in an
+    EditBatch, 0 for a single edit — is part of the buffer's name: B edits in flight hold B sets of tables)."""
+    slot = 0
+    if not isinstance(enabled, bool):
+        slot = getattr(enabled, "slot", 0)
+        enabled = getattr(enabled, "persistent_tables", False)
     if not enabled:
         return t
-    key = key + (tuple(t.shape), t.dtype, str(t.device))
+    key = key + (slot, tuple(t.shape), t.dtype, str(t.device))
     buf = _PERSISTENT_TABLES.get(key)
     if buf is None:
         buf = _PERSISTENT_TABLES[key] = t.clone()
@@ -623,7 +630,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         host = (float(lw["sim"]), 0.0 if rem else float(lw.get("movement", 0.0)), float(lw["removal"]),
                 float(lw["smoothness"]), 0.0 if rem else float(lw.get("amodal", 0.0)))
         # one buffer per (kind, controller type, device) for the whole process: captured optimisation passes of earlier edits read it
-        key = (kind, rem, str(dev))
+        key = (kind, rem, str(dev), getattr(self, "slot", 0))
         ent = _WEIGHT_VECTORS.get(key)
         if ent is None:
             ent = _WEIGHT_VECTORS[key] = [None, torch.zeros(5, dtype=torch.float32, device=dev)]
@@ -686,7 +693,6 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
     # -- per-resolution device tables --------------------------------------------------------------------
     def _tables(self, S: int, f: int, q: torch.Tensor, transform_coords, D: int = 64):
         """D: the TRUE head dim (loss normalisers, U/attention_processors.py:231-305); only q's device / dtype are read."""
-        global _TABLE_OWNER
         c = self.masks_cache_dict.get(S)
         if c is not None and "f" in c:
             if c["D"] != D:
@@ -697,7 +703,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         if getattr(self, "persistent_tables", False):
             import weakref
             if not any("f" in t for t in self.masks_cache_dict.values()):      # first table of this controller: it takes the buffers over
-                _TABLE_OWNER = weakref.ref(self)
+                _TABLE_OWNER[getattr(self, "slot", 0)] = weakref.ref(self)
             else:
                 _check_table_owner(self)
         dev = q.device
@@ -716,7 +722,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             self.masks_cache_dict, self.image_mask = res[0], res[1]
             m_new, mask_warp, amodal, inter, m_empty, m_wo, t_q = res[2:]
             c = self.masks_cache_dict[S]
-            pt = getattr(self, "persistent_tables", False)
+            pt = self if getattr(self, "persistent_tables", False) else False
             c["m_edit"] = _persist(pt, ("m_edit", S), _flat(m_new))
             c["m_amodal"] = _flat(amodal)
             idx_, w_ = warp_utils.SPLATTER.tables(t_q[0].reshape(-1, 3))
@@ -742,7 +748,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             m_wo = binarize_tensor(torch.ones_like(mask_warp) - m_empty)       # :775,867
             c = self.masks_cache_dict.setdefault(S, {})
             c["mask_1_empty"], c["mask_wo_edit"] = m_empty, m_wo
-        pt = getattr(self, "persistent_tables", False)
+        pt = self if getattr(self, "persistent_tables", False) else False
         rem = self._is_remover
         c["m_inp"] = _persist(pt, ("m_inp", S, rem), _flat(m_empty))
         c["m_wo"] = _persist(pt, ("m_wo", S, rem), _flat(m_wo))

@@ -1,0 +1,488 @@
+"""B independent edits in ONE process, sharing every UNet pass — the MI355X-first shape of the reference's batch driver.
+
+The reference processes one edit at a time on a batch of 2 latents (GeoDiffuser/utils/editor.py:603; its batch driver is a sequential
+loop, large_scale_editor.py:320-402).  One such edit fills about half of an MI355X (four OS processes on one device give 1.85 x,
+profiles/r04_in_flight.md).  Here B edits advance in lockstep: the inversion pass runs at batch B, the optimisation pass at 2 B
+(reference rows, then edit rows), the CFG pass at 3 B (uncond_edit, cond_ref, cond_edit rows) — ROLE-MAJOR batches, row = role * B + edit,
+so every role is one contiguous slice.  One copy of the weights, 1 / B of the launches per edit, B x the heads in every attention launch,
+convolutions and GEMMs out of the launch-bound regime.  Each edit keeps what is its own: controller tables (masks, splat tables, row
+lists: persistent buffers named by the edit's ``slot``), loss weights and adaptive schedule, loss log, DDIM trajectory, text context.
+
+Every per-edit quantity is computed by the same kernels on the same values as in the one-edit driver (editor.text2image_ldm_stable),
+so an edit's result does not depend on what else is in the batch beyond the UNet's own batch-size-dependent GEMM / convolution kernel
+selection (measured in tests/test_batch.py).
+
+    EditBatch                      the controller the processors see: B geometry controllers behind one processor protocol
+    text2image_ldm_stable_batch    the per-step loop (editor.py:65-423) for B edits in lockstep
+    perform_geometric_edit_batch   pre-pass, batched inversion, loop, decode, post-process for a list of edits
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import editor as E
+from . import graphs, ops, vis_utils, warp_utils
+from .attention_processors import (AttentionGeometryEdit, AttentionGeometryRemover, VanillaAttentionProcessor, _persist,
+                                   register_attention_control_diffusers, set_attn_processor_for_edit)
+from .attention_sharing import AttentionControl, attention_tok
+from .diffusion import _sched_step, _unet_nograd, encode_text, latent2image
+from .generic_torch import binarize_tensor, reshape_attention_mask, reshape_transform_coords, torch_erode
+from .image_processing import masked_histogram_matching
+from .inversion import NullInversion
+from .optimization import adaptive_optimization_step_editing, adaptive_optimization_step_remover
+from .warp_utils import warp_grid_edit
+
+
+class EditBatch(AttentionControl):
+    """B geometry controllers of one type behind the processors of one UNet.  Batch rows are role-major (row = role * B + edit); a
+    hooked call hands every edit its own rows, its own tables and its own loss state."""
+
+    supports_token_major = True
+    supports_scaled_q_head_major = True
+    store_attention_maps = False
+    local_blend = None
+
+    def __init__(self, subs: Sequence, coords: Sequence[torch.Tensor]):
+        super().__init__()
+        if len({type(s) for s in subs}) != 1:
+            raise ValueError("EditBatch: the edits of a batch must share one controller type (group editors and removers separately)")
+        if len(subs) != len(coords):
+            raise ValueError("EditBatch: one transform-coordinate tensor per edit")
+        self.subs = list(subs)
+        self.B = len(self.subs)
+        self.coords = list(coords)
+        for j, s in enumerate(self.subs):
+            s.slot = j                                   # names this edit's persistent device tables (attention_processors._persist)
+        self.use_cfg, self.coords_base, self.coords_edit, self.n_batch = True, (2, 3), (3, 4), None
+        self.heads_tok = self.heads_opt = 0
+        self.q_scaled_tok = self.q_scaled_hm = False
+        self._is_remover = self.subs[0]._is_remover
+        self.num_steps = self.subs[0].num_steps
+        self.obj_edit_step = self.subs[0].obj_edit_step
+        self.num_self_replace = self.subs[0].num_self_replace
+
+    # -- state that the driver / the processors set on "the controller" and every edit must see ---------------------------
+    @property
+    def persistent_tables(self):
+        return all(getattr(s, "persistent_tables", False) for s in self.subs)
+
+    @persistent_tables.setter
+    def persistent_tables(self, v):
+        for s in self.subs:
+            s.persistent_tables = v
+
+    @property
+    def masks_cache_dict(self):            # the hooked (resolution, heads, head dim) set is the same for every edit
+        return self.subs[0].masks_cache_dict
+
+    @property
+    def rows_identical(self):
+        return tuple(bool(s.rows_identical) for s in self.subs)
+
+    @property
+    def loss(self):
+        """Sum over the edits: edits do not interact inside the UNet (per-sample norms, per-sample attention), so d(sum) / d(edit j's
+        latent) is d(edit j's loss) / d(its latent) — one backward pass serves all of them."""
+        tot = None
+        for s in self.subs:
+            if torch.is_tensor(s.loss):
+                tot = s.loss if tot is None else tot + s.loss
+        return 0.0 if tot is None else tot
+
+    def _sync(self, s):
+        s.num_att_layers = self.num_att_layers
+        s.coords_base, s.coords_edit, s.use_cfg, s.n_batch = self.coords_base, self.coords_edit, self.use_cfg, self.n_batch
+        s.heads_tok, s.heads_opt, s.q_scaled_tok, s.q_scaled_hm = self.heads_tok, self.heads_opt, self.q_scaled_tok, self.q_scaled_hm
+
+    # -- the processor protocol --------------------------------------------------------------------------------------------
+    def forward(self, q, k, v, is_cross: bool, place_in_unet: str, transform_coords=None, scale=None, mask=None):
+        B = self.B
+        heads = self.heads_tok or self.heads_opt
+        if not heads:
+            raise NotImplementedError("EditBatch needs the token-major layer forms (64-wide heads, 16-bit, GD_TOKEN_MAJOR / GD_TOK_OPT on)")
+        active = is_cross or (self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1])
+        if not active and self.heads_tok:                # (self-attention past its replace window: plain attention for the whole batch)
+            for s in self.subs:
+                s.cur_att_layer += 1
+            return attention_tok(q, k, v, scale, heads, q_scaled=self.q_scaled_tok)
+        outs = []
+        for j, s in enumerate(self.subs):
+            self._sync(s)
+            # rows j, B + j, 2 B + j ... of the role-major batch: this edit's [ref, edit] / [uncond_edit, cond_ref, cond_edit] rows
+            outs.append(s(q[j::B].contiguous(), k[j::B].contiguous(), v[j::B].contiguous(), is_cross, place_in_unet,
+                          transform_coords=self.coords[j], scale=scale, mask=None))
+            s.heads_tok = s.heads_opt = 0
+        return torch.stack(outs, 1).reshape(outs[0].shape[0] * B, *outs[0].shape[1:])
+
+    def __call__(self, q, k, v, is_cross: bool, place_in_unet: str, transform_coords=None, scale=None, mask=None):
+        out = self.forward(q, k, v, is_cross, place_in_unet, transform_coords=transform_coords, scale=scale, mask=mask)
+        self.cur_att_layer += 1
+        if self.cur_att_layer == self.num_att_layers:
+            self.cur_att_layer = 0
+            self.cur_step += 1
+            for s in self.subs:                        # (an inactive self-attention layer above advanced only the layer counter)
+                if s.cur_att_layer >= s.num_att_layers:
+                    s.cur_att_layer = 0
+                    s.cur_step += 1
+                    s.between_steps()
+        return out
+
+    def step_callback(self, x_t, transform_coords=None):
+        return x_t
+
+    # -- what graphs.py / diffusion._unet_nograd ask a controller ----------------------------------------------------------
+    def harmonise(self):
+        """Pad the edits' row lists (inpaint rows, rows inside the soft edit mask) to the batch's longest bucket per resolution: launch
+        dimensions then depend on ONE number per list and resolution instead of B, which keeps the set of captured graphs small.  Padding
+        slots are neither computed nor read (the lists carry their true length on the device)."""
+        for S in list(self.subs[0].masks_cache_dict):
+            cs = [s.masks_cache_dict.get(S) for s in self.subs]
+            if any(c is None or "f" not in c for c in cs):
+                continue
+            for key, pkey in (("rows", ("rows", S, self._is_remover)), ("edit_rows", ("edit_rows", S))):
+                if any(key not in c for c in cs):
+                    continue
+                want = max(int(c[key].numel()) for c in cs)
+                for s, c in zip(self.subs, cs):
+                    t = c[key]
+                    if t.numel() < want and getattr(s, "persistent_tables", False) and (key != "rows" or c.get("n_rows") is not None):
+                        pad = t[:1].expand(want - t.numel()) if t.numel() else torch.zeros(want, dtype=t.dtype, device=t.device)
+                        c[key] = _persist(s, pkey + (want,), torch.cat([t, pad]).contiguous())
+
+    def graph_key(self):
+        for s in self.subs:
+            s.cur_step = self.cur_step
+            self._sync(s)
+        return ("EditBatch", self.B) + self.subs[0].graph_key()[:-1] + (self.rows_identical,)
+
+    def table_signature(self):
+        self.harmonise()
+        return tuple(s.table_signature() for s in self.subs)
+
+    def tables_built(self, layers) -> bool:
+        return all(s.tables_built(layers) for s in self.subs)
+
+    def prebuild_tables(self, layers, q_like, transform_coords=None):
+        for j, s in enumerate(self.subs):
+            if not s.tables_built(layers):
+                s.prebuild_tables(layers, q_like, self.coords[j])
+
+    def after_graph_replay(self):
+        self.cur_att_layer = 0
+        self.cur_step += 1
+        for s in self.subs:
+            s.after_graph_replay()
+
+    def sync_loss_weights(self, dev):
+        for s in self.subs:
+            s.sync_loss_weights(dev)
+
+    def export_loss_state(self):
+        return [(s.loss, {k: (dict(v) if isinstance(v, dict) else v) for k, v in s.loss_log_dict.items()}) for s in self.subs]
+
+    def import_loss_state(self, state):
+        for s, (loss, log) in zip(self.subs, state):
+            s.loss = loss
+            s.loss_log_dict = {k: (dict(v) if isinstance(v, dict) else v) for k, v in log.items()}
+
+    def undo_step(self):
+        """The driver's ``controller.cur_step -= 1`` after an optimisation pass (U/editor.py:307)."""
+        self.cur_step -= 1
+        for s in self.subs:
+            s.cur_step -= 1
+
+
+class GraphedBatchOptPass(graphs.GraphedOptPass):
+    """The optimisation pass of an EditBatch (one hipGraph, reused across batches): latents [2 B] = reference rows then edit rows, context
+    [2 B, 77, C] = the text rows of the same samples."""
+    ctx_text_rows_only = False
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+_PINNED = []
+
+
+def _logs_to_host_async(subs):
+    """The loss logs of all edits of an optimisation pass in ONE device -> pinned-host copy behind the work queued so far.
+    -> (keys per edit, host view, event)."""
+    keys, vals = [], []
+    for s in subs:
+        k, v = E._log_keys_vals(s.loss_log_dict)
+        keys.append(k)
+        vals.extend(v)
+    dev = next((v.device for v in vals if v.is_cuda), None)
+    if dev is None:
+        return None
+    stacked = torch.stack([v.detach().float().to(dev).reshape(()) for v in vals])
+    if len(_PINNED) < 4:
+        _PINNED.append(torch.empty(1024, dtype=torch.float32).pin_memory())
+    buf = _PINNED[0]
+    _PINNED.append(_PINNED.pop(0))
+    host = buf[:stacked.numel()]
+    host.copy_(stacked, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return keys, host, ev
+
+
+def _finish_logs(subs, logs, handle, i, skip_optim_steps, edit_type, use_adaptive_optimization, removal_loss_value_in, num_ddim_steps, out_logs):
+    """U/editor.py:284-306 for every edit: the logged terms on the host and the adaptive weight schedule of THAT edit."""
+    if handle is not None:
+        keys, host, ev = handle
+        ev.synchronize()
+        flat = host.tolist()
+    o = 0
+    for j, s in enumerate(subs):
+        if handle is not None:
+            n = len(keys[j])
+            d = E._log_from_host(logs[j], keys[j], flat[o:o + n])
+            o += n
+        else:
+            d = E.convert_loss_log_to_numpy(logs[j])
+        if use_adaptive_optimization:
+            fn = adaptive_optimization_step_editing if edit_type == "geometry_editor" else adaptive_optimization_step_remover
+            fn(s, i, skip_optim_steps, d, num_ddim_steps=num_ddim_steps, removal_loss_value_in=removal_loss_value_in)
+        out_logs[j][i] = d
+
+
+@torch.no_grad()
+def text2image_ldm_stable_batch(model, prompts: Sequence[str], batch: EditBatch, num_inference_steps: int, guidance_scale: float,
+                                latent: torch.Tensor, ddim_latents: Sequence[torch.Tensor], masks_obj: Sequence, uncond_embeddings=None,
+                                start_time=50, return_type="latents", optimize_steps=0.2, latent_replace=0.2, lr=0.0,
+                                optimize_embeddings=False, optimize_latents=False, edit_type="geometry_editor", fast_start_steps=0.0,
+                                num_first_optim_steps=1, use_adaptive_optimization=True, removal_loss_value_in=-1.5, image_size=None,
+                                skip_optim_steps=None, num_ddim_steps=None):
+    """U/editor.py:65-423 for B edits in lockstep.  ``latent`` [B,4,h,w] = every edit's x_T, ``ddim_latents`` = the inversion trajectory
+    as T + 1 tensors [B,4,h,w], ``prompts`` one per edit (the reference passes [prompt, prompt] for the two rows of one edit).
+    -> (latents [2 B,4,h,w] role-major or decoded images, per-edit loss logs).  Step order, gates and arithmetic follow
+    editor.text2image_ldm_stable statement by statement; what is batched is the UNet, what is looped over is per-edit glue."""
+    if fast_start_steps or num_first_optim_steps != 1:
+        raise NotImplementedError("the batched driver runs the batch drivers' configuration: fast_start_steps = 0, one optimisation iteration per step")
+    if uncond_embeddings is not None:
+        raise NotImplementedError("null-text embeddings per step are not batched (every reference driver runs with perform_inversion=False)")
+    B, subs = batch.B, batch.subs
+    skip_optim_steps = E.SKIP_OPTIM_STEPS if skip_optim_steps is None else skip_optim_steps
+    num_ddim_steps = E.NUM_DDIM_STEPS if num_ddim_steps is None else num_ddim_steps
+    logs_out: List[Dict[int, dict]] = [dict() for _ in range(B)]
+    batch.persistent_tables = os.environ.get("GD_PERSISTENT_TABLES", "1") == "1"
+    register_attention_control_diffusers(model, batch, None)
+    for s in subs:
+        s.num_att_layers = batch.num_att_layers
+    dev = model.device
+
+    tok = model.tokenizer
+    embs = []
+    for p in prompts:
+        ti = tok([p], padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt")
+        embs.append(encode_text(model, ti.input_ids))
+    text = torch.cat(embs)                                                         # [B, 77, C]
+    ui = tok([E.UNCOND_TEXT], padding="max_length", max_length=tok.model_max_length, return_tensors="pt", truncation=True)
+    ctx_uncond = encode_text(model, ui.input_ids).expand(B, -1, -1).contiguous()   # the uncond_edit rows
+    ctx_text = torch.cat([text, text])                                             # cond_ref rows, then cond_edit rows
+
+    latents = torch.cat([latent, latent]).to(dev)                                  # :134-139 (expand to the two rows of every edit)
+    model.scheduler.set_timesteps(num_inference_steps)
+    for p in model.unet.parameters():
+        p.requires_grad = False
+    timesteps = model.scheduler.timesteps[-start_time:]
+    T = len(timesteps)
+
+    upd_masks = []
+    for j, s in enumerate(subs):                                                   # :147-149 (512^2 mask warp, once per edit)
+        t_m = reshape_transform_coords(batch.coords[j].to(dev).float(), in_mat_shape=s.image_mask.shape)
+        t_m = t_m.tile(s.image_mask.shape[0], 1, 1, 1).to(E._coords_dtype(text))
+        s.mask_new_warped = binarize_tensor(warp_grid_edit(s.image_mask[:, None].to(dev).float(), t_m)).type_as(text)
+        # the mask of _update_latent (U/optimization.py:228: resized, NOT re-binarised), constant over the steps
+        m = s.mask_new_warped[:1]
+        m = reshape_attention_mask(m[None, None].to(dev).float().reshape(1, 1, *m.shape[-2:]), in_mat_shape=latents[-1:].shape)
+        upd_masks.append(m[-1, 0].reshape(-1).contiguous())
+
+    def cfg_pass(lat, ctx_t, tt):
+        assert not torch.is_grad_enabled()
+        set_attn_processor_for_edit(model, coords_base=(1, 2), coords_edit=(2, 3), use_cfg=True, n_batch=3)
+        lat_in = torch.cat([lat[B:], lat[:B], lat[B:]])                            # [uncond_edit | cond_ref | cond_edit] x B (U/diffusion.py:43 less uncond_ref)
+        ctx3 = torch.cat([ctx_uncond.to(ctx_t.dtype), ctx_t])
+        eps = _unet_nograd(model, batch, lat_in, tt, ctx3, "cfg3", None, ctx_src=ctx_t)
+        edit_out = _sched_step(model.scheduler, eps[:B], tt, lat[B:], eps[2 * B:], guidance_scale)
+        warp_utils.SPLATTER.clear_cache()
+        return torch.cat([lat[:B].to(edit_out.dtype), edit_out])
+
+    opt_pass = GraphedBatchOptPass(model, None, guidance_scale)
+    remover = type(subs[0]).__name__ == "AttentionGeometryRemover"
+    for i, t in enumerate(timesteps):
+        for s in subs:
+            E.clear_controller_loss(s)
+        if (i < optimize_steps * T) and (i % skip_optim_steps == 0):                                    # :181
+            l_eff = lr * (50 - i) * skip_optim_steps * (50 / (num_ddim_steps + 1e-8))                  # :207
+            set_attn_processor_for_edit(model, coords_base=(0, 1), coords_edit=(1, 2), use_cfg=False)   # :213
+            n0 = [ops.sumsq(latents[B + j].detach().float().contiguous()) for j in range(B)]            # orig_norm^2 (:219)
+            for j, s in enumerate(subs):
+                s.rows_identical = bool(E.TIE_IDENTICAL_ROWS and i == 0 and remover and torch.equal(latents[j], latents[B + j])
+                                        and torch.equal(ctx_text[j], ctx_text[B + j]))
+            g_lat, g_ctx, lat_in, ctx_in = opt_pass.grads(batch, latents, ctx_text, t)                  # :218-273
+            new_rows = [ops.masked_latent_update(lat_in[B + j].detach().float().contiguous(), g_lat[B + j].detach().float().contiguous(),
+                                                 upd_masks[j], float(l_eff)) for j in range(B)]         # U/optimization.py:230-245
+            lat_upd = torch.cat([lat_in[:B].detach(), torch.stack(new_rows).to(lat_in.dtype)])
+            g_c = torch.nan_to_num(g_ctx, posinf=0.0, neginf=0.0, nan=0.0)
+            ctx_upd = torch.cat([ctx_in[:B].detach(), ctx_in[B:].detach() - l_eff * g_c[B:]])
+            logs = [s.loss_log_dict for s in subs]
+            handle = _logs_to_host_async(subs) if E.LATE_LOSS_SYNC else None
+            if not E.LATE_LOSS_SYNC:
+                _finish_logs(subs, logs, None, i, skip_optim_steps, edit_type, use_adaptive_optimization, removal_loss_value_in, num_ddim_steps, logs_out)
+            for s in subs:
+                E.clear_controller_loss(s)
+                s.rows_identical = False
+            batch.undo_step()                                                                           # :307
+            if optimize_latents:                                                                        # :312-316
+                latents = lat_upd.detach()
+                rows = []
+                for j in range(B):
+                    last = latents[B + j].float().contiguous()
+                    rows.append(ops.norm_rescale(last, n0[j], ops.sumsq(last)))
+                latents = torch.cat([latents[:B], torch.stack(rows).to(latents.dtype)])
+            if optimize_embeddings:                                                                     # :319-322
+                ctx_text = ctx_upd.detach()
+            latents = cfg_pass(latents, ctx_text, t)                                                    # :343-351
+            if E.LATE_LOSS_SYNC:
+                _finish_logs(subs, logs, handle, i, skip_optim_steps, edit_type, use_adaptive_optimization, removal_loss_value_in, num_ddim_steps, logs_out)
+        else:
+            latents = cfg_pass(latents, ctx_text, t)                                                    # :366-368
+
+        i_n = len(ddim_latents) - 2 - i                                                                 # :375-377
+        latents = torch.cat([ddim_latents[i_n].type_as(latents.detach()), latents[B:].detach()])
+
+        if not remover and i < T * latent_replace:                                                      # :382-399 latent warp
+            s_ = latents.shape[-1]
+            rows = []
+            for j, s in enumerate(subs):
+                if masks_obj[j] is None:
+                    rows.append(latents[B + j])
+                    continue
+                t_c = reshape_transform_coords(batch.coords[j].to(dev).float(), in_mat_shape=latents[:1].shape).to(E._coords_dtype(latents))
+                i_mask = ((E._resize_mask(s.mask_new_warped[:1].detach().float(), s_) > 0.5) * 1.0).type_as(latents)
+                warped = warp_grid_edit(latents[j:j + 1].detach().clone(), t_c)
+                rows.append((latents[B + j:B + j + 1] * (1 - i_mask) + i_mask * warped.type_as(latents))[0])
+            latents = torch.cat([latents[:B], torch.stack(rows)])
+
+    if return_type == "image":
+        return latent2image(model.vae, latents), logs_out
+    return latents, logs_out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def ddim_inversion_batch(model, images: Sequence[np.ndarray], prompts: Sequence[str], num_ddim_steps: int, guidance_scale: float, device):
+    """NullInversion.invert (U/inversion.py:131-196,261-277; perform_inversion=False) for B images at once: VAE encode at batch B, then
+    the 50 inversion passes at batch B (prompt == unconditional text: the two CFG rows of an edit are one sample, inversion.py
+    SINGLE_ROW) or 2 B.  -> list over time of [B,4,h,w] latents (index 0 = the encoded images, -1 = x_T)."""
+    ni = NullInversion(model, num_ddim_steps=num_ddim_steps, uncond_text=E.UNCOND_TEXT, device=device, progress_bar=None, guidance_scale=guidance_scale)
+    x = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(im) for im in images]))).to(device).float() / 127.5 - 1
+    latent = model.vae.encode(x.permute(0, 3, 1, 2))["latent_dist"].mean * model.vae.config.scaling_factor
+    B = latent.shape[0]
+    tok = model.tokenizer
+    un = encode_text(model, tok([E.UNCOND_TEXT], padding="max_length", max_length=tok.model_max_length, return_tensors="pt").input_ids)
+    cond = torch.cat([encode_text(model, tok([p], padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt").input_ids)
+                      for p in prompts])
+    single = all(bool(torch.equal(cond[j], un[0])) for j in range(B))
+    ctx = cond.contiguous() if single else torch.cat([un.expand(B, -1, -1), cond]).contiguous()
+    model.unet.set_attn_processor(VanillaAttentionProcessor())
+    inv = ni._inverse
+    inv.set_timesteps(num_ddim_steps, device=device)
+    traj = [latent]
+    latents = latent.clone().detach()
+    runner = model.__dict__.get("_graphed")
+    if runner is None:
+        runner = model.__dict__["_graphed"] = graphs.GraphedUNet(model.unet)
+    for t in inv.timesteps:
+        x_in = latents if single else torch.cat([latents] * 2)
+        if graphs.ENABLED:
+            eps, _ = runner(("inversion",), x_in, t, ctx, ctx_src=ctx)
+        else:
+            eps = model.unet(x_in, t, encoder_hidden_states=ctx, return_dict=False)[0]
+        if single:
+            latents = inv.step(eps, t, latents, return_dict=False)[0]
+        else:
+            e_u, e_c = eps.chunk(2)
+            latents = inv.step(e_u, t, latents, eps_cond=e_c, guidance_scale=guidance_scale, return_dict=False)[0]
+        traj.append(latents.detach())
+    return traj
+
+
+def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, tokenizer_model=None, scheduler_in=None,
+                                 cross_replace_steps={"default_": 0.95}, self_replace_steps=0.95, optimize_steps=0.6, lr=0.03,
+                                 latent_replace=0.6, optimize_embeddings=True, optimize_latents=True, obj_edit_step=1.0,
+                                 perform_inversion=False, guidance_scale=7.5, skip_optim_steps=1, num_ddim_steps=50, splatting_radius=1.3,
+                                 edit_type="geometry_editor", loss_weights_dict=None, return_loss_log_dict=False, splatting_tau=1.0,
+                                 splatting_points_per_pixel=15, use_adaptive_optimization=True, removal_loss_value_in=-1.5,
+                                 return_latents=False, **ignored):
+    """``editor.perform_geometric_edit`` (U/editor.py:428-710) for a LIST of edits that share one configuration (what the batch driver
+    does: one column of settings for every folder, large_scale_editor.py:196-317).  ``edits``: dicts with image, depth, image_mask,
+    transform_in and optionally prompt.  -> one result per edit, each what perform_geometric_edit returns for it (images[, loss log]
+    [, final latents [2,4,h,w]]).  The keyword arguments mean what they mean there; ``loss_weights_dict`` is deep-copied per edit (every
+    edit's adaptive schedule edits its own)."""
+    import copy
+    if perform_inversion:
+        raise NotImplementedError("null-text optimisation is per edit: use perform_geometric_edit (every reference driver passes perform_inversion=False)")
+    if edit_type not in ("geometry_editor", "geometry_remover"):
+        raise NotImplementedError(edit_type)
+    prev_grad = torch.is_grad_enabled()
+    torch.set_grad_enabled(False)
+    try:
+        torch.manual_seed(E.SEED)
+        torch.cuda.manual_seed_all(E.SEED)
+        max_opt = max(self_replace_steps, cross_replace_steps["default_"])
+        optimize_steps = min(optimize_steps, max_opt)
+        warp_utils.SPLATTER.clear_cache()
+        E.GUIDANCE_SCALE, E.SKIP_OPTIM_STEPS, E.NUM_DDIM_STEPS = guidance_scale, skip_optim_steps, num_ddim_steps
+        if scheduler_in is not None:
+            model, tokenizer = ldm_stable_model, tokenizer_model
+        else:
+            from .diffusion import load_model
+            model, tokenizer, _ = load_model(diffusion_model=E.DIFFUSION_MODEL, device=E.DEVICE)
+        dev = E.DEVICE
+        B = len(edits)
+        prompts = [e.get("prompt", "") for e in edits]
+        subs, coords, masks, images = [], [], [], []
+        cls = AttentionGeometryEdit if edit_type == "geometry_editor" else AttentionGeometryRemover
+        for e in edits:
+            image = np.asarray(e["image"])
+            image_mask = torch.as_tensor(np.asarray(e["image_mask"])).float()
+            H = image.shape[0]
+            t_coords_depth, _, amodal = vis_utils.get_transform_coordinates(
+                image / 255.0, e["depth"], image_mask.numpy(), transform_in=e["transform_in"],
+                focal_length=550 * H / 512.0 if H != 512 else 550, return_mesh=True, device=str(dev), as_torch=True)
+            c = cls([e.get("prompt", "")] * 2, num_ddim_steps, cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
+                    equalizer=None, local_blend=None, controller=None, image_mask=image_mask.numpy(), empty_scale=0.0, use_all=False,
+                    obj_edit_step=obj_edit_step, tokenizer=tokenizer, device=dev, mode=E.MODE)
+            c.amodal_mask = torch_erode(amodal.float())
+            if loss_weights_dict is not None:
+                lw = copy.deepcopy(loss_weights_dict)
+                c.loss_weight_dict = lw
+                c.default_loss_weights = lw
+            subs.append(c); coords.append(t_coords_depth[None].detach()); masks.append(image_mask); images.append(image)
+        batch = EditBatch(subs, coords)
+        traj = ddim_inversion_batch(model, images, prompts, num_ddim_steps, guidance_scale, dev)
+        out, logs = text2image_ldm_stable_batch(
+            model, prompts, batch, num_ddim_steps, guidance_scale, latent=traj[-1], ddim_latents=traj, masks_obj=[m[None, None] for m in masks],
+            optimize_steps=optimize_steps, latent_replace=latent_replace, lr=lr, optimize_embeddings=optimize_embeddings,
+            optimize_latents=optimize_latents, edit_type=edit_type, use_adaptive_optimization=use_adaptive_optimization,
+            removal_loss_value_in=removal_loss_value_in, return_type="latents", image_size=images[0].shape[0],
+            skip_optim_steps=skip_optim_steps, num_ddim_steps=num_ddim_steps)
+        decoded = latent2image(model.vae, out, as_tensor=True)                     # [2 B, H, W, 3] uint8 on the device, role-major
+        results = []
+        for j, e in enumerate(edits):
+            imgs = [decoded[j].cpu().numpy(), E.post_process(images[j], masks[j], decoded[B + j], coords[j], subs[j].mask_new_warped, edit_type)]
+            ret = [imgs]
+            if return_loss_log_dict:
+                ret.append(logs[j])
+            if return_latents:
+                ret.append(torch.stack([out[j], out[B + j]]))
+            results.append(ret[0] if len(ret) == 1 else tuple(ret))
+        model.unet.set_attn_processor(VanillaAttentionProcessor())
+        return results
+    finally:
+        torch.set_grad_enabled(prev_grad)

@@ -138,11 +138,14 @@ def diffusion_step(model, controller, latents, context, t, guidance_scale, low_r
 
 
 @torch.no_grad()
-def latent2image(vae, latents):
-    """diffusion.py:61-68."""
+def latent2image(vae, latents, as_tensor: bool = False):
+    """diffusion.py:61-68.  ``as_tensor``: the uint8 images stay on the device ([n,H,W,3] tensor; same float32 arithmetic and the same
+    truncation as numpy's ``astype``) for the post-process that follows."""
     latents = 1 / 0.18215 * latents
     image = vae.decode(latents)["sample"]
     image = (image.float() / 2 + 0.5).clamp(0, 1)
+    if as_tensor:
+        return (image.permute(0, 2, 3, 1) * 255).to(torch.uint8).contiguous()
     image = image.cpu().permute(0, 2, 3, 1).numpy()
     return (image * 255).astype(np.uint8)
 

@@ -307,6 +307,33 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
     return image, latent, global_loss_log_dict
 
 
+@torch.no_grad()
+def post_process(image, image_mask, edited, transform_coordinates, mask_new_warped, edit_type, as_numpy: bool = True):
+    """U/editor.py:660-693 — the histogram post-process of the decoded edit, entirely on the device.
+    geometry_editor: the input image warped by the edit's transform is pasted over the input wherever the moved object lands, the pixels
+    the object left are masked out, and the decoded edit's per-channel histograms are matched to that composite inside the remaining
+    region; geometry_remover: matched to the input image outside the object mask.
+    image [H,W,3] uint8 (numpy or tensor), image_mask [H,W] in {0,1}, edited [H,W,3] uint8 tensor on the device, transform_coordinates
+    [1,H,W,3], mask_new_warped [>=1,1,H,W] -> the reference's float64 image ``lut[edited]`` (numpy unless ``as_numpy=False``).
+    The integer arithmetic is the reference's: masks are {0,1}, so mask*uint8 sums are exact and the ``astype('uint8')`` truncations act
+    on the same values."""
+    dev = edited.device
+    img = torch.as_tensor(np.ascontiguousarray(image)).to(dev)                                  # [H,W,3] uint8
+    m_im = torch.as_tensor(np.asarray(image_mask) if not torch.is_tensor(image_mask) else image_mask).to(dev).float()
+    if edit_type == "geometry_editor":
+        img_t = (img[None].permute(0, 3, 1, 2) / 255.0).float()
+        warped = warp_grid_edit(img_t, transform_coordinates.to(dev).float())                   # fp16 [1,3,H,W] (warp_utils.py:176)
+        moved = (warped[0].permute(1, 2, 0).float() * 255.0).to(torch.uint8)                    # the warped image as uint8 (truncated)
+        m_edit = mask_new_warped[0, 0].detach().float()
+        keep = 1.0 - ((m_edit + m_im) > 0.5).float()                                            # neither the object's old nor its new place
+        target = (keep[..., None] * img.float() + m_edit[..., None] * moved.float()).to(torch.uint8)
+        region = ((m_edit + keep) > 0.5).float()
+        out = masked_histogram_matching(edited, target, region, region)
+    else:
+        out = masked_histogram_matching(edited, img, 1.0 - m_im)
+    return out.cpu().numpy() if as_numpy else out
+
+
 def run_and_display(ldm_stable, prompts, controller, latent=None, run_baseline=False, generator=None, uncond_embeddings=None,
                     verbose=True, transform_coordinates=None, mask_obj=None, optimize_steps=0.0, latent_replace=0.0, lr=0.0,
                     optimize_embeddings=False, optimize_latents=True, ddim_latents=None, ddim_noise=None, edit_type="geometry_editor",
@@ -411,27 +438,12 @@ def _perform_geometric_edit(image, depth, image_mask, transform_in, prompt, ldm_
         optimize_embeddings=optimize_embeddings, optimize_latents=optimize_latents, ddim_latents=ddim_latents, verbose=False,
         ddim_noise=ddim_noise, edit_type=edit_type, fast_start_steps=fast_start_steps, num_first_optim_steps=num_first_optim_steps,
         use_adaptive_optimization=use_adaptive_optimization, removal_loss_value_in=removal_loss_value_in,
-        return_type="latents" if return_latents else "image", image_size=H)
+        return_type="latents", image_size=H)
     final_latents = out if return_latents else None
-    images = latent2image(ldm_stable.vae, out) if return_latents else out
-    images = list(images)
-
-    edited_image = images[-1]
-    if edit_type == "geometry_editor":                                                                     # :660-682
-        img_t = (torch.from_numpy(np.ascontiguousarray(image[None])).to(DEVICE).permute(0, 3, 1, 2) / 255.0).float()   # on the device
-        image_warped = warp_grid_edit(img_t.to(DEVICE), transform_coordinates.float())
-        p_image = (image_warped[0].permute(1, 2, 0).float().cpu().numpy() * 255.0).astype("uint8")
-        mask_edit = controller.mask_new_warped[0, 0].detach().float().cpu().numpy()
-        mask_im = image_mask.numpy()
-        mask_changed = ((mask_edit + mask_im) > 0.5) * 1.0
-        mask_wo_edit = ((np.ones_like(mask_changed) - mask_changed) > 0.5) * 1.0
-        p_image_new = (mask_wo_edit[..., None] * image + mask_edit[..., None] * p_image).astype("uint8")
-        mask_source = ((mask_edit + mask_wo_edit) > 0.5) * 1.0
-        edited_image = masked_histogram_matching(edited_image, p_image_new, mask_source, mask_source)
-    else:                                                                                                  # :687-693
-        edited_image = masked_histogram_matching(edited_image, image, 1.0 - image_mask.numpy())
-    images[-1] = edited_image
-
+    decoded = latent2image(ldm_stable.vae, out, as_tensor=True)                    # [2, H, W, 3] uint8, still on the device
+    # :660-693 on the device: one download of the finished images instead of image -> host -> device -> host
+    edited = post_process(image, image_mask, decoded[-1], transform_coordinates, controller.mask_new_warped, edit_type)
+    images = [decoded[0].cpu().numpy(), edited]
     ldm_stable.unet.set_attn_processor(VanillaAttentionProcessor())                                        # :698
     ret = [images]
     if return_loss_log_dict:

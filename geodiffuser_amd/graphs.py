@@ -158,6 +158,22 @@ def reset_opt_graphs():
     release_backward_weights()
 
 
+def _export_loss_state(controller):
+    """What a captured optimisation pass leaves in the controller's Python state (device scalars the graph writes on every replay)."""
+    fn = getattr(controller, "export_loss_state", None)
+    if fn is not None:                                     # batch.EditBatch: one (loss, log) pair per edit
+        return fn()
+    return controller.loss, {k: (dict(v) if isinstance(v, dict) else v) for k, v in controller.loss_log_dict.items()}
+
+
+def _import_loss_state(controller, state):
+    fn = getattr(controller, "import_loss_state", None)
+    if fn is not None:
+        return fn(state)
+    controller.loss = state[0]
+    controller.loss_log_dict = {k: (dict(v) if isinstance(v, dict) else v) for k, v in state[1].items()}
+
+
 class GraphedOptPass:
     """The optimisation pass — UNet forward with the geometry controller's losses, then autograd back to the latent and the
     text embedding — as one hipGraph, reused across edits.
@@ -172,6 +188,8 @@ class GraphedOptPass:
     The first optimisation pass a UNet ever sees runs eagerly (MIOpen / rocBLAS warm-up, and it tells which (resolution, heads) pairs
     the hooked layers have); from then on a new edit builds its tables up front (one host sync per resolution) and replays."""
 
+    ctx_text_rows_only = True        # the driver's context is [uncond_ref, uncond_edit, cond_ref, cond_edit]: the pass runs on the last two
+
     def __init__(self, model, transform_coords, guidance_scale):
         self.model = model
         self.transform_coords = transform_coords
@@ -181,8 +199,8 @@ class GraphedOptPass:
         from .diffusion import diffusion_step
         from .optimization import _latent_grads
         with torch.enable_grad():
-            diffusion_step(self.model, controller, lat, ctx[2:], t, self.guidance_scale, transform_coords=self.transform_coords,
-                           use_cfg=False, return_noise=True, skip_scheduler=skip_scheduler)
+            diffusion_step(self.model, controller, lat, ctx[2:] if self.ctx_text_rows_only else ctx, t, self.guidance_scale,
+                           transform_coords=self.transform_coords, use_cfg=False, return_noise=True, skip_scheduler=skip_scheduler)
             return _latent_grads(lat, controller.loss, ctx)
 
     def _key(self, controller, lat, ctx):
@@ -226,8 +244,7 @@ class GraphedOptPass:
             with torch.cuda.graph(g):
                 st["g_lat"], st["g_ctx"] = self._eager(controller, st["lat"], st["ctx"], st["t"], skip_scheduler=True)
             ops.zero_pool_reset()
-            st["loss"] = controller.loss
-            st["log"] = {k: (dict(v) if isinstance(v, dict) else v) for k, v in controller.loss_log_dict.items()}
+            st["state"] = _export_loss_state(controller)
             st["graph"] = g
             _OPT_GRAPHS[key] = st
             g.replay()                                                         # the capture itself executed nothing
@@ -237,8 +254,7 @@ class GraphedOptPass:
             st["ctx"].copy_(ctx)
             st["t"].fill_(int(t))
         st["graph"].replay()
-        controller.loss = st["loss"]
-        controller.loss_log_dict = {k: (dict(v) if isinstance(v, dict) else v) for k, v in st["log"].items()}
+        _import_loss_state(controller, st["state"])
         controller.after_graph_replay()
         return st["g_lat"], st["g_ctx"], st["lat"], st["ctx"]
 

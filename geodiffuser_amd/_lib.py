@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(HERE, "csrc", "libgeodiff_hip.so")
 
 GD_F16, GD_BF16, GD_F32 = 0, 1, 2
 GD_TOKEN_MAJOR, GD_CHANNEL_MAJOR = 0, 1
-GD_ATTN_MAX_SEGS = 4
+GD_ATTN_MAX_SEGS = 12
+GD_ATTN_MAX_PAIRS = 8
 GD_ABI_VERSION = 5
 
 
@@ -62,8 +63,8 @@ class GdHeadsSplit(Structure):               # gd_heads_split_t
 
 
 class GdHeadsMerge(Structure):               # gd_heads_merge_t
-    _fields_ = [("src", c_void_p * 4), ("blend_b", c_void_p), ("m", c_void_p), ("out", c_void_p),
-                ("blend_row", c_int32), ("src_f32", c_int32), ("B", c_int32), ("rows", c_int32), ("heads", c_int32), ("D", c_int32)]
+    _fields_ = [("src", c_void_p * 16), ("blend_b", c_void_p * 16), ("m", c_void_p * 16), ("out", c_void_p),
+                ("src_f32", c_int32), ("B", c_int32), ("rows", c_int32), ("heads", c_int32), ("D", c_int32)]
 
 
 class GeodiffError(RuntimeError):
@@ -115,10 +116,10 @@ SIGNATURES = {
     "gd_edit_losses_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, POINTER(GdRemovalBwd), c_int, c_void_p]),
     "gd_blend_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
-    "gd_attn_fwd_pair": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "gd_attn_fwd_pair": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "gd_heads_split": (c_int, [c_void_p, c_int, c_void_p]),
     "gd_heads_merge": (c_int, [c_void_p, c_int, c_void_p]),
-    "gd_edit_dq_fold": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "gd_edit_dq_fold": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gd_group_norm_nhwc_scratch_floats": (c_int64, [c_int, c_int, c_int]),
     "gd_group_norm_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p,
                                    c_void_p, c_int, c_void_p]),

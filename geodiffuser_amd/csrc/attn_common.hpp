@@ -101,7 +101,7 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 }
 
 // ---- forward kernels: launch arguments and fragment helpers shared by attn_fwd.hip and attn_fwd_mp.hip ----
-#define GD_ATTN_MAX_ORDER 160
+#define GD_ATTN_MAX_ORDER 256
 struct FwdArgs {
     gd_attn_seg_t seg[GD_ATTN_MAX_SEGS];
     int bh_end[GD_ATTN_MAX_SEGS];   // exclusive prefix of bh
@@ -117,8 +117,11 @@ struct FwdArgs {
     // of different segments are interleaved (n_order == 0: segment after segment, via bh_end)
     int n_order;
     unsigned short order[GD_ATTN_MAX_ORDER];
-    // segment with a query row list (gd_attn_seg_t::q_rows; -1: none): its units (tiles_c per head) follow the units of all other segments
-    int cseg, tiles_c, units_full;
+    // segments with a query row list (gd_attn_seg_t::q_rows; cseg = the first one, -1: none): their units (tiles_cs[i] per head of the i-th
+    // such segment, cu_end[i] = exclusive prefix of their unit counts) follow the units of all other segments
+    int cseg, ncseg, units_full;
+    int cu_end[GD_ATTN_MAX_ROWLIST_SEGS], tiles_cs[GD_ATTN_MAX_ROWLIST_SEGS];
+    unsigned char cseg_of[GD_ATTN_MAX_ROWLIST_SEGS];
     // split-KV (launches that would leave most CUs idle): split sp handles key tiles [sp*tps, (sp+1)*tps) and leaves an
     // un-normalised partial (O, m, l) in the workspace; k_attn_combine merges them
     int nsplit, tps, tot_bh;
@@ -212,6 +215,19 @@ __device__ __forceinline__ void load_q_frags(const gd_attn_seg_t& sg, const T* _
     }
 }
 
+
+// unit (>= units_full) of a launch -> (segment with a query row list, head in it, query tile of its list)
+__device__ __forceinline__ void compact_unit(const FwdArgs& a, int unit, int& sidx, int& bh, int& tile) {
+    int uc = unit - a.units_full, ci = 0;
+#pragma unroll
+    for (int i = 0; i < GD_ATTN_MAX_ROWLIST_SEGS - 1; ++i)
+        if (i < a.ncseg - 1 && uc >= a.cu_end[i]) ci = i + 1;
+    uc -= ci ? a.cu_end[ci - 1] : 0;
+    const int tc = a.tiles_cs[ci];
+    bh = uc / tc;
+    tile = uc - bh * tc;
+    sidx = a.cseg_of[ci];
+}
 
 // software-pipelined forward (attn_fwd_mp.hip): QB query blocks x KS key ranges per workgroup; a.seg / bh_end / N / M / c / scale filled in
 int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st);

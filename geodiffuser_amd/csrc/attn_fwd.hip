@@ -285,11 +285,11 @@ k_attn_fwd(const FwdArgs a) {
 // store.  Bit-identical to the two launches, one launch less.  (First version: one 128-query workgroup running side A then side B —
 // 20 instead of 25 heads of workgroups, but the two dependent chains in a row made the launch 2 us slower than attention + blend.)
 struct PairArgs {
-    gd_attn_seg_t seg[GD_ATTN_MAX_SEGS];      // seg[nseg - 1] is side A of the pair; its `out` receives the blend
-    gd_attn_seg_t b;                          // side B (same bh / heads as side A; out unused)
-    const float* m;                           // [N] blend mask
+    gd_attn_seg_t seg[GD_ATTN_MAX_SEGS];      // seg[nseg - npair + p] is side A of pair p; its `out` receives the blend
+    gd_attn_seg_t b[GD_ATTN_MAX_PAIRS];       // side B of pair p (same bh / heads as side A; out unused)
+    const float* m[GD_ATTN_MAX_PAIRS];        // [N] blend mask of pair p
     int bh_end[GD_ATTN_MAX_SEGS];
-    int nseg, N, M, tiles, tiles_p, nwg_plain, nwg;
+    int nseg, npair, N, M, tiles, tiles_p, nwg_plain, nwg_pair, nwg;
     float c;
 };
 
@@ -323,24 +323,26 @@ k_attn_fwd_pair(const PairArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int wg = xcd_remap(blockIdx.x, a.nwg);
     const bool paired = wg >= a.nwg_plain;                                    // workgroup-uniform
-    int sidx, bh, tile;
+    int sidx, bh, tile, pair = 0;
     if (!paired) {
         const int gbh = wg / a.tiles;
         tile = wg - gbh * a.tiles;
         sidx = 0;
 #pragma unroll
         for (int i = 0; i < GD_ATTN_MAX_SEGS - 1; ++i)
-            if (i < a.nseg - 2 && gbh >= a.bh_end[i]) sidx = i + 1;
+            if (i < a.nseg - a.npair - 1 && gbh >= a.bh_end[i]) sidx = i + 1;
         bh = gbh - (sidx ? a.bh_end[sidx - 1] : 0);
     } else {
-        const int w2 = wg - a.nwg_plain;
+        int w2 = wg - a.nwg_plain;
+        pair = w2 / a.nwg_pair;                                               // every pair has the same head count
+        w2 -= pair * a.nwg_pair;
         bh = w2 / a.tiles_p;
         tile = w2 - bh * a.tiles_p;
-        sidx = a.nseg - 1;
+        sidx = a.nseg - a.npair + pair;
     }
     const int side = paired ? (wave >> 1) : 0;                                // wave-uniform
     const gd_attn_seg_t sa = a.seg[sidx];
-    const gd_attn_seg_t sg = (paired && side) ? a.b : sa;                     // the segment THIS wave attends with
+    const gd_attn_seg_t sg = (paired && side) ? a.b[pair] : sa;               // the segment THIS wave attends with
     const int N = a.N, M = a.M;
     const int rs = sa.heads > 0 ? sa.heads * D : D;
     size_t qoff, koff;
@@ -357,7 +359,7 @@ k_attn_fwd_pair(const PairArgs a) {
     const FragOffs fo = make_frag_offs(lane);
     const int T_all = (M + ATT_BN - 1) / ATT_BN;                              // 1 or 2 (launcher)
     const int T_full = M / ATT_BN;
-    const bool same_k = !paired || a.b.k == sa.k, same_v = !paired || a.b.v == sa.v;
+    const bool same_k = !paired || a.b[pair].k == sa.k, same_v = !paired || a.b[pair].v == sa.v;
 
     // every wave's own queries (side A: the gather-composite prologue when the segment carries warp tables) and, by all four waves, the
     // K / V tiles of side A and whichever of side B's differ: one round trip, as in the two-segment launch
@@ -366,8 +368,8 @@ k_attn_fwd_pair(const PairArgs a) {
         u32x4 kr[2][2], vr[2][2], kbr[2][2], vbr[2][2];
         const T* __restrict__ kp = (const T*)sa.k + koff;
         const T* __restrict__ vp = (const T*)sa.v + koff;
-        const T* __restrict__ kbp = (const T*)a.b.k + koff;
-        const T* __restrict__ vbp = (const T*)a.b.v + koff;
+        const T* __restrict__ kbp = (const T*)a.b[pair].k + koff;
+        const T* __restrict__ vbp = (const T*)a.b[pair].v + koff;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
             if (t < T_all) {
@@ -385,7 +387,7 @@ k_attn_fwd_pair(const PairArgs a) {
             }
     }
     load_q_frags<T>(sg, (const T*)sg.q + qoff, rs, qld, h, qf);
-    const float mraw = (paired && !side) ? a.m[qld] : 0.f;
+    const float mraw = (paired && !side) ? a.m[pair][qld] : 0.f;
     __syncthreads();
 
     const int sk = (side && !same_k) ? 1 : 0, sv = (side && !same_v) ? 1 : 0;
@@ -440,10 +442,10 @@ k_attn_fwd_pair(const PairArgs a) {
         }
 }
 
-extern "C" int gd_attn_fwd_pair(const gd_attn_seg_t* segs, int nseg, const gd_attn_seg_t* side_b, const float* blend_m, int N, int M, int D,
-                                float scale, int dtype, void* stream) {
-    GD_REQUIRE(segs && side_b && blend_m && nseg >= 1 && nseg <= GD_ATTN_MAX_SEGS, GD_EINVAL, "gd_attn_fwd_pair: null pointer or nseg=%d (1..%d)", nseg,
-               GD_ATTN_MAX_SEGS);
+extern "C" int gd_attn_fwd_pair(const gd_attn_seg_t* segs, int nseg, const gd_attn_seg_t* side_b, const float* const* blend_m, int npair, int N,
+                                int M, int D, float scale, int dtype, void* stream) {
+    GD_REQUIRE(segs && side_b && blend_m && nseg >= 1 && nseg <= GD_ATTN_MAX_SEGS && npair >= 1 && npair <= GD_ATTN_MAX_PAIRS && npair <= nseg, GD_EINVAL,
+               "gd_attn_fwd_pair: null pointer, nseg=%d (1..%d) or npair=%d (1..%d, <= nseg)", nseg, GD_ATTN_MAX_SEGS, npair, GD_ATTN_MAX_PAIRS);
     GD_REQUIRE(D == ATT_D && M > 0 && M <= 2 * ATT_BN && N > 0, GD_EUNSUPPORTED, "gd_attn_fwd_pair: head dim 64 and at most %d keys (D=%d, M=%d)", 2 * ATT_BN, D, M);
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_attn_fwd_pair: dtype must be f16/bf16");
     PairArgs a;
@@ -457,16 +459,22 @@ extern "C" int gd_attn_fwd_pair(const gd_attn_seg_t* segs, int nseg, const gd_at
         tot += segs[i].bh;
         a.bh_end[i] = tot;
     }
-    const gd_attn_seg_t& sa = segs[nseg - 1];
-    GD_REQUIRE(side_b->q && side_b->k && side_b->v && side_b->bh == sa.bh && side_b->heads == sa.heads && !side_b->lse && !side_b->q_rows &&
-               (side_b->q_scaled != 0) == (sa.q_scaled != 0), GD_EINVAL, "gd_attn_fwd_pair: side B must match side A's head count, layout and query scaling");
-    a.b = *side_b;
-    a.m = blend_m;
-    a.nseg = nseg; a.N = N; a.M = M;
+    const gd_attn_seg_t& sa0 = segs[nseg - npair];
+    for (int p = 0; p < npair; ++p) {
+        const gd_attn_seg_t& sa = segs[nseg - npair + p];
+        const gd_attn_seg_t& sb = side_b[p];
+        GD_REQUIRE(sa.bh == sa0.bh && sa.heads == sa0.heads, GD_EINVAL, "gd_attn_fwd_pair: the pairs of a launch must share one head count and layout");
+        GD_REQUIRE(sb.q && sb.k && sb.v && sb.bh == sa.bh && sb.heads == sa.heads && !sb.lse && !sb.q_rows && (sb.q_scaled != 0) == (sa.q_scaled != 0) && blend_m[p],
+                   GD_EINVAL, "gd_attn_fwd_pair: pair %d: side B must match side A's head count, layout and query scaling; the mask must not be NULL", p);
+        a.b[p] = sb;
+        a.m[p] = blend_m[p];
+    }
+    a.nseg = nseg; a.npair = npair; a.N = N; a.M = M;
     a.tiles = (N + ATT_BM - 1) / ATT_BM;
-    a.tiles_p = (N + 63) / 64;                                                // the pair's workgroups hold 64 queries (two waves per side)
-    a.nwg_plain = a.tiles * (tot - sa.bh);
-    a.nwg = a.nwg_plain + a.tiles_p * sa.bh;
+    a.tiles_p = (N + 63) / 64;                                                // a pair's workgroups hold 64 queries (two waves per side)
+    a.nwg_plain = a.tiles * (tot - npair * sa0.bh);
+    a.nwg_pair = a.tiles_p * sa0.bh;
+    a.nwg = a.nwg_plain + npair * a.nwg_pair;
     a.c = segs[0].q_scaled ? 1.0f : scale * 1.4426950408889634f;
     hipStream_t st = as_stream(stream);
     if (dtype == GD_F16) k_attn_fwd_pair<f16_t><<<a.nwg, 256, 0, st>>>(a);
@@ -595,7 +603,7 @@ extern "C" int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, in
     FwdArgs a;
     memset(&a, 0, sizeof(a));
     a.cseg = -1;
-    int tot = 0;
+    int tot = 0, ncs = 0;
     for (int i = 0; i < nseg; ++i) {
         GD_REQUIRE(segs[i].q && segs[i].k && segs[i].v && segs[i].out && segs[i].bh > 0, GD_EINVAL,
                    "gd_attn_fwd: segment %d has a null pointer or bh<=0", i);
@@ -604,9 +612,11 @@ extern "C" int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, in
         tot += segs[i].bh;
         a.bh_end[i] = tot;
         if (segs[i].q_rows) {
-            GD_REQUIRE(a.cseg < 0, GD_EUNSUPPORTED, "gd_attn_fwd: at most one segment of a launch may carry a query row list");
+            GD_REQUIRE(ncs < GD_ATTN_MAX_ROWLIST_SEGS, GD_EUNSUPPORTED, "gd_attn_fwd: at most %d segments of a launch may carry a query row list",
+                       GD_ATTN_MAX_ROWLIST_SEGS);
             GD_REQUIRE(segs[i].q_rows_n && segs[i].q_rows_len > 0, GD_EINVAL, "gd_attn_fwd: segment %d: q_rows without q_rows_n / q_rows_len", i);
-            a.cseg = i;
+            if (a.cseg < 0) a.cseg = i;
+            ++ncs;
         }
     }
     // without split-KV a workspace is the even split's (arrival counters, zero before the first launch, + part slots)
@@ -652,7 +662,8 @@ extern "C" int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, in
         int qb = 0, ks = 0;
         // 32-query blocks of the launch (a row-list segment counts its list, not N)
         long long blocks = (long long)((N + 31) / 32) * tot;
-        if (a.cseg >= 0) blocks -= (long long)((N + 31) / 32 - (segs[a.cseg].q_rows_len + 31) / 32) * segs[a.cseg].bh;
+        for (int i = 0; i < nseg; ++i)
+            if (segs[i].q_rows) blocks -= (long long)((N + 31) / 32 - (segs[i].q_rows_len + 31) / 32) * segs[i].bh;
         mp_config(blocks, N, M, &qb, &ks, a.q_prescaled, cfg.qb, cfg.ks);
         if (qb > 0) return gd_attn_fwd_mp_launch(a, qb, ks, dtype, st);       // software-pipelined kernels (attn_fwd_mp.hip)
     }

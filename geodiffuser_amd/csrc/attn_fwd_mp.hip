@@ -236,10 +236,7 @@ k_attn_fwd_mp(const FwdArgs a) {
     int sidx = 0, bh, tile;
     const bool compact = a.cseg >= 0 && unit >= a.units_full;      // the segment with a query row list: units after everyone else's
     if (compact) {
-        const int uc = unit - a.units_full;
-        bh = uc / a.tiles_c;
-        tile = uc - bh * a.tiles_c;
-        sidx = a.cseg;
+        compact_unit(a, unit, sidx, bh, tile);
     } else {
         const int gbh = unit / a.tiles;
         tile = unit - gbh * a.tiles;
@@ -894,10 +891,7 @@ k_attn_fwd_w64(const FwdArgs a) {
     int sidx = 0, bh, tile;
     const bool compact = a.cseg >= 0 && unit >= a.units_full;      // the segment with a query row list (see k_attn_fwd_mp)
     if (compact) {
-        const int uc = unit - a.units_full;
-        bh = uc / a.tiles_c;
-        tile = uc - bh * a.tiles_c;
-        sidx = a.cseg;
+        compact_unit(a, unit, sidx, bh, tile);
     } else {
         const int gbh = unit / a.tiles;
         tile = unit - gbh * a.tiles;
@@ -1287,14 +1281,20 @@ size_t gd_attn_sk_workspace_bytes(int tot_bh, int N, int M) {
 // units of a launch: `unit_rows` queries of one head; a segment with a query row list has its own (shorter) row count
 static int set_units(FwdArgs& a, int tot, int unit_rows) {
     a.tiles = (a.N + unit_rows - 1) / unit_rows;
-    a.tiles_c = 0;
-    int bh_c = 0;
-    if (a.cseg >= 0) {
-        a.tiles_c = (a.seg[a.cseg].q_rows_len + unit_rows - 1) / unit_rows;
-        bh_c = a.seg[a.cseg].bh;
+    int bh_c = 0, cu = 0;
+    a.ncseg = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        if (!a.seg[i].q_rows) continue;
+        const int tc = (a.seg[i].q_rows_len + unit_rows - 1) / unit_rows;
+        cu += tc * a.seg[i].bh;
+        bh_c += a.seg[i].bh;
+        a.tiles_cs[a.ncseg] = tc;
+        a.cu_end[a.ncseg] = cu;
+        a.cseg_of[a.ncseg] = (unsigned char)i;
+        ++a.ncseg;
     }
     a.units_full = a.tiles * (tot - bh_c);
-    return a.units_full + a.tiles_c * bh_c;
+    return a.units_full + cu;
 }
 
 // sk_ws != NULL (set by the caller from its workspace): deal the key tiles out evenly where that pays
@@ -1418,13 +1418,13 @@ int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st) 
         int n = 0, start = 0;
         for (int sgi = 0; sgi < a.nseg; ++sgi) {
             const int cnt = a.bh_end[sgi] - start;
-            for (int i = 0; i < cnt && sgi != a.cseg; ++i) {                // (the row-list segment's units come after the others')
+            for (int i = 0; i < cnt && !a.seg[sgi].q_rows; ++i) {              // (the row-list segments' units come after the others')
                 key[n] = ((float)i + (a.seg[sgi].warp_idx ? 0.25f : 0.5f)) / (float)cnt + 1e-4f * (float)sgi;
                 a.order[n++] = (unsigned short)((sgi << 12) | i);
             }
             start = a.bh_end[sgi];
         }
-        for (int i = 1; i < n; ++i) {                                        // insertion sort by key (n <= 160)
+        for (int i = 1; i < n; ++i) {                                        // insertion sort by key (n <= GD_ATTN_MAX_ORDER)
             const float kx = key[i];
             const unsigned short ox = a.order[i];
             int j = i - 1;

@@ -374,7 +374,7 @@ __global__ void k_heads_merge(const gd_heads_merge_t a) {
     const int h = (int)(t % heads); t /= heads;
     const int r = (int)(t % rows);
     const int b = (int)(t / rows);
-    const void* sp = b == 0 ? a.src[0] : (b == 1 ? a.src[1] : (b == 2 ? a.src[2] : a.src[3]));
+    const void* sp = a.src[b];
     const long long si = ((long long)h * rows + r) * D8 + c;
     V8 o8;
     if (!sp) {
@@ -386,9 +386,9 @@ __global__ void k_heads_merge(const gd_heads_merge_t a) {
         for (int j = 0; j < 4; ++j) { o8[j] = (T)lo[j]; o8[4 + j] = (T)hi[j]; }
     } else {
         o8 = __builtin_bit_cast(V8, ((const u32x4*)sp)[si]);
-        if (b == a.blend_row) {          // a*m + b*(1-m), op by op in the tensor dtype (k_blend)
-            const V8 b8 = __builtin_bit_cast(V8, ((const u32x4*)a.blend_b)[si]);
-            const float mm = (float)(T)a.m[r];
+        if (a.blend_b[b]) {              // a*m + b*(1-m), op by op in the tensor dtype
+            const V8 b8 = __builtin_bit_cast(V8, ((const u32x4*)a.blend_b[b])[si]);
+            const float mm = (float)(T)a.m[b][r];
             const float om = (float)(T)(1.0f - mm);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -403,11 +403,10 @@ __global__ void k_heads_merge(const gd_heads_merge_t a) {
 
 extern "C" int gd_heads_merge(const gd_heads_merge_t* a, int dtype, void* stream) {
     GD_REQUIRE(a && a->out, GD_EINVAL, "gd_heads_merge: null pointer");
-    GD_REQUIRE(a->B >= 1 && a->B <= 4 && a->rows > 0 && a->heads > 0 && a->D > 0 && a->D % 8 == 0, GD_EINVAL,
-               "gd_heads_merge: bad sizes (B <= 4, D a multiple of 8)");
-    GD_REQUIRE(a->blend_row < a->B, GD_EINVAL, "gd_heads_merge: blend_row outside the batch");
-    GD_REQUIRE(a->blend_row < 0 || (!a->src_f32 && a->blend_b && a->m && a->src[a->blend_row]), GD_EINVAL,
-               "gd_heads_merge: the blend needs 16-bit sources, blend_b and m");
+    GD_REQUIRE(a->B >= 1 && a->B <= GD_HEADS_MERGE_MAX_ROWS && a->rows > 0 && a->heads > 0 && a->D > 0 && a->D % 8 == 0, GD_EINVAL,
+               "gd_heads_merge: bad sizes (B <= %d, D a multiple of 8)", GD_HEADS_MERGE_MAX_ROWS);
+    for (int b = 0; b < a->B; ++b)
+        GD_REQUIRE(!a->blend_b[b] || (!a->src_f32 && a->m[b] && a->src[b]), GD_EINVAL, "gd_heads_merge: row %d: the blend needs 16-bit sources and a mask", b);
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_heads_merge: dtype must be f16/bf16");
     const long long tot = (long long)a->B * a->rows * a->heads * (a->D / 8);
     const int blocks = (int)((tot + 255) / 256);
@@ -572,8 +571,8 @@ extern "C" int gd_edit_losses_bwd(const void* eo, const void* ro, const float* t
 // 4 elements per thread.  The removal partials lie at rm_workspace + H*R (gd_removal_bwd's layout: row dots first).
 // part == NULL (the dq kernel did not split its key range and wrote dq directly): only the live inpaint rows are touched, T(float(dq) + s).
 template <typename T>
-__global__ void k_edit_dq_fold(const float* __restrict__ part, int kchunks, int BH, int N, int D, const float* __restrict__ rm_part, int msplit, int R,
-                               const int32_t* __restrict__ inp_pos, const float* __restrict__ wgt, T* dq) {
+__global__ void k_edit_dq_fold(const float* __restrict__ part, int kchunks, long long cstride4, int BH, int N, int D, const float* __restrict__ rm_part,
+                               int msplit, int R, const int32_t* __restrict__ inp_pos, const float* __restrict__ wgt, T* dq) {
     using TR = elem_traits<T>;
     const long long n4 = (long long)BH * N * D / 4;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -582,7 +581,7 @@ __global__ void k_edit_dq_fold(const float* __restrict__ part, int kchunks, int 
     if (part) {
         acc = *(const f32x4*)(part + i * 4);
         for (int c = 1; c < kchunks; ++c) {
-            const f32x4 p = *(const f32x4*)(part + ((long long)c * n4 + i) * 4);
+            const f32x4 p = *(const f32x4*)(part + ((long long)c * cstride4 + i) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] += p[j];
         }
@@ -618,9 +617,11 @@ __global__ void k_edit_dq_fold(const float* __restrict__ part, int kchunks, int 
     *(typename TR::vec4*)(dq + i * 4) = w;
 }
 
-extern "C" int gd_edit_dq_fold(const float* dq_part, int kchunks, int BH, int N, int D, const float* rm_workspace, int M, int R,
+extern "C" int gd_edit_dq_fold(const float* dq_part, int kchunks, int64_t chunk_stride, int BH, int N, int D, const float* rm_workspace, int M, int R,
                                const int32_t* inp_pos, const float* wgt, void* dq16, int dtype, void* stream) {
     GD_REQUIRE(dq16 && kchunks >= 1 && (dq_part || rm_workspace), GD_EINVAL, "gd_edit_dq_fold: null pointer / kchunks < 1");
+    GD_REQUIRE(chunk_stride == 0 || (chunk_stride >= (int64_t)BH * N * D && chunk_stride % 4 == 0), GD_EINVAL,
+               "gd_edit_dq_fold: chunk_stride must be 0 (= BH*N*D) or a multiple of 4 >= BH*N*D");
     GD_REQUIRE(BH > 0 && N > 0 && D > 0 && D % 4 == 0, GD_EINVAL, "gd_edit_dq_fold: bad sizes");
     GD_REQUIRE(!rm_workspace || (inp_pos && wgt && R > 0 && M > 0), GD_EINVAL, "gd_edit_dq_fold: removal partials need inp_pos, wgt, R, M");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_edit_dq_fold: dtype must be f16/bf16");
@@ -629,8 +630,9 @@ extern "C" int gd_edit_dq_fold(const float* dq_part, int kchunks, int BH, int N,
     const long long n4 = (long long)BH * N * D / 4;
     const int blocks = (int)((n4 + 255) / 256);
     hipStream_t st = as_stream(stream);
-    if (dtype == GD_F16) k_edit_dq_fold<f16_t><<<blocks, 256, 0, st>>>(dq_part, kchunks, BH, N, D, rm_part, msplit, R, inp_pos, wgt, (f16_t*)dq16);
-    else k_edit_dq_fold<bf16_t><<<blocks, 256, 0, st>>>(dq_part, kchunks, BH, N, D, rm_part, msplit, R, inp_pos, wgt, (bf16_t*)dq16);
+    const long long cs4 = (chunk_stride ? chunk_stride : (int64_t)BH * N * D) / 4;
+    if (dtype == GD_F16) k_edit_dq_fold<f16_t><<<blocks, 256, 0, st>>>(dq_part, kchunks, cs4, BH, N, D, rm_part, msplit, R, inp_pos, wgt, (f16_t*)dq16);
+    else k_edit_dq_fold<bf16_t><<<blocks, 256, 0, st>>>(dq_part, kchunks, cs4, BH, N, D, rm_part, msplit, R, inp_pos, wgt, (bf16_t*)dq16);
     GD_CHECK_LAUNCH("gd_edit_dq_fold");
     return GD_OK;
 }

@@ -256,18 +256,28 @@ def _attn_seg_array(segs: Sequence[tuple], heads: int, q_scaled, what: str = "at
     return arr, n, N, M, D, dt, tot_bh
 
 
-def attn_fwd_pair(segs: Sequence[tuple], side_b: tuple, m: torch.Tensor, scale: float, heads: int = 0, q_scaled: bool = False) -> None:
-    """Short-key launches (at most 128 keys) with the blend inside: ``segs`` as attn_fwd (no LSE, no row lists); the LAST segment is side A of
-    a pair, ``side_b`` = (q, k, v[, warp]) its side B: segs[-1]'s out = A*m + B*(1-m) as blend_tokens computes it from the two attention
-    outputs (gd_attn_fwd_pair).  m [N] f32."""
+def attn_fwd_pair(segs: Sequence[tuple], side_b, m, scale: float, heads: int = 0, q_scaled: bool = False) -> None:
+    """Short-key launches (at most 128 keys) with the blend inside: ``segs`` as attn_fwd (no LSE, no row lists).  One pair: the LAST segment
+    is side A, ``side_b`` = (q, k, v[, warp]) its side B and ``m`` [N] f32 the mask: segs[-1]'s out = A*m + B*(1-m) as blend_tokens computes
+    it from the two attention outputs.  P pairs (one per edit of a batch): ``side_b`` a LIST of P such tuples, ``m`` a list of P masks and
+    the LAST P segments their A sides (gd_attn_fwd_pair)."""
     lib = _lib.load()
+    many = isinstance(side_b, list)
+    bs, ms = (side_b, m) if many else ([side_b], [m])
+    P = len(bs)
+    if len(ms) != P or P > len(segs):
+        raise _lib.GeodiffError("attn_fwd_pair: one mask and one A side per B side")
     arr, n, N, M, D, dt, _ = _attn_seg_array(segs, heads, q_scaled, "attn_fwd_pair")
-    b = (side_b[0], side_b[1], side_b[2], None, None) + tuple(side_b[3:4])
-    arr_b, _, Nb, Mb, _, _, _ = _attn_seg_array([b], heads, q_scaled, "attn_fwd_pair")
-    _need(m, "m", torch.float32)
-    if Nb != N or Mb != M or m.numel() != N or b[0].shape != segs[-1][0].shape:
+    arr_b, _, Nb, Mb, _, _, _ = _attn_seg_array([(b[0], b[1], b[2], None, None) + tuple(b[3:4]) for b in bs], heads, q_scaled, "attn_fwd_pair")
+    mp = (ctypes.c_void_p * P)()
+    for i, (b, mm) in enumerate(zip(bs, ms)):
+        _need(mm, "m", torch.float32)
+        if mm.numel() != N or b[0].shape != segs[len(segs) - P + i][0].shape:
+            raise _lib.GeodiffError("attn_fwd_pair: side B / mask do not match side A")
+        mp[i] = mm.data_ptr()
+    if Nb != N or Mb != M:
         raise _lib.GeodiffError("attn_fwd_pair: side B / mask do not match side A")
-    check(lib.gd_attn_fwd_pair(arr, n, arr_b, _p(m), N, M, D, scale, dt, _stream()), "gd_attn_fwd_pair")
+    check(lib.gd_attn_fwd_pair(arr, n, arr_b, mp, P, N, M, D, scale, dt, _stream()), "gd_attn_fwd_pair")
 
 
 def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Optional[int] = None, q_scaled: bool = False,
@@ -599,15 +609,19 @@ def heads_split(tensors: Sequence[torch.Tensor], heads: int) -> List[torch.Tenso
     return outs
 
 
-def heads_merge(srcs: Sequence[Optional[torch.Tensor]], heads: int, rows: int, D: int, dtype: torch.dtype, device, blend: Optional[tuple] = None):
+def heads_merge(srcs: Sequence[Optional[torch.Tensor]], heads: int, rows: int, D: int, dtype: torch.dtype, device, blend=None, out=None):
     """-> token-major [B, rows, heads*D]: batch row b from the head-major srcs[b] [heads, rows, D] (16-bit, or f32 for all: rounded once),
-    zeros where srcs[b] is None.  blend = (row, b, m): that row is srcs[row]*m + b*(1-m) as blend_tokens computes it.  One launch
-    (batch_to_head_dim of the output, the blend before it, and the autograd of head_to_batch_dim with its zero rows)."""
+    zeros where srcs[b] is None.  blend = (row, b, m) or a list of such triples: that row is srcs[row]*m + b*(1-m) as blend_tokens
+    computes it (every edit of a batch blends with its own mask).  One launch (batch_to_head_dim of the output, the blend before it, and
+    the autograd of head_to_batch_dim with its zero rows).  B <= 16."""
     lib = _lib.load()
     B = len(srcs)
-    if not 1 <= B <= 4:
-        raise _lib.GeodiffError("heads_merge: 1..4 batch rows")
-    out = torch.empty(B, rows, heads * D, dtype=dtype, device=device)
+    if not 1 <= B <= 16:
+        raise _lib.GeodiffError("heads_merge: 1..16 batch rows")
+    if out is None:
+        out = torch.empty(B, rows, heads * D, dtype=dtype, device=device)
+    elif tuple(out.shape) != (B, rows, heads * D) or out.dtype != dtype:
+        raise _lib.GeodiffError("heads_merge: out must be [B, rows, heads*D] of the tensor dtype")
     dt = _dt16(out, "out")
     a = GdHeadsMerge()
     f32 = None
@@ -622,13 +636,12 @@ def heads_merge(srcs: Sequence[Optional[torch.Tensor]], heads: int, rows: int, D
         if tuple(t.shape) != (heads, rows, D):
             raise _lib.GeodiffError("heads_merge: sources must be [heads, rows, D]")
         a.src[b] = t.data_ptr()
-    a.blend_row = -1
     if blend is not None:
-        row, bb, m = blend
-        _need(bb, "blend b", dtype); _need(m, "blend m", torch.float32)
-        if tuple(bb.shape) != (heads, rows, D) or m.numel() != rows or f32 or srcs[row] is None:
-            raise _lib.GeodiffError("heads_merge: blend operands disagree")
-        a.blend_row, a.blend_b, a.m = row, bb.data_ptr(), m.data_ptr()
+        for row, bb, m in ([blend] if isinstance(blend, tuple) else blend):
+            _need(bb, "blend b", dtype); _need(m, "blend m", torch.float32)
+            if tuple(bb.shape) != (heads, rows, D) or m.numel() != rows or f32 or srcs[row] is None:
+                raise _lib.GeodiffError("heads_merge: blend operands disagree")
+            a.blend_b[row], a.m[row] = bb.data_ptr(), m.data_ptr()
     a.out, a.src_f32, a.B, a.rows, a.heads, a.D = out.data_ptr(), int(bool(f32)), B, rows, heads, D
     check(lib.gd_heads_merge(ctypes.byref(a), dt, _stream()), "gd_heads_merge")
     return out
@@ -671,11 +684,11 @@ def removal_corr_max_nz(Pe, Pb, m_inp, m_wo, n_valid, best):
 
 
 def edit_losses_fused(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int, best, rows, n_valid, inv5, inv_rm, wv, inv5_bwd, use_amodal: bool,
-                      log_acc=None, running=False):
+                      log_acc=None, running=False, loss_out=None):
     """edit_losses_fwd + removal_loss_reduce + the fold + loss_assemble in one launch.
     -> (terms [5], loss (), coefs [5], rm_coef [1], aux | None) — what loss_assemble and removal_fwd return.
     log_acc (f32 [>= 4], updated in place): += the four logged terms.  running: False = no running loss; None or a 0-d / [1] f32 tensor =
-    the controller's loss so far (None: 0) — a sixth result, running + loss, is appended."""
+    the controller's loss so far (None: 0) — a sixth result, running + loss, is appended (written to ``loss_out`` [1] f32 if given)."""
     lib = _lib.load()
     dt = _dt16(eo, "eo")
     _need(eo, "eo"); _need(ro, "ro", eo.dtype)
@@ -703,11 +716,12 @@ def edit_losses_fused(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, S: int, best, r
                      _ip(aux["j_wo"]) if aux else 0, _ip(aux["wgt"]) if aux else 0,
                      inv5.data_ptr(), inv_rm.data_ptr(), wv.data_ptr(), inv5_bwd.data_ptr(),
                      out.data_ptr(), ws.data_ptr(), _ticket(dev).data_ptr(),
-                     _ip(log_acc), 0 if running is False else _ip(running), 0 if running is False else out[12:].data_ptr(),
+                     _ip(log_acc), 0 if running is False else _ip(running),
+                     0 if running is False else (loss_out.data_ptr() if loss_out is not None else out[12:].data_ptr()),
                      H, S, D, R, int(bool(use_amodal)))
     check(lib.gd_edit_losses_fwd(ctypes.byref(a), dt, _stream()), "gd_edit_losses_fwd")
     if running is not False:
-        return out[0:5], out[5], out[6:11], out[11:12], aux, out[12]
+        return out[0:5], out[5], out[6:11], out[11:12], aux, (loss_out if loss_out is not None else out[12])
     return out[0:5], out[5], out[6:11], out[11:12], aux
 
 
@@ -765,15 +779,21 @@ def removal_bwd_nofold(rm, dtype: torch.dtype):
     check(lib.gd_removal_bwd(ctypes.byref(rm), None, None, _DT[dtype], _stream()), "gd_removal_bwd (products only)")
 
 
-def edit_dq_fold(dq_part_ptr, kchunks: int, BH: int, N: int, D: int, rm_ws, M: int, R: int, inp_pos, wgt, dq16):
-    """dq16 = T(sum of the attention partials (dq_part_ptr None / 0: dq16 itself) + the removal partials of live inpaint rows): one rounding."""
+def edit_dq_fold(dq_part_ptr, kchunks: int, BH: int, N: int, D: int, rm_ws, M: int, R: int, inp_pos, wgt, dq16, head0: int = 0, nheads: int = 0):
+    """dq16 = T(sum of the attention partials (dq_part_ptr None / 0: dq16 itself) + the removal partials of live inpaint rows): one rounding.
+    head0 / nheads: fold only heads [head0, head0 + nheads) of the BH-head backward (one edit of a batch, whose removal partials rm_ws are
+    its own): dq16 is still the full [BH, N, D] tensor."""
     lib = _lib.load()
     dt = _dt16(dq16, "dq16")
     _need(dq16, "dq16")
     if rm_ws is not None:
         _need(inp_pos, "inp_pos", torch.int32); _need(wgt, "wgt", torch.float32)
-    check(lib.gd_edit_dq_fold(ctypes.c_void_p(dq_part_ptr) if dq_part_ptr else None, kchunks, BH, N, D, _p(rm_ws), M, R, _p(inp_pos) if rm_ws is not None else None,
-                              _p(wgt) if rm_ws is not None else None, _p(dq16), dt, _stream()), "gd_edit_dq_fold")
+    nh = nheads if nheads else BH
+    off = head0 * N * D
+    part = ctypes.c_void_p(dq_part_ptr + off * 4) if dq_part_ptr else None
+    dq_ptr = ctypes.c_void_p(dq16.data_ptr() + off * dq16.element_size())
+    check(lib.gd_edit_dq_fold(part, kchunks, BH * N * D if nheads else 0, nh, N, D, _p(rm_ws), M, R, _p(inp_pos) if rm_ws is not None else None,
+                              _p(wgt) if rm_ws is not None else None, dq_ptr, dt, _stream()), "gd_edit_dq_fold")
 
 
 def softsplat_fwd(tenIn, tenFlow):

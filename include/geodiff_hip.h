@@ -125,7 +125,7 @@ typedef struct {
      * reference is.  For launches whose outputs are compared with each other by L1 losses (the optimisation pass); lse then carries the
      * rounding of the probabilities (~1e-3 relative).  Honoured by the 64-query kernel (64^2-token launches); elsewhere the same as 1. */
     int32_t q_scaled;
-    /* Query ROW LIST (at most one segment of a launch; NULL: all N rows).  The segment attends only with rows q_rows[0 .. *q_rows_n) of q
+    /* Query ROW LIST (at most GD_ATTN_MAX_ROWLIST_SEGS segments of a launch — one per edit of a batch; NULL: all N rows).  The segment attends only with rows q_rows[0 .. *q_rows_n) of q
      * (taken from the full [.., N, ..] tensor; the warp tables, if any, are indexed by the same row ids) and writes a DENSE result:
      * out [bh, q_rows_len, D] / [B, q_rows_len, heads*D], lse [bh, q_rows_len]; list slots >= *q_rows_n are padding (computed on row
      * q_rows[i] but not stored; the list is padded so that launch dimensions repeat from edit to edit).  Use: the edit attention
@@ -136,7 +136,8 @@ typedef struct {
     int32_t q_rows_len;
 } gd_attn_seg_t;
 
-#define GD_ATTN_MAX_SEGS 4
+#define GD_ATTN_MAX_SEGS 12      /* vanilla rows + replace rows of B edits as two segments + one warped / row-list segment per edit (B <= 8) */
+#define GD_ATTN_MAX_ROWLIST_SEGS 8
 
 /* Per-call launch configuration of gd_attn_fwd (NULL = all defaults).  Replaces the process-wide gd_attn_fwd_set_even_split /
  * gd_attn_fwd_set_config hooks of ABI <= 4 and the GD_ATTN_* environment variables the library used to read. */
@@ -174,13 +175,14 @@ int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, int D, float 
                 size_t workspace_bytes, int dtype, void* stream);
 
 /* Short-key launches (M <= 128: the 77-key text context of every cross-attention layer, the 8^2 self-attention layer) with the blend
- * of U/attention_processors.py:502-508,617-622 (remover: :831-834) inside the launch.  segs[0 .. nseg-2]: plain segments as
- * gd_attn_fwd; segs[nseg-1] is side A of ONE pair and `side_b` its side B (same bh / heads / layout; lse, row lists unsupported; its
- * `out` is ignored): segs[nseg-1].out = A*m + B*(1-m), A = attention(side A), B = attention(side B), both rounded to the tensor dtype
- * first and blended op by op like gd_blend_merge — bit-identical to gd_attn_fwd over nseg + 1 segments followed by gd_blend_merge.
- * blend_m [N] f32.  D = 64 only. */
-int gd_attn_fwd_pair(const gd_attn_seg_t* segs, int nseg, const gd_attn_seg_t* side_b, const float* blend_m, int N, int M, int D,
-                     float scale, int dtype, void* stream);
+ * of U/attention_processors.py:502-508,617-622 (remover: :831-834) inside the launch.  segs[0 .. nseg-npair-1]: plain segments as
+ * gd_attn_fwd; segs[nseg-npair+p] is side A of pair p and side_b[p] its side B (same bh / heads / layout for every pair; lse, row lists
+ * unsupported; side B's `out` is ignored): side A's out = A*m + B*(1-m), A = attention(side A), B = attention(side B), both rounded to the
+ * tensor dtype first and blended op by op like gd_blend_merge — bit-identical to gd_attn_fwd over nseg + npair segments followed by
+ * gd_blend_merge.  blend_m[p]: [N] f32 mask of pair p (one pair per edit of a batch: npair <= GD_ATTN_MAX_PAIRS).  D = 64 only. */
+#define GD_ATTN_MAX_PAIRS 8
+int gd_attn_fwd_pair(const gd_attn_seg_t* segs, int nseg, const gd_attn_seg_t* side_b, const float* const* blend_m, int npair, int N, int M,
+                     int D, float scale, int dtype, void* stream);
 
 /*
  * Backward of out = softmax(scale q k^T) v w.r.t. q (always) and k (dk_f32 != NULL).
@@ -387,29 +389,32 @@ int gd_blend_merge(const void* base, const void* act, const int32_t* pos, const 
 
 /* The last launch of a hooked layer's backward: dq16[h,n,:] = T( sum_c dq_part[c][h,n,:]  (+ sum_c removal partials of row n, if n is
  * a live inpaint row) ) — ONE rounding (a complete gd_attn_bwd followed by a complete gd_removal_bwd rounds twice).
- * dq_part / kchunks: what gd_attn_bwd left (kchunks_out / dq_part_out).  inp_pos [N] i32: slot of row n in the inpaint-row list or -1;
+ * dq_part / kchunks: what gd_attn_bwd left (kchunks_out / dq_part_out); chunk_stride: floats from one run's partials to the next (0 = BH*N*D;
+ * larger when BH heads are a slice of a wider backward — one edit's heads of a batch: dq_part and dq16 then point at that slice).  inp_pos [N] i32: slot of row n in the inpaint-row list or -1;
  * rm_workspace: the removal backward's workspace (its partials [msplit, H, R, D] f32 start H*R floats in), NULL = none.
  * dq_part == NULL (kchunks == 1: the dq kernel wrote dq16 directly): only the live inpaint rows are touched,
  * dq16 = T(float(dq16) + removal contribution). */
-int gd_edit_dq_fold(const float* dq_part, int kchunks, int BH, int N, int D, const float* rm_workspace, int M, int R,
+int gd_edit_dq_fold(const float* dq_part, int kchunks, int64_t chunk_stride, int BH, int N, int D, const float* rm_workspace, int M, int R,
                     const int32_t* inp_pos, const float* wgt, void* dq16, int dtype, void* stream);
 
 /* The layer's layout boundary in ONE launch each way (U/attention_processors.py:118-120,201-203 head_to_batch_dim of q / k / v and
  * :124,213 batch_to_head_dim of the output, and their autograd): the projections hand over token-major [B, rows, heads*D] tensors, the
  * optimisation pass's kernels work on head-major [B*heads, rows, D] ones.
  *   gd_heads_split : n <= 3 tensors at once, dst[i][(b*heads + h), r, :] = src[i][b, r, h*D : (h+1)*D]   (rows[i] rows each; 16-bit)
- *   gd_heads_merge : out[b, r, h*D:(h+1)*D] = src[b][h, r, :] for every batch row b < B (<= 4) whose source is non-NULL, zeros for a NULL
- *                    source (the rows that receive no gradient); src_f32 != 0: the sources are f32 and are rounded once (the key
- *                    gradient); blend_row >= 0: that row is  src[blend_row]*m + blend_b*(1-m)  op by op in the tensor dtype, exactly
- *                    gd_blend_tokens (U/attention_processors.py:502-508,617-622) — the blend and the layout change in one pass. */
+ *   gd_heads_merge : out[b, r, h*D:(h+1)*D] = src[b][h, r, :] for every batch row b < B (<= 16: the two roles of up to 8 edits) whose
+ *                    source is non-NULL, zeros for a NULL source (the rows that receive no gradient); src_f32 != 0: the sources are f32
+ *                    and are rounded once (the key gradient); blend_b[b] != NULL: row b is  src[b]*m[b] + blend_b[b]*(1-m[b])  op by op
+ *                    in the tensor dtype, exactly gd_blend_merge's blend (U/attention_processors.py:502-508,617-622) — the blend and
+ *                    the layout change in one pass (one mask per row: every edit of a batch blends with its own). */
 typedef struct gd_heads_split {
     const void* src[3]; void* dst[3]; int32_t rows[3];
     int32_t n, B, heads, D;
 } gd_heads_split_t;
 int gd_heads_split(const gd_heads_split_t* a, int dtype, void* stream);
+#define GD_HEADS_MERGE_MAX_ROWS 16
 typedef struct gd_heads_merge {
-    const void* src[4]; const void* blend_b; const float* m; void* out;
-    int32_t blend_row, src_f32, B, rows, heads, D;
+    const void* src[GD_HEADS_MERGE_MAX_ROWS]; const void* blend_b[GD_HEADS_MERGE_MAX_ROWS]; const float* m[GD_HEADS_MERGE_MAX_ROWS]; void* out;
+    int32_t src_f32, B, rows, heads, D;
 } gd_heads_merge_t;
 int gd_heads_merge(const gd_heads_merge_t* a, int dtype, void* stream);
 

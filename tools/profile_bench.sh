@@ -4,7 +4,7 @@ TAG=${1:-r02}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 export GD_BENCH_MARK=1
-rocprofv3 --kernel-trace --stats -d $OUT -o bench --output-format csv -- python3 $ROOT/bench.py --steps ${STEPS:-2} --warmup ${WARMUP:-3} --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT -o bench --output-format csv -- python3 $ROOT/bench.py --steps ${STEPS:-2} --warmup ${WARMUP:-3} --no-cpu-baseline ${BENCH_ARGS} > $OUT/bench.json 2> $OUT/bench.err
 cd $ROOT
 TR=$(find $OUT -name "*kernel_trace.csv" | head -1)
 GD_PROF_EDITS=${STEPS:-2} python3 tools/prof_summary.py $TR gpurun_out/${TAG}_bench_summary.md gpurun_out/${TAG}_bench_kernel_stats.csv "$TAG - rocprofv3 --kernel-trace --stats of bench.py --steps ${STEPS:-2} --warmup ${WARMUP:-3} --no-cpu-baseline (MI355X, bf16)"

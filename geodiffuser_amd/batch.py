@@ -705,6 +705,15 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
         raise NotImplementedError(edit_type)
     prev_grad = torch.is_grad_enabled()
     torch.set_grad_enabled(False)
+    import time
+    t_last = [time.perf_counter()]
+
+    def _tm(what):                      # GD_BATCH_TIMING=1: host-side section times (development; synchronises)
+        if os.environ.get("GD_BATCH_TIMING") == "1":
+            h = time.perf_counter() - t_last[0]
+            torch.cuda.synchronize()
+            print(f"[batch] {what}: host {1e3 * h:.1f} ms, with the device {1e3 * (time.perf_counter() - t_last[0]):.1f} ms", flush=True)
+            t_last[0] = time.perf_counter()
     try:
         torch.manual_seed(E.SEED)
         torch.cuda.manual_seed_all(E.SEED)
@@ -738,14 +747,17 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
                 c.loss_weight_dict = lw
                 c.default_loss_weights = lw
             subs.append(c); coords.append(t_coords_depth[None].detach()); masks.append(image_mask); images.append(image)
+        _tm("pre-pass + controllers")
         batch = EditBatch(subs, coords)
         traj = ddim_inversion_batch(model, images, prompts, num_ddim_steps, guidance_scale, dev)
+        _tm("inversion")
         out, logs = text2image_ldm_stable_batch(
             model, prompts, batch, num_ddim_steps, guidance_scale, latent=traj[-1], ddim_latents=traj, masks_obj=[m[None, None] for m in masks],
             optimize_steps=optimize_steps, latent_replace=latent_replace, lr=lr, optimize_embeddings=optimize_embeddings,
             optimize_latents=optimize_latents, edit_type=edit_type, use_adaptive_optimization=use_adaptive_optimization,
             removal_loss_value_in=removal_loss_value_in, return_type="latents", image_size=images[0].shape[0],
             skip_optim_steps=skip_optim_steps, num_ddim_steps=num_ddim_steps)
+        _tm("edit loop")
         decoded = latent2image(model.vae, out, as_tensor=True)                     # [2 B, H, W, 3] uint8 on the device, role-major
         results = []
         for j, e in enumerate(edits):
@@ -757,6 +769,7 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
                 ret.append(torch.stack([out[j], out[B + j]]))
             results.append(ret[0] if len(ret) == 1 else tuple(ret))
         model.unet.set_attn_processor(VanillaAttentionProcessor())
+        _tm("decode + post-process")
         return results
     finally:
         torch.set_grad_enabled(prev_grad)

@@ -170,6 +170,33 @@ def run_exp_on_folder_single(exp_folder, exp_type, ldm_stable, tokenizer, schedu
     return images
 
 
+def run_exp_on_folders_batched(exp_folders, exp_type, ldm_stable, tokenizer, scheduler, **overrides):
+    """``run_exp_on_folder_single`` for a group of folders of ONE edit type whose edits share every UNet pass
+    (geodiffuser_amd.batch.perform_geometric_edit_batch): same inputs, same configuration column, same result files per folder."""
+    from .batch import perform_geometric_edit_batch
+    kw = edit_config(exp_type, **overrides)
+    dicts, edits = [], []
+    for f in exp_folders:
+        log.info("Performing edit on: %s with exp type: %s (batch of %d)", f, exp_type, len(exp_folders))
+        d = read_exp(complete_path(f))
+        dicts.append(d)
+        edits.append(dict(image=d["input_image_png"], image_mask=(d["input_mask_png"] / 255.0)[..., 0], depth=d["depth_npy"],
+                          transform_in=torch.tensor(d["transform_npy"]).float(), prompt=""))
+    res = perform_geometric_edit_batch(edits, ldm_stable_model=ldm_stable, tokenizer_model=tokenizer, scheduler_in=scheduler, edit_type=exp_type,
+                                       return_loss_log_dict=True, **kw)
+    for d, (images, loss_dict) in zip(dicts, res):
+        save_results(d, images[-1], loss_dict, exp_type, step_store=None)
+    return [r[0] for r in res]
+
+
+def group_for_batches(work: List[Tuple[str, str]], per_pass: int) -> List[Tuple[List[str], str]]:
+    """A rank's work list -> groups of at most ``per_pass`` folders of one edit type, in work-list order within a type."""
+    by_type = {}
+    for folder, etype in work:
+        by_type.setdefault(etype, []).append(folder)
+    return [(fs[i:i + per_pass], etype) for etype, fs in by_type.items() for i in range(0, len(fs), per_pass)]
+
+
 def list_experiments(exp_root_folder: str, exp_type: Optional[str] = None) -> List[Tuple[str, str]]:
     """The folder walk of ``__main__`` :358-402 as a flat, sorted work list of (experiment folder, edit type)."""
     folder_list = sorted(glob.glob(complete_path(exp_root_folder) + "**/"))
@@ -198,6 +225,9 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=0, help="start this many GPUs' worth of ranks here (0: run as the one process / rank this is)")
     ap.add_argument("--edits-in-flight", type=int, default=1,
                     help="with --gpus: independent edits in flight per GPU = ranks per device (4 gives 1.85 x the edits/min of 1 on an MI355X)")
+    ap.add_argument("--edits-per-pass", type=int, default=1,
+                    help="B > 1: every rank runs its folders B at a time in ONE process, sharing every UNet pass (geodiffuser_amd/batch.py; one "
+                         "copy of the weights; 4 gives 1.7 x, 8 gives 1.9 x the edits/min of 1 on an MI355X)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     from . import dist as gdist
@@ -230,9 +260,18 @@ def main(argv=None):
         work = work[:args.limit]
     mine = gdist.shard(work, rank, world)
     log.info("rank %d/%d: %d of %d experiments", rank, world, len(mine), len(work))
-    for folder, etype in mine:
-        run_exp_on_folder_single(folder, etype, pipe, tok, sched)
-        log.info("Completed: %s", folder)
+    if args.edits_per_pass > 1:
+        for folders, etype in group_for_batches(mine, args.edits_per_pass):
+            if len(folders) == 1:
+                run_exp_on_folder_single(folders[0], etype, pipe, tok, sched)
+            else:
+                run_exp_on_folders_batched(folders, etype, pipe, tok, sched)
+            for f in folders:
+                log.info("Completed: %s", f)
+    else:
+        for folder, etype in mine:
+            run_exp_on_folder_single(folder, etype, pipe, tok, sched)
+            log.info("Completed: %s", folder)
     gdist.barrier()
 
 

@@ -188,3 +188,45 @@ def test_two_rank_gloo_batch_driver_on_experiment_folders(tmp_path):
             a, b = outs[1][0] / rel / name, data2 / rel / name
             assert a.exists() and b.exists(), (rel, name)
             assert a.read_bytes() == b.read_bytes(), (rel, name)      # rank 1's results were computed with rank 0's weights
+
+
+def test_batched_driver_groups_by_edit_type_and_writes_the_same_result_files(tmp_path, monkeypatch):
+    """``large_scale_editor --edits-per-pass 2``: a rank's folders go through geodiffuser_amd.batch.perform_geometric_edit_batch in groups of
+    one edit type (editors and removers never share a batch); every folder gets the result files of the one-at-a-time driver.  The edit
+    itself is stubbed (it needs the GPU): a deterministic function of the experiment's inputs."""
+    import shutil
+    import types
+    import geodiffuser_amd.batch as GB
+    from geodiffuser_amd import diffusion, editor, large_scale_editor as L
+
+    def fake_edit(image, depth, image_mask, transform_in, prompt="", edit_type="geometry_editor", **kw):
+        out = np.clip(image.astype(np.float64) * 0.5 + 40.0 * (np.asarray(image_mask)[..., None] > 0.5) + (3.0 if edit_type == "geometry_remover" else 0.0), 0, 255)
+        log = {0: {"self": {"sim": float(kw["guidance_scale"])}, "cross": {"sim": float(np.asarray(transform_in).sum())}, "num_layers": 16}}
+        return [image, out], log
+
+    seen = []
+
+    def fake_batch(edits, edit_type="geometry_editor", **kw):
+        seen.append((edit_type, len(edits)))
+        kw.pop("return_loss_log_dict", None)
+        return [fake_edit(e["image"], e["depth"], e["image_mask"], e["transform_in"], edit_type=edit_type, **kw) for e in edits]
+
+    monkeypatch.setattr(diffusion, "load_model", lambda **kw: (types.SimpleNamespace(unet=torch.nn.Linear(2, 2), vae=torch.nn.Linear(2, 2),
+                                                                                       text_encoder=torch.nn.Linear(2, 2)), None, None))
+    monkeypatch.setattr(editor, "perform_geometric_edit", fake_edit)
+    monkeypatch.setattr(GB, "perform_geometric_edit_batch", fake_batch)
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(v, raising=False)
+    runs = {}
+    for per_pass in (1, 2):
+        data = tmp_path / f"b{per_pass}"
+        shutil.copytree(ROOT, data)
+        L.main(["--root", str(data)] + (["--edits-per-pass", "2"] if per_pass > 1 else []))
+        runs[per_pass] = data
+    assert seen == [("geometry_editor", 2)]                    # Mix/1 + Mix/2 as one batch; the single Removal folder ran on its own
+    assert L.group_for_batches([("a", "geometry_editor"), ("r", "geometry_remover"), ("b", "geometry_editor"), ("c", "geometry_editor")], 2) == \
+        [(["a", "b"], "geometry_editor"), (["c"], "geometry_editor"), (["r"], "geometry_remover")]
+    for rel in ("Mix/1", "Mix/2", "Removal/1"):
+        for name in ("result_ls.png", "resized_result_ls.png", "experiment.png", "loss.pkl", "loss.log"):
+            a, b = runs[1] / rel / name, runs[2] / rel / name
+            assert a.exists() and b.exists() and a.read_bytes() == b.read_bytes(), (rel, name)

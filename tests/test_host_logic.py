@@ -413,3 +413,69 @@ def test_batch_driver_starts_its_own_ranks(monkeypatch):
     with pytest.raises(SystemExit) as ex:
         L.main(["--root", "/data/x", "--gpus", "2"])
     assert ex.value.code == 2 and len(calls) == 1
+
+
+def test_edit_batch_routes_role_major_rows_and_keeps_counters_in_step(monkeypatch):
+    """geodiffuser_amd.batch.EditBatch on CPU with stand-in controllers: edit j of B sees rows j, B + j, 2 B + j of the role-major batch
+    (its own [uncond_edit, cond_ref, cond_edit] rows) with its own transform coordinates, the outputs come back role-major, the batch's
+    layer / step counters and every edit's advance together, the driver's `cur_step -= 1` reaches every edit, and the graph key / table
+    signature / loss state the hipGraph code asks for are assembled per edit."""
+    import geodiffuser_amd.batch as GB
+    from geodiffuser_amd.attention_sharing import AttentionControl
+
+    class Sub(AttentionControl):
+        _is_remover = False
+        rows_identical = False
+
+        def __init__(self, tag):
+            super().__init__()
+            self.tag, self.seen = tag, []
+            self.num_steps, self.obj_edit_step, self.num_self_replace = 50, 0.9, (0, 47)
+            self.masks_cache_dict = {32: {"f": 4, "D": 64, "S": 32}}
+            self.loss, self.loss_log_dict = 0.0, {"self": {"sim": 0.0}, "cross": {"sim": 0.0}, "num_layers": 0}
+
+        def forward(self, q, k, v, is_cross, place_in_unet, transform_coords=None, scale=None, mask=None):
+            self.seen.append((q[:, 0, 0].tolist(), float(transform_coords), self.coords_base, self.heads_tok))
+            return q + self.tag
+
+        def graph_key(self):
+            return ("Sub", True, True, self.n_batch, self.coords_base, self.coords_edit, self.use_cfg, False, bool(self.rows_identical))
+
+        def table_signature(self):
+            return ((32, 256 + self.tag, 4, 15, 0),)
+
+        def tables_built(self, layers):
+            return True
+
+        def after_graph_replay(self):
+            self.cur_att_layer = 0
+            self.cur_step += 1
+
+    monkeypatch.setattr(GB, "MERGED", False)
+    B = 3
+    subs = [Sub(100 * (j + 1)) for j in range(B)]
+    batch = GB.EditBatch(subs, [torch.tensor(float(j)) for j in range(B)])
+    assert [s.slot for s in subs] == [0, 1, 2]
+    batch.num_att_layers = 2
+    batch.coords_base, batch.coords_edit, batch.use_cfg, batch.n_batch = (1, 2), (2, 3), True, 3
+    q = torch.arange(9.0).view(9, 1, 1).expand(9, 4, 8).contiguous()          # row r of the role-major batch carries the value r
+    for layer in range(2):
+        batch.heads_tok = 4
+        out = batch(q, q, q, False, "up", scale=0.125)
+    assert [s.seen[0][0] for s in subs] == [[0.0, 3.0, 6.0], [1.0, 4.0, 7.0], [2.0, 5.0, 8.0]]
+    assert [s.seen[0][1:] for s in subs] == [(float(j), (1, 2), 4) for j in range(B)]
+    assert out[:, 0, 0].tolist() == [100.0, 201.0, 302.0, 103.0, 204.0, 305.0, 106.0, 207.0, 308.0]       # role-major again, edit j's tag on its rows
+    assert (batch.cur_att_layer, batch.cur_step) == (0, 1) and all((s.cur_att_layer, s.cur_step) == (0, 1) for s in subs)
+    batch.undo_step()
+    assert batch.cur_step == 0 and all(s.cur_step == 0 for s in subs)
+    assert batch.graph_key()[:2] == ("EditBatch", 3) and batch.graph_key()[-1] == (False, False, False)
+    assert batch.table_signature() == tuple(s.table_signature() for s in subs)
+    subs[1].loss_log_dict["self"]["sim"] = 7.0
+    st = batch.export_loss_state()
+    subs[1].loss_log_dict["self"]["sim"] = 0.0
+    batch.import_loss_state(st)
+    assert subs[1].loss_log_dict["self"]["sim"] == 7.0 and st[1][1] is not subs[1].loss_log_dict
+    batch.after_graph_replay()
+    assert batch.cur_step == 1 and all(s.cur_step == 1 for s in subs)
+    with pytest.raises(ValueError):
+        GB.EditBatch([Sub(1), type("Other", (Sub,), {})(2)], [torch.tensor(0.0), torch.tensor(0.0)])

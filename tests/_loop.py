@@ -111,3 +111,62 @@ def run_device_loop(kind_name, dtype, skip_refs=(False, True)):
         editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS, editor.SKIP_UNCOND_REF = prev
         p.unet.set_attn_processor(VanillaAttentionProcessor())
     return g, fixture, runs
+
+
+def run_device_loop_batch(kind_name, dtype, extra_seeds=(5,)):
+    """The fixture's edit as edit 0 of an in-process BATCH (geodiffuser_amd.batch.text2image_ldm_stable_batch) next to ``len(extra_seeds)``
+    other edits of the same configuration (other masks, transforms and trajectories: cases.loop_inputs with another seed / ellipse).
+    -> (fixture dict, fixture name, (latents [2,4,h,w] f32 cpu of edit 0, its loss log, its final removal weight, its weight trajectory),
+    [(latents, log) of the other edits])."""
+    import numpy as np
+    from geodiffuser_amd import batch as GB, editor
+    from geodiffuser_amd.attention_processors import VanillaAttentionProcessor
+    fixture, cfgname, kind, full, name = LOOP_KINDS[kind_name]
+    g = load(fixture)
+    c = getattr(cases, cfgname)
+    p, tok, sched = cached_model(name, not full, dtype)
+    probe = torch.cat([q.detach().float().reshape(-1)[:64] for q in p.unet.parameters()]).cpu()
+    if not torch.allclose(probe, torch.from_numpy(g["weight_probe"]), atol=2e-3 if dtype == torch.float16 else 2e-2):
+        fixture_mismatch("seeded weights differ from the fixture's (different torch build): the fixture does not apply")
+    cfgs = [c] + [dict(c, seed=c["seed"] + 1000 * s_, transform=None if c.get("transform") == "rotate" else c.get("transform"),
+                       ellipse=dict(cx=0.42 * c["size"] + 7 * s_, cy=0.55 * c["size"] - 5 * s_, ax=0.13 * c["size"], ay=0.1 * c["size"]))
+                  for s_ in extra_seeds]
+    inps = [cases.loop_inputs(cc) for cc in cfgs]
+    subs, coords = [], []
+    for cc, inp in zip(cfgs, inps):
+        ctrl, lw = make_controller(kind, cc, inp)
+        ctrl.default_loss_weights = {k: dict(v) for k, v in lw.items()}
+        ctrl.initialize_default_loss_weights()
+        subs.append(ctrl); coords.append(torch.from_numpy(inp["coords"]))
+    B = len(subs)
+    batch = GB.EditBatch(subs, coords)
+    prev = (editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS)
+    editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS = c["steps"], c["guidance"], c["skip_optim"]
+    weights = []
+    orig = GB.ops.masked_latent_update
+    calls = [0]
+
+    def rec(x, gr, m, step):                                  # edit 0's adaptive weight in effect AT each optimisation pass
+        if calls[0] % B == 0:
+            weights.append(float(subs[0].loss_weight_dict["self"]["removal"]))
+        calls[0] += 1
+        return orig(x, gr, m, step)
+
+    GB.ops.masked_latent_update = rec
+    try:
+        T = c["steps"]
+        ddim = [torch.cat([torch.from_numpy(inp["ddim_latents"][t]) for inp in inps]).to("cuda").to(dtype) for t in range(T + 1)]
+        x_T = torch.cat([torch.from_numpy(inp["x_T"]) for inp in inps]).to("cuda").to(dtype)
+        lat, logs = GB.text2image_ldm_stable_batch(
+            p, [""] * B, batch, c["steps"], c["guidance"], latent=x_T, ddim_latents=ddim, masks_obj=[torch.from_numpy(inp["mask"]) for inp in inps],
+            optimize_steps=c["optimize_steps"], latent_replace=c["latent_replace"], lr=c["lr"], optimize_embeddings=True, optimize_latents=True,
+            edit_type=kind, use_adaptive_optimization=True, return_type="latents", image_size=c["size"], skip_optim_steps=c["skip_optim"],
+            num_ddim_steps=c["steps"])
+    finally:
+        GB.ops.masked_latent_update = orig
+        editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS = prev
+        p.unet.set_attn_processor(VanillaAttentionProcessor())
+    lat = lat.float().cpu()
+    first = (torch.stack([lat[0], lat[B]]), logs[0], float(subs[0].loss_weight_dict["self"]["removal"]), list(weights))
+    others = [(torch.stack([lat[j], lat[B + j]]), logs[j]) for j in range(1, B)]
+    return g, fixture, first, others

@@ -443,6 +443,39 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
         assert e_fin < 2.0 * emu_final + 1e-3
 
 
+@pytest.mark.parametrize("kind", ["geometry_remover", "cfg1_t50", "cfg1_full_t50"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_loop_inside_a_batch_matches_reference_driver(kind, dtype):
+    """The in-process multi-edit batch (geodiffuser_amd/batch.py) held to the REFERENCE's driver: the fixture's edit runs as edit 0 of a
+    batch of two (the other edit: another mask, a translation instead of the rotation, another trajectory) — inversion-free loop at batch
+    2, optimisation passes at batch 4, CFG passes at batch 6, merged attention launches — and must land where the one-edit loop test puts
+    it: the same optimisation steps, the same adaptive-weight trajectory at every pass (rel 1e-6), a bit-identical reference row, the
+    edited latent inside the same bound.  G19 (remover, 6 steps), G28 (configs[1]'s length, narrow) and G30 (configs[1] itself)."""
+    from _loop import LOOP_KINDS, run_device_loop_batch
+    dn = "fp16" if dtype == torch.float16 else "bf16"
+    g, fixture, (lat, log, w_rm, w_traj), others = run_device_loop_batch(kind, dtype)
+    emu = _emulation()[fixture]
+    floor = max(emu.get("fp32_other_partition", 0.0), emu.get("fp32_xT_perturbed_1e6", 0.0))
+    emu_final = max(emu["emulated_" + dn], floor)
+    ref_lat = torch.from_numpy(g["latents"])
+    assert sorted(log) == list(g["steps"])
+    if "weights_self_removal" in g:
+        assert w_traj == pytest.approx([float(x) for x in g["weights_self_removal"]], rel=1e-6), (w_traj, g["weights_self_removal"])
+    assert w_rm == pytest.approx(float(g["final_weights_self_removal"]), rel=1e-6)
+    first = int(g["steps"][0])
+    for att in ("self", "cross"):
+        for k, v in log[first][att].items():
+            ref = float(g[f"log_{first}_{att}_{k}"])
+            assert abs(float(v) - ref) <= (2e-2 if dtype == torch.float16 else 6e-2) * abs(ref) + (5e-4 if dtype == torch.float16 else 4e-3), (att, k, float(v), ref)
+    assert torch.equal(lat[0], ref_lat[0].to(dtype).float())
+    e_fin = rel_l2(lat[1], ref_lat[1])
+    print(f"[batch loop] {fixture} {dn}: edit 0 of a batch of 2 vs the reference driver: {e_fin:.4f} (ideal {dn} storage: {emu_final:.4f})")
+    assert e_fin < 2.0 * emu_final + 1e-3
+    for o_lat, o_log in others:                              # the neighbour ran its own schedule on its own tables
+        assert torch.isfinite(o_lat).all() and sorted(o_log) == list(g["steps"])
+        assert rel_l2(o_lat[1], lat[1]) > 1e-2               # ... and is a different edit
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 def test_unet_pass_error_budget_g24(dtype):
     """One UNet pass of the narrow model on the device (16-bit weights / activations, HIP attention + fused norms, MIOpen / rocBLAS)

@@ -40,6 +40,11 @@ def switches():
         "miopen_convs": ("MIOpen convolutions instead of k_conv3x3 / the 1x1-as-linear route", [(un, "CONV3X3", False), (un, "CONV1X1", False)]),
         "stock_unet_ops": ("torch GroupNorm / LayerNorm / GEGLU / bias-residual instead of the fused glue kernels", [(un, "FUSED", False)]),
         "eager": ("no hipGraphs (same kernels, eager dispatch)", [(graphs, "ENABLED", False)]),
+        "everything_stock": ("ALL of the above at once: torch / MIOpen for every non-attention op, head-major unfused hooked layers, eager",
+                             [(ap, "SCALED_Q", False), (ap, "SCALED_Q_OPT", False), (ap, "OPT_PRE", False), (ap, "WARP_ROWS", False),
+                              (ap, "FUSED_LAYER", False), (ap, "TAIL_SUMS", False), (ap, "TOK_OPT", False), (ap, "TOKEN_MAJOR", False),
+                              (ap, "BATCHED_QKV", False), (ap, "PAIR_BLEND", False), (un, "CONV3X3", False), (un, "CONV1X1", False),
+                              (un, "FUSED", False), (graphs, "ENABLED", False)]),
     }
 
 

@@ -157,12 +157,11 @@ class _EditLayerBatch(torch.autograd.Function):
                 if Pe is not None:
                     rm_args, rm_ws = ops.removal_bwd_args(Pe, Pb, q_edit[sl[j]], K[sl[j]], c["rows"], aux, c["m_inp"], c["m_wo"], 1.0, gscale, rm_coef,
                                                           m["scale"], c.get("n_rows"), need_dk)
-                d_j = ops.edit_losses_bwd_rowdot(eo[sl[j]], replace_out[sl[j]], tgt, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), gout, coefs,
-                                                 gscale, blend=(m["blend"] and not m["remover"]), S=S, rm=rm_args, gout_tok=True)
+                ops.edit_losses_bwd_rowdot(eo[sl[j]], replace_out[sl[j]], tgt, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), gout, coefs,
+                                           gscale, blend=(m["blend"] and not m["remover"]), S=S, rm=rm_args, gout_tok=True, out=dro[sl[j]])
             else:
-                d_j = ops.edit_losses_bwd(eo[sl[j]], replace_out[sl[j]], None, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), gout,
-                                          AP._zeros5(dev), None, blend=(m["blend"] and not m["remover"]), S=S, gout_tok=True)
-            dro[sl[j]].copy_(d_j)
+                ops.edit_losses_bwd(eo[sl[j]], replace_out[sl[j]], None, c["m_wo"], m_edit_l, c.get("w_dist"), c.get("m_amodal"), gout,
+                                    AP._zeros5(dev), None, blend=(m["blend"] and not m["remover"]), S=S, gout_tok=True, out=dro[sl[j]])
             rms.append((rm_args, rm_ws))
         dq = torch.empty(Bf, N, D, dtype=dt, device=dev)
         dk32, kchunks, part_ptr, bwd_ws = ops.attn_bwd_nofold(q_edit, K, v_base, replace_out, lse_e, dro, m["scale"], need_dk, dq)   # all edits' rows

@@ -525,11 +525,11 @@ def _gout_flag(gout, eo, blend, gout_tok: bool) -> int:
     return int(bool(blend)) | (2 if (gout_tok and gout is not None) else 0)
 
 
-def edit_losses_bwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend: bool, S: int, gout_tok: bool = False):
+def edit_losses_bwd(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend: bool, S: int, gout_tok: bool = False, out=None):
     """coefs: device f32 [5] tensor (or a host sequence, uploaded here — not capture-safe)."""
     if not isinstance(coefs, torch.Tensor):
         coefs = torch.tensor([float(x) for x in coefs], dtype=torch.float32, device=eo.device)
-    return edit_losses_bwd_rowdot(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend, S, None, gout_tok)
+    return edit_losses_bwd_rowdot(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend, S, None, gout_tok, out=out)
 
 
 def blend_tokens(a, b, m, out=None):
@@ -739,13 +739,18 @@ def removal_bwd_args(Pe, Pb, q, k, rows, aux, m_inp, m_wo, coef: float, gscale, 
     return a, ws
 
 
-def edit_losses_bwd_rowdot(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend: bool, S: int, rm, gout_tok: bool = False):
-    """edit_losses_bwd's grid + the removal backward's row dots (into rm's workspace) in one launch; rm None: plain edit_losses_bwd."""
+def edit_losses_bwd_rowdot(eo, ro, tgt, m_wo, m_edit, w_am, m_amodal, gout, coefs, gscale, blend: bool, S: int, rm, gout_tok: bool = False, out=None):
+    """edit_losses_bwd's grid + the removal backward's row dots (into rm's workspace) in one launch; rm None: plain edit_losses_bwd.
+    out: write d(loss)/d(ro) there (ro's shape and dtype, contiguous: e.g. one edit's slice of a batch's gradient)."""
     lib = _lib.load()
     dt = _dt16(eo, "eo")
     H, N, D = eo.shape
     blend = _gout_flag(gout, eo, blend, gout_tok)
-    dro = torch.empty_like(ro)
+    if out is not None:
+        _need(out, "out", ro.dtype)
+        if out.shape != ro.shape:
+            raise _lib.GeodiffError("edit_losses_bwd: out must have ro's shape")
+    dro = out if out is not None else torch.empty_like(ro)
     _need(coefs, "coefs", torch.float32)
     check(lib.gd_edit_losses_bwd(_p(eo), _p(ro), _p(tgt), _p(m_wo), _p(m_edit), _p(w_am), _p(m_amodal), _p(gout), _p(coefs), _p(gscale),
                                  int(blend), H, S, D, _p(dro), ctypes.byref(rm) if rm is not None else None, dt, _stream()),

@@ -78,9 +78,12 @@ class round_every_op:
                     return out
                 rets = func._schema.returns
                 aliases = [r.alias_info for r in rets]
+                # reductions (a mean / sum / variance over a large tensor) are not STORAGE: a 16-bit model's kernels keep them in fp32
+                # (a sum of 10^6 activations does not even fit fp16's range); only tensor-sized results are rounded
+                big = max((a_.numel() for a_ in args if torch.is_tensor(a_)), default=0)
 
                 def fix(t, info):
-                    if not (torch.is_tensor(t) and t.dtype == torch.float32):
+                    if not (torch.is_tensor(t) and t.dtype == torch.float32) or t.numel() * 16 <= big:
                         return t
                     if info is None:
                         return t.to(dtype).to(torch.float32)

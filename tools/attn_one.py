@@ -22,6 +22,28 @@ if os.environ.get("FORM") == "cfg":
             (q[1:2], k[1:2], v[1:2], act, None, (idx, w, m), (rows_p, n_dev)), (q[2:3], k[1:2], v[1:2], o[2], None)]
     for _ in range(reps):
         ops.attn_fwd(segs, 0.125, heads=heads, q_scaled=True)        # the product path: even-split workspace, parts for the row-list units
+elif os.environ.get("FORM") == "cfgb4":
+    # the CFG pass's 64^2 launch of a BATCH of 4 edits (geodiffuser_amd/batch.py): the vanilla rows of all edits as one segment (8 rows x 5
+    # heads), one warped / row-list segment per edit (own tables), the replace attention of all edits as one segment: 80 heads, 6 segments
+    heads, K, C, B = 5, 15, 320, 4
+    q = (torch.randn(3 * B, N, C, device="cuda") * 0.2).bfloat16(); k = torch.randn(3 * B, N, C, device="cuda").bfloat16(); v = torch.randn(3 * B, N, C, device="cuda").bfloat16()
+    yy, xx = torch.meshgrid(torch.arange(64), torch.arange(64), indexing="ij")
+    out = torch.empty(2 * B, N, C, device="cuda", dtype=torch.bfloat16); rep = torch.empty(B, N, C, device="cuda", dtype=torch.bfloat16)
+    segs = [(q[:2 * B], k[:2 * B], v[:2 * B], out, None)]
+    keep = []
+    for j in range(B):
+        m = (((yy - 25 - 5 * j) ** 2 + (xx - 30 + 3 * j) ** 2) < (11 + j) ** 2).float().reshape(-1).cuda()
+        idx = torch.full((N, K), -1, dtype=torch.int32, device="cuda"); w = torch.zeros(N, K, device="cuda")
+        for jj in range(4):
+            idx[:, jj] = torch.where(m > 0, (torch.arange(N, device="cuda") + 64 * 3 + 5 + jj) % N, torch.full((N,), -1, device="cuda")).int(); w[:, jj] = 0.25
+        rows = torch.nonzero(m > 0).reshape(-1).int(); R = rows.numel(); Rp = 512
+        rows_p = torch.cat([rows, torch.zeros(Rp - R, dtype=torch.int32, device="cuda")]).contiguous(); n_dev = torch.tensor([R], dtype=torch.int32, device="cuda")
+        act = torch.empty(1, Rp, C, device="cuda", dtype=torch.bfloat16)
+        keep.append((m, idx, w, rows_p, n_dev, act))
+        segs.append((q[B + j:B + j + 1], k[B + j:B + j + 1], v[B + j:B + j + 1], act, None, (idx, w, m), (rows_p, n_dev)))
+    segs.append((q[2 * B:], k[B:2 * B], v[B:2 * B], rep, None))
+    for _ in range(reps):
+        ops.attn_fwd(segs, 0.125, heads=heads, q_scaled=True)
 elif os.environ.get("FORM") == "opt":
     # the optimisation pass's launch (head-major, 5 heads: reference rows + LSE, row-list edit rows with the fused warp, replace rows + LSE;
     # pre-scaled queries with row sums over the rounded probabilities: q_scaled = 2, k_attn_fwd_w64 LSUM)

@@ -45,77 +45,33 @@ class _RoundSTE(torch.autograd.Function):
         return g.to(ctx.dtype).to(g.dtype), None
 
 
-def emulate_16bit(dtype):
+def emulate_16bit(dtype, stored=False):
+    """``stored``: round EVERY tensor a model held in 16 bits stores, not only what its leaf modules return — the residual sums (outputs
+    of ResnetBlock2D / Transformer2DModel / BasicTransformerBlock and the two inner sums of a transformer block), the GEGLU product and
+    the attention output before ``to_out`` (U/attention_processors.py:213).  That is where the device path (and any torch model in
+    fp16 / bf16) rounds; "module outputs only" leaves these in fp32."""
+    import types
+
+    def R(x):
+        return _RoundSTE.apply(x, dtype)
+
     def prepare(pipe):
         for mod in (pipe.unet,):
             with torch.no_grad():
                 for p in mod.parameters():
                     p.copy_(p.to(dtype).to(p.dtype))
             for m in mod.modules():
-                if len(list(m.children())) == 0:                      # leaf modules: conv, linear, norms, activations
+                if len(list(m.children())) == 0 or (stored and m is not mod):      # leaf modules: conv, linear, norms, activations
                     m.register_forward_hook(lambda _m, _i, out: _RoundSTE.apply(out, dtype) if torch.is_tensor(out) and out.is_floating_point() else out)
+                if stored and type(m).__name__ == "BasicTransformerBlock":
+                    def fwd(self, x, ctx):
+                        x = R(self.attn1(self.norm1(x)) + x)
+                        x = R(self.attn2(self.norm2(x), encoder_hidden_states=ctx) + x)
+                        return self.ff(self.norm3(x)) + x                            # (rounded by the block's own output hook)
+                    m.forward = types.MethodType(fwd, m)
+                if stored and hasattr(m, "batch_to_head_dim") and hasattr(m, "to_q"):
+                    m.batch_to_head_dim = (lambda t, _o=m.batch_to_head_dim: R(_o(t)))
     return prepare
-
-
-class round_every_op:
-    """A model HELD in 16 bits rounds more often than `emulate_16bit` does: not only what its conv / linear / norm modules return, but the
-    result of every element-wise operation between them (residual sums, the time-embedding add, the GEGLU product, the attention
-    output) — and the same in the backward.  Context manager: every aten operation's floating-point result is rounded through `dtype`
-    (views alias rounded storage and are left alone; in-place results are rounded in place), EXCEPT inside the controller's forward
-    (`paused()`: the reference's own attention / loss arithmetic, which the device path runs inside fp32 kernels).  fp32 accumulation
-    inside an operation is kept, as on the device.  Used for the `emulated_*_every_op` yardsticks."""
-
-    def __init__(self, dtype):
-        from torch.utils._python_dispatch import TorchDispatchMode
-        from torch.utils._pytree import tree_map
-        outer = self
-        self.off = 0
-
-        class Mode(TorchDispatchMode):
-            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
-                out = func(*args, **(kwargs or {}))
-                if outer.off:
-                    return out
-                rets = func._schema.returns
-                aliases = [r.alias_info for r in rets]
-                # reductions (a mean / sum / variance over a large tensor) are not STORAGE: a 16-bit model's kernels keep them in fp32
-                # (a sum of 10^6 activations does not even fit fp16's range); only tensor-sized results are rounded
-                big = max((a_.numel() for a_ in args if torch.is_tensor(a_)), default=0)
-
-                def fix(t, info):
-                    if not (torch.is_tensor(t) and t.dtype == torch.float32) or t.numel() * 16 <= big:
-                        return t
-                    if info is None:
-                        return t.to(dtype).to(torch.float32)
-                    if info.is_write:                      # in-place / out= result: round the storage the caller keeps
-                        t.copy_(t.to(dtype).to(torch.float32))
-                    return t                               # a view: its source has been rounded
-                if isinstance(out, (tuple, list)):
-                    return type(out)(fix(t, aliases[i] if i < len(aliases) else None) for i, t in enumerate(out))
-                return fix(out, aliases[0] if aliases else None)
-
-        self.mode = Mode()
-
-    def __enter__(self):
-        self.mode.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        return self.mode.__exit__(*exc)
-
-    def pause_in(self, obj, name):
-        """Wrap obj.<name> so that nothing is rounded while it runs (forward only: its backward is rounded like every other op)."""
-        orig = getattr(obj, name)
-        outer = self
-
-        def wrapped(*a, **k):
-            outer.off += 1
-            try:
-                return orig(*a, **k)
-            finally:
-                outer.off -= 1
-        setattr(obj, name, wrapped)
-        return orig
 
 
 class controller_16bit:
@@ -233,28 +189,25 @@ def main():
             json.dump(out, open(path, "w"), indent=1)
             return
         torch.set_num_threads(gen_golden.GEN_THREADS)
-        if "--every-op" in sys.argv or "--incl-probabilities" in sys.argv:
-            # two more yardsticks for the error budget (tools/loop_error_budget.py): the reference's probability maps rounded as well
-            # (controller_16bit), and EVERY operation of the model rounded (round_every_op) instead of module outputs only
-            ap = R.attention_processors
+        if "--stored" in sys.argv:
+            # the yardstick that rounds where a 16-bit model rounds (emulate_16bit(stored=True)) + the probability maps (controller_16bit)
             for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
                 if ("--" + dn) in sys.argv or not any(a in sys.argv for a in ("--fp16", "--bf16")):
-                    if "--incl-probabilities" in sys.argv:
-                        with controller_16bit(R, dt):
-                            lat, _, ce, _ = gen_golden.run_reference_loop(R, kind, cfg, prepare=emulate_16bit(dt), **kw)
-                        e["emulated_" + dn + "_incl_probabilities"] = rel_l2(lat[-1:], ref[-1:])
-                    if "--every-op" in sys.argv:
-                        rd = round_every_op(dt)
-                        origs = [(c, rd.pause_in(c, "forward")) for c in (ap.AttentionGeometryEdit, ap.AttentionGeometryRemover)]
-                        try:
-                            with rd:
-                                lat, _, ce, _ = gen_golden.run_reference_loop(R, kind, cfg, prepare=emulate_16bit(dt), **kw)
-                        finally:
-                            for c, o in origs:
-                                c.forward = o
-                        e["emulated_" + dn + "_every_op"] = rel_l2(lat[-1:], ref[-1:])
-                        e["emulated_" + dn + "_every_op_first_update"] = rel_l2(ce._recorded_updates[0], up32)
-                    print(fixture, dn, {k: v for k, v in e.items() if not isinstance(v, dict)}, flush=True)
+                    with controller_16bit(R, dt):
+                        lat, _, ce, _ = gen_golden.run_reference_loop(R, kind, cfg, prepare=emulate_16bit(dt, stored=True), **kw)
+                    e["emulated_" + dn + "_stored_tensors"] = rel_l2(lat[-1:], ref[-1:])
+                    e["emulated_" + dn + "_stored_tensors_first_update"] = rel_l2(ce._recorded_updates[0], up32)
+                    print(fixture, dn, "stored tensors:", e["emulated_" + dn + "_stored_tensors"], flush=True)
+                    out[fixture] = e
+                    json.dump(out, open(path, "w"), indent=1)
+            return
+        if "--incl-probabilities" in sys.argv:
+            # module outputs + the reference's probability maps rounded as well (controller_16bit)
+            for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+                if ("--" + dn) in sys.argv or not any(a in sys.argv for a in ("--fp16", "--bf16")):
+                    with controller_16bit(R, dt):
+                        lat, _, ce, _ = gen_golden.run_reference_loop(R, kind, cfg, prepare=emulate_16bit(dt), **kw)
+                    e["emulated_" + dn + "_incl_probabilities"] = rel_l2(lat[-1:], ref[-1:])
                     out[fixture] = e
                     json.dump(out, open(path, "w"), indent=1)
             return

@@ -735,8 +735,8 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
             image_mask = torch.as_tensor(np.asarray(e["image_mask"])).float()
             H = image.shape[0]
             t_coords_depth, _, amodal = vis_utils.get_transform_coordinates(
-                image / 255.0, e["depth"], image_mask.numpy(), transform_in=e["transform_in"],
-                focal_length=550 * H / 512.0 if H != 512 else 550, return_mesh=True, device=str(dev), as_torch=True)
+                image, e["depth"], image_mask.numpy(), transform_in=e["transform_in"],
+                focal_length=550 * H / 512.0 if H != 512 else 550, return_mesh=True, device=str(dev), as_torch=True, preview=False)
             c = cls([e.get("prompt", "")] * 2, num_ddim_steps, cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
                     equalizer=None, local_blend=None, controller=None, image_mask=image_mask.numpy(), empty_scale=0.0, use_all=False,
                     obj_edit_step=obj_edit_step, tokenizer=tokenizer, device=dev, mode=E.MODE)

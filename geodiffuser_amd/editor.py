@@ -402,9 +402,9 @@ def _perform_geometric_edit(image, depth, image_mask, transform_in, prompt, ldm_
     image = np.asarray(image)
     image_mask = torch.as_tensor(np.asarray(image_mask)).float()
     H = image.shape[0]
-    t_coords_depth, p_image, amodal = vis_utils.get_transform_coordinates(image / 255.0, depth, image_mask.numpy(), transform_in=transform_in,
-                                                                          focal_length=550 * H / 512.0 if H != 512 else 550,
-                                                                          return_mesh=True, device=str(DEVICE), as_torch=True)
+    t_coords_depth, _, amodal = vis_utils.get_transform_coordinates(image, depth, image_mask.numpy(), transform_in=transform_in,
+                                                                    focal_length=550 * H / 512.0 if H != 512 else 550,
+                                                                    return_mesh=True, device=str(DEVICE), as_torch=True, preview=False)
     transform_coordinates = t_coords_depth[None].detach()
 
     ldm_stable, tokenizer, scheduler = LDM_STABLE, TOKENIZER, SCHEDULER

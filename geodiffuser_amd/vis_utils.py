@@ -58,10 +58,13 @@ def get_mesh(t_coords_hw3: torch.Tensor, mask_hw: torch.Tensor):
 
 @torch.no_grad()
 def get_transform_coordinates(image, depth, obj_mask=None, transform_in=torch.eye(4), use_softsplat=True, focal_length=550,
-                              return_mesh=False, device="cuda", as_torch=False):
+                              return_mesh=False, device="cuda", as_torch=False, preview=True):
     """-> (t_coords [H,W,3] f32, projected image [H,W,3] in [0,1][, amodal mask [1,1,H,W]]).
-    numpy arrays like the reference unless ``as_torch``."""
-    image = np.asarray(image)
+    numpy arrays like the reference unless ``as_torch``.  ``preview=False``: the projected preview image (a notebook aid: the edit drivers
+    discard it, U/editor.py:546-547) is not computed — None is returned in its place (one upload, one 512^2 rasterisation and one
+    composite less per edit); ``image`` may then be anything with the right ``shape``."""
+    if preview:
+        image = np.asarray(image)
     H, W = image.shape[0], image.shape[1]
     K = camera_matrix(focal_length, focal_length, W / 2.0, H / 2.0)
     depth = np.array(depth, copy=True)
@@ -98,6 +101,9 @@ def get_transform_coordinates(image, depth, obj_mask=None, transform_in=torch.ey
     if return_mesh:                                                                    # get_mesh + splatter_mesh
         verts, faces = get_mesh(t_coords[0], mask_t[0, 0])
         amodal = ops.mesh_coverage(verts, faces, H)[None, None]
+    if not preview:
+        out = (t_coords[0], None) if as_torch else (t_coords[0].cpu().numpy(), None)
+        return out + (((amodal if as_torch else amodal.cpu().numpy()),) if return_mesh else ())
     # preview image (warp_utils.py:470); depth_projected of the reference is garbage and unused
     img = torch.from_numpy(image)[None].permute(0, 3, 1, 2).float().to(dev)
     idx, w = warp_utils.SPLATTER.tables(t_coords[0].reshape(-1, 3))

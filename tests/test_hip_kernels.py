@@ -1131,6 +1131,10 @@ def test_mesh_coverage_bit_exact_vs_oracle(ops, S):
     for name, T in cases_T.items():
         t, _, amodal = vis_utils.get_transform_coordinates(image, depth.copy(), mask, transform_in=T.float(), focal_length=550 * S / 512.0,
                                                            return_mesh=True, device=DEV, as_torch=True)
+        # what the edit drivers call: no preview image (they discard it) — the same coordinates and coverage, bit for bit
+        t2, none, amodal2 = vis_utils.get_transform_coordinates(image, depth.copy(), mask, transform_in=T.float(), focal_length=550 * S / 512.0,
+                                                                return_mesh=True, device=DEV, as_torch=True, preview=False)
+        assert none is None and torch.equal(t2, t) and torch.equal(amodal2, amodal)
         vo, fo = O.get_mesh(t.float().cpu().numpy(), mask)
         ref = O.splatter_mesh(vo, fo, S)
         got = amodal.cpu().numpy()

@@ -36,7 +36,7 @@ elif os.environ.get("FORM") == "cfgb4":
         idx = torch.full((N, K), -1, dtype=torch.int32, device="cuda"); w = torch.zeros(N, K, device="cuda")
         for jj in range(4):
             idx[:, jj] = torch.where(m > 0, (torch.arange(N, device="cuda") + 64 * 3 + 5 + jj) % N, torch.full((N,), -1, device="cuda")).int(); w[:, jj] = 0.25
-        rows = torch.nonzero(m > 0).reshape(-1).int(); R = rows.numel(); Rp = 512
+        rows = torch.nonzero(m > 0).reshape(-1).int(); R = rows.numel(); Rp = -(-R // 256) * 256
         rows_p = torch.cat([rows, torch.zeros(Rp - R, dtype=torch.int32, device="cuda")]).contiguous(); n_dev = torch.tensor([R], dtype=torch.int32, device="cuda")
         act = torch.empty(1, Rp, C, device="cuda", dtype=torch.bfloat16)
         keep.append((m, idx, w, rows_p, n_dev, act))

@@ -248,3 +248,48 @@ def test_merged_batch_layer_vs_oracle(name, dtype, monkeypatch):
             res["loss"] = float(subs[j].loss)
         P._check_losses_and_grads(case, subs[j], co, res, loss_ref, log_ref, dq_ref, dk_ref, 1.0, tols,
                                   regrad=P._make_regrad(case, q, k, v, mask, coords, scale, gout, nn_ties="index"))
+
+
+def test_second_batch_replays_with_its_own_tables(pipe):
+    """Captured CFG / optimisation-pass graphs of a batch outlive it and read every edit's per-resolution tables by address from the
+    slot-named persistent buffers.  A second batch (other masks / transforms / row-list lengths) served by replays must land where the same
+    batch lands without graphs (a stale table of the previous batch would move the object somewhere else: an O(1) difference)."""
+    from geodiffuser_amd import graphs
+    graphs.reset_opt_graphs()
+    _batch(pipe, [0, 2])                                         # batch A: eager warm-up passes + captures with A's geometry
+    _batch(pipe, [0, 2])
+    got = _batch(pipe, [3, 6])                                   # batch B on replays
+    prev = graphs.ENABLED
+    graphs.ENABLED = False
+    try:
+        want = _batch(pipe, [3, 6])
+        again = _batch(pipe, [3, 6])
+    finally:
+        graphs.ENABLED = prev
+    for (_, log_g, lat_g), (_, log_e, lat_e), (_, _, lat_e2) in zip(got, want, again):
+        noise = rel_l2(lat_e2, lat_e)
+        assert sorted(log_g) == sorted(log_e)
+        assert rel_l2(lat_g, lat_e) < max(5 * noise, 2e-2), (rel_l2(lat_g, lat_e), noise)
+
+
+def test_batched_folder_driver_end_to_end(pipe, tmp_path):
+    """N3 with --edits-per-pass: experiment folders in the reference's wire format go through run_exp_on_folders_batched (read_exp ->
+    perform_geometric_edit_batch -> save_results per folder) and every folder gets the reference's result files."""
+    import os
+    from geodiffuser_amd import large_scale_editor as L
+    from geodiffuser_amd.synthetic import make_edit
+    from geodiffuser_amd.ui_utils import read_image, save_exp
+    p, tok, sched = pipe
+    folders = []
+    for s in (4, 6):
+        image, depth, mask, T = make_edit(s, size=256, kind="translate")
+        folders.append(save_exp(str(tmp_path), image, depth, depth / depth.max(), mask, T.numpy(), h=256, w=256, exp_transform_type="Translation_2D"))
+    assert L.group_for_batches([(f, "geometry_editor") for f in folders], 2) == [(folders, "geometry_editor")]
+    images = L.run_exp_on_folders_batched(folders, "geometry_editor", p, tok, sched, num_ddim_steps=6)
+    assert len(images) == 2 and all(len(im) == 2 for im in images)
+    for f in folders:
+        res = read_image(os.path.join(f, "result_ls.png"))
+        assert res.shape == (256, 256, 3) and res.dtype == np.uint8
+        assert {"loss.log", "loss.pkl", "resized_result_ls.png", "experiment.png"} <= set(os.listdir(f))
+        assert len(L.load_dictionary(os.path.join(f, "loss.pkl"))) >= 1
+    assert not np.array_equal(read_image(os.path.join(folders[0], "result_ls.png")), read_image(os.path.join(folders[1], "result_ls.png")))

@@ -727,6 +727,11 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
             model, tokenizer, _ = load_model(diffusion_model=E.DIFFUSION_MODEL, device=E.DEVICE)
         dev = E.DEVICE
         B = len(edits)
+        if B == 0:
+            return []
+        shapes = {tuple(np.asarray(e["image"]).shape) for e in edits}
+        if len(shapes) != 1:
+            raise ValueError(f"perform_geometric_edit_batch: the edits of a batch must share one image size (got {sorted(shapes)}); group them by size")
         prompts = [e.get("prompt", "") for e in edits]
         subs, coords, masks, images = [], [], [], []
         cls = AttentionGeometryEdit if edit_type == "geometry_editor" else AttentionGeometryRemover

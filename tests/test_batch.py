@@ -25,22 +25,22 @@ def _kw(pipe, kind, steps):
     return kw
 
 
-def _single(pipe, seed, kind="geometry_editor", steps=8, size=256):
+def _single(pipe, seed, kind="geometry_editor", steps=8, size=256, prompt=""):
     from geodiffuser_amd import editor
     from geodiffuser_amd.synthetic import make_edit
     image, depth, mask, T = make_edit(seed, size=size, kind="translate" if seed % 2 == 0 else "rotate")
-    images, log, lat = editor.run_geodiffuser(image, depth, mask, T, **_kw(pipe, kind, steps))
+    images, log, lat = editor.run_geodiffuser(image, depth, mask, T, prompt, **_kw(pipe, kind, steps))
     torch.cuda.synchronize()
     return images, log, lat.float().cpu()
 
 
-def _batch(pipe, seeds, kind="geometry_editor", steps=8, size=256):
+def _batch(pipe, seeds, kind="geometry_editor", steps=8, size=256, prompts=None):
     from geodiffuser_amd.batch import perform_geometric_edit_batch
     from geodiffuser_amd.synthetic import make_edit
     edits = []
-    for s in seeds:
+    for i, s in enumerate(seeds):
         image, depth, mask, T = make_edit(s, size=size, kind="translate" if s % 2 == 0 else "rotate")
-        edits.append(dict(image=image, depth=depth, image_mask=mask, transform_in=T, prompt=""))
+        edits.append(dict(image=image, depth=depth, image_mask=mask, transform_in=T, prompt=prompts[i] if prompts else ""))
     kw = _kw(pipe, kind, steps)
     kw.pop("edit_type")
     res = perform_geometric_edit_batch(edits, edit_type=kind, **kw)
@@ -68,6 +68,23 @@ def test_batch_of_one_is_the_single_edit_driver(pipe, kind):
     assert im[0].dtype == np.uint8 and im[0].shape == a[0][0].shape and im[1].shape == a[0][1].shape and im[1].dtype == a[0][1].dtype
     lv = lambda x, y: float(np.abs(x.astype(np.float64) - y.astype(np.float64)).mean())      # mean difference in 8-bit levels
     assert lv(im[1], a[0][1]) <= 3 * lv(b[0][1], a[0][1]) + 1.0 and lv(im[0], a[0][0]) <= 3 * lv(b[0][0], a[0][0]) + 1.0
+
+
+def test_batch_with_text_prompts_runs_the_cfg_inversion(pipe):
+    """A prompt that differs from the unconditional text: the inversion's two CFG rows are different samples, so the batched inversion runs
+    at 2 B rows with the guided combine (U/inversion.py:131-196) instead of the single-row shortcut, and every edit carries its own text
+    rows through the loop.  Edit 0 against its one-edit run; an image-size mismatch inside a batch is refused."""
+    from geodiffuser_amd.batch import perform_geometric_edit_batch
+    a = _single(pipe, 4, prompt="a photo of a chair")
+    b = _single(pipe, 4, prompt="a photo of a chair")
+    noise = rel_l2(b[2], a[2])
+    res = _batch(pipe, [4, 7], prompts=["a photo of a chair", ""])
+    d = rel_l2(res[0][2], a[2])
+    print(f"[batch] prompted edit in a batch of 2 vs alone {d:.2e} (two runs alone: {noise:.2e})")
+    assert sorted(res[0][1]) == sorted(a[1]) and d < max(6 * noise, 5e-2)
+    with pytest.raises(ValueError):
+        perform_geometric_edit_batch([dict(image=np.zeros((256, 256, 3), np.uint8), depth=None, image_mask=None, transform_in=None),
+                                      dict(image=np.zeros((512, 512, 3), np.uint8), depth=None, image_mask=None, transform_in=None)])
 
 
 def test_mixed_batch_every_edit_lands_on_its_own_single_run(pipe):

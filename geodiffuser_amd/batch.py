@@ -698,10 +698,20 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
     [, final latents [2,4,h,w]]).  The keyword arguments mean what they mean there; ``loss_weights_dict`` is deep-copied per edit (every
     edit's adaptive schedule edits its own)."""
     import copy
+    # the rest of perform_geometric_edit's signature: accepted where it does not change the result, refused where it would
+    allowed = dict(image_stitch=None, progress=None, fast_start_steps=0.0, num_first_optim_steps=1, return_attention_maps=False, unet_path="",
+                   use_optimizer=True)
+    for k_, v_ in ignored.items():
+        if k_ not in allowed:
+            raise TypeError(f"perform_geometric_edit_batch() got an unexpected keyword argument {k_!r}")
+        if k_ in ("fast_start_steps", "return_attention_maps", "image_stitch", "unet_path") and v_ != allowed[k_] and v_:
+            raise NotImplementedError(f"perform_geometric_edit_batch: {k_}={v_!r} is only supported by the one-edit driver (perform_geometric_edit)")
     if perform_inversion:
         raise NotImplementedError("null-text optimisation is per edit: use perform_geometric_edit (every reference driver passes perform_inversion=False)")
     if edit_type not in ("geometry_editor", "geometry_remover"):
         raise NotImplementedError(edit_type)
+    if len(edits) == 0:
+        return []
     prev_grad = torch.is_grad_enabled()
     torch.set_grad_enabled(False)
     import time
@@ -727,8 +737,6 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
             model, tokenizer, _ = load_model(diffusion_model=E.DIFFUSION_MODEL, device=E.DEVICE)
         dev = E.DEVICE
         B = len(edits)
-        if B == 0:
-            return []
         shapes = {tuple(np.asarray(e["image"]).shape) for e in edits}
         if len(shapes) != 1:
             raise ValueError(f"perform_geometric_edit_batch: the edits of a batch must share one image size (got {sorted(shapes)}); group them by size")

@@ -479,3 +479,15 @@ def test_edit_batch_routes_role_major_rows_and_keeps_counters_in_step(monkeypatc
     assert batch.cur_step == 1 and all(s.cur_step == 1 for s in subs)
     with pytest.raises(ValueError):
         GB.EditBatch([Sub(1), type("Other", (Sub,), {})(2)], [torch.tensor(0.0), torch.tensor(0.0)])
+
+
+def test_batch_entry_point_refuses_what_it_does_not_implement():
+    """perform_geometric_edit_batch takes perform_geometric_edit's keyword arguments; what only the one-edit driver implements is refused
+    loudly (before anything touches the device), unknown names are a TypeError like any Python call."""
+    from geodiffuser_amd.batch import perform_geometric_edit_batch
+    with pytest.raises(TypeError):
+        perform_geometric_edit_batch([], no_such_argument=1)
+    for kw in (dict(fast_start_steps=0.2), dict(return_attention_maps=True), dict(perform_inversion=True), dict(edit_type="geometry_stitch")):
+        with pytest.raises(NotImplementedError):
+            perform_geometric_edit_batch([], **kw)
+    assert perform_geometric_edit_batch([], progress=None, use_optimizer=True, num_first_optim_steps=1) == []

@@ -591,8 +591,13 @@ extern "C" int gd_attn_fwd(const gd_attn_seg_t* segs, int nseg, int N, int M, in
         const int c = cfg.qb * 10 + cfg.ks;
         GD_REQUIRE(c == 41 || c == 22 || c == 42 || c == 24 || c == 81, GD_EINVAL, "gd_attn_fwd: cfg: no kernel for QB=%d KS=%d", cfg.qb, cfg.ks);
     }
-    GD_REQUIRE(cfg.even_split >= -1 && cfg.even_split <= 2 && cfg.handoff >= 0 && cfg.handoff <= 2, GD_EINVAL,
-               "gd_attn_fwd: cfg: even_split=%d (-1..2), handoff=%d (0..2)", cfg.even_split, cfg.handoff);
+#if defined(GD_MP_DBG) && GD_MP_DBG
+    const int max_handoff = 2;       // timing builds only: 2 = no merge (WRONG outputs)
+#else
+    const int max_handoff = 1;
+#endif
+    GD_REQUIRE(cfg.even_split >= -1 && cfg.even_split <= 2 && cfg.handoff >= 0 && cfg.handoff <= max_handoff, GD_EINVAL,
+               "gd_attn_fwd: cfg: even_split=%d (-1..2), handoff=%d (0..%d)", cfg.even_split, cfg.handoff, max_handoff);
     int nsplit = cfg.nsplit > 1 ? cfg.nsplit : 1;
     GD_REQUIRE(segs && nseg >= 1 && nseg <= GD_ATTN_MAX_SEGS, GD_EINVAL, "gd_attn_fwd: nseg=%d (1..%d)", nseg, GD_ATTN_MAX_SEGS);
     GD_REQUIRE(D == 64 || D == 128 || D == 192, GD_EUNSUPPORTED,

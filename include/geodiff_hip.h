@@ -151,8 +151,9 @@ typedef struct gd_attn_cfg {
     int32_t nsplit;      /* > 1: split-KV — the keys cut into nsplit ranges handled by separate workgroups whose un-normalised partial
                             results (O, reference max, row sum; f32) go through `workspace` (gd_attn_fwd_plan's size) and are merged by a
                             second small kernel; same result up to f32 summation order.  0 / 1: off (default) */
-    int32_t handoff;     /* development: how the parts of an even split are handed over (0 = agent-scope release / acquire fences,
-                            1 = device-scope stores and loads, the default; 2 = no merge, TIMING ONLY, wrong outputs) */
+    int32_t handoff;     /* how the parts of an even split are handed over: 0 = agent-scope release / acquire fences around the ticket,
+                            1 = device-scope stores and loads (default).  (Timing builds compiled with GD_MP_DBG also take 2 = no merge;
+                            a release library returns GD_EINVAL for it: it produces wrong outputs by construction.) */
 } gd_attn_cfg_t;
 #define GD_ATTN_CFG_DEFAULT {-1, -1, 0, 0, 1}
 

@@ -94,7 +94,7 @@ class Tune:
         return 0
 
     def gd_attn_fwd_set_even_split(self, on):
-        # 0 = never, 1 = where it pays, 2 = every launch that can be split; 10 / 11 / 12 = as 2 with the hand-off mode 0 / 1 / 2
+        # 0 = never, 1 = where it pays, 2 = every launch that can be split; 10 / 11 = as 2 with the hand-off mode 0 / 1
         from geodiffuser_amd import ops
         ops.ATTN_CFG.update(even_split=2 if on >= 10 else on, handoff=on - 10 if on >= 10 else 1)
         return 0

@@ -67,6 +67,8 @@ def test_argument_validation_without_gpu(lib):
     # per-call configuration is validated per call: an unknown kernel shape / split mode is an argument error, not a sticky setting
     bad = GdAttnCfg(-1, 3, 3, 0, 1)
     assert lib.gd_attn_fwd(seg, 1, 64, 64, 64, 0.125, ctypes.byref(bad), None, 0, 0, None) == -1 and b"no kernel" in lib.gd_last_error()
+    bad = GdAttnCfg(-1, -1, 0, 0, 2)         # the timing-only "no merge" hand-off is not reachable from a release library
+    assert lib.gd_attn_fwd(seg, 1, 64, 64, 64, 0.125, ctypes.byref(bad), None, 0, 0, None) == -1 and b"handoff" in lib.gd_last_error()
     bad = GdAttnCfg(7, -1, 0, 0, 1)
     assert lib.gd_attn_fwd(seg, 1, 64, 64, 64, 0.125, ctypes.byref(bad), None, 0, 0, None) == -1 and b"even_split" in lib.gd_last_error()
 

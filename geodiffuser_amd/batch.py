@@ -741,28 +741,30 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
         if len(shapes) != 1:
             raise ValueError(f"perform_geometric_edit_batch: the edits of a batch must share one image size (got {sorted(shapes)}); group them by size")
         prompts = [e.get("prompt", "") for e in edits]
-        subs, coords, masks, images = [], [], [], []
-        cls = AttentionGeometryEdit if edit_type == "geometry_editor" else AttentionGeometryRemover
-        for e in edits:
-            image = np.asarray(e["image"])
-            image_mask = torch.as_tensor(np.asarray(e["image_mask"])).float()
-            H = image.shape[0]
-            t_coords_depth, _, amodal = vis_utils.get_transform_coordinates(
-                image, e["depth"], image_mask.numpy(), transform_in=e["transform_in"],
-                focal_length=550 * H / 512.0 if H != 512 else 550, return_mesh=True, device=str(dev), as_torch=True, preview=False)
-            c = cls([e.get("prompt", "")] * 2, num_ddim_steps, cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
-                    equalizer=None, local_blend=None, controller=None, image_mask=image_mask.numpy(), empty_scale=0.0, use_all=False,
-                    obj_edit_step=obj_edit_step, tokenizer=tokenizer, device=dev, mode=E.MODE)
-            c.amodal_mask = torch_erode(amodal.float())
-            if loss_weights_dict is not None:
-                lw = copy.deepcopy(loss_weights_dict)
-                c.loss_weight_dict = lw
-                c.default_loss_weights = lw
-            subs.append(c); coords.append(t_coords_depth[None].detach()); masks.append(image_mask); images.append(image)
-        _tm("pre-pass + controllers")
-        batch = EditBatch(subs, coords)
+        images = [np.asarray(e["image"]) for e in edits]
+        # the inversion's passes are only QUEUED when this returns; the geometry pre-passes and the controllers (host work with device
+        # round trips, independent of the inversion) run on a side stream while the GPU inverts (see editor.side_stream)
         traj = ddim_inversion_batch(model, images, prompts, num_ddim_steps, guidance_scale, dev)
-        _tm("inversion")
+        subs, coords, masks = [], [], []
+        cls = AttentionGeometryEdit if edit_type == "geometry_editor" else AttentionGeometryRemover
+        with E.side_stream():
+            for e, image in zip(edits, images):
+                image_mask = torch.as_tensor(np.asarray(e["image_mask"])).float()
+                H = image.shape[0]
+                t_coords_depth, _, amodal = vis_utils.get_transform_coordinates(
+                    image, e["depth"], image_mask.numpy(), transform_in=e["transform_in"],
+                    focal_length=550 * H / 512.0 if H != 512 else 550, return_mesh=True, device=str(dev), as_torch=True, preview=False)
+                c = cls([e.get("prompt", "")] * 2, num_ddim_steps, cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
+                        equalizer=None, local_blend=None, controller=None, image_mask=image_mask.numpy(), empty_scale=0.0, use_all=False,
+                        obj_edit_step=obj_edit_step, tokenizer=tokenizer, device=dev, mode=E.MODE)
+                c.amodal_mask = torch_erode(amodal.float())
+                if loss_weights_dict is not None:
+                    lw = copy.deepcopy(loss_weights_dict)
+                    c.loss_weight_dict = lw
+                    c.default_loss_weights = lw
+                subs.append(c); coords.append(t_coords_depth[None].detach()); masks.append(image_mask)
+            batch = EditBatch(subs, coords)
+        _tm("inversion + pre-pass + controllers")
         out, logs = text2image_ldm_stable_batch(
             model, prompts, batch, num_ddim_steps, guidance_scale, latent=traj[-1], ddim_latents=traj, masks_obj=[m[None, None] for m in masks],
             optimize_steps=optimize_steps, latent_replace=latent_replace, lr=lr, optimize_embeddings=optimize_embeddings,

@@ -8,6 +8,7 @@ the SGD optimizer branch (``use_optimizer`` is never forwarded), t
 """
 from __future__ import annotations
 
+import contextlib
 import logging
 import os
 from typing import Dict, List, Optional
@@ -350,6 +351,28 @@ def run_and_display(ldm_stable, prompts, controller, latent=None, run_baseline=F
                                  return_type=return_type, image_size=image_size)
 
 
+_SIDE_STREAMS = {}
+
+
+@contextlib.contextmanager
+def side_stream():
+    """Run the body on a second HIP stream of DEVICE; the current stream waits for it on exit.  Host synchronisations inside the body
+    (``nonzero`` / ``.item()`` / downloads) then wait for the body's own kernels only, not for work already queued on the current
+    stream.  Tensors made inside are used on the current stream afterwards and are released only after the edit's final download (a
+    full synchronisation), so the caching allocator cannot hand their blocks out while the current stream still reads them."""
+    dev = torch.device(DEVICE)
+    if dev.type != "cuda":
+        yield
+        return
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(dev)
+    if side is None:
+        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        yield
+    main.wait_stream(side)
+
+
 def perform_geometric_edit(image, depth, image_mask, transform_in, prompt="", ldm_stable_model=None, tokenizer_model=None,
                            scheduler_in=None, cross_replace_steps={"default_": 0.95}, self_replace_steps=0.95, optimize_steps=0.6,
                            lr=0.03, latent_replace=0.6, optimize_embeddings=True, optimize_latents=True, obj_edit_step=1.0,
@@ -402,11 +425,6 @@ def _perform_geometric_edit(image, depth, image_mask, transform_in, prompt, ldm_
     image = np.asarray(image)
     image_mask = torch.as_tensor(np.asarray(image_mask)).float()
     H = image.shape[0]
-    t_coords_depth, _, amodal = vis_utils.get_transform_coordinates(image, depth, image_mask.numpy(), transform_in=transform_in,
-                                                                    focal_length=550 * H / 512.0 if H != 512 else 550,
-                                                                    return_mesh=True, device=str(DEVICE), as_torch=True, preview=False)
-    transform_coordinates = t_coords_depth[None].detach()
-
     ldm_stable, tokenizer, scheduler = LDM_STABLE, TOKENIZER, SCHEDULER
     if scheduler_in is not None and (unet_path == "" or unet_path == UNET_NAME):
         ldm_stable, tokenizer, scheduler = ldm_stable_model, tokenizer_model, scheduler_in
@@ -421,12 +439,19 @@ def _perform_geometric_edit(image, depth, image_mask, transform_in, prompt, ldm_
                                                                                       perform_inversion=perform_inversion, image_2=None)
     prompts = [prompt, prompt]
     cls = AttentionGeometryEdit if edit_type == "geometry_editor" else AttentionGeometryRemover
-    controller = cls(prompts, NUM_DDIM_STEPS, cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
-                     equalizer=None, local_blend=None, controller=None, image_mask=image_mask.numpy(), empty_scale=0.0, use_all=False,
-                     obj_edit_step=obj_edit_step, tokenizer=tokenizer, device=DEVICE, mode=MODE)
+    # The geometry pre-pass (editor.py:497-503) and the controller do not depend on the inversion, and the inversion's passes above are
+    # only QUEUED at this point: this host work (with its device round trips) runs on a side stream while the GPU inverts.
+    with side_stream():
+        t_coords_depth, _, amodal = vis_utils.get_transform_coordinates(image, depth, image_mask.numpy(), transform_in=transform_in,
+                                                                        focal_length=550 * H / 512.0 if H != 512 else 550,
+                                                                        return_mesh=True, device=str(DEVICE), as_torch=True, preview=False)
+        transform_coordinates = t_coords_depth[None].detach()
+        controller = cls(prompts, NUM_DDIM_STEPS, cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
+                         equalizer=None, local_blend=None, controller=None, image_mask=image_mask.numpy(), empty_scale=0.0, use_all=False,
+                         obj_edit_step=obj_edit_step, tokenizer=tokenizer, device=DEVICE, mode=MODE)
+        controller.amodal_mask = torch_erode(amodal.float())                                              # :633
     if return_attention_maps:
         controller.store_attention_maps = True
-    controller.amodal_mask = torch_erode(amodal.float())                                                  # :633
     if loss_weights_dict is not None:                                                                      # :636-638
         controller.loss_weight_dict = loss_weights_dict
         controller.default_loss_weights = loss_weights_dict

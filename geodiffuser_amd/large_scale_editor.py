@@ -158,35 +158,120 @@ def save_results(exp_dict, out_image, loss_dict, edit_type="geometry_editor", st
     generate_output_plot_and_save(exp_dict)
 
 
-def run_exp_on_folder_single(exp_folder, exp_type, ldm_stable, tokenizer, scheduler, **overrides):
-    """:179-192."""
+class FolderIO:
+    """Read-ahead / write-behind for a rank's work list.  One experiment's files cost ~0.1 s to read and ~1 s to write on the host
+    (seven PNGs through zlib, :133-176) — more than the edit itself takes on an MI355X — and the reference does both in line with the
+    edit.  Here ``read_exp`` of the NEXT group and ``save_results`` of finished experiments run on worker threads (PNG decode / encode
+    and the numpy resizes release the GIL) while the device runs the current group.  Same files, same bytes; at most ``max_pending``
+    unfinished writes (the oldest is waited for beyond that); an exception in a worker is raised by the next call or by ``close()``.
+    ``threads = 0``: everything in line, as in the reference."""
+
+    def __init__(self, threads: int = 8, max_pending: int = 32):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=threads, thread_name_prefix="gd-folder-io") if threads > 0 else None
+        self.max_pending = max(1, max_pending)
+        self.pending = []
+
+    def read(self, folders):
+        """-> a handle whose ``result()`` is [read_exp(folder) for folder in folders] (started now)."""
+        folders = [complete_path(f) for f in folders]
+        if self.pool is None:
+            return _Done([read_exp(f) for f in folders])
+        futs = [self.pool.submit(read_exp, f) for f in folders]
+        return _Gather(futs)
+
+    def save(self, exp_dict, out_image, loss_dict, edit_type, step_store=None):
+        if self.pool is None:
+            return save_results(exp_dict, out_image, loss_dict, edit_type, step_store=step_store)
+        self._reap(block_over=self.max_pending - 1)
+        self.pending.append(self.pool.submit(save_results, exp_dict, out_image, loss_dict, edit_type, step_store=step_store))
+
+    def _reap(self, block_over=None):
+        while self.pending and (self.pending[0].done() or (block_over is not None and len(self.pending) > block_over)):
+            self.pending.pop(0).result()                       # raises what the worker raised
+
+    def close(self):
+        try:
+            while self.pending:
+                self.pending.pop(0).result()
+        finally:
+            if self.pool is not None:
+                self.pool.shutdown(wait=True)
+                self.pool = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+class _Done:
+    def __init__(self, v):
+        self.v = v
+
+    def result(self):
+        return self.v
+
+
+class _Gather:
+    def __init__(self, futs):
+        self.futs = futs
+
+    def result(self):
+        return [f.result() for f in self.futs]
+
+
+def run_exp_on_folder_single(exp_folder, exp_type, ldm_stable, tokenizer, scheduler, *, exp_dict=None, io: Optional[FolderIO] = None,
+                             **overrides):
+    """:179-192.  ``exp_dict``: the folder's files if already read (FolderIO.read); ``io``: write the result files behind the next edit."""
     log.info("Performing edit on: %s with exp type: %s", exp_folder, exp_type)
     exp_folder = complete_path(exp_folder)
-    exp_dict = read_exp(exp_folder)
+    if exp_dict is None:
+        exp_dict = read_exp(exp_folder)
     list_exp_details(exp_dict, printer=lambda *a: log.debug(" ".join(str(x) for x in a)))
     images, loss_dict, step_store = perform_exp(exp_dict, edit_type=exp_type, ldm_stable_model=ldm_stable, tokenizer_model=tokenizer,
                                                 scheduler_in=scheduler, **overrides)
-    save_results(exp_dict, images[-1], loss_dict, exp_type, step_store=step_store)
+    (io.save if io is not None else save_results)(exp_dict, images[-1], loss_dict, exp_type, step_store=step_store)
     return images
 
 
-def run_exp_on_folders_batched(exp_folders, exp_type, ldm_stable, tokenizer, scheduler, **overrides):
+def run_exp_on_folders_batched(exp_folders, exp_type, ldm_stable, tokenizer, scheduler, *, exp_dicts=None, io: Optional[FolderIO] = None,
+                               **overrides):
     """``run_exp_on_folder_single`` for a group of folders of ONE edit type whose edits share every UNet pass
     (geodiffuser_amd.batch.perform_geometric_edit_batch): same inputs, same configuration column, same result files per folder."""
     from .batch import perform_geometric_edit_batch
     kw = edit_config(exp_type, **overrides)
     dicts, edits = [], []
-    for f in exp_folders:
+    for j, f in enumerate(exp_folders):
         log.info("Performing edit on: %s with exp type: %s (batch of %d)", f, exp_type, len(exp_folders))
-        d = read_exp(complete_path(f))
+        d = exp_dicts[j] if exp_dicts is not None else read_exp(complete_path(f))
         dicts.append(d)
         edits.append(dict(image=d["input_image_png"], image_mask=(d["input_mask_png"] / 255.0)[..., 0], depth=d["depth_npy"],
                           transform_in=torch.tensor(d["transform_npy"]).float(), prompt=""))
     res = perform_geometric_edit_batch(edits, ldm_stable_model=ldm_stable, tokenizer_model=tokenizer, scheduler_in=scheduler, edit_type=exp_type,
                                        return_loss_log_dict=True, **kw)
     for d, (images, loss_dict) in zip(dicts, res):
-        save_results(d, images[-1], loss_dict, exp_type, step_store=None)
+        (io.save if io is not None else save_results)(d, images[-1], loss_dict, exp_type, step_store=None)
     return [r[0] for r in res]
+
+
+def run_work_list(work: List[Tuple[str, str]], ldm_stable, tokenizer, scheduler, edits_per_pass: int = 1, io_threads: int = 8, **overrides):
+    """A rank's whole work list: groups of ``edits_per_pass`` folders per pass (1: the reference's one edit at a time, in work-list
+    order), the next group's files read ahead and the result files written behind by ``io_threads`` workers (FolderIO)."""
+    groups = group_for_batches(work, edits_per_pass) if edits_per_pass > 1 else [([f], t) for f, t in work]
+    with FolderIO(io_threads) as io:
+        ahead = io.read(groups[0][0]) if groups else None
+        for i, (folders, etype) in enumerate(groups):
+            dicts = ahead.result()
+            ahead = io.read(groups[i + 1][0]) if i + 1 < len(groups) else None
+            if len(folders) == 1:
+                run_exp_on_folder_single(folders[0], etype, ldm_stable, tokenizer, scheduler, exp_dict=dicts[0], io=io, **overrides)
+            else:
+                run_exp_on_folders_batched(folders, etype, ldm_stable, tokenizer, scheduler, exp_dicts=dicts, io=io, **overrides)
+            for f in folders:
+                log.info("Completed: %s", f)           # the edit; its files are on disk when this function returns
 
 
 def group_for_batches(work: List[Tuple[str, str]], per_pass: int) -> List[Tuple[List[str], str]]:
@@ -228,6 +313,8 @@ def main(argv=None):
     ap.add_argument("--edits-per-pass", type=int, default=1,
                     help="B > 1: every rank runs its folders B at a time in ONE process, sharing every UNet pass (geodiffuser_amd/batch.py; one "
                          "copy of the weights; 4 gives 1.7 x, 8 gives 1.9 x the edits/min of 1 on an MI355X)")
+    ap.add_argument("--io-threads", type=int, default=8,
+                    help="worker threads that read the next experiments' files and write finished results while the GPU edits (0: in line)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     from . import dist as gdist
@@ -260,18 +347,7 @@ def main(argv=None):
         work = work[:args.limit]
     mine = gdist.shard(work, rank, world)
     log.info("rank %d/%d: %d of %d experiments", rank, world, len(mine), len(work))
-    if args.edits_per_pass > 1:
-        for folders, etype in group_for_batches(mine, args.edits_per_pass):
-            if len(folders) == 1:
-                run_exp_on_folder_single(folders[0], etype, pipe, tok, sched)
-            else:
-                run_exp_on_folders_batched(folders, etype, pipe, tok, sched)
-            for f in folders:
-                log.info("Completed: %s", f)
-    else:
-        for folder, etype in mine:
-            run_exp_on_folder_single(folder, etype, pipe, tok, sched)
-            log.info("Completed: %s", folder)
+    run_work_list(mine, pipe, tok, sched, edits_per_pass=max(1, args.edits_per_pass), io_threads=max(0, args.io_threads))
     gdist.barrier()
 
 

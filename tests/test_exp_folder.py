@@ -230,3 +230,69 @@ def test_batched_driver_groups_by_edit_type_and_writes_the_same_result_files(tmp
         for name in ("result_ls.png", "resized_result_ls.png", "experiment.png", "loss.pkl", "loss.log"):
             a, b = runs[1] / rel / name, runs[2] / rel / name
             assert a.exists() and b.exists() and a.read_bytes() == b.read_bytes(), (rel, name)
+
+
+def test_folder_io_writes_behind_the_same_bytes_and_raises_worker_errors(tmp_path, monkeypatch):
+    """``--io-threads``: reading the next folders ahead and writing results behind on worker threads (FolderIO) leaves byte-identical
+    files to the in-line driver (--io-threads 0 = the reference's order of operations), keeps at most max_pending writes in flight, and
+    an exception in a worker surfaces from the driver instead of being lost."""
+    import shutil
+    import threading
+    import types
+    from geodiffuser_amd import diffusion, editor, large_scale_editor as L
+
+    edit_threads = set()
+
+    def fake_edit(image, depth, image_mask, transform_in, prompt="", edit_type="geometry_editor", **kw):
+        edit_threads.add(threading.current_thread().name)
+        out = np.clip(image.astype(np.float64) * 0.5 + 40.0 * (np.asarray(image_mask)[..., None] > 0.5), 0, 255)
+        return [image, out], {0: {"self": {"sim": 1.0}, "cross": {"sim": float(np.asarray(transform_in).sum())}, "num_layers": 16}}
+
+    monkeypatch.setattr(diffusion, "load_model", lambda **kw: (types.SimpleNamespace(unet=torch.nn.Linear(2, 2), vae=torch.nn.Linear(2, 2),
+                                                                                       text_encoder=torch.nn.Linear(2, 2)), None, None))
+    monkeypatch.setattr(editor, "perform_geometric_edit", fake_edit)
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(v, raising=False)
+    runs = {}
+    for threads in (0, 3):
+        data = tmp_path / f"io{threads}"
+        shutil.copytree(ROOT, data)
+        L.main(["--root", str(data), "--io-threads", str(threads)])
+        runs[threads] = data
+    assert edit_threads == {threading.current_thread().name}             # the edits themselves stay on the caller's thread
+    for rel in ("Mix/1", "Mix/2", "Removal/1"):
+        names = sorted(os.listdir(runs[0] / rel))
+        assert names == sorted(os.listdir(runs[3] / rel))
+        for name in names:
+            assert (runs[0] / rel / name).read_bytes() == (runs[3] / rel / name).read_bytes(), (rel, name)
+
+    # back-pressure: never more than max_pending unfinished writes
+    gate, peak, live = threading.Event(), [0], [0]
+    lock = threading.Lock()
+
+    def slow_save(*a, **k):
+        with lock:
+            live[0] += 1
+            peak[0] = max(peak[0], live[0])
+        gate.wait(5)
+        with lock:
+            live[0] -= 1
+
+    monkeypatch.setattr(L, "save_results", slow_save)
+    io = L.FolderIO(threads=8, max_pending=2)
+    threading.Timer(0.3, gate.set).start()
+    for i in range(6):
+        io.save({"path_name": str(tmp_path) + "/"}, None, {}, "geometry_editor")
+        assert len(io.pending) <= 2
+    io.close()
+    assert peak[0] <= 2 and io.pending == []
+
+    # a failing writer is reported
+    def bad_save(*a, **k):
+        raise OSError("disk full")
+
+    monkeypatch.setattr(L, "save_results", bad_save)
+    data = tmp_path / "bad"
+    shutil.copytree(ROOT, data)
+    with pytest.raises(OSError, match="disk full"):
+        L.main(["--root", str(data), "--io-threads", "2"])

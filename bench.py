@@ -322,6 +322,12 @@ def cpu_baseline(budget_s=45.0):
                        + ", ".join(f"{k}={v:.2f}s" for k, v in times.items()) + f" (mean of {total_reps} calls); 64^2 (N=4096, 5 heads, one call each) "
                        + ", ".join(f"{k}={v:.2f}s" for k, v in times64.items())
                        + f"; per-pass sums extrapolated by call counts to 17 opt + 50 CFG + 50 inversion passes = {edit_s:.0f} s/edit"))
+    # NOT measured by this run — a recorded fact beside the extrapolation: the reference's OWN loop on this very workload took 12.5 min
+    # of CPU when tests/golden/G30 was recorded (oracle/gen_golden.py, its provenance field names the machine)
+    out["whole_edit_recorded"] = dict(seconds=750, cores=8, kind="reference", live=False,
+                                      what="the reference's text2image_ldm_stable in fp32 on configs[1] (865 M-parameter UNet, 512^2, 50 steps, 17 "
+                                           "optimisation passes; no inversion, no VAE), timed once in the build container while recording "
+                                           "tests/golden/G30_loop_cfg1_full_t50.npz")
     try:
         out["configs0_end_to_end"] = cpu_baseline_configs0(cores)
     except Exception as e:  # noqa: BLE001

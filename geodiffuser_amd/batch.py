@@ -745,7 +745,7 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
         # the inversion's passes are only QUEUED when this returns; the geometry pre-passes and the controllers (host work with device
         # round trips, independent of the inversion) run on a side stream while the GPU inverts (see editor.side_stream)
         traj = ddim_inversion_batch(model, images, prompts, num_ddim_steps, guidance_scale, dev)
-        subs, coords, masks = [], [], []
+        subs, coords, masks, dev_in = [], [], [], []
         cls = AttentionGeometryEdit if edit_type == "geometry_editor" else AttentionGeometryRemover
         with E.side_stream():
             for e, image in zip(edits, images):
@@ -763,6 +763,7 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
                     c.loss_weight_dict = lw
                     c.default_loss_weights = lw
                 subs.append(c); coords.append(t_coords_depth[None].detach()); masks.append(image_mask)
+                dev_in.append((torch.from_numpy(np.ascontiguousarray(image)).to(dev), image_mask.to(dev)))      # for the post-process
             batch = EditBatch(subs, coords)
         _tm("inversion + pre-pass + controllers")
         out, logs = text2image_ldm_stable_batch(
@@ -773,9 +774,13 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
             skip_optim_steps=skip_optim_steps, num_ddim_steps=num_ddim_steps)
         _tm("edit loop")
         decoded = latent2image(model.vae, out, as_tensor=True)                     # [2 B, H, W, 3] uint8 on the device, role-major
+        # every edit's post-process queued first, then ONE download per kind (a download per edit is a synchronisation per edit)
+        edited = torch.stack([E.post_process(dev_in[j][0], dev_in[j][1], decoded[B + j], coords[j], subs[j].mask_new_warped, edit_type, as_numpy=False)
+                              for j in range(B)]).cpu().numpy()
+        recon = decoded[:B].cpu().numpy()
         results = []
         for j, e in enumerate(edits):
-            imgs = [decoded[j].cpu().numpy(), E.post_process(images[j], masks[j], decoded[B + j], coords[j], subs[j].mask_new_warped, edit_type)]
+            imgs = [recon[j], edited[j]]
             ret = [imgs]
             if return_loss_log_dict:
                 ret.append(logs[j])

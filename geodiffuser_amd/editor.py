@@ -319,7 +319,8 @@ def post_process(image, image_mask, edited, transform_coordinates, mask_new_warp
     The integer arithmetic is the reference's: masks are {0,1}, so mask*uint8 sums are exact and the ``astype('uint8')`` truncations act
     on the same values."""
     dev = edited.device
-    img = torch.as_tensor(np.ascontiguousarray(image)).to(dev)                                  # [H,W,3] uint8
+    # (device tensors are taken as they are: the drivers upload both during the pre-pass, an upload here would wait for the decode)
+    img = image.to(dev) if torch.is_tensor(image) else torch.as_tensor(np.ascontiguousarray(image)).to(dev)          # [H,W,3] uint8
     m_im = torch.as_tensor(np.asarray(image_mask) if not torch.is_tensor(image_mask) else image_mask).to(dev).float()
     if edit_type == "geometry_editor":
         img_t = (img[None].permute(0, 3, 1, 2) / 255.0).float()
@@ -450,6 +451,7 @@ def _perform_geometric_edit(image, depth, image_mask, transform_in, prompt, ldm_
                          equalizer=None, local_blend=None, controller=None, image_mask=image_mask.numpy(), empty_scale=0.0, use_all=False,
                          obj_edit_step=obj_edit_step, tokenizer=tokenizer, device=DEVICE, mode=MODE)
         controller.amodal_mask = torch_erode(amodal.float())                                              # :633
+        image_dev, mask_dev = torch.from_numpy(np.ascontiguousarray(image)).to(DEVICE), image_mask.to(DEVICE)   # for the post-process
     if return_attention_maps:
         controller.store_attention_maps = True
     if loss_weights_dict is not None:                                                                      # :636-638
@@ -467,7 +469,7 @@ def _perform_geometric_edit(image, depth, image_mask, transform_in, prompt, ldm_
     final_latents = out if return_latents else None
     decoded = latent2image(ldm_stable.vae, out, as_tensor=True)                    # [2, H, W, 3] uint8, still on the device
     # :660-693 on the device: one download of the finished images instead of image -> host -> device -> host
-    edited = post_process(image, image_mask, decoded[-1], transform_coordinates, controller.mask_new_warped, edit_type)
+    edited = post_process(image_dev, mask_dev, decoded[-1], transform_coordinates, controller.mask_new_warped, edit_type)
     images = [decoded[0].cpu().numpy(), edited]
     ldm_stable.unet.set_attn_processor(VanillaAttentionProcessor())                                        # :698
     ret = [images]

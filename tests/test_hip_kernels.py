@@ -1036,6 +1036,37 @@ def test_hist_match_full_size_counts_and_lut(ops):
         masked_histogram_matching(src.astype(np.float32), tmpl, m_t, m_s)
 
 
+@pytest.mark.parametrize("edit_type", ["geometry_editor", "geometry_remover"])
+@pytest.mark.parametrize("inputs_on", ["host", "device"])
+def test_edit_post_process_on_device_matches_the_reference_block(ops, edit_type, inputs_on):
+    """editor.post_process (U/editor.py:660-693 on the device: warped-image composite, masks, histogram match) is bit-identical to the
+    numpy restatement of that block for the same warped image, with the inputs handed over as host arrays (the reference's call) or as
+    device tensors (what the drivers pass: uploaded during the pre-pass)."""
+    from geodiffuser_amd import editor, vis_utils
+    from geodiffuser_amd.synthetic import make_edit
+    from geodiffuser_amd.warp_utils import warp_grid_edit
+    editor.DEVICE = torch.device(DEV)
+    image, depth, mask, T = make_edit(5, size=512, kind="rotate")
+    rng = np.random.default_rng(3)
+    edited = np.clip(image.astype(np.float64) * 0.8 + rng.normal(10, 25, image.shape), 0, 255).astype(np.uint8)
+    coords, _, _ = vis_utils.get_transform_coordinates(image, depth, mask, transform_in=T, focal_length=550, return_mesh=True, device=DEV,
+                                                       as_torch=True, preview=False)
+    coords = coords[None].detach()
+    m_edit = np.roll(mask, 37, axis=1).astype(np.float32)                                  # where the object lands ({0,1})
+    m_new = torch.from_numpy(m_edit)[None, None].tile(2, 1, 1, 1).to(DEV)
+    img_t = (torch.from_numpy(image).to(DEV)[None].permute(0, 3, 1, 2) / 255.0).float()
+    warped = warp_grid_edit(img_t, coords.float())[0].float().cpu().numpy()
+    want = O.edit_post_process(image, mask, edited, edit_type, image_warped=warped, mask_edit=m_edit)
+    if inputs_on == "device":
+        im_in, mk_in = torch.from_numpy(image).to(DEV), torch.from_numpy(mask).to(DEV)
+    else:
+        im_in, mk_in = image, torch.from_numpy(mask)
+    got = editor.post_process(im_in, mk_in, torch.from_numpy(edited).to(DEV), coords, m_new, edit_type)
+    assert got.dtype == np.float64 and np.array_equal(got, want)
+    on_dev = editor.post_process(im_in, mk_in, torch.from_numpy(edited).to(DEV), coords, m_new, edit_type, as_numpy=False)
+    assert on_dev.is_cuda and np.array_equal(on_dev.cpu().numpy(), want)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # N4  bilinear forward splatting (softsplat): HIP vs the torch restatement, forward and both gradients
 # ---------------------------------------------------------------------------------------------------------

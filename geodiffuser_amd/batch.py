@@ -742,12 +742,12 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
             raise ValueError(f"perform_geometric_edit_batch: the edits of a batch must share one image size (got {sorted(shapes)}); group them by size")
         prompts = [e.get("prompt", "") for e in edits]
         images = [np.asarray(e["image"]) for e in edits]
-        # the inversion's passes are only QUEUED when this returns; the geometry pre-passes and the controllers (host work with device
-        # round trips, independent of the inversion) run on a side stream while the GPU inverts (see editor.side_stream)
-        traj = ddim_inversion_batch(model, images, prompts, num_ddim_steps, guidance_scale, dev)
-        subs, coords, masks, dev_in = [], [], [], []
         cls = AttentionGeometryEdit if edit_type == "geometry_editor" else AttentionGeometryRemover
-        with E.side_stream():
+
+        def prepass():
+            # the geometry pre-passes and the controllers (host work with device round trips, independent of the inversion) run beside
+            # the inversion: on a worker thread and a side stream (editor.start_ahead)
+            subs, coords, masks, dev_in = [], [], [], []
             for e, image in zip(edits, images):
                 image_mask = torch.as_tensor(np.asarray(e["image_mask"])).float()
                 H = image.shape[0]
@@ -764,7 +764,13 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
                     c.default_loss_weights = lw
                 subs.append(c); coords.append(t_coords_depth[None].detach()); masks.append(image_mask)
                 dev_in.append((torch.from_numpy(np.ascontiguousarray(image)).to(dev), image_mask.to(dev)))      # for the post-process
-            batch = EditBatch(subs, coords)
+            return subs, coords, masks, dev_in, EditBatch(subs, coords)
+
+        ahead = E.start_ahead(prepass)
+        try:
+            traj = ddim_inversion_batch(model, images, prompts, num_ddim_steps, guidance_scale, dev)
+        finally:
+            subs, coords, masks, dev_in, batch = ahead.result()
         _tm("inversion + pre-pass + controllers")
         out, logs = text2image_ldm_stable_batch(
             model, prompts, batch, num_ddim_steps, guidance_scale, latent=traj[-1], ddim_latents=traj, masks_obj=[m[None, None] for m in masks],

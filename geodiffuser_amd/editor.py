@@ -374,6 +374,57 @@ def side_stream():
     main.wait_stream(side)
 
 
+PREPASS_THREAD = os.environ.get("GD_PREPASS_THREAD", "1") == "1"
+_WORKER = None
+
+
+class _Now:
+    def __init__(self, fn):
+        with side_stream():
+            self.v = fn()
+
+    def result(self):
+        return self.v
+
+
+class _Ahead:
+    """``fn()`` on the module's worker thread, on the side stream (see ``start_ahead``)."""
+
+    def __init__(self, fn, dev):
+        global _WORKER
+        from concurrent.futures import ThreadPoolExecutor
+        if _WORKER is None:
+            _WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gd-prepass")   # one long-lived thread: library handles stay warm
+        self.dev = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.side = _SIDE_STREAMS.get(dev)
+        if self.side is None:
+            self.side = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev)
+        self.side.wait_stream(torch.cuda.current_stream(dev))        # uploads the caller has already queued
+        self.fut = _WORKER.submit(self._run, fn)
+
+    def _run(self, fn):
+        torch.cuda.set_device(self.dev)                              # current device, grad mode and current stream are per thread
+        with torch.no_grad(), torch.cuda.stream(self.side):
+            return fn()
+
+    def result(self):
+        v = self.fut.result()                                        # re-raises what fn raised
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        return v
+
+
+def start_ahead(fn):
+    """Start ``fn()`` — host work with device round trips that does not depend on what the caller queues next — and return a handle;
+    ``handle.result()`` gives its value once the caller needs it.  On a GPU the body runs on a worker thread with the side stream
+    current, so it overlaps BOTH the device work the caller queues meanwhile and the caller's own host time (a graph launch holds the
+    host for milliseconds and releases the GIL); ``result()`` makes the caller's stream wait for the side stream.  The lifetime rule of
+    ``side_stream`` applies to the tensors ``fn`` makes.  GD_PREPASS_THREAD=0 (or a CPU device): ``fn`` runs here, now."""
+    dev = torch.device(DEVICE)
+    if dev.type != "cuda" or not PREPASS_THREAD:
+        return _Now(fn)
+    return _Ahead(fn, dev)
+
+
 def perform_geometric_edit(image, depth, image_mask, transform_in, prompt="", ldm_stable_model=None, tokenizer_model=None,
                            scheduler_in=None, cross_replace_steps={"default_": 0.95}, self_replace_steps=0.95, optimize_steps=0.6,
                            lr=0.03, latent_replace=0.6, optimize_embeddings=True, optimize_latents=True, obj_edit_step=1.0,
@@ -434,24 +485,29 @@ def _perform_geometric_edit(image, depth, image_mask, transform_in, prompt, ldm_
         UNET_NAME = unet_path or DIFFUSION_MODEL
     LDM_STABLE, TOKENIZER, SCHEDULER = ldm_stable, tokenizer, scheduler
 
-    null_inversion = NullInversion(ldm_stable, num_ddim_steps=NUM_DDIM_STEPS, uncond_text=UNCOND_TEXT, device=DEVICE,
-                                   progress_bar=PROGRESS_BAR, guidance_scale=GUIDANCE_SCALE)
-    (_, _), x_t, uncond_embeddings, ddim_latents, ddim_noise = null_inversion.invert(image, prompt, offsets=(0, 0, 0, 0), verbose=False,
-                                                                                      perform_inversion=perform_inversion, image_2=None)
     prompts = [prompt, prompt]
     cls = AttentionGeometryEdit if edit_type == "geometry_editor" else AttentionGeometryRemover
-    # The geometry pre-pass (editor.py:497-503) and the controller do not depend on the inversion, and the inversion's passes above are
-    # only QUEUED at this point: this host work (with its device round trips) runs on a side stream while the GPU inverts.
-    with side_stream():
+
+    def prepass():
+        # the geometry pre-pass (editor.py:497-503) and the controller do not depend on the inversion: they run beside it
         t_coords_depth, _, amodal = vis_utils.get_transform_coordinates(image, depth, image_mask.numpy(), transform_in=transform_in,
                                                                         focal_length=550 * H / 512.0 if H != 512 else 550,
                                                                         return_mesh=True, device=str(DEVICE), as_torch=True, preview=False)
-        transform_coordinates = t_coords_depth[None].detach()
         controller = cls(prompts, NUM_DDIM_STEPS, cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
                          equalizer=None, local_blend=None, controller=None, image_mask=image_mask.numpy(), empty_scale=0.0, use_all=False,
                          obj_edit_step=obj_edit_step, tokenizer=tokenizer, device=DEVICE, mode=MODE)
         controller.amodal_mask = torch_erode(amodal.float())                                              # :633
-        image_dev, mask_dev = torch.from_numpy(np.ascontiguousarray(image)).to(DEVICE), image_mask.to(DEVICE)   # for the post-process
+        # (image and mask on the device for the post-process)
+        return t_coords_depth[None].detach(), controller, torch.from_numpy(np.ascontiguousarray(image)).to(DEVICE), image_mask.to(DEVICE)
+
+    ahead = start_ahead(prepass)
+    null_inversion = NullInversion(ldm_stable, num_ddim_steps=NUM_DDIM_STEPS, uncond_text=UNCOND_TEXT, device=DEVICE,
+                                   progress_bar=PROGRESS_BAR, guidance_scale=GUIDANCE_SCALE)
+    try:
+        (_, _), x_t, uncond_embeddings, ddim_latents, ddim_noise = null_inversion.invert(image, prompt, offsets=(0, 0, 0, 0), verbose=False,
+                                                                                          perform_inversion=perform_inversion, image_2=None)
+    finally:
+        transform_coordinates, controller, image_dev, mask_dev = ahead.result()
     if return_attention_maps:
         controller.store_attention_maps = True
     if loss_weights_dict is not None:                                                                      # :636-638

@@ -380,7 +380,7 @@ _WORKER = None
 
 class _Now:
     def __init__(self, fn):
-        with side_stream():
+        with torch.no_grad(), side_stream():
             self.v = fn()
 
     def result(self):

@@ -1036,6 +1036,43 @@ def test_hist_match_full_size_counts_and_lut(ops):
         masked_histogram_matching(src.astype(np.float32), tmpl, m_t, m_s)
 
 
+def test_pre_pass_on_the_worker_thread_equals_the_in_line_pre_pass(ops):
+    """editor.start_ahead: the geometry pre-pass run on the worker thread + side stream while the caller's stream is busy gives the
+    bit-identical grid / amodal mask, usable on the caller's stream right after result(); grad mode and current stream of the caller are
+    untouched; an exception in the body surfaces from result()."""
+    import threading
+    from geodiffuser_amd import editor, vis_utils
+    from geodiffuser_amd.synthetic import make_edit
+    editor.DEVICE = torch.device(DEV)
+    image, depth, mask, T = make_edit(9, size=512, kind="mixed")
+
+    def prepass():
+        assert not torch.is_grad_enabled()
+        t, _, am = vis_utils.get_transform_coordinates(image, depth, mask, transform_in=T, focal_length=550, return_mesh=True, device=DEV,
+                                                       as_torch=True, preview=False)
+        return t, am, threading.current_thread().name
+
+    with torch.no_grad():
+        want_t, want_am, here = prepass()
+    main = torch.cuda.current_stream()
+    busy = torch.randn(4096, 4096, device=DEV)
+    for on in (True, False):
+        editor.PREPASS_THREAD = on
+        try:
+            h = editor.start_ahead(prepass)
+            for _ in range(20):
+                busy = busy @ busy * 1e-3                                  # the caller keeps its own stream busy meanwhile
+            t, am, where = h.result()
+            both = t.sum() + am.float().sum()                              # consumed on the caller's stream immediately
+            assert torch.cuda.current_stream() == main and torch.is_grad_enabled()
+            assert (where != here) == on
+            assert torch.equal(t, want_t) and torch.equal(am, want_am) and torch.isfinite(both)
+            with pytest.raises(ZeroDivisionError):
+                editor.start_ahead(lambda: 1 / 0).result()
+        finally:
+            editor.PREPASS_THREAD = True
+
+
 @pytest.mark.parametrize("edit_type", ["geometry_editor", "geometry_remover"])
 @pytest.mark.parametrize("inputs_on", ["host", "device"])
 def test_edit_post_process_on_device_matches_the_reference_block(ops, edit_type, inputs_on):

@@ -491,3 +491,16 @@ def test_batch_entry_point_refuses_what_it_does_not_implement():
         with pytest.raises(NotImplementedError):
             perform_geometric_edit_batch([], **kw)
     assert perform_geometric_edit_batch([], progress=None, use_optimizer=True, num_first_optim_steps=1) == []
+
+
+def test_start_ahead_runs_in_line_without_a_gpu_and_reports_errors(monkeypatch):
+    """editor.start_ahead: on a CPU device (or GD_PREPASS_THREAD=0) the body runs on the caller's thread at the call; its value comes
+    back through result(); an exception in the body is raised, not swallowed."""
+    import threading
+    from geodiffuser_amd import editor
+    monkeypatch.setattr(editor, "DEVICE", torch.device("cpu"))
+    seen = []
+    h = editor.start_ahead(lambda: seen.append(threading.current_thread().name) or 41 + 1)
+    assert seen == [threading.current_thread().name] and h.result() == 42
+    with pytest.raises(ZeroDivisionError):
+        editor.start_ahead(lambda: 1 / 0).result()

@@ -401,6 +401,9 @@ class _Ahead:
             self.side = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev)
         self.side.wait_stream(torch.cuda.current_stream(dev))        # uploads the caller has already queued
         self.fut = _WORKER.submit(self._run, fn)
+        from . import graphs
+        graphs.IN_FLIGHT.append(self.fut)                            # a graph capture waits for it (graphs.wait_in_flight)
+        self.fut.add_done_callback(lambda f: graphs.IN_FLIGHT.remove(f) if f in graphs.IN_FLIGHT else None)
 
     def _run(self, fn):
         torch.cuda.set_device(self.dev)                              # current device, grad mode and current stream are per thread

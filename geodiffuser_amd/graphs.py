@@ -25,6 +25,16 @@ OPT_PASS_ENABLED = os.environ.get("GD_OPT_GRAPH", "1") == "1"
 KV_CACHE = os.environ.get("GD_KV_CACHE", "1") == "1"     # captured no-grad passes: text-row K / V projections outside the graph, per context
 
 
+IN_FLIGHT = []       # futures of host work that runs on another thread beside the caller (editor.start_ahead)
+
+
+def wait_in_flight():
+    """Before every capture: a stream capture (global mode) forbids allocations and synchronisations on EVERY thread of the process, so
+    work running beside the caller has to finish first (its result or exception stays in its future for the caller to collect)."""
+    for f in list(IN_FLIGHT):
+        f.exception()
+
+
 class _Entry:
     __slots__ = ("seen", "graph", "x", "t", "ctx", "out", "kv", "kv_src", "kv_ver")
 
@@ -116,6 +126,7 @@ class GraphedUNet:
                 e.kv_src, e.kv_ver = _src_version(ctx_src)
             torch.cuda.synchronize()
             CAPTURES["unet"] += 1
+            wait_in_flight()
             g = torch.cuda.CUDAGraph()
             ops.zero_pool_reset()
             from . import attention_processors as _ap
@@ -237,6 +248,7 @@ class GraphedOptPass:
                 _OPT_GRAPHS.pop(next(iter(_OPT_GRAPHS)))["graph"].reset()
             st = {"lat": lat.detach().clone().requires_grad_(True), "ctx": ctx.detach().clone().requires_grad_(True),
                   "t": torch.tensor([int(t)], device=dev, dtype=torch.long)}
+            wait_in_flight()
             torch.cuda.synchronize()
             CAPTURES["opt"] += 1
             g = torch.cuda.CUDAGraph()

@@ -824,13 +824,39 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         active = self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1]
         blend = self.cur_step < int(self.num_steps * self.obj_edit_step)
         return (type(self).__name__, active, blend, getattr(self, "n_batch", None), self.coords_base, self.coords_edit,
-                self.use_cfg, self.store_attention_maps, bool(self.rows_identical))
+                self.use_cfg, self.store_attention_maps, bool(self.rows_identical), self.ref_stash_serial if self.use_ref_stash else None)
 
     def after_graph_replay(self):
         """A replayed pass ran no Python: advance the counters as its num_att_layers hooked calls would have."""
         self.cur_att_layer = 0
         self.cur_step += 1
         self.between_steps()
+
+    # REFERENCE ROWS OF THE CFG PASS FROM THE OPTIMISATION PASS (editor.REF_FROM_OPT).  At a step with an optimisation pass the reference
+    # sample goes through the UNet twice with the same latent, timestep and text rows (the update touches the edit row only, and the
+    # reference row's text gradient is zero: its tensors are detached in the hooked layers): once beside the edit row in the
+    # optimisation pass, once as `cond_ref` in the CFG pass, where only its per-layer q / k / v and attention output are used.  The
+    # optimisation pass leaves those four tensors per hooked layer (ref_stash: token-major [1, N | M, C] views of its own tensors, in
+    # call order; None for a layer that ran plain attention) and the CFG pass of the same step runs [uncond_edit, cond_edit] only.
+    # Inside hipGraphs the tensors are static addresses of the optimisation pass's graph: ref_stash_serial names that graph and is
+    # part of the CFG pass's graph key.
+    collect_ref = False          # set by the driver around an optimisation pass
+    use_ref_stash = False        # set by the driver around the CFG pass that takes its reference rows from ref_stash
+    ref_stash = None
+    ref_stash_serial = None
+    ref_stash_t = None
+    _ref_pos = 0
+
+    def _leave_ref(self, entry):
+        if self.collect_ref:
+            if self.cur_att_layer == 0 or self.ref_stash is None:
+                self.ref_stash = []
+            self.ref_stash.append(entry)
+
+    def _take_ref(self):
+        entry = self.ref_stash[self._ref_pos]
+        self._ref_pos += 1
+        return entry
 
     supports_token_major = True
     heads_tok = 0
@@ -854,18 +880,23 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         tied = t[b0 * f:b1 * f].detach() + (te - te.detach())
         return torch.cat([t[:e0 * f], tied, t[e1 * f:]], 0)
 
-    def _forward_tok(self, q, k, v, is_cross: bool, transform_coords, scale: float, heads: int):
+    def _forward_tok(self, q, k, v, is_cross: bool, transform_coords, scale: float, heads: int, ref=None):
         """No-grad CFG pass on token-major q/k/v [B, N, heads*64]; the caller (EditProcessor) routes passes that accumulate
         losses (use_cfg False) through the head-major _EditLayer instead.  Same launches as _EditLayer.forward with batch
         rows in place of head blocks; the edit attention, whose output only feeds the blend, is skipped when not blending."""
         (b0, b1), (e0, e1) = self.coords_base, self.coords_edit
-        cb = self.coords_base[-1]
+        cb = self.coords_base[-1] if ref is None else e0         # vanilla roles ahead of the edit row
         S = int(math.isqrt(q.shape[1]))
         c = self._tables(S, heads, q, transform_coords)
         remover = self._is_remover
         blend = self.cur_step < int(self.num_steps * self.obj_edit_step)
         out_full = torch.empty(cb + 1, q.shape[1], q.shape[2], dtype=q.dtype, device=q.device)
-        q_base, k_base, v_base = q[b0:b1], k[b0:b1], v[b0:b1]
+        if ref is None:
+            q_base, k_base, v_base, van_base = q[b0:b1], k[b0:b1], v[b0:b1], out_full[b0:b1]
+        else:                                                    # the reference row as the optimisation pass of this step left it
+            if not self.q_scaled_tok or ref[0].shape[1:] != q.shape[1:] or ref[0].dtype != q.dtype:
+                raise RuntimeError("ref_stash does not match this pass (query scaling / shape / dtype): disable GD_REF_FROM_OPT")
+            q_base, k_base, v_base, van_base = ref
         q_edit, k_edit, v_edit = q[e0:e1], k[e0:e1], v[e0:e1]
         segs = [(q[:cb], k[:cb], v[:cb], out_full[:cb], None)]
         replace_out = out_full[cb:]
@@ -902,10 +933,10 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         segs.append((q_edit, K, v_base, replace_out, None))
         ops.attn_fwd(segs, scale, heads=heads, q_scaled=self.q_scaled_tok)
         if edit_act is not None and FUSED_LAYER:                # rows outside the soft edit mask: the reference row's output — merged and
-            ops.blend_merge(out_full[b0:b1], edit_act, c["edit_pos"], replace_out, c["m_edit"], eo_out=None, out=out_full[cb:])   # blended in one pass
+            ops.blend_merge(van_base, edit_act, c["edit_pos"], replace_out, c["m_edit"], eo_out=None, out=out_full[cb:])   # blended in one pass
             return out_full
         if edit_act is not None:
-            ops.rows_merge(out_full[b0:b1], edit_act, c["edit_pos"], out=edit_out)
+            ops.rows_merge(van_base, edit_act, c["edit_pos"], out=edit_out)
         if edit_out is not None:
             ops.blend_tokens(edit_out, replace_out, c["m_edit"], out=out_full[cb:])
         elif ident_out is not None:
@@ -917,11 +948,12 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         active = is_cross or (self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1])
         heads = self.heads_tok
         if heads:
+            ref = self._take_ref() if self.use_ref_stash else None
             if not active:
                 return attention_tok(q, k, v, scale, heads, q_scaled=self.q_scaled_tok)
             if is_cross:
                 _ = self.cross_replace_alpha[self.cur_step]
-            return self._forward_tok(q, k, v, is_cross, transform_coords, float(scale), heads)
+            return self._forward_tok(q, k, v, is_cross, transform_coords, float(scale), heads, ref=ref)
         ho = self.heads_opt              # token-major q / k / v [B, N, heads*64] (EditProcessor, TOK_OPT)
         f = ho if ho else q.shape[0] // nb
         self._place_in_unet = place_in_unet
@@ -929,6 +961,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         if q_pre:                        # q carries scale*log2(e) (_project_qkv): s = ln2 * q'.k for everything that takes a scale
             scale = LN2
         if not active:
+            self._leave_ref(None)                                              # (plain attention in the CFG pass of this step too)
             if ho:
                 B, N, C = q.shape
                 hm = lambda t: t.view(B, t.shape[1], ho, C // ho).permute(0, 2, 1, 3).reshape(B * ho, t.shape[1], C // ho)
@@ -966,8 +999,13 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             if views and ok_loss:
                 running, log_acc = lo, acc
         self._tail_summed = False
-        out, loss, terms = _EditLayer.apply(q.contiguous(), k.contiguous(), v.contiguous(), self, is_cross, float(scale), c, q_pre, ho,
-                                            running, log_acc)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out, loss, terms = _EditLayer.apply(q, k, v, self, is_cross, float(scale), c, q_pre, ho, running, log_acc)
+        if self.collect_ref:
+            (b0, b1) = self.coords_base
+            ok = ho and q_pre and D == 64 and not self.rows_identical and q.dtype in (torch.float16, torch.bfloat16)
+            # (token-major 16-bit rows with pre-scaled queries: what _forward_tok takes; anything else ends the collection for this pass)
+            self._leave_ref((q[b0:b1].detach(), k[b0:b1].detach(), v[b0:b1].detach(), out[b0:b1].detach()) if ok else False)
         if not ho:
             out = out[..., :D]
         if lossy:

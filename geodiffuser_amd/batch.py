@@ -211,6 +211,17 @@ class EditBatch(AttentionControl):
         self.num_steps = self.subs[0].num_steps
         self.obj_edit_step = self.subs[0].obj_edit_step
         self.num_self_replace = self.subs[0].num_self_replace
+        # reference rows of the CFG pass from the optimisation pass of the same step (attention_processors.ref_stash, for B edits:
+        # token-major [B, N | M, C] views per hooked layer)
+        self.collect_ref = self.use_ref_stash = False
+        self.ref_stash = self.ref_stash_serial = self.ref_stash_t = None
+        self._ref_pos = 0
+
+    def _leave_ref(self, entry):
+        if self.collect_ref:
+            if self.cur_att_layer == 0 or self.ref_stash is None:
+                self.ref_stash = []
+            self.ref_stash.append(entry)
 
     # -- state that the driver / the processors set on "the controller" and every edit must see ---------------------------
     @property
@@ -252,6 +263,10 @@ class EditBatch(AttentionControl):
         if not heads:
             raise NotImplementedError("EditBatch needs the token-major layer forms (64-wide heads, 16-bit, GD_TOKEN_MAJOR / GD_TOK_OPT on)")
         active = is_cross or (self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1])
+        ref = None
+        if self.use_ref_stash and self.heads_tok:
+            ref = self.ref_stash[self._ref_pos]
+            self._ref_pos += 1
         if not active and self.heads_tok:                # (self-attention past its replace window: plain attention for the whole batch)
             for s in self.subs:
                 s.cur_att_layer += 1
@@ -260,12 +275,16 @@ class EditBatch(AttentionControl):
                 and not any(self.rows_identical):
             for s in self.subs:
                 self._sync(s)
-            out = self._forward_cfg(q, k, v, is_cross, float(scale), heads) if self.heads_tok else self._forward_opt(q, k, v, is_cross, scale, heads)
+            out = self._forward_cfg(q, k, v, is_cross, float(scale), heads, ref=ref) if self.heads_tok else self._forward_opt(q, k, v, is_cross, scale, heads)
             if out is not None:
                 for s in self.subs:
                     s.cur_att_layer += 1
                     s.heads_tok = s.heads_opt = 0
                 return out
+        if self.use_ref_stash:
+            raise RuntimeError("EditBatch: a CFG pass without its reference rows needs the merged layer forms (disable GD_REF_FROM_OPT)")
+        if not self.heads_tok:
+            self._leave_ref(False)                       # the per-edit route leaves nothing for the CFG pass: the collection is void
         outs = []
         for j, s in enumerate(self.subs):
             self._sync(s)
@@ -275,13 +294,15 @@ class EditBatch(AttentionControl):
             s.heads_tok = s.heads_opt = 0
         return torch.stack(outs, 1).reshape(outs[0].shape[0] * B, *outs[0].shape[1:])
 
-    def _forward_cfg(self, q, k, v, is_cross: bool, scale: float, heads: int):
+    def _forward_cfg(self, q, k, v, is_cross: bool, scale: float, heads: int, ref=None):
         """The no-grad CFG pass of all edits, token-major q / k / v [(cb + 1) B, N | M, heads*64] role-major (cb vanilla roles, then the edit
         rows): what _GeometryControllerBase._forward_tok does for one edit, with ONE attention launch for the batch — the vanilla rows of all
         edits as one segment, the replace attention of all edits as one segment (both read contiguous role slices), one warped / row-list
         segment (or one blend pair) per edit with that edit's tables."""
         B, subs = self.B, self.subs
         b0, e0, cb = self.coords_base[0], self.coords_edit[0], self.coords_base[-1]
+        if ref is not None:                               # rows [uncond_edit x B | cond_edit x B]: the reference rows come from ref
+            cb = e0
         N, C = q.shape[1], q.shape[2]
         S = int(math.isqrt(N))
         cs = [s._tables(S, heads, q, self.coords[j]) for j, s in enumerate(subs)]
@@ -290,7 +311,13 @@ class EditBatch(AttentionControl):
         qs = self.q_scaled_tok
         out_full = torch.empty((cb + 1) * B, N, C, dtype=q.dtype, device=q.device)
         van = (q[:cb * B], k[:cb * B], v[:cb * B], out_full[:cb * B], None)
-        q_base, k_base, v_base = q[b0 * B:(b0 + 1) * B], k[b0 * B:(b0 + 1) * B], v[b0 * B:(b0 + 1) * B]
+        if ref is None:
+            q_base, k_base, v_base = q[b0 * B:(b0 + 1) * B], k[b0 * B:(b0 + 1) * B], v[b0 * B:(b0 + 1) * B]
+            van_base = out_full[b0 * B:(b0 + 1) * B]
+        else:
+            if not qs or ref[0].shape != (B, N, C) or ref[0].dtype != q.dtype:
+                raise RuntimeError("ref_stash does not match this pass (query scaling / shape / dtype): disable GD_REF_FROM_OPT")
+            q_base, k_base, v_base, van_base = ref
         q_edit, k_edit, v_edit = q[e0 * B:(e0 + 1) * B], k[e0 * B:(e0 + 1) * B], v[e0 * B:(e0 + 1) * B]
         o_edit = out_full[cb * B:]
         r = lambda t, j: t[j:j + 1]
@@ -335,7 +362,7 @@ class EditBatch(AttentionControl):
         ops.attn_fwd(segs, scale, heads=heads, q_scaled=qs)
         for j, c in enumerate(cs):
             if acts is not None:          # rows outside the soft edit mask: the reference row's output — merged and blended in one pass
-                ops.blend_merge(r(out_full, b0 * B + j), acts[j], c["edit_pos"], r(replace_out, j), c["m_edit"], eo_out=None, out=r(o_edit, j))
+                ops.blend_merge(r(van_base, j), acts[j], c["edit_pos"], r(replace_out, j), c["m_edit"], eo_out=None, out=r(o_edit, j))
             elif edit_outs is not None:
                 ops.blend_tokens(r(edit_outs, j), r(replace_out, j), c["m_edit"], out=r(o_edit, j))
             elif ident_out is not None:
@@ -383,8 +410,11 @@ class EditBatch(AttentionControl):
                 runs.append(lo)
                 log_accs[j] = acc
             running = torch.cat(runs)
-        out, new_running = _EditLayerBatch.apply(q.contiguous(), k.contiguous(), v.contiguous(), self, cs, is_cross, float(scale), q_pre, heads,
-                                                 running, log_accs)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out, new_running = _EditLayerBatch.apply(q, k, v, self, cs, is_cross, float(scale), q_pre, heads, running, log_accs)
+        if self.collect_ref:                              # the reference rows of this layer, for the CFG pass of the same step
+            ok = q_pre and q.dtype in (torch.float16, torch.bfloat16)
+            self._leave_ref((q[:B].detach(), k[:B].detach(), v[:B].detach(), out[:B].detach()) if ok else False)
         if lossy:
             for j, s in enumerate(subs):
                 s.loss = new_running[j]
@@ -430,7 +460,7 @@ class EditBatch(AttentionControl):
         for s in self.subs:
             s.cur_step = self.cur_step
             self._sync(s)
-        return ("EditBatch", self.B) + self.subs[0].graph_key()[:-1] + (self.rows_identical,)
+        return ("EditBatch", self.B) + self.subs[0].graph_key()[:-2] + (self.rows_identical, self.ref_stash_serial if self.use_ref_stash else None)
 
     def table_signature(self):
         self.harmonise()
@@ -574,8 +604,24 @@ def text2image_ldm_stable_batch(model, prompts: Sequence[str], batch: EditBatch,
         m = reshape_attention_mask(m[None, None].to(dev).float().reshape(1, 1, *m.shape[-2:]), in_mat_shape=latents[-1:].shape)
         upd_masks.append(m[-1, 0].reshape(-1).contiguous())
 
+    ref_from_opt = E.REF_FROM_OPT and E.AP_SCALED_Q_BOTH() and MERGED
+
     def cfg_pass(lat, ctx_t, tt):
         assert not torch.is_grad_enabled()
+        if ref_from_opt and batch.ref_stash_serial is not None and batch.ref_stash_t == int(tt):
+            # a step with an optimisation pass: every edit's reference row is already there, layer by layer (ref_stash)
+            E.REF_FROM_OPT_PASSES += 1
+            set_attn_processor_for_edit(model, coords_base=(1, 1), coords_edit=(1, 2), use_cfg=True, n_batch=2)
+            batch.use_ref_stash, batch._ref_pos = True, 0
+            try:
+                lat_in = torch.cat([lat[B:], lat[B:]])                                 # [uncond_edit | cond_edit] x B
+                ctx2 = torch.cat([ctx_uncond.to(ctx_t.dtype), ctx_t[B:]])
+                eps = _unet_nograd(model, batch, lat_in, tt, ctx2, "cfg2s", None, ctx_src=ctx_t)
+            finally:
+                batch.use_ref_stash, batch.ref_stash_t = False, None
+            edit_out = _sched_step(model.scheduler, eps[:B], tt, lat[B:], eps[B:], guidance_scale)
+            warp_utils.SPLATTER.clear_cache()
+            return torch.cat([lat[:B].to(edit_out.dtype), edit_out])
         set_attn_processor_for_edit(model, coords_base=(1, 2), coords_edit=(2, 3), use_cfg=True, n_batch=3)
         lat_in = torch.cat([lat[B:], lat[:B], lat[B:]])                            # [uncond_edit | cond_ref | cond_edit] x B (U/diffusion.py:43 less uncond_ref)
         ctx3 = torch.cat([ctx_uncond.to(ctx_t.dtype), ctx_t])
@@ -592,6 +638,7 @@ def text2image_ldm_stable_batch(model, prompts: Sequence[str], batch: EditBatch,
         if (i < optimize_steps * T) and (i % skip_optim_steps == 0):                                    # :181
             l_eff = lr * (50 - i) * skip_optim_steps * (50 / (num_ddim_steps + 1e-8))                  # :207
             set_attn_processor_for_edit(model, coords_base=(0, 1), coords_edit=(1, 2), use_cfg=False)   # :213
+            batch.collect_ref = ref_from_opt
             n0 = [ops.sumsq(latents[B + j].detach().float().contiguous()) for j in range(B)]            # orig_norm^2 (:219)
             for j, s in enumerate(subs):
                 s.rows_identical = bool(E.TIE_IDENTICAL_ROWS and i == 0 and remover and torch.equal(latents[j], latents[B + j])

@@ -101,10 +101,19 @@ def _sched_step(scheduler, eps_uncond, t, sample, eps_cond, guidance_scale):
 
 
 def diffusion_step(model, controller, latents, context, t, guidance_scale, low_resource=False, transform_coords=None,
-                   use_cfg=True, return_noise=False, skip_uncond_ref=False, skip_scheduler=False):
+                   use_cfg=True, return_noise=False, skip_uncond_ref=False, skip_scheduler=False, ref_from_stash=False):
     """diffusion.py:39-59: UNet -> (CFG combine) -> scheduler.step(eta=0) -> controller.step_callback.
     The CFG combine is fused into the DDIM kernel (gd_ddim_step) unless the caller asks for the combined noise."""
-    if use_cfg and skip_uncond_ref:
+    if use_cfg and skip_uncond_ref and ref_from_stash:
+        # the `cond_ref` row's per-layer q / k / v and attention outputs were left by the optimisation pass of this step (same latent,
+        # timestep and text row: attention_processors.ref_stash).  Batch [uncond_edit, cond_edit].
+        latents_input = torch.cat([latents[1:2], latents[1:2]])
+        ctx2 = torch.cat([context[1:2], context[3:4]])
+        noise_pred = _unet_nograd(model, controller, latents_input, t, ctx2, "cfg2s", transform_coords, ctx_src=context)
+        edit_out = _sched_step(model.scheduler, noise_pred[0:1], t, latents[1:2], noise_pred[1:2], guidance_scale)
+        latents_out = torch.cat([latents[0:1].to(edit_out.dtype), edit_out])
+        noise_pred_out = None
+    elif use_cfg and skip_uncond_ref:
         # The reference latent is overwritten by the inversion trajectory after every step (editor.py:375-377), so the
         # reference rows' noise prediction is never used; `cond_ref` is still needed for its per-layer q/k/v, `uncond_ref`
         # is not (vanilla attention, per-sample norms => no influence on other rows).  Batch [uncond_edit, cond_ref, cond_edit].

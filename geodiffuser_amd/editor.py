@@ -50,6 +50,16 @@ TIE_IDENTICAL_ROWS = os.environ.get("GD_TIE_ROWS", "1") == "1"   # first optimis
 HONOUR_SPLAT_ARGS = os.environ.get("GD_HONOUR_SPLAT_ARGS", "0") == "1"   # see _perform_geometric_edit: the reference ignores them (F3)
 SPLATTER = warp_utils.RasterizePointsXYsBlending()      # editor.py:50 — the reference's dead object, kept for attribute compatibility
 SKIP_UNCOND_REF = True      # drop the CFG pass's unused `uncond_ref` batch row (identical edit output)
+# at a step with an optimisation pass the CFG pass takes the reference row's layer tensors from that pass instead of running the
+# reference sample through the UNet a second time with the same inputs (attention_processors.ref_stash; captured passes only)
+REF_FROM_OPT = os.environ.get("GD_REF_FROM_OPT", "1") == "1"
+REF_FROM_OPT_PASSES = 0     # CFG passes that ran without their reference row so far (both drivers count here)
+
+
+def AP_SCALED_Q_BOTH() -> bool:
+    """Both passes hand the hooked layers queries that carry scale * log2(e) from the projection's epilogue (the same 16-bit values)."""
+    from . import attention_processors as AP
+    return bool(AP.SCALED_Q and AP.SCALED_Q_OPT and AP.TOK_OPT and AP.TOKEN_MAJOR and AP.FUSED_WARP)
 
 
 def clear_controller_loss(controller):
@@ -196,9 +206,22 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
     # parity-preserving saving: with an inversion trajectory the CFG pass runs 3 batch rows, not 4
     skip_ref = ddim_latents is not None and batch_size == 2 and SKIP_UNCOND_REF
 
+    ref_from_opt = (REF_FROM_OPT and skip_ref and is_geo and AP_SCALED_Q_BOTH() and getattr(controller, "supports_token_major", False))
+
     def cfg_pass(lat, ctx, tt):
         # the reference decorates this driver with @torch.no_grad() (editor.py:64); the graph / token-major fast paths depend on it
         assert not torch.is_grad_enabled(), "text2image_ldm_stable: the CFG pass must run without autograd"
+        if ref_from_opt and controller.ref_stash_serial is not None and controller.ref_stash_t == int(tt):
+            # a step with an optimisation pass: the reference row's layer tensors are already there (attention_processors.ref_stash)
+            global REF_FROM_OPT_PASSES
+            REF_FROM_OPT_PASSES += 1
+            set_attn_processor_for_edit(model, coords_base=(1, 1), coords_edit=(1, 2), use_cfg=True, n_batch=2)
+            controller.use_ref_stash, controller._ref_pos = True, 0
+            try:
+                return diffusion_step(model, controller, lat, ctx, tt, guidance_scale, transform_coords=transform_coordinates,
+                                      skip_uncond_ref=True, ref_from_stash=True)
+            finally:
+                controller.use_ref_stash, controller.ref_stash_t = False, None
         if skip_ref:
             set_attn_processor_for_edit(model, coords_base=(1, 2), coords_edit=(2, 3), use_cfg=True, n_batch=3)
             return diffusion_step(model, controller, lat, ctx, tt, guidance_scale, transform_coords=transform_coordinates,
@@ -225,6 +248,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
         if (i < optimize_steps * T) and (i % skip_optim_steps == 0) and (i >= fast_start_steps * T):      # :181
             l_eff = lr * (50 - i) * skip_optim_steps * (50 / (NUM_DDIM_STEPS + 1e-8))                      # :207
             set_attn_processor_for_edit(model, coords_base=(0, 1), coords_edit=(1, 2), use_cfg=False)    # :213
+            controller.collect_ref = ref_from_opt
             n0 = ops.sumsq(latents[-1].detach().float().contiguous())                                      # orig_norm^2 (:219)
             ctx_cur = context if context_save is None else context_save
             lat_cur = latents

@@ -12,6 +12,7 @@ controller, which need one host sync), captured the second time, replayed afterw
 """
 from __future__ import annotations
 
+import itertools
 import os
 import weakref
 from typing import Callable, Dict, Hashable, Optional, Tuple
@@ -185,6 +186,20 @@ def _import_loss_state(controller, state):
     controller.loss_log_dict = {k: (dict(v) if isinstance(v, dict) else v) for k, v in state[1].items()}
 
 
+_SERIAL = itertools.count(1)
+
+
+def _hand_over_ref(controller, st, t):
+    """After a captured / replayed optimisation pass: the controller of the CURRENT edit gets the pass's reference-row tensors (static
+    addresses of this graph, named by its serial number — never reused, unlike id())."""
+    if getattr(controller, "collect_ref", False):
+        stash = st.get("ref_stash")
+        ok = stash is not None and len(stash) > 0 and all(e is not False for e in stash)
+        controller.ref_stash = stash if ok else None
+        controller.ref_stash_serial = st["serial"] if ok else None
+        controller.ref_stash_t = int(t) if ok else None
+
+
 class GraphedOptPass:
     """The optimisation pass — UNet forward with the geometry controller's losses, then autograd back to the latent and the
     text embedding — as one hipGraph, reused across edits.
@@ -216,12 +231,13 @@ class GraphedOptPass:
 
     def _key(self, controller, lat, ctx):
         return (id(self.model.unet), controller.graph_key(), controller.table_signature(), tuple(lat.shape), tuple(ctx.shape),
-                self.model.unet.dtype)
+                self.model.unet.dtype, bool(getattr(controller, "collect_ref", False)))   # (a pass captured without the collection keeps nothing)
 
     def grads(self, controller, latents: torch.Tensor, context: torch.Tensor, t):
         lat = latents.detach().float().requires_grad_(True)                    # editor.py:218
         ctx = context.detach().float().requires_grad_(True)                    # editor.py:221-224
         usable = (ENABLED and OPT_PASS_ENABLED and lat.is_cuda and hasattr(controller, "graph_key") and getattr(controller, "persistent_tables", False))
+        controller.ref_stash_serial = controller.ref_stash_t = None           # (an eager pass leaves tensors no captured CFG pass may read)
         if not usable:
             return self._eager(controller, lat, ctx, t) + (lat, ctx)
         uid = (id(self.model.unet), tuple(lat.shape))                          # the hooked layers' resolutions follow the latent size
@@ -258,8 +274,11 @@ class GraphedOptPass:
             ops.zero_pool_reset()
             st["state"] = _export_loss_state(controller)
             st["graph"] = g
+            # the reference rows this pass leaves for the CFG pass of the same step (controller.collect_ref): tensors of THIS graph
+            st["ref_stash"], st["serial"] = getattr(controller, "ref_stash", None), next(_SERIAL)
             _OPT_GRAPHS[key] = st
             g.replay()                                                         # the capture itself executed nothing
+            _hand_over_ref(controller, st, t)
             return st["g_lat"], st["g_ctx"], st["lat"], st["ctx"]              # Python side effects ran during capture
         with torch.no_grad():
             st["lat"].copy_(lat)
@@ -268,6 +287,7 @@ class GraphedOptPass:
         st["graph"].replay()
         _import_loss_state(controller, st["state"])
         controller.after_graph_replay()
+        _hand_over_ref(controller, st, t)
         return st["g_lat"], st["g_ctx"], st["lat"], st["ctx"]
 
 

@@ -411,6 +411,49 @@ def test_token_major_cfg_pass_equals_head_major(kind, cross, step):
         assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("kind", ["edit", "remover"])
+@pytest.mark.parametrize("cross", [False, True])
+@pytest.mark.parametrize("S,step", [(32, 3), (64, 3), (32, 45)])
+def test_cfg_layer_with_the_reference_row_handed_in_equals_the_three_row_layer(kind, cross, S, step):
+    """editor.REF_FROM_OPT at layer level: a CFG layer call on rows [uncond_edit, cond_edit] whose reference row (q, k, v and its attention
+    output) is handed in — what the optimisation pass of the step leaves in ref_stash — gives the rows the 3-row call [uncond_edit,
+    cond_ref, cond_edit] gives for them: the same kernels on the same values (bit-identical wherever the launch partitions the keys the
+    same way; the key-range split of a launch depends on its row count, so a few ulps are allowed)."""
+    mask = cases.ellipse_mask()
+    coords = torch.from_numpy(cases.make_coords("translate", mask))
+    H = 5
+    N, M = S * S, (77 if cross else S * S)
+    torch.manual_seed(S + step)
+    q = (torch.randn(3, N, H * 64, device=DEV) * (1.2 * 0.125 * 1.4427)).half()        # queries as the projections hand them over: scale * log2(e) folded in
+    k = (torch.randn(3, M, H * 64, device=DEV) * 1.2).half()
+    v = torch.randn(3, M, H * 64, device=DEV).half()
+
+    def ctrl():
+        c = _make_hip_controller(dict(kind=kind, coords="translate", cur_step=step, quant=True, cfg=True), mask)
+        c.num_att_layers, c.cur_step, c.use_cfg = 32, step, True
+        c.heads_tok, c.q_scaled_tok = H, True
+        return c
+
+    with torch.no_grad():
+        c3 = ctrl()
+        c3.coords_base, c3.coords_edit, c3.n_batch = (1, 2), (2, 3), 3
+        o3 = c3(q, k, v, is_cross=cross, place_in_unet="up", transform_coords=coords, scale=0.125)
+        c2 = ctrl()
+        c2.coords_base, c2.coords_edit, c2.n_batch = (1, 1), (1, 2), 2
+        c2.ref_stash, c2.use_ref_stash, c2._ref_pos = [(q[1:2], k[1:2], v[1:2], o3[1:2].clone())], True, 0
+        rows = [0, 2]
+        o2 = c2(q[rows].contiguous(), k[rows].contiguous(), v[rows].contiguous(), is_cross=cross, place_in_unet="up", transform_coords=coords, scale=0.125)
+    assert o2.shape == (2, N, H * 64) and c2._ref_pos == 1
+    d = (o2.float() - o3[rows].float()).abs().max().item()
+    assert d <= 2e-3 * o3.float().abs().max().item(), d
+    assert c2.graph_key() != c3.graph_key()
+    c2.q_scaled_tok = False                                # a pass whose queries are scaled differently must not take the handed-in row
+    c2._ref_pos = 0
+    if step < 45 or cross:                                  # (layers inside the replace window: the others run plain attention and ignore it)
+        with pytest.raises(RuntimeError), torch.no_grad():
+            c2(q[rows].contiguous(), k[rows].contiguous(), v[rows].contiguous(), is_cross=cross, place_in_unet="up", transform_coords=coords, scale=0.125)
+
+
 def test_store_attention_maps_slow_path():
     """N4: with store_attention_maps the HIP controller keeps the edit row's probability maps of the N <= 16^2 layers exactly where
     the reference keeps them (oracle pinned by G17), at head dim 64."""

@@ -468,7 +468,11 @@ def test_edit_batch_routes_role_major_rows_and_keeps_counters_in_step(monkeypatc
     assert (batch.cur_att_layer, batch.cur_step) == (0, 1) and all((s.cur_att_layer, s.cur_step) == (0, 1) for s in subs)
     batch.undo_step()
     assert batch.cur_step == 0 and all(s.cur_step == 0 for s in subs)
-    assert batch.graph_key()[:2] == ("EditBatch", 3) and batch.graph_key()[-1] == (False, False, False)
+    # (last entry: the serial number of the optimisation-pass graph whose reference rows a "cfg2s" pass reads; None otherwise)
+    assert batch.graph_key()[:2] == ("EditBatch", 3) and batch.graph_key()[-2:] == ((False, False, False), None)
+    batch.use_ref_stash, batch.ref_stash_serial = True, 7
+    assert batch.graph_key()[-1] == 7
+    batch.use_ref_stash = False
     assert batch.table_signature() == tuple(s.table_signature() for s in subs)
     subs[1].loss_log_dict["self"]["sim"] = 7.0
     st = batch.export_loss_state()

@@ -4,8 +4,8 @@ TAG=${1:-r02}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 export GD_BENCH_MARK=1
-# the tracer stalls graph replays for tens of ms when a second host thread launches work (not seen untraced: bench.py A/B in
-# profiles/README.md), so the traced run keeps the pre-pass on the caller's thread (side stream only)
+# one traced run with two launching host threads died inside the tracer at exit (heap corruption, then a hung signal handler), so the
+# traced run keeps the pre-pass on the caller's thread (side stream only); profiles/README.md has the bench A/B of the thread
 export GD_PREPASS_THREAD=${GD_PREPASS_THREAD:-0}
 rocprofv3 --kernel-trace --stats -d $OUT -o bench --output-format csv -- python3 $ROOT/bench.py --steps ${STEPS:-2} --warmup ${WARMUP:-3} --no-cpu-baseline ${BENCH_ARGS} > $OUT/bench.json 2> $OUT/bench.err
 cd $ROOT

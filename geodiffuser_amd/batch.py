@@ -604,7 +604,7 @@ def text2image_ldm_stable_batch(model, prompts: Sequence[str], batch: EditBatch,
         m = reshape_attention_mask(m[None, None].to(dev).float().reshape(1, 1, *m.shape[-2:]), in_mat_shape=latents[-1:].shape)
         upd_masks.append(m[-1, 0].reshape(-1).contiguous())
 
-    ref_from_opt = E.REF_FROM_OPT and E.AP_SCALED_Q_BOTH() and MERGED
+    ref_from_opt = E.REF_FROM_OPT and E.ref_from_opt_supported() and MERGED
 
     def cfg_pass(lat, ctx_t, tt):
         assert not torch.is_grad_enabled()

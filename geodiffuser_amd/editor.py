@@ -56,7 +56,7 @@ REF_FROM_OPT = os.environ.get("GD_REF_FROM_OPT", "1") == "1"
 REF_FROM_OPT_PASSES = 0     # CFG passes that ran without their reference row so far (both drivers count here)
 
 
-def AP_SCALED_Q_BOTH() -> bool:
+def ref_from_opt_supported() -> bool:
     """Both passes hand the hooked layers queries that carry scale * log2(e) from the projection's epilogue (the same 16-bit values)."""
     from . import attention_processors as AP
     return bool(AP.SCALED_Q and AP.SCALED_Q_OPT and AP.TOK_OPT and AP.TOKEN_MAJOR and AP.FUSED_WARP)
@@ -206,7 +206,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
     # parity-preserving saving: with an inversion trajectory the CFG pass runs 3 batch rows, not 4
     skip_ref = ddim_latents is not None and batch_size == 2 and SKIP_UNCOND_REF
 
-    ref_from_opt = (REF_FROM_OPT and skip_ref and is_geo and AP_SCALED_Q_BOTH() and getattr(controller, "supports_token_major", False))
+    ref_from_opt = (REF_FROM_OPT and skip_ref and is_geo and ref_from_opt_supported() and getattr(controller, "supports_token_major", False))
 
     def cfg_pass(lat, ctx, tt):
         # the reference decorates this driver with @torch.no_grad() (editor.py:64); the graph / token-major fast paths depend on it

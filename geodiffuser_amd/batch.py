@@ -759,6 +759,19 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
         raise NotImplementedError(edit_type)
     if len(edits) == 0:
         return []
+    if len(edits) > MAX_EDITS:
+        # a launch carries one row-list / pair segment per edit (GD_ATTN_MAX_ROWLIST_SEGS): longer lists run MAX_EDITS at a time
+        kw = dict(ldm_stable_model=ldm_stable_model, tokenizer_model=tokenizer_model, scheduler_in=scheduler_in, cross_replace_steps=cross_replace_steps,
+                  self_replace_steps=self_replace_steps, optimize_steps=optimize_steps, lr=lr, latent_replace=latent_replace,
+                  optimize_embeddings=optimize_embeddings, optimize_latents=optimize_latents, obj_edit_step=obj_edit_step,
+                  perform_inversion=perform_inversion, guidance_scale=guidance_scale, skip_optim_steps=skip_optim_steps, num_ddim_steps=num_ddim_steps,
+                  splatting_radius=splatting_radius, edit_type=edit_type, loss_weights_dict=loss_weights_dict, return_loss_log_dict=return_loss_log_dict,
+                  splatting_tau=splatting_tau, splatting_points_per_pixel=splatting_points_per_pixel,
+                  use_adaptive_optimization=use_adaptive_optimization, removal_loss_value_in=removal_loss_value_in, return_latents=return_latents, **ignored)
+        out = []
+        for i in range(0, len(edits), MAX_EDITS):
+            out += perform_geometric_edit_batch(edits[i:i + MAX_EDITS], **kw)
+        return out
     prev_grad = torch.is_grad_enabled()
     torch.set_grad_enabled(False)
     import time

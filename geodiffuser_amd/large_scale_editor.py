@@ -250,8 +250,16 @@ def run_exp_on_folders_batched(exp_folders, exp_type, ldm_stable, tokenizer, sch
         dicts.append(d)
         edits.append(dict(image=d["input_image_png"], image_mask=(d["input_mask_png"] / 255.0)[..., 0], depth=d["depth_npy"],
                           transform_in=torch.tensor(d["transform_npy"]).float(), prompt=""))
-    res = perform_geometric_edit_batch(edits, ldm_stable_model=ldm_stable, tokenizer_model=tokenizer, scheduler_in=scheduler, edit_type=exp_type,
-                                       return_loss_log_dict=True, **kw)
+    # a batch shares one image size: folders of other sizes in this group run as batches of their own (a dataset is normally uniform)
+    by_size = {}
+    for j, e in enumerate(edits):
+        by_size.setdefault(tuple(np.asarray(e["image"]).shape), []).append(j)
+    res = [None] * len(edits)
+    for idx in by_size.values():
+        part = perform_geometric_edit_batch([edits[j] for j in idx], ldm_stable_model=ldm_stable, tokenizer_model=tokenizer, scheduler_in=scheduler,
+                                            edit_type=exp_type, return_loss_log_dict=True, **kw)
+        for j, r in zip(idx, part):
+            res[j] = r
     for d, (images, loss_dict) in zip(dicts, res):
         (io.save if io is not None else save_results)(d, images[-1], loss_dict, exp_type, step_store=None)
     return [r[0] for r in res]

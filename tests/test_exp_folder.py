@@ -296,3 +296,31 @@ def test_folder_io_writes_behind_the_same_bytes_and_raises_worker_errors(tmp_pat
     shutil.copytree(ROOT, data)
     with pytest.raises(OSError, match="disk full"):
         L.main(["--root", str(data), "--io-threads", "2"])
+
+
+def test_batched_folder_group_of_mixed_image_sizes_runs_one_batch_per_size(tmp_path, monkeypatch):
+    """A batch shares one image size (the UNet pass is one tensor): a group with folders of another size runs them as a batch of their own,
+    results and files in folder order."""
+    import geodiffuser_amd.batch as GB
+    from geodiffuser_amd import large_scale_editor as L
+    seen = []
+
+    def fake_batch(edits, edit_type="geometry_editor", **kw):
+        sizes = {np.asarray(e["image"]).shape for e in edits}
+        assert len(sizes) == 1
+        seen.append((sizes.pop()[0], len(edits)))
+        return [([e["image"], np.clip(e["image"].astype(np.float64) + 1.0, 0, 255)], {0: {"self": {"sim": 1.0}, "cross": {"sim": 2.0}, "num_layers": 16}}) for e in edits]
+
+    monkeypatch.setattr(GB, "perform_geometric_edit_batch", fake_batch)
+    dicts = []
+    for j, size in enumerate((64, 32, 64)):
+        d = tmp_path / str(j)
+        d.mkdir()
+        img = np.full((size, size, 3), 10 * (j + 1), dtype=np.uint8)
+        dicts.append({"input_image_png": img, "input_mask_png": np.zeros((size, size, 3), dtype=np.uint8), "depth_npy": np.ones((size, size), np.float32),
+                      "transform_npy": np.eye(4, dtype=np.float32), "image_shape_npy": np.array([size, size]), "path_name": str(d) + "/"})
+    out = L.run_exp_on_folders_batched([str(tmp_path / str(j)) for j in range(3)], "geometry_editor", None, None, None, exp_dicts=dicts)
+    assert sorted(seen) == [(32, 1), (64, 2)]
+    assert [o[0].shape[0] for o in out] == [64, 32, 64] and [int(o[0][0, 0, 0]) for o in out] == [10, 20, 30]
+    for j in range(3):
+        assert (tmp_path / str(j) / "result_ls.png").exists() and (tmp_path / str(j) / "loss.pkl").exists()

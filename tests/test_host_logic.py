@@ -508,3 +508,20 @@ def test_start_ahead_runs_in_line_without_a_gpu_and_reports_errors(monkeypatch):
     assert seen == [threading.current_thread().name] and h.result() == 42
     with pytest.raises(ZeroDivisionError):
         editor.start_ahead(lambda: 1 / 0).result()
+
+
+def test_batch_entry_point_runs_long_lists_in_chunks(monkeypatch):
+    """More edits than one launch has per-edit segments (batch.MAX_EDITS): the list runs MAX_EDITS at a time, results in list order."""
+    import geodiffuser_amd.batch as GB
+    orig, calls = GB.perform_geometric_edit_batch, []
+
+    def spy(edits, **kw):
+        calls.append((len(edits), kw.get("edit_type"), kw.get("guidance_scale")))
+        if len(edits) > GB.MAX_EDITS:
+            return orig(edits, **kw)
+        return [("result", e["id"]) for e in edits]
+
+    monkeypatch.setattr(GB, "perform_geometric_edit_batch", spy)
+    res = spy([{"id": i} for i in range(19)], edit_type="geometry_remover", guidance_scale=5.0)
+    assert [c[0] for c in calls] == [19, 8, 8, 3] and all(c[1:] == ("geometry_remover", 5.0) for c in calls)
+    assert res == [("result", i) for i in range(19)]

@@ -450,7 +450,7 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
         assert e_fin < 2.0 * emu_final + 1e-3
 
 
-@pytest.mark.parametrize("kind", ["geometry_remover", "cfg1_t50", "cfg1_full_t50"])
+@pytest.mark.parametrize("kind", ["geometry_remover", "cfg1_t50", "rem768_t75", "cfg1_full_t50"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 def test_loop_inside_a_batch_matches_reference_driver(kind, dtype):
     """The in-process multi-edit batch (geodiffuser_amd/batch.py) held to the REFERENCE's driver: the fixture's edit runs as edit 0 of a

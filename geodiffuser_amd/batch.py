@@ -41,7 +41,48 @@ from .warp_utils import warp_grid_edit
 
 
 MERGED = os.environ.get("GD_BATCH_MERGED", "1") == "1"     # 0: every edit's rows through its own controller (gather / scatter copies)
-MAX_EDITS = 8                                              # gd_attn_fwd: one row-list / pair segment per edit
+GROUP = 8                                                  # gd_attn_fwd / gd_attn_fwd_pair: one row-list / pair segment per edit, 8 per launch
+MAX_EDITS = 16                                             # more than GROUP edits: the UNet passes run on all, a hooked layer launches per group
+
+
+def _rows(seg, a, b):
+    """Rows [a, b) of the q / k / v / out / lse tensors of an attention segment tuple (whatever follows — warp tables, row list — is kept)."""
+    return tuple(t[a:b] if t is not None else None for t in seg[:5]) + tuple(seg[5:])
+
+
+def _groups(B):
+    return [(j0, min(j0 + GROUP, B)) for j0 in range(0, B, GROUP)]
+
+
+def _attn_fwd_grouped(plain, per_edit, tails, unit, B, scale, **kw):
+    """ops.attn_fwd over plain + per_edit + tails, at most GROUP edits per launch.  ``plain``: segments whose rows are independent of the
+    edits' order (vanilla rows: any contiguous share of them goes with any launch); ``per_edit``: one segment per edit; ``tails``: segments
+    with ``unit`` rows per edit, in edit order (the replace attention: token-major unit 1, head-major unit f).  B <= GROUP: ONE launch."""
+    gs = _groups(B)
+    for g, (j0, j1) in enumerate(gs):
+        segs = []
+        for seg in plain:
+            R = seg[0].shape[0]
+            a, b = g * R // len(gs), (g + 1) * R // len(gs)
+            if b > a:
+                segs.append(_rows(seg, a, b) if len(gs) > 1 else seg)
+        segs += per_edit[j0:j1]
+        segs += [_rows(seg, j0 * unit, j1 * unit) if len(gs) > 1 else seg for seg in tails]
+        ops.attn_fwd(segs, scale, **kw)
+
+
+def _attn_fwd_pair_grouped(plain, a_sides, b_sides, ms, scale, **kw):
+    """ops.attn_fwd_pair with one blend pair per edit, at most GROUP pairs per launch (the plain segments' rows shared out as above)."""
+    B = len(a_sides)
+    gs = _groups(B)
+    for g, (j0, j1) in enumerate(gs):
+        segs = []
+        for seg in plain:
+            R = seg[0].shape[0]
+            a, b = g * R // len(gs), (g + 1) * R // len(gs)
+            if b > a:
+                segs.append(_rows(seg, a, b) if len(gs) > 1 else seg)
+        ops.attn_fwd_pair(segs + a_sides[j0:j1], b_sides[j0:j1], ms[j0:j1], scale, **kw)
 
 
 class _EditLayerBatch(torch.autograd.Function):
@@ -72,22 +113,23 @@ class _EditLayerBatch(torch.autograd.Function):
         lse_van = torch.empty(Bf, N, dtype=torch.float32, device=dev) if want_losses else None
         replace_out = torch.empty(Bf, N, D, dtype=dt, device=dev)
         lse_e = torch.empty(Bf, N, dtype=torch.float32, device=dev)
-        segs = [(q_base, k_base, v_base, van, lse_van)]
+        plain = [(q_base, k_base, v_base, van, lse_van)]
+        per_edit = []
         acts = None
         if not remover:
             edit_out = torch.empty(Bf, N, D, dtype=dt, device=dev)
             if AP.WARP_ROWS and (not is_cross) and all("edit_rows" in c for c in cs) and k_base.shape[1] % 256 == 0:
                 acts = [torch.empty(f, c["edit_rows"].numel(), D, dtype=dt, device=dev) for c in cs]
                 for j, c in enumerate(cs):                                             # only the rows inside each edit's soft mask
-                    segs.append((q_base[sl[j]], k_base[sl[j]], v_base[sl[j]], acts[j], None, (c["idx"], c["w"], c["m_edit"]), (c["edit_rows"], c["n_edit_rows"])))
+                    per_edit.append((q_base[sl[j]], k_base[sl[j]], v_base[sl[j]], acts[j], None, (c["idx"], c["w"], c["m_edit"]), (c["edit_rows"], c["n_edit_rows"])))
             else:
                 for j, c in enumerate(cs):
-                    segs.append((q_base[sl[j]], k_base[sl[j]], v_base[sl[j]], edit_out[sl[j]], None, (c["idx"], c["w"], c["m_edit"])))
+                    per_edit.append((q_base[sl[j]], k_base[sl[j]], v_base[sl[j]], edit_out[sl[j]], None, (c["idx"], c["w"], c["m_edit"])))
             K = k_edit if is_cross else k_base                                         # :432 / :555
         else:
             K = k_base                                                                 # :790,882
-        segs.append((q_edit, K, v_base, replace_out, lse_e))                           # :433,557 / :791,883
-        ops.attn_fwd(segs, scale, q_scaled=2 if (q_pre and AP.OPT_PRE and dt == torch.bfloat16) else 0)
+        tails = [(q_edit, K, v_base, replace_out, lse_e)]                              # :433,557 / :791,883
+        _attn_fwd_grouped(plain, per_edit, tails, f, B, scale, q_scaled=2 if (q_pre and AP.OPT_PRE and dt == torch.bfloat16) else 0)
         if remover:
             edit_out = van.clone() if want_losses else van
         elif acts is not None:
@@ -335,9 +377,9 @@ class EditBatch(AttentionControl):
                 a_sides = [(r(q_edit, j), r(k_edit, j), r(v_edit, j), r(o_edit, j), None) for j in range(B)]
                 b_sides = [(r(q_edit, j), r(k_base, j), r(v_base, j)) for j in range(B)]
                 ms = [c["m_inp"] for c in cs]
-            ops.attn_fwd_pair([van] + a_sides, b_sides, ms, scale, heads=heads, q_scaled=qs)
+            _attn_fwd_pair_grouped([van], a_sides, b_sides, ms, scale, heads=heads, q_scaled=qs)
             return out_full
-        segs = [van]
+        per_edit, tails = [], []
         acts = edit_outs = ident_out = None
         replace_out = o_edit                                                              # no blend to come: straight into the edit rows
         if not remover:
@@ -347,19 +389,19 @@ class EditBatch(AttentionControl):
                 if AP.WARP_ROWS and (not is_cross) and all("edit_rows" in c for c in cs) and k_base.shape[1] % 256 == 0:
                     acts = [torch.empty(1, c["edit_rows"].numel(), C, dtype=q.dtype, device=q.device) for c in cs]
                     for j, c in enumerate(cs):
-                        segs.append((r(q_base, j), r(k_base, j), r(v_base, j), acts[j], None, (c["idx"], c["w"], c["m_edit"]), (c["edit_rows"], c["n_edit_rows"])))
+                        per_edit.append((r(q_base, j), r(k_base, j), r(v_base, j), acts[j], None, (c["idx"], c["w"], c["m_edit"]), (c["edit_rows"], c["n_edit_rows"])))
                 else:
                     edit_outs = torch.empty(B, N, C, dtype=q.dtype, device=q.device)
                     for j, c in enumerate(cs):
-                        segs.append((r(q_base, j), r(k_base, j), r(v_base, j), r(edit_outs, j), None, (c["idx"], c["w"], c["m_edit"])))
+                        per_edit.append((r(q_base, j), r(k_base, j), r(v_base, j), r(edit_outs, j), None, (c["idx"], c["w"], c["m_edit"])))
         else:
             K = k_base
             if not blend:
                 ident_out = torch.empty(B, N, C, dtype=q.dtype, device=q.device)
                 replace_out = torch.empty(B, N, C, dtype=q.dtype, device=q.device)
-                segs.append((q_edit, k_edit, v_edit, ident_out, None))
-        segs.append((q_edit, K, v_base, replace_out, None))
-        ops.attn_fwd(segs, scale, heads=heads, q_scaled=qs)
+                tails.append((q_edit, k_edit, v_edit, ident_out, None))
+        tails.append((q_edit, K, v_base, replace_out, None))
+        _attn_fwd_grouped([van], per_edit, tails, 1, B, scale, heads=heads, q_scaled=qs)
         for j, c in enumerate(cs):
             if acts is not None:          # rows outside the soft edit mask: the reference row's output — merged and blended in one pass
                 ops.blend_merge(r(van_base, j), acts[j], c["edit_pos"], r(replace_out, j), c["m_edit"], eo_out=None, out=r(o_edit, j))

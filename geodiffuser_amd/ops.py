@@ -613,15 +613,21 @@ def heads_merge(srcs: Sequence[Optional[torch.Tensor]], heads: int, rows: int, D
     """-> token-major [B, rows, heads*D]: batch row b from the head-major srcs[b] [heads, rows, D] (16-bit, or f32 for all: rounded once),
     zeros where srcs[b] is None.  blend = (row, b, m) or a list of such triples: that row is srcs[row]*m + b*(1-m) as blend_tokens
     computes it (every edit of a batch blends with its own mask).  One launch (batch_to_head_dim of the output, the blend before it, and
-    the autograd of head_to_batch_dim with its zero rows).  B <= 16."""
+    the autograd of head_to_batch_dim with its zero rows); 16 rows per launch."""
     lib = _lib.load()
     B = len(srcs)
-    if not 1 <= B <= 16:
-        raise _lib.GeodiffError("heads_merge: 1..16 batch rows")
+    if B < 1:
+        raise _lib.GeodiffError("heads_merge: at least one batch row")
     if out is None:
         out = torch.empty(B, rows, heads * D, dtype=dtype, device=device)
     elif tuple(out.shape) != (B, rows, heads * D) or out.dtype != dtype:
         raise _lib.GeodiffError("heads_merge: out must be [B, rows, heads*D] of the tensor dtype")
+    if B > 16:                                             # GD_HEADS_MERGE_MAX_ROWS per launch: 16 rows at a time into slices of `out`
+        triples = [] if blend is None else ([blend] if isinstance(blend, tuple) else list(blend))
+        for i in range(0, B, 16):
+            part = [(row - i, bb, m) for row, bb, m in triples if i <= row < i + 16]
+            heads_merge(srcs[i:i + 16], heads, rows, D, dtype, device, blend=part or None, out=out[i:i + 16])
+        return out
     dt = _dt16(out, "out")
     a = GdHeadsMerge()
     f32 = None

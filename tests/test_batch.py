@@ -110,12 +110,33 @@ def test_mixed_batch_every_edit_lands_on_its_own_single_run(pipe):
         assert d < max(6 * noise, 5e-2)
 
 
-@pytest.mark.parametrize("merged", [False, True], ids=["per_edit", "merged"])
+def test_batch_of_ten_edits_two_launch_groups_per_layer(pipe):
+    """More edits than one attention launch has per-edit segments for (batch.GROUP = 8): the UNet passes run on all ten, every hooked layer
+    launches twice.  Every edit lands on its own one-edit run as in the mixed batch of three above."""
+    seeds = list(range(20, 30))
+    singles = [_single(pipe, s) for s in seeds]
+    again = _single(pipe, seeds[0])
+    noise = rel_l2(again[2], singles[0][2])
+    res = _batch(pipe, seeds)
+    assert len(res) == 10
+    for (im, log, lat), (im1, log1, lat1), s in zip(res, singles, seeds):
+        assert sorted(log) == sorted(log1)
+        first = min(log)
+        for att in ("self", "cross"):
+            for k, v in log1[first][att].items():
+                assert abs(log[first][att][k] - v) <= 2e-2 * abs(v) + 2e-3, (s, att, k, log[first][att][k], v)
+        assert torch.equal(lat[0], lat1[0]) or rel_l2(lat[0], lat1[0]) < 2e-3
+        d = rel_l2(lat[1], lat1[1])
+        assert d < max(6 * noise, 5e-2), (s, d, noise)
+        assert im[1].shape == im1[1].shape
+
+
+@pytest.mark.parametrize("merged,B", [(False, 2), (True, 2), (True, 11)], ids=["per_edit", "merged", "merged_11_edits"])
 @pytest.mark.parametrize("cross", [False, True], ids=["self", "cross"])
 @pytest.mark.parametrize("S", [32, 64])
 @pytest.mark.parametrize("cfg", [False, True], ids=["opt", "cfg"])
-def test_batched_hooked_layer_equals_every_edits_own_controller(cfg, S, cross, merged, monkeypatch):
-    """One hooked call, 2 edits with different masks / transforms: EditBatch on the role-major batch against each edit's own controller on
+def test_batched_hooked_layer_equals_every_edits_own_controller(cfg, S, cross, merged, B, monkeypatch):
+    """One hooked call, 2 edits (11: more than one launch carries per-edit segments for — two launches per layer, batch.GROUP) with different masks / transforms: EditBatch on the role-major batch against each edit's own controller on
     its own rows — outputs, and in the optimisation layout the loss and the query gradient.  per_edit (GD_BATCH_MERGED=0): the same
     kernels on gathered rows — bit for bit.  merged: ONE attention launch for the batch (the reference rows / the replace attention of all
     edits as one segment each, one warped / row-list segment or blend pair per edit) — a launch of B x the heads may be served by another
@@ -128,14 +149,17 @@ def test_batched_hooked_layer_equals_every_edits_own_controller(cfg, S, cross, m
     from geodiffuser_amd.batch import EditBatch
     from geodiffuser_amd.generic_torch import torch_erode
     dev, dtype, heads = "cuda:0", torch.bfloat16, (5 if S == 64 else 10)          # SD2.1's head counts at these resolutions
-    N, C, B = S * S, heads * 64, 2
+    N, C = S * S, heads * 64
     M = 77 if cross else N
     g = torch.Generator(device=dev).manual_seed(5)
     roles = 3 if cfg else 2
 
     def controller(j):
-        mask = cases.ellipse_mask(cx=200 + 60 * j, cy=250 - 30 * j, ax=70 + 10 * j, ay=50)
-        coords = torch.from_numpy(cases.make_coords("translate" if j == 0 else "rotate", mask))
+        if B == 2:
+            mask = cases.ellipse_mask(cx=200 + 60 * j, cy=250 - 30 * j, ax=70 + 10 * j, ay=50)
+        else:
+            mask = cases.ellipse_mask(cx=130 + 24 * j, cy=300 - 11 * j, ax=55 + 5 * j, ay=40 + 3 * (j % 4))
+        coords = torch.from_numpy(cases.make_coords("translate" if j % 2 == 0 else "rotate", mask))
         c = AttentionGeometryEdit(["", ""], 50, {"default_": 0.95}, 0.95, image_mask=mask, obj_edit_step=0.9, device=dev)
         c.amodal_mask = torch_erode(torch.from_numpy(cases.amodal_input(mask)))
         c.num_att_layers = 32

@@ -522,6 +522,9 @@ def test_batch_entry_point_runs_long_lists_in_chunks(monkeypatch):
         return [("result", e["id"]) for e in edits]
 
     monkeypatch.setattr(GB, "perform_geometric_edit_batch", spy)
-    res = spy([{"id": i} for i in range(19)], edit_type="geometry_remover", guidance_scale=5.0)
-    assert [c[0] for c in calls] == [19, 8, 8, 3] and all(c[1:] == ("geometry_remover", 5.0) for c in calls)
-    assert res == [("result", i) for i in range(19)]
+    n = 2 * GB.MAX_EDITS + 3
+    res = spy([{"id": i} for i in range(n)], edit_type="geometry_remover", guidance_scale=5.0)
+    assert [c[0] for c in calls] == [n, GB.MAX_EDITS, GB.MAX_EDITS, 3] and all(c[1:] == ("geometry_remover", 5.0) for c in calls)
+    assert res == [("result", i) for i in range(n)]
+    # a hooked layer of a batch of B edits launches per group of GROUP: [0, 8), [8, B)
+    assert GB._groups(5) == [(0, 5)] and GB._groups(GB.GROUP) == [(0, GB.GROUP)] and GB._groups(11) == [(0, 8), (8, 11)] and GB.MAX_EDITS == 2 * GB.GROUP

@@ -320,7 +320,7 @@ def main(argv=None):
                     help="with --gpus: independent edits in flight per GPU = ranks per device (4 gives 1.85 x the edits/min of 1 on an MI355X)")
     ap.add_argument("--edits-per-pass", type=int, default=1,
                     help="B > 1: every rank runs its folders B at a time in ONE process, sharing every UNet pass (geodiffuser_amd/batch.py; one "
-                         "copy of the weights; 4 gives 1.8 x, 8 gives 2.1 x the edits/min of 1 on an MI355X)")
+                         "copy of the weights; 4 gives 1.8 x, 8 gives 2.1 x, 16 gives 2.2 x the edits/min of 1 on an MI355X)")
     ap.add_argument("--io-threads", type=int, default=8,
                     help="worker threads that read the next experiments' files and write finished results while the GPU edits (0: in line)")
     args = ap.parse_args(argv)

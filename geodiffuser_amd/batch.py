@@ -19,7 +19,7 @@ selection (measured in tests/test_batch.py).
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Sequence
 
 import numpy as np
 import torch
@@ -34,7 +34,6 @@ from .attention_processors import (AttentionGeometryEdit, AttentionGeometryRemov
 from .attention_sharing import AttentionControl, attention_tok
 from .diffusion import _sched_step, _unet_nograd, encode_text, latent2image
 from .generic_torch import binarize_tensor, reshape_attention_mask, reshape_transform_coords, torch_erode
-from .image_processing import masked_histogram_matching
 from .inversion import NullInversion
 from .optimization import adaptive_optimization_step_editing, adaptive_optimization_step_remover
 from .warp_utils import warp_grid_edit

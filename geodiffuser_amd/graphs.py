@@ -15,7 +15,7 @@ from __future__ import annotations
 import itertools
 import os
 import weakref
-from typing import Callable, Dict, Hashable, Optional, Tuple
+from typing import Dict, Hashable, Optional, Tuple
 
 import torch
 

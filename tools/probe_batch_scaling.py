@@ -33,7 +33,7 @@ def timed(g, n=20):
 
 print("no-grad pass (inversion / CFG shape), captured:")
 base = None
-for nb in (1, 2, 3, 4, 6, 8, 12, 16, 24):
+for nb in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48):
     x = torch.randn(nb, 4, 64, 64, device="cuda", dtype=dt)
     ctx = emb.expand(nb, -1, -1).contiguous()
     t = torch.tensor([500], device="cuda")
@@ -51,7 +51,7 @@ for nb in (1, 2, 3, 4, 6, 8, 12, 16, 24):
 
 print("forward + backward to the latent and the context (optimisation-pass shape, vanilla attention), captured:")
 base = None
-for nb in (2, 4, 8, 16):
+for nb in (1, 2, 4, 8, 16, 32):
     x = torch.randn(nb, 4, 64, 64, device="cuda", dtype=torch.float32).requires_grad_(True)
     ctx = emb.float().expand(nb, -1, -1).contiguous().requires_grad_(True)
     t = torch.tensor([500], device="cuda")
@@ -68,5 +68,5 @@ for nb in (2, 4, 8, 16):
         gr = run()
     ms = timed(g, 10)
     base = base or ms
-    print(f"  batch {nb:3d}: {ms:8.2f} ms  = {ms / nb:7.2f} ms per row  ({ms / base:5.2f} x batch 2)", flush=True)
+    print(f"  batch {nb:3d}: {ms:8.2f} ms  = {ms / nb:7.2f} ms per row  ({ms / base:5.2f} x the first)", flush=True)
     del g, gr

@@ -196,10 +196,11 @@ WARP_ROWS_MIN_TOKENS = 64 ** 2
 # as the last workgroup's tail, the row dots beside the loss backward, one fold for the attention and removal dq partials.  Same
 # arithmetic in the same order; GD_FUSED_LAYER=0 restores the stand-alone launches (the parity tests run both).
 FUSED_LAYER = os.environ.get("GD_FUSED_LAYER", "1") == "1"
-# The optimisation pass's bf16 launches with pre-scaled queries run the forward's PRE-SCALED variant (fixed softmax reference, row sums on
+# The optimisation pass's launches with pre-scaled queries run the forward's PRE-SCALED variant (fixed softmax reference, row sums on
 # the matrix pipe: k_attn_fwd_w64 LSUM) instead of the exact-scale rescue variant: with numerator and denominator summed over the same
-# rounded probabilities a dominant probability is exact again, which is what the rescue variant was kept for (DESIGN 4a').  fp16 stays on
-# the rescue variant (its probabilities must stay inside fp16's range).  GD_OPT_PRE=0: the round-3 routing.
+# rounded probabilities a dominant probability is exact again, which is what the rescue variant was kept for (DESIGN 4a').  fp16 too (r06:
+# a probability that leaves fp16's range shows as an infinite row sum and the segment is repeated with exact row maxima).  GD_OPT_PRE=0:
+# the round-3 routing.
 OPT_PRE = os.environ.get("GD_OPT_PRE", "1") == "1"
 # The passes that accumulate losses (use_cfg False: the optimisation pass) hand the layer token-major q / k / v as the projections produce
 # them and take a token-major output back: the head_to_batch_dim / batch_to_head_dim permutes of the reference (:201-203,213) and their
@@ -445,7 +446,7 @@ class _EditLayer(torch.autograd.Function):
                 ident_out = torch.empty(f, N, D, dtype=dt, device=dev)
                 segs.append((q_edit, k_edit, v_edit, ident_out, None))
         segs.append((q_edit, K, v_base, replace_out, lse_e))                # :433,557 / :791,883
-        ops.attn_fwd(segs, scale, q_scaled=2 if (q_pre and OPT_PRE and dt == torch.bfloat16) else 0)
+        ops.attn_fwd(segs, scale, q_scaled=2 if (q_pre and OPT_PRE and dt in (torch.bfloat16, torch.float16)) else 0)
         fused = FUSED_LAYER
         blend_done = False
         if (not remover) and edit_act is not None:

@@ -128,7 +128,7 @@ class _EditLayerBatch(torch.autograd.Function):
         else:
             K = k_base                                                                 # :790,882
         tails = [(q_edit, K, v_base, replace_out, lse_e)]                              # :433,557 / :791,883
-        _attn_fwd_grouped(plain, per_edit, tails, f, B, scale, q_scaled=2 if (q_pre and AP.OPT_PRE and dt == torch.bfloat16) else 0)
+        _attn_fwd_grouped(plain, per_edit, tails, f, B, scale, q_scaled=2 if (q_pre and AP.OPT_PRE and dt in (torch.bfloat16, torch.float16)) else 0)
         if remover:
             edit_out = van.clone() if want_losses else van
         elif acts is not None:

@@ -572,7 +572,7 @@ k_attn_fwd_mp(const FwdArgs a) {
 // one direct-to-LDS piece (1 KB) per 8 gaps.  Segments, token-major rows, fused query warp, query row lists as in k_attn_fwd_mp;
 // units are 256 queries.  What differs:
 //   * softmax reference: PRE (queries carry scale*log2 e): the first key tile's row maximum, fixed; a segment whose half-step sums ever
-//     exceed 2^60 is repeated with exact row maxima (see the attempt loop).  !PRE (exact scale: the optimisation pass): raw scores in
+//     exceed 2^60 (fp16: 2^14, the range of its probabilities) is repeated with exact row maxima (see the attempt loop).  !PRE (exact scale: the optimisation pass): raw scores in
 //     the tiles and k_attn_fwd_mp's in-loop rescue, which only touches O, l and the reference (w64_rescue);
 //   * SK: the linear range of k_attn_fwd_mp, or — launches of at most 128 units — every unit in 2-4 parts, one per workgroup
 //     (FwdArgs::sk_parts); hand-off: the holder of a unit's first part merges without storing its own (see the epilogue);
@@ -1120,7 +1120,10 @@ k_attn_fwd_w64(const FwdArgs a) {
     }
     W64_STAMP(2)
     if (attempt) break;
-    if (__builtin_amdgcn_ballot_w64(!(chk <= W64_SUM_LIMIT)) != 0 && lane == 0) w_abort = 1;
+    // fp16 probabilities: a half-step sum of at most 2^14 keeps every one of its probabilities finite in 16 bits (vector-pipe sums); with the
+    // row sums on the matrix pipe an overflowed probability is an infinite (or NaN) sum.  bf16 has fp32's range: only the sums can overflow.
+    const float sum_limit = (__is_same(T, f16_t) && !LSUM) ? P_SUM_LIMIT : W64_SUM_LIMIT;
+    if (__builtin_amdgcn_ballot_w64(!(chk <= sum_limit)) != 0 && lane == 0) w_abort = 1;
     __syncthreads();
     if (!w_abort) break;
     __syncthreads();                  // everyone has seen the flag before the next attempt clears it
@@ -1381,9 +1384,11 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
         else if (pre) { if (sk) GD_W64_LAUNCH(T_, true, true); else GD_W64_LAUNCH(T_, true, false); }   \
         else { if (sk) GD_W64_LAUNCH(T_, false, true); else GD_W64_LAUNCH(T_, false, false); }     \
     }
-    // fp16: always the rescue variant — its probabilities stay below the half-step limit of 2^14, inside fp16's range, where the fixed
-    // reference of the pre-scaled variant lets them grow to 2^60 (pre-scaled queries are fine with it: the multiplier is then 1)
-    if (dtype == GD_F16) { if (sk) GD_W64_LAUNCH(f16_t, false, true); else GD_W64_LAUNCH(f16_t, false, false); }
+    // fp16 (r06): the same variants.  The fixed reference lets a probability grow past fp16's range where bf16 has fp32's, so the segment's
+    // check is tighter (see sum_limit in the kernel: half-step sums <= 2^14, or a finite matrix-pipe row sum) and a segment that fails it is
+    // repeated with the exact row maxima like any other — exact for every input; r05 ran fp16 on the exact-scale rescue variant with a
+    // multiplier of 1 (one fma per score more: 57.9 vs 50.4 us per launch over the bench's mix)
+    if (dtype == GD_F16) GD_W64_T(f16_t)
     else GD_W64_T(bf16_t)
 #undef GD_W64_T
 #undef GD_W64_LAUNCH_L

@@ -237,7 +237,7 @@ def test_attention_forward_pipelined_configs(ops, dtype, BH, N, M):
         for (qb, ks) in ((4, 1), (2, 2), (4, 2), (2, 4), (8, 1)):
             if (M // 64) % (2 * ks) != 0 or (qb == 8 and M % 256 != 0):
                 continue
-            lib.gd_attn_fwd_set_config(qb, ks)          # (8, 1) = the 64-query-per-wave kernel (bf16; fp16 falls back to 4 x 1)
+            lib.gd_attn_fwd_set_config(qb, ks)          # (8, 1) = the 64-query-per-wave kernel
             out = torch.zeros_like(q); lse = torch.zeros(BH, N, device=DEV)
             ops.attn_fwd([(q, k, v, out, lse)], 0.125, nsplit=1)
             out2 = torch.zeros_like(q); lse2 = torch.zeros(BH, N, device=DEV)
@@ -251,6 +251,47 @@ def test_attention_forward_pipelined_configs(ops, dtype, BH, N, M):
     finally:
         lib.gd_attn_fwd_set_config(-1, 0)
     assert ran >= 1
+
+
+@pytest.mark.parametrize("q_scaled", [1, 2])
+@pytest.mark.parametrize("climb", [0.0, 6.0, 15.0, 60.0])
+def test_attention_w64_fp16_prescaled_range(ops, q_scaled, climb):
+    """fp16 on the 64-query kernel's PRE-SCALED variants (r06; until r05 fp16 ran the exact-scale rescue variant).  The softmax reference is
+    the first key tile's row maximum and never moves, so a later key `climb` nats above it is a probability of e^climb: 6 stays inside
+    fp16 (no repeat), 15 is inside bf16's range but OUTSIDE fp16's (the segment must be repeated with exact row maxima: half-step sums
+    > 2^14 on the vector-pipe sums, an infinite row sum on the matrix-pipe sums of q_scaled = 2), 60 leaves both.  Whole units and unit
+    parts (5 heads: every unit in three parts), against the fp64 formulation at the unchanged fp16 tolerance; bit-reproducible."""
+    from _util import Tune
+    lib = Tune()
+    dtype = torch.float16
+    N = M = 4096
+    C2 = 0.125 * 1.4426950408889634
+    try:
+        lib.gd_attn_fwd_set_config(8, 1)
+        for BH in (5, 12):
+            torch.manual_seed(BH + int(climb))
+            q = (torch.randn(BH, N, 64, device=DEV) * 1.2); k = (torch.randn(BH, M, 64, device=DEV) * 1.2)
+            v = torch.randn(BH, M, 64, device=DEV).to(dtype)
+            # head 0: scores climbing by `climb` nats across the keys (q . e0 = 8, scale 0.125); head 1: one late outlier key
+            k[0, :, 0] += torch.linspace(0, climb, M, device=DEV); q[0, :, 0] = 8.0
+            k[1, M - 70, :] = q[1, 100] * (climb / 0.125) / float((q[1, 100] ** 2).sum())
+            k = k.to(dtype)
+            qs = (q * C2).to(dtype)                                       # what the projections' epilogue hands over
+            rows = torch.cat([torch.arange(5, N, 53), torch.tensor([100])])
+            ro, rl, _ = _ref_attn(qs[:, rows].cpu(), k.cpu(), v.cpu(), 0.6931471805599453)
+            outs = []
+            for _ in range(2):
+                out = torch.zeros_like(qs); lse = torch.zeros(BH, N, device=DEV)
+                ops.attn_fwd([(qs, k, v, out, lse)], 0.125, nsplit=1, q_scaled=q_scaled)
+                torch.cuda.synchronize()
+                outs.append((out, lse))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+            out, lse = outs[0]
+            assert torch.isfinite(out.float()).all()
+            assert rel_err(out[:, rows].float().cpu(), ro) < TOL16, (BH, climb)
+            assert float((lse[:, rows].cpu().double() - rl).abs().max()) < 2e-4 * max(1.0, float(rl.abs().max())), (BH, climb)
+    finally:
+        lib.gd_attn_fwd_set_config(-1, 0)
 
 
 @pytest.mark.parametrize("cfg", [(4, 1), (8, 1)])

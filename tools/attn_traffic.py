@@ -4,7 +4,7 @@
                                                                                  "15" = the optimisation pass's form, "15_plain" = 15 plain heads"""
 import csv, glob, json, os, sys
 out = sys.argv[1]
-res = {"comment": "Attention forward at HEAD (round 4), N = M = 4096, D = 64, bf16: HBM bytes per launch = 2*FETCH_SIZE*1024 (gfx950 half-count "
+res = {"comment": "Attention forward at HEAD (round of the file name), N = M = 4096, D = 64, bf16: HBM bytes per launch = 2*FETCH_SIZE*1024 (gfx950 half-count "
                   "correction for wide reads) + WRITE_SIZE*1024; rocprofv3 --pmc, one counter per pass (tools/pmc_attn.sh -> tools/attn_one.py; tables: "
                   "profiles/pmc_r04_*.md).  '5' / '15_plain' / '32': plain head-major launches with pre-scaled queries; '20': the CFG pass's launch as an edit "
                   "issues it (4 token-major segments x 5 heads, fused warp + row list); '15': the optimisation pass's launch (3 segments x 5 heads, "

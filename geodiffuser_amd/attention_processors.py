@@ -28,6 +28,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
+from . import _lib
 from . import ops
 from . import warp_utils
 from ._lib import GD_TOKEN_MAJOR
@@ -389,7 +390,7 @@ class _EditLayer(torch.autograd.Function):
     replace_{self,cross}_attention inlined).  Returns (out [(cb+1)*f, N, D], layer_loss [] f32, terms [5] f32)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, ctrl, is_cross, scale, c, q_pre=False, heads=0, running=False, log_acc=None):
+    def forward(ctx, q, k, v, ctrl, is_cross, scale, c, q_pre=False, heads=0, running=False, log_acc=None, ref=None):
         # q_pre: the queries carry scale*log2(e) and ``scale`` is ln 2 (controller forward): every kernel computes
         # exp(scale * q.k - lse) as it stands.  The forward is NOT told (gd_attn_seg_t::q_scaled stays 0, its multiplier becomes
         # ln2 * log2(e) = 1): the pre-scaled variant of the 64-query kernel takes the first key tile's maximum as the softmax reference
@@ -399,14 +400,21 @@ class _EditLayer(torch.autograd.Function):
         # `sim` term of an SDXL-shaped bf16 case moved by 1.6 %), so the optimisation pass pays the 6-9 us per 64^2 launch.
         # heads > 0 (TOK_OPT): q / k / v arrive token-major [B, rows, heads*64] and the output leaves token-major; one split launch here,
         # one merge launch at the end (which also does the blend), everything in between on head-major tensors as before
+        # ref (editor.REF_AHEAD): q / k / v hold the EDIT row only; the reference row's token-major q / k / v [1, N | M, heads*64] come from
+        # the previous step's CFG pass (detached 16-bit tensors: the reference row never received a gradient here either).  Everything
+        # below then runs as for the two-row batch [reference, edit] — the same launches on the same kinds of tensors — and the output /
+        # the gradients cover the edit row alone.
         f = c["f"]
         tok_shapes = None
+        if ref is not None and not heads:
+            raise _lib.GeodiffError("_EditLayer: reference rows handed in need the token-major layer form (64-wide heads, GD_TOK_OPT)")
         if heads:
             tok_shapes = (q.shape, k.shape)
             q, k, v = ops.heads_split((q, k, v), heads)
         remover = ctrl._is_remover
         (b0, b1), (e0, e1) = ctrl.coords_base, ctrl.coords_edit
         cb = ctrl.coords_base[-1] * f
+        n_van_live = cb // f                                    # vanilla batch rows in front of the edit row in the LIVE tensors
         N, D = q.shape[1], q.shape[2]
         S = c["S"]
         dev, dt = q.device, q.dtype
@@ -414,11 +422,20 @@ class _EditLayer(torch.autograd.Function):
         want_losses = (N >= 32 ** 2) and (not ctrl.use_cfg)
         blend = ctrl.cur_step < int(ctrl.num_steps * ctrl.obj_edit_step)
 
-        q_base, k_base, v_base = q[b0 * f:b1 * f], k[b0 * f:b1 * f], v[b0 * f:b1 * f]
-        q_edit, k_edit, v_edit = q[e0 * f:e1 * f], k[e0 * f:e1 * f], v[e0 * f:e1 * f]
+        if ref is not None:
+            if ref[0].dtype != dt or ref[0].shape[1] != N or ref[0].shape[2] != heads * D or ref[1].shape[2] != heads * D:
+                raise _lib.GeodiffError("_EditLayer: the reference rows handed in do not match this layer (dtype / tokens / width)")
+            q_base, k_base, v_base = ops.heads_split((ref[0], ref[1], ref[2]), heads)
+            q_edit, k_edit, v_edit = q, k, v
+            van_q, van_k, van_v = q_base, k_base, v_base
+            (b0, b1), (e0, e1), cb, n_van_live = (0, 1), (0, 1), f, 0
+        else:
+            q_base, k_base, v_base = q[b0 * f:b1 * f], k[b0 * f:b1 * f], v[b0 * f:b1 * f]
+            q_edit, k_edit, v_edit = q[e0 * f:e1 * f], k[e0 * f:e1 * f], v[e0 * f:e1 * f]
+            van_q, van_k, van_v = q[:cb], k[:cb], v[:cb]
         out_full = torch.empty(cb if heads else cb + f, N, D, dtype=dt, device=dev)
         lse_van = torch.empty(cb, N, dtype=torch.float32, device=dev) if want_losses else None
-        segs = [(q[:cb], k[:cb], v[:cb], out_full[:cb], lse_van)]
+        segs = [(van_q, van_k, van_v, out_full[:cb], lse_van)]
         replace_out = torch.empty(f, N, D, dtype=dt, device=dev)
         # opt-in slow path of the reference (:452-454,562-564): keep the edit row's probability map of layers with N <= 16^2
         store = ctrl.use_cfg and ctrl.store_attention_maps and (not remover) and N <= 16 ** 2
@@ -516,7 +533,7 @@ class _EditLayer(torch.autograd.Function):
                 last, blend_with = edit_out, (replace_out, c["m_edit"])
             elif remover and not blend:
                 last, blend_with = ident_out, (replace_out, c["m_inp"])
-            nb_ = cb // f
+            nb_ = n_van_live                                    # (reference rows handed in: the output is the edit row alone)
             out_full = ops.heads_merge([out_full[i * f:(i + 1) * f] for i in range(nb_)] + [last], heads, N, D, dt, dev,
                                        blend=None if blend_with is None else (nb_, blend_with[0], blend_with[1]))
         elif not remover:
@@ -535,7 +552,8 @@ class _EditLayer(torch.autograd.Function):
             ctx.save_for_backward(q_edit, K, v_base, replace_out, lse_e, edit_out if want_losses else None, tgt, Pe, Pb, coefs, rm_coef)
             ctx.aux, ctx.c = aux, c
             ctx.meta = dict(f=f, cb=cb, e0=e0, e1=e1, is_cross=is_cross, scale=scale, remover=remover, blend=blend,
-                            want_losses=want_losses, q_shape=q.shape, k_shape=k.shape, S=S, fused=fused, heads=heads, tok_shapes=tok_shapes)
+                            want_losses=want_losses, q_shape=q.shape, k_shape=k.shape, S=S, fused=fused, heads=heads, tok_shapes=tok_shapes,
+                            n_van_live=n_van_live)
         ctx.mark_non_differentiable(terms)
         return out_full, loss, terms
 
@@ -550,7 +568,7 @@ class _EditLayer(torch.autograd.Function):
                                       "never taken by the reference driver (optimize_steps <= obj_edit_step)")
         heads = m.get("heads", 0)
         if heads and g_out is not None:           # token-major [B, N, heads*D]: the loss backward reads the edit row's slice in place
-            gout = g_out[cb // f:].contiguous()
+            gout = g_out[m["n_van_live"]:].contiguous()
         else:
             gout = g_out[cb:].contiguous() if g_out is not None else None
         gtok = bool(heads)
@@ -604,7 +622,7 @@ class _EditLayer(torch.autograd.Function):
             grad_k = torch.zeros(m["k_shape"], dtype=dt, device=dev)
             grad_k[m["e0"] * f:m["e1"] * f] = dk32.to(dt)
         g_run = g_loss if (len(ctx.needs_input_grad) > 9 and ctx.needs_input_grad[9]) else None      # d(running + loss) / d running = 1
-        return grad_q, grad_k, None, None, None, None, None, None, None, g_run, None
+        return grad_q, grad_k, None, None, None, None, None, None, None, g_run, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -859,6 +877,22 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         self._ref_pos += 1
         return entry
 
+    # THE REFERENCE ROW OF AN OPTIMISATION STEP ONE STEP AHEAD (editor.REF_AHEAD).  The reference sample of step i+1 is known while step i
+    # runs (the inversion trajectory's entry for t_{i+1}, U/editor.py:375-377) and no row of a UNet batch depends on another outside the
+    # hooked layers.  The CFG pass of step i therefore carries it as one more vanilla row (row 0, its own timestep) and keeps, per hooked
+    # call, that row's token-major (q, k, v, attention output) (collect_ahead -> ref_stash, same entry format as above; `out` is row 0
+    # of the pass's vanilla segment).  The optimisation pass of step i+1 then runs forward + backward on the EDIT ROW ALONE with the
+    # reference q / k / v handed to _EditLayer (use_ahead), and that step's CFG pass reads the same entries (use_ref_stash).
+    collect_ahead = False        # set by the driver around the CFG pass that carries the next step's reference row
+    use_ahead = False            # set by the driver around the optimisation pass that takes its reference rows from ref_stash
+    _ahead = None
+
+    def _leave_ahead(self, q, k, v, out):
+        if self.collect_ahead:
+            if self.cur_att_layer == 0 or self._ahead is None:
+                self._ahead = []
+            self._ahead.append((q[0:1].detach(), k[0:1].detach(), v[0:1].detach(), out[0:1].detach()))
+
     supports_token_major = True
     heads_tok = 0
     heads_opt = 0                # > 0: forward() was handed token-major q / k / v by a pass that accumulates losses (TOK_OPT)
@@ -951,11 +985,21 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         if heads:
             ref = self._take_ref() if self.use_ref_stash else None
             if not active:
-                return attention_tok(q, k, v, scale, heads, q_scaled=self.q_scaled_tok)
+                out = attention_tok(q, k, v, scale, heads, q_scaled=self.q_scaled_tok)
+                self._leave_ahead(q, k, v, out)
+                return out
             if is_cross:
                 _ = self.cross_replace_alpha[self.cur_step]
-            return self._forward_tok(q, k, v, is_cross, transform_coords, float(scale), heads, ref=ref)
+            out = self._forward_tok(q, k, v, is_cross, transform_coords, float(scale), heads, ref=ref)
+            self._leave_ahead(q, k, v, out)
+            return out
         ho = self.heads_opt              # token-major q / k / v [B, N, heads*64] (EditProcessor, TOK_OPT)
+        ref_in = None
+        if self.use_ahead:               # the live batch is the edit row alone; this layer's reference row was left by the previous CFG pass
+            ref_in = self._take_ref()
+            if not ho or not self.q_scaled_hm or self.rows_identical or not isinstance(ref_in, tuple):
+                raise _lib.GeodiffError("use_ahead needs the token-major optimisation-pass layers with pre-scaled queries (GD_TOK_OPT, "
+                                        "GD_SCALED_Q_OPT) and a complete ref_stash: disable GD_REF_AHEAD")
         f = ho if ho else q.shape[0] // nb
         self._place_in_unet = place_in_unet
         q_pre = bool(self.q_scaled_hm)
@@ -1001,7 +1045,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
                 running, log_acc = lo, acc
         self._tail_summed = False
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        out, loss, terms = _EditLayer.apply(q, k, v, self, is_cross, float(scale), c, q_pre, ho, running, log_acc)
+        out, loss, terms = _EditLayer.apply(q, k, v, self, is_cross, float(scale), c, q_pre, ho, running, log_acc, ref_in)
         if self.collect_ref:
             (b0, b1) = self.coords_base
             ok = ho and q_pre and D == 64 and not self.rows_identical and q.dtype in (torch.float16, torch.bfloat16)

@@ -31,7 +31,7 @@ from . import editor as E
 from . import graphs, ops, vis_utils, warp_utils
 from .attention_processors import (AttentionGeometryEdit, AttentionGeometryRemover, VanillaAttentionProcessor, _persist,
                                    register_attention_control_diffusers, set_attn_processor_for_edit)
-from .attention_sharing import AttentionControl, attention_tok
+from .attention_sharing import AttentionControl, attention, attention_tok
 from .diffusion import _sched_step, _unet_nograd, encode_text, latent2image
 from .generic_torch import binarize_tensor, reshape_attention_mask, reshape_transform_coords, torch_erode
 from .inversion import NullInversion
@@ -49,15 +49,33 @@ def _rows(seg, a, b):
     return tuple(t[a:b] if t is not None else None for t in seg[:5]) + tuple(seg[5:])
 
 
-def _groups(B):
-    return [(j0, min(j0 + GROUP, B)) for j0 in range(0, B, GROUP)]
+def _groups(B, group=GROUP):
+    return [(j0, min(j0 + group, B)) for j0 in range(0, B, group)]
+
+
+MAX_ROWLIST_HEADS = 256        # GD_ATTN_MAX_ORDER: a launch whose segments carry query row lists addresses its heads through order[]
+
+
+def _group_size(plain, per_edit, tails, unit, B, hpr):
+    """Edits per launch: GROUP, fewer where the launch carries query row lists and its heads would exceed the kernel's order table (10-head
+    64^2 layers of SDXL-shaped UNets: 4 * B * 10 heads — ADVICE r05: this used to end in GD_EUNSUPPORTED in the middle of an edit)."""
+    g = min(GROUP, B)
+    if not any(len(seg) > 6 and seg[6] is not None for seg in per_edit):
+        return max(1, g)
+    while g > 1:
+        ng = -(-B // g)
+        rows = sum(-(-seg[0].shape[0] // ng) for seg in plain) + sum(seg[0].shape[0] for seg in per_edit[:g]) + unit * g * len(tails)
+        if rows * hpr <= MAX_ROWLIST_HEADS:
+            break
+        g -= 1
+    return max(1, g)
 
 
 def _attn_fwd_grouped(plain, per_edit, tails, unit, B, scale, **kw):
     """ops.attn_fwd over plain + per_edit + tails, at most GROUP edits per launch.  ``plain``: segments whose rows are independent of the
     edits' order (vanilla rows: any contiguous share of them goes with any launch); ``per_edit``: one segment per edit; ``tails``: segments
     with ``unit`` rows per edit, in edit order (the replace attention: token-major unit 1, head-major unit f).  B <= GROUP: ONE launch."""
-    gs = _groups(B)
+    gs = _groups(B, _group_size(plain, per_edit, tails, unit, B, kw.get("heads") or 1))
     for g, (j0, j1) in enumerate(gs):
         segs = []
         for seg in plain:
@@ -308,10 +326,19 @@ class EditBatch(AttentionControl):
         if self.use_ref_stash and self.heads_tok:
             ref = self.ref_stash[self._ref_pos]
             self._ref_pos += 1
-        if not active and self.heads_tok:                # (self-attention past its replace window: plain attention for the whole batch)
+        if not active:                                   # (self-attention past its replace window: plain attention for the whole batch)
             for s in self.subs:
                 s.cur_att_layer += 1
-            return attention_tok(q, k, v, scale, heads, q_scaled=self.q_scaled_tok)
+            if self.heads_tok:
+                return attention_tok(q, k, v, scale, heads, q_scaled=self.q_scaled_tok)
+            # the optimisation pass (self_replace_steps < optimize_steps): like _GeometryControllerBase.forward and the reference (:646-647) —
+            # plain attention with autograd, no loss, nothing left for the CFG pass of this step (this used to fall into the
+            # merged edit layer)
+            self._leave_ref(None)
+            Bq, N, C = q.shape
+            sc = AP.LN2 if self.q_scaled_hm else scale
+            hm = lambda t: t.view(Bq, t.shape[1], heads, C // heads).permute(0, 2, 1, 3).reshape(Bq * heads, t.shape[1], C // heads)
+            return attention(hm(q), hm(k), hm(v), sc).view(Bq, heads, N, C // heads).permute(0, 2, 1, 3).reshape(Bq, N, C)
         if MERGED and AP.FUSED_WARP and AP.FUSED_LAYER and q.is_cuda and q.shape[2] == heads * 64 and B <= MAX_EDITS \
                 and not any(self.rows_identical):
             for s in self.subs:

@@ -24,9 +24,18 @@ def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None, ctx_s
     model / latent size, and a controller that has not built them yet (a new edit whose first UNet pass is a CFG pass:
     optimize_steps == 0, or fast_start_steps > 0) builds them up front.  The table shapes are part of the graph key."""
     key_fn = getattr(controller, "graph_key", None)
+
+    def eager():
+        # (per-row timesteps arrive as a tuple; an eager pass leaves no reference rows a captured pass may read: see GraphedUNet)
+        tt = torch.tensor([int(v) for v in t], device=x.device, dtype=torch.long) if isinstance(t, tuple) else t
+        out = model.unet(x, tt, encoder_hidden_states=ctx)["sample"]
+        if getattr(controller, "collect_ahead", False):
+            controller.ref_stash, controller.ref_stash_serial = None, None
+        return out
+
     if not graphs.ENABLED or torch.is_grad_enabled() or key_fn is None or getattr(controller, "store_attention_maps", False) \
             or not getattr(controller, "persistent_tables", False):
-        return model.unet(x, t, encoder_hidden_states=ctx)["sample"]
+        return eager()
     seen = model.__dict__.setdefault("_cfg_layers", {})
     # the hooked (resolution, heads, head dim) set is learnt per (latent size, controller type); a model whose hooks changed since is
     # caught by the `learnt() != layers` comparison below (the controller then holds a table the list does not know) and learns it again
@@ -37,7 +46,7 @@ def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None, ctx_s
         return sorted((S, c["f"], c["D"]) for S, c in controller.masks_cache_dict.items() if "f" in c)
 
     if layers is None:                                    # first hooked no-grad pass at this latent size: eager, learn the layers
-        out = model.unet(x, t, encoder_hidden_states=ctx)["sample"]
+        out = eager()
         seen[lk] = learnt()
         return out
     if not controller.tables_built(layers):
@@ -46,13 +55,13 @@ def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None, ctx_s
     if learnt() != layers:
         # the controller holds a table the learnt list does not know (the first pass did not reach every hooked resolution, or the hooks
         # changed on this model object): a capture would build it lazily, with host syncs, inside torch.cuda.graph — run eagerly and relearn
-        out = model.unet(x, t, encoder_hidden_states=ctx)["sample"]
+        out = eager()
         seen[lk] = learnt()
         return out
     runner = model.__dict__.get("_graphed")
     if runner is None:
         runner = model.__dict__["_graphed"] = graphs.GraphedUNet(model.unet)
-    out, replayed = runner((tag,) + key_fn() + (controller.table_signature(),), x, t, ctx, ctx_src=ctx_src)
+    out, replayed = runner((tag,) + key_fn() + (controller.table_signature(),), x, t, ctx, ctx_src=ctx_src, controller=controller)
     if replayed:
         controller.after_graph_replay()
     return out
@@ -101,10 +110,24 @@ def _sched_step(scheduler, eps_uncond, t, sample, eps_cond, guidance_scale):
 
 
 def diffusion_step(model, controller, latents, context, t, guidance_scale, low_resource=False, transform_coords=None,
-                   use_cfg=True, return_noise=False, skip_uncond_ref=False, skip_scheduler=False, ref_from_stash=False):
+                   use_cfg=True, return_noise=False, skip_uncond_ref=False, skip_scheduler=False, ref_from_stash=False, ref_ahead=None):
     """diffusion.py:39-59: UNet -> (CFG combine) -> scheduler.step(eta=0) -> controller.step_callback.
     The CFG combine is fused into the DDIM kernel (gd_ddim_step) unless the caller asks for the combined noise."""
-    if use_cfg and skip_uncond_ref and ref_from_stash:
+    if use_cfg and skip_uncond_ref and ref_ahead is not None:
+        # The 3-row pass below with the NEXT step's reference sample riding along as row 0 (editor.REF_AHEAD): ref_ahead = (its latent — the
+        # inversion trajectory's entry for the next timestep —, that timestep).  Rows are independent inside the UNet (per-sample norms,
+        # per-sample attention) and row 0 is a vanilla row for the controller, which keeps its per-layer q / k / v and attention output
+        # (collect_ahead); its noise prediction is not used.  Batch [ref_next, uncond_edit, cond_ref, cond_edit] with per-row timesteps:
+        # the layout of the reference's own 4-row CFG batch (coords_base (2, 3), coords_edit (3, 4)) with row 0 put to use.
+        ref_next, t_next = ref_ahead
+        latents_input = torch.cat([ref_next.to(latents.dtype), latents[1:2], latents[0:1], latents[1:2]])
+        ctx4 = torch.cat([context[2:3], context[1:2], context[2:3], context[3:4]])
+        noise_pred = _unet_nograd(model, controller, latents_input, (int(t_next), int(t), int(t), int(t)), ctx4, "cfg4n", transform_coords,
+                                  ctx_src=context)
+        edit_out = _sched_step(model.scheduler, noise_pred[1:2], t, latents[1:2], noise_pred[3:4], guidance_scale)
+        latents_out = torch.cat([latents[0:1].to(edit_out.dtype), edit_out])
+        noise_pred_out = None
+    elif use_cfg and skip_uncond_ref and ref_from_stash:
         # the `cond_ref` row's per-layer q / k / v and attention outputs were left by the optimisation pass of this step (same latent,
         # timestep and text row: attention_processors.ref_stash).  Batch [uncond_edit, cond_edit].
         latents_input = torch.cat([latents[1:2], latents[1:2]])

@@ -54,6 +54,13 @@ SKIP_UNCOND_REF = True      # drop the CFG pass's unused `uncond_ref` batch row 
 # reference sample through the UNet a second time with the same inputs (attention_processors.ref_stash; captured passes only)
 REF_FROM_OPT = os.environ.get("GD_REF_FROM_OPT", "1") == "1"
 REF_FROM_OPT_PASSES = 0     # CFG passes that ran without their reference row so far (both drivers count here)
+# ... and one step further (r06): the reference sample of an optimisation step rides in the CFG pass of the step BEFORE it as a fourth,
+# vanilla row with its own timestep (its latent is the inversion trajectory's, known ahead; rows do not interact outside the hooked
+# layers), so the optimisation pass runs forward + backward on the edit row alone (attention_processors "ONE STEP AHEAD").  Applies where
+# REF_FROM_OPT does, from the second optimisation step of an edit on (the first has no CFG pass in front of it) and where the pass in
+# front is the plain 3-row form; anything else falls back to the two-row optimisation pass.
+REF_AHEAD = os.environ.get("GD_REF_AHEAD", "1") == "1"
+REF_AHEAD_PASSES = 0        # optimisation passes that ran on the edit row alone so far
 
 
 def ref_from_opt_supported() -> bool:
@@ -206,9 +213,17 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
     # parity-preserving saving: with an inversion trajectory the CFG pass runs 3 batch rows, not 4
     skip_ref = ddim_latents is not None and batch_size == 2 and SKIP_UNCOND_REF
 
-    ref_from_opt = (REF_FROM_OPT and skip_ref and is_geo and ref_from_opt_supported() and getattr(controller, "supports_token_major", False))
+    # (not with store_attention_maps: the processors then leave the token-major path the stash is written and read on — ADVICE r05; the
+    #  flag is set on the controller before this driver runs, U/editor.py:538)
+    ref_from_opt = (REF_FROM_OPT and skip_ref and is_geo and ref_from_opt_supported() and getattr(controller, "supports_token_major", False)
+                    and not getattr(controller, "store_attention_maps", False))
 
-    def cfg_pass(lat, ctx, tt):
+    ref_ahead = REF_AHEAD and ref_from_opt and fast_start_steps == 0.0 and hasattr(controller, "collect_ahead")
+
+    def is_opt_step(j):
+        return j < T and (j < optimize_steps * T) and (j % skip_optim_steps == 0) and (j >= fast_start_steps * T)      # :181
+
+    def cfg_pass(lat, ctx, tt, ahead=None):
         # the reference decorates this driver with @torch.no_grad() (editor.py:64); the graph / token-major fast paths depend on it
         assert not torch.is_grad_enabled(), "text2image_ldm_stable: the CFG pass must run without autograd"
         if ref_from_opt and controller.ref_stash_serial is not None and controller.ref_stash_t == int(tt):
@@ -222,6 +237,18 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
                                       skip_uncond_ref=True, ref_from_stash=True)
             finally:
                 controller.use_ref_stash, controller.ref_stash_t = False, None
+        if skip_ref and ahead is not None:
+            # the next step optimises: its reference sample rides along as row 0 and leaves its layer tensors (REF_AHEAD)
+            set_attn_processor_for_edit(model, coords_base=(2, 3), coords_edit=(3, 4), use_cfg=True, n_batch=4)
+            controller.collect_ahead = True
+            controller.ref_stash_serial = controller.ref_stash_t = None
+            try:
+                out = diffusion_step(model, controller, lat, ctx, tt, guidance_scale, transform_coords=transform_coordinates,
+                                     skip_uncond_ref=True, ref_ahead=ahead)
+            finally:
+                controller.collect_ahead = False
+            controller.ref_stash_t = int(ahead[1]) if controller.ref_stash_serial is not None else None
+            return out
         if skip_ref:
             set_attn_processor_for_edit(model, coords_base=(1, 2), coords_edit=(2, 3), use_cfg=True, n_batch=3)
             return diffusion_step(model, controller, lat, ctx, tt, guidance_scale, transform_coords=transform_coordinates,
@@ -245,10 +272,17 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
             continue
 
         clear_controller_loss(controller)
+        # the reference row of the NEXT step, if that step optimises (REF_AHEAD): the trajectory entry the end of this step puts in row 0
+        ahead = None
+        if ref_ahead and is_opt_step(i + 1) and len(ddim_latents) - 2 - i >= 0:
+            ahead = (ddim_latents[len(ddim_latents) - 2 - i].type_as(latents.detach()), timesteps[i + 1])
         if (i < optimize_steps * T) and (i % skip_optim_steps == 0) and (i >= fast_start_steps * T):      # :181
             l_eff = lr * (50 - i) * skip_optim_steps * (50 / (NUM_DDIM_STEPS + 1e-8))                      # :207
             set_attn_processor_for_edit(model, coords_base=(0, 1), coords_edit=(1, 2), use_cfg=False)    # :213
-            controller.collect_ref = ref_from_opt
+            # this step's reference row already went through the UNet (the CFG pass of the step before): the edit row alone
+            edit_row_only = bool(ref_ahead and controller.ref_stash_serial is not None and controller.ref_stash_t == int(t)
+                                 and latents.shape[0] == 2)
+            controller.collect_ref = ref_from_opt and not edit_row_only
             n0 = ops.sumsq(latents[-1].detach().float().contiguous())                                      # orig_norm^2 (:219)
             ctx_cur = context if context_save is None else context_save
             lat_cur = latents
@@ -258,6 +292,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
             controller.rows_identical = bool(TIE_IDENTICAL_ROWS and i == 0 and is_geo and batch_size == 2 and latents.shape[0] == 2
                                              and type(controller).__name__ == "AttentionGeometryRemover"
                                              and torch.equal(latents[0], latents[1]) and torch.equal(ctx_cur[2], ctx_cur[3]))
+            edit_row_only = edit_row_only and not controller.rows_identical
             # :183-187 — the first optimised step after a fast start runs num_first_optim_steps iterations and keeps the inputs of
             # the lowest-loss one (:236-239); every other step runs one iteration and keeps its updated latents (:252-254)
             if (not first_optim_complete) and fast_start_steps > 0.0:
@@ -268,7 +303,16 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
             best_loss, latents_new, context_new = 1e8, None, None
             for _opt_iter in range(num_optim_steps):
                 # :218-273 — forward with losses + autograd back to latent / embedding (one hipGraph, reused across edits)
-                g_lat, g_ctx, latents_in, context_in = opt_pass.grads(controller, lat_cur, ctx_cur, t)
+                if edit_row_only and num_optim_steps == 1:
+                    global REF_AHEAD_PASSES
+                    REF_AHEAD_PASSES += 1
+                    controller.use_ahead, controller._ref_pos = True, 0
+                    try:
+                        g_lat, g_ctx, latents_in, context_in = opt_pass.grads(controller, lat_cur, ctx_cur, t, edit_row_only=True)
+                    finally:
+                        controller.use_ahead = False
+                else:
+                    g_lat, g_ctx, latents_in, context_in = opt_pass.grads(controller, lat_cur, ctx_cur, t)
                 if num_optim_steps > 1:
                     loss_val = float(controller.loss)                                                      # :236 (host sync)
                     if loss_val < best_loss:
@@ -298,7 +342,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
             if context_new is not None and optimize_embeddings:                                            # :319-322
                 context = context_new.detach()
                 context_save = context
-            latents = cfg_pass(latents, context, t)                                                          # :343-351
+            latents = cfg_pass(latents, context, t, ahead)                                                   # :343-351
             if late:
                 _after_opt_pass(controller, log_dev, i, skip_optim_steps, edit_type, use_adaptive_optimization, removal_loss_value_in, global_loss_log_dict,
                                 handle=log_handle)
@@ -307,7 +351,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
         else:
             if context_save is not None:
                 context = context_save
-            latents = cfg_pass(latents, context, t)                                                          # :366-368
+            latents = cfg_pass(latents, context, t, ahead)                                                   # :366-368
 
         if ddim_latents is not None:                                                                       # :375-377
             i_n = len(ddim_latents) - 2 - i

@@ -37,7 +37,7 @@ def wait_in_flight():
 
 
 class _Entry:
-    __slots__ = ("seen", "graph", "x", "t", "ctx", "out", "kv", "kv_src", "kv_ver")
+    __slots__ = ("seen", "graph", "x", "t", "ctx", "out", "kv", "kv_src", "kv_ver", "ahead", "serial")
 
     def __init__(self):
         self.seen = 0
@@ -45,6 +45,8 @@ class _Entry:
         self.kv = None
         self.kv_src = None
         self.kv_ver = -1
+        self.ahead = None        # reference rows this pass leaves for the NEXT step's optimisation pass (controller.collect_ahead)
+        self.serial = None
 
 
 def _src_version(ctx_src):
@@ -55,6 +57,7 @@ def _src_version(ctx_src):
     return ctx_src, ctx_src._version
 
 
+_SERIAL = itertools.count(1)   # names a captured pass whose tensors another captured pass reads by address (never reused, unlike id())
 CAPTURES = {"unet": 0, "opt": 0}      # hipGraph captures so far in this process (no-grad passes / optimisation passes): reporting only
 
 
@@ -101,45 +104,88 @@ class GraphedUNet:
             else:
                 torch.bmm(e2.unsqueeze(0).expand(2, -1, -1), w2, out=buf)
 
+    @staticmethod
+    def _fill_t(buf, t):
+        """Timestep(s) of a replay into the pass's device vector without a host-to-device copy: one fill per run of equal values."""
+        if isinstance(t, tuple):
+            i = 0
+            while i < len(t):
+                j = i
+                while j + 1 < len(t) and int(t[j + 1]) == int(t[i]):
+                    j += 1
+                buf[i:j + 1].fill_(int(t[i]))
+                i = j + 1
+        else:
+            buf.fill_(int(t))
+
     @torch.no_grad()
-    def __call__(self, key: Hashable, x: torch.Tensor, t, ctx: torch.Tensor, ctx_src: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, bool]:
+    def __call__(self, key: Hashable, x: torch.Tensor, t, ctx: torch.Tensor, ctx_src: Optional[torch.Tensor] = None,
+                 controller=None) -> Tuple[torch.Tensor, bool]:
         """-> (noise_pred, replayed).  ``replayed`` tells the caller that no Python side effect ran.
+        ``t``: one timestep, or a tuple with one timestep per batch row (the CFG pass that carries the next step's reference row).
         ``ctx_src``: the tensor ``ctx`` is a pure function of (the caller's context tensor itself, or the one it was sliced / concatenated
         from).  While the SAME tensor object at the SAME ``_version`` comes back, the cached K / V of the text rows stay valid; a strong
-        reference is held, so another tensor cannot take its identity.  None: re-compute on every call."""
+        reference is held, so another tensor cannot take its identity.  None: re-compute on every call.
+        ``controller`` with ``collect_ahead`` set: the pass leaves row 0's per-layer (q, k, v, out) (attention_processors._leave_ahead); a
+        captured pass hands the controller the STATIC tensors of its graph, named by the entry's serial number (an eager pass: serial
+        None — its tensors are not addresses a captured consumer may bake in)."""
+        collect = controller is not None and getattr(controller, "collect_ahead", False)
+
+        def t_tensor():
+            return torch.tensor([int(v) for v in t], device=x.device, dtype=torch.long) if isinstance(t, tuple) else t
+
+        def eager():
+            out = self.unet(x, t_tensor(), encoder_hidden_states=ctx)["sample"]
+            if collect:
+                controller.ref_stash, controller.ref_stash_serial = None, None
+            return out, False
+
         if not ENABLED or torch.is_grad_enabled():
-            return self.unet(x, t, encoder_hidden_states=ctx)["sample"], False
+            return eager()
         key = (key, tuple(x.shape), x.dtype, tuple(ctx.shape), ctx.dtype)
         e = self.entries.get(key)
         if e is None:
             e = self.entries[key] = _Entry()
         e.seen += 1
         if e.seen == 1:                                        # warm-up pass, eager
-            return self.unet(x, t, encoder_hidden_states=ctx)["sample"], False
-        tval = int(t)
+            return eager()
+
+        def hand_over():
+            if collect:
+                ok = e.ahead is not None and len(e.ahead) == controller.num_att_layers and all(isinstance(a, tuple) for a in e.ahead)
+                controller.ref_stash = e.ahead if ok else None
+                controller.ref_stash_serial = e.serial if ok else None
+
         if e.graph is None:                                    # capture (the captured pass also executes once: replay below)
             e.x = x.clone()
             e.ctx = ctx.clone()
-            e.t = torch.tensor([tval], device=x.device, dtype=torch.long)
+            e.t = torch.zeros(len(t) if isinstance(t, tuple) else 1, device=x.device, dtype=torch.long)
+            self._fill_t(e.t, t)
             if KV_CACHE:
                 e.kv = {}
                 self._refresh_kv(e)
                 e.kv_src, e.kv_ver = _src_version(ctx_src)
+            wait_in_flight()                                   # first: work the side thread queues after a synchronize would not be drained
             torch.cuda.synchronize()
             CAPTURES["unet"] += 1
-            wait_in_flight()
             g = torch.cuda.CUDAGraph()
             ops.zero_pool_reset()
             from . import attention_processors as _ap
             _ap.KV_PROVIDER = e.kv
+            if collect:
+                controller._ahead = None
             try:
                 with torch.cuda.graph(g):
                     e.out = self.unet(e.x, e.t, encoder_hidden_states=e.ctx)["sample"]
             finally:
                 _ap.KV_PROVIDER = None
             ops.zero_pool_reset()
+            if collect:
+                e.ahead, e.serial = controller._ahead, next(_SERIAL)       # (the list keeps the graph's tensors alive: never reused inside its pool)
+                controller._ahead = None
             e.graph = g
             e.graph.replay()
+            hand_over()
             return e.out, False                                # Python side effects DID run (during capture)
         e.x.copy_(x)
         e.ctx.copy_(ctx)
@@ -148,15 +194,16 @@ class GraphedUNet:
             self._refresh_kv(e)
             e.kv_src, e.kv_ver = src, ver
             self.kv_refreshes += 1
-        e.t.fill_(tval)
+        self._fill_t(e.t, t)
         e.graph.replay()
         self.replays += 1
+        hand_over()
         return e.out, True
 
 
 # Captured optimisation passes, shared by all edits of the process.  key -> dict(graph, lat, ctx, t, g_lat, g_ctx, loss, log)
 _OPT_GRAPHS: Dict[Hashable, dict] = {}
-_OPT_GRAPH_LIMIT = 6            # each holds the activations of a batch-2 forward + backward in its private pool
+_OPT_GRAPH_LIMIT = 10           # each holds the activations of a batch-1 or batch-2 forward + backward in its private pool
 _SEEN_LAYERS: Dict[tuple, tuple] = {}   # (id(unet), latent shape) -> (weakref, [(S, heads)] of the hooked layers), learnt from the first eager pass
 
 
@@ -184,9 +231,6 @@ def _import_loss_state(controller, state):
         return fn(state)
     controller.loss = state[0]
     controller.loss_log_dict = {k: (dict(v) if isinstance(v, dict) else v) for k, v in state[1].items()}
-
-
-_SERIAL = itertools.count(1)
 
 
 def _hand_over_ref(controller, st, t):
@@ -221,25 +265,34 @@ class GraphedOptPass:
         self.transform_coords = transform_coords
         self.guidance_scale = guidance_scale
 
-    def _eager(self, controller, lat, ctx, t, skip_scheduler=False):
+    def _eager(self, controller, lat, ctx, t, skip_scheduler=False, edit_row_only=False):
         from .diffusion import diffusion_step
         from .optimization import _latent_grads
         with torch.enable_grad():
-            diffusion_step(self.model, controller, lat, ctx[2:] if self.ctx_text_rows_only else ctx, t, self.guidance_scale,
+            if edit_row_only:          # the reference row's layer tensors come from controller.ref_stash (editor.REF_AHEAD): the UNet runs the edit row
+                lat_in, ctx_in = lat[-1:], ctx[-1:]
+            else:
+                lat_in, ctx_in = lat, (ctx[2:] if self.ctx_text_rows_only else ctx)
+            diffusion_step(self.model, controller, lat_in, ctx_in, t, self.guidance_scale,
                            transform_coords=self.transform_coords, use_cfg=False, return_noise=True, skip_scheduler=skip_scheduler)
             return _latent_grads(lat, controller.loss, ctx)
 
-    def _key(self, controller, lat, ctx):
+    def _key(self, controller, lat, ctx, edit_row_only=False):
         return (id(self.model.unet), controller.graph_key(), controller.table_signature(), tuple(lat.shape), tuple(ctx.shape),
-                self.model.unet.dtype, bool(getattr(controller, "collect_ref", False)))   # (a pass captured without the collection keeps nothing)
+                self.model.unet.dtype, bool(getattr(controller, "collect_ref", False)),   # (a pass captured without the collection keeps nothing)
+                controller.ref_stash_serial if edit_row_only else None)                   # (the captured pass whose tensors this one reads by address)
 
-    def grads(self, controller, latents: torch.Tensor, context: torch.Tensor, t):
+    def grads(self, controller, latents: torch.Tensor, context: torch.Tensor, t, edit_row_only: bool = False):
+        """``edit_row_only``: the reference row of this step went through the UNet in the previous step's CFG pass, which left its per-layer
+        q / k / v in ``controller.ref_stash`` (a captured pass's static tensors, ``ref_stash_serial``); forward + backward then run on
+        the edit row alone.  Gradients keep the full shapes (zero rows for the reference sample, as before)."""
         lat = latents.detach().float().requires_grad_(True)                    # editor.py:218
         ctx = context.detach().float().requires_grad_(True)                    # editor.py:221-224
         usable = (ENABLED and OPT_PASS_ENABLED and lat.is_cuda and hasattr(controller, "graph_key") and getattr(controller, "persistent_tables", False))
-        controller.ref_stash_serial = controller.ref_stash_t = None           # (an eager pass leaves tensors no captured CFG pass may read)
+        if not edit_row_only:
+            controller.ref_stash_serial = controller.ref_stash_t = None       # (an eager pass leaves tensors no captured CFG pass may read)
         if not usable:
-            return self._eager(controller, lat, ctx, t) + (lat, ctx)
+            return self._eager(controller, lat, ctx, t, edit_row_only=edit_row_only) + (lat, ctx)
         uid = (id(self.model.unet), tuple(lat.shape))                          # the hooked layers' resolutions follow the latent size
         seen = _SEEN_LAYERS.get(uid)
         if seen is not None and seen[0]() is not self.model.unet:              # a dead model's id was recycled
@@ -247,7 +300,7 @@ class GraphedOptPass:
             for k in [k for k in _OPT_GRAPHS if k[0] == uid[0]]:
                 _OPT_GRAPHS.pop(k)["graph"].reset()
         if seen is None:                                                       # very first pass on this UNet: eager, learn the layers
-            out = self._eager(controller, lat, ctx, t)
+            out = self._eager(controller, lat, ctx, t, edit_row_only=edit_row_only)
             _SEEN_LAYERS[uid] = (weakref.ref(self.model.unet),
                                  sorted((S, c["f"], c["D"]) for S, c in controller.masks_cache_dict.items() if "f" in c))
             return out + (lat, ctx)
@@ -257,7 +310,7 @@ class GraphedOptPass:
             controller.prebuild_tables(layers, q_like, self.transform_coords)
         dev = lat.device
         controller.sync_loss_weights(dev)
-        key = self._key(controller, lat, ctx)
+        key = self._key(controller, lat, ctx, edit_row_only)
         st = _OPT_GRAPHS.get(key)
         if st is None:
             while len(_OPT_GRAPHS) >= _OPT_GRAPH_LIMIT:                        # oldest first
@@ -270,7 +323,7 @@ class GraphedOptPass:
             g = torch.cuda.CUDAGraph()
             ops.zero_pool_reset()
             with torch.cuda.graph(g):
-                st["g_lat"], st["g_ctx"] = self._eager(controller, st["lat"], st["ctx"], st["t"], skip_scheduler=True)
+                st["g_lat"], st["g_ctx"] = self._eager(controller, st["lat"], st["ctx"], st["t"], skip_scheduler=True, edit_row_only=edit_row_only)
             ops.zero_pool_reset()
             st["state"] = _export_loss_state(controller)
             st["graph"] = g

@@ -5,6 +5,7 @@ tensor or a missing library raises.
 from __future__ import annotations
 
 import ctypes
+import threading
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -55,17 +56,30 @@ class _ZeroPool:
         return v
 
 
-_ZEROS = _ZeroPool()
+# One pool / workspace / ticket PER LAUNCHING THREAD: the library's contract is one stream at a time per caller, and
+# editor.start_ahead adds a second launching thread on a side stream beside the caller's.  A chunk zero-filled on one stream must not be
+# sliced and consumed on the other before the fill has run there, and the even split's arrival counters / part slots and the loss tail's
+# ticket must not be shared by two launches in flight on different streams.  Captures and replays all happen on the caller's thread.
+_TLS = threading.local()
+_POOL_GEN = [0]
+
+
+def _zeros_pool() -> _ZeroPool:
+    pool = getattr(_TLS, "zeros", None)
+    if pool is None:
+        pool = _TLS.zeros = _ZeroPool()
+    pool.gen = _POOL_GEN[0]
+    return pool
 
 
 def zeros_f32(n: int, device) -> torch.Tensor:
-    """n zeroed floats (a slice of the current pre-zeroed chunk)."""
-    return _ZEROS.take(n, device)
+    """n zeroed floats (a slice of the calling thread's current pre-zeroed chunk)."""
+    return _zeros_pool().take(n, device)
 
 
 def zero_pool_reset() -> None:
-    """Called around every hipGraph capture (graphs.py): the next request starts a fresh chunk."""
-    _ZEROS.gen += 1
+    """Called around every hipGraph capture (graphs.py): the next request (of any thread) starts a fresh chunk."""
+    _POOL_GEN[0] += 1
 
 
 def _need(t: torch.Tensor, name: str, dtype=None):
@@ -179,22 +193,23 @@ def _attn_cfg(cfg: Optional[dict], nsplit: int = 0):
     return _lib.GdAttnCfg(int(c["even_split"]), int(c["qb"]), int(c["ks"]), int(nsplit), int(c["handoff"]))
 
 
-_SK_WS = {}          # device index -> zero-initialised workspace of the even split (persistent: captured graphs hold its address)
+_SK_WS = {}          # (thread, device index) -> zero-initialised workspace of the even split (persistent: captured graphs hold its address)
 _SK_WS_RETIRED = []  # buffers replaced by a larger one (never freed: see _attn_ws)
 
 
 def _attn_ws(lib, dev: torch.device, tot_bh: int, N: int, M: int):
     """Workspace of the even split (gd_attn_fwd): arrival counters (zero before the first launch, every launch leaves them zero) + part slots.  One
-    buffer per device, grown on demand — all launches of a process run on one stream at a time (the library's contract)."""
+    buffer per launching thread and device, grown on demand — all launches of a thread run on one stream at a time (the library's contract)."""
     need = int(lib.gd_attn_fwd_workspace_bytes(tot_bh, N, M))
-    ws = _SK_WS.get(dev.index)
+    wkey = (threading.get_ident(), dev.index)
+    ws = _SK_WS.get(wkey)
     if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
             # (a buffer allocated during a capture lives in that graph's private pool and would be zero-filled again by every replay)
             raise _lib.GeodiffError("attn_fwd: the even-split workspace must exist before a graph capture (run one eager pass first)")
         if ws is not None:
             _SK_WS_RETIRED.append(ws)                      # captured passes may still address the smaller buffer: it stays alive
-        ws = _SK_WS[dev.index] = torch.zeros(max(need, 40 << 20), dtype=torch.uint8, device=dev)
+        ws = _SK_WS[wkey] = torch.zeros(max(need, 40 << 20), dtype=torch.uint8, device=dev)
     return ws
 
 
@@ -547,15 +562,16 @@ def _ip(t):
     return 0 if t is None else t.data_ptr()
 
 
-_TICKETS = {}        # device index -> one zeroed int32 (the arrival ticket of gd_edit_losses_fwd's tail: zero before every launch, left zero by it)
+_TICKETS = {}        # (thread, device index) -> one zeroed int32 (the arrival ticket of gd_edit_losses_fwd's tail: zero before every launch, left zero by it)
 
 
 def _ticket(dev: torch.device) -> torch.Tensor:
-    t = _TICKETS.get(dev.index)
+    tkey = (threading.get_ident(), dev.index)
+    t = _TICKETS.get(tkey)
     if t is None:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.GeodiffError("edit_losses_fused: the arrival ticket must exist before a graph capture (run one eager pass first)")
-        t = _TICKETS[dev.index] = torch.zeros(4, dtype=torch.int32, device=dev)
+        t = _TICKETS[tkey] = torch.zeros(4, dtype=torch.int32, device=dev)
     return t
 
 

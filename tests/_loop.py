@@ -59,11 +59,13 @@ def make_controller(kind, c, inp, device="cuda:0"):
     return ctrl, lw
 
 
-def run_device_loop(kind_name, dtype, skip_refs=(False, "3rows", True)):
+def run_device_loop(kind_name, dtype, skip_refs=(False, "3rows", True, "ahead")):
     """-> (fixture dict, fixture name, runs) with runs = [(latents f32 cpu, loss log, final removal weight, first latent update, weight
-    trajectory, CFG passes that took their reference row from the optimisation pass)] — one run per entry of ``skip_refs``: False = the
-    reference's 4-row CFG batch; "3rows" = without the unused uncond_ref row; True = the product default: that, and at steps with an
-    optimisation pass the reference row's layer tensors come from that pass (editor.REF_FROM_OPT: 2 rows)."""
+    trajectory, CFG passes that took their reference row from another pass, optimisation passes that ran on the edit row alone)] — one run
+    per entry of ``skip_refs``: False = the reference's 4-row CFG batch; "3rows" = without the unused uncond_ref row; True = that, and at
+    steps with an optimisation pass the reference row's layer tensors come from that pass (editor.REF_FROM_OPT: 2 rows); "ahead" = the
+    product default (r06): additionally the reference row of an optimisation step goes through the UNet one step ahead, in the previous
+    step's CFG pass, and the optimisation pass runs forward + backward on the edit row alone (editor.REF_AHEAD)."""
     from geodiffuser_amd import editor
     from geodiffuser_amd.attention_processors import VanillaAttentionProcessor
     fixture, cfgname, kind, full, name = LOOP_KINDS[kind_name]
@@ -79,7 +81,7 @@ def run_device_loop(kind_name, dtype, skip_refs=(False, "3rows", True)):
     coords = torch.from_numpy(inp["coords"])
     ctrl, lw = make_controller(kind, c, inp)
     prev = (editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS, editor.SKIP_UNCOND_REF)
-    prev_rfo = editor.REF_FROM_OPT
+    prev_rfo, prev_ahead = editor.REF_FROM_OPT, editor.REF_AHEAD
     editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS = c["steps"], c["guidance"], c["skip_optim"]
     runs, updates, weights = [], [], []
     orig_apply = editor._apply_latent_update
@@ -95,8 +97,9 @@ def run_device_loop(kind_name, dtype, skip_refs=(False, "3rows", True)):
     try:
         for skip_ref in skip_refs:
             editor.SKIP_UNCOND_REF = bool(skip_ref)
-            editor.REF_FROM_OPT = prev_rfo and skip_ref is True
-            n_rfo = editor.REF_FROM_OPT_PASSES
+            editor.REF_FROM_OPT = prev_rfo and skip_ref in (True, "ahead")
+            editor.REF_AHEAD = prev_ahead and skip_ref == "ahead"
+            n_rfo, n_ahead = editor.REF_FROM_OPT_PASSES, editor.REF_AHEAD_PASSES
             updates.clear()
             weights.clear()
             ctrl.reset() if hasattr(ctrl, "reset") else None
@@ -111,10 +114,10 @@ def run_device_loop(kind_name, dtype, skip_refs=(False, "3rows", True)):
                 optimize_latents=True, ddim_latents=ddim, ddim_noise=None, edit_type=kind, fast_start_steps=0.0,
                 num_first_optim_steps=1, use_adaptive_optimization=True, return_type="latents", image_size=c["size"])
             runs.append((lat.float().cpu(), log, float(ctrl.loss_weight_dict["self"]["removal"]), updates[0].clone(), list(weights),
-                         editor.REF_FROM_OPT_PASSES - n_rfo))
+                         editor.REF_FROM_OPT_PASSES - n_rfo, editor.REF_AHEAD_PASSES - n_ahead))
     finally:
         editor._apply_latent_update = orig_apply
-        editor.REF_FROM_OPT = prev_rfo
+        editor.REF_FROM_OPT, editor.REF_AHEAD = prev_rfo, prev_ahead
         editor.NUM_DDIM_STEPS, editor.GUIDANCE_SCALE, editor.SKIP_OPTIM_STEPS, editor.SKIP_UNCOND_REF = prev
         p.unet.set_attn_processor(VanillaAttentionProcessor())
     return g, fixture, runs

@@ -589,6 +589,8 @@ def main():
             d = 1e3 * (time.perf_counter() - gc_stat["t"])
             gc_stat["pauses"] += 1; gc_stat["ms"] += d; gc_stat["max_ms"] = max(gc_stat["max_ms"], d)
     gdist.barrier()
+    if getattr(editor, "PASS_TIMES", None) is not None:
+        editor.PASS_TIMES.clear()                 # (the warm-up edits' eager passes and captures are not what the report is about)
     from geodiffuser_amd import graphs as _graphs
     cap0 = dict(_graphs.CAPTURES)
     ms0 = torch.cuda.memory_stats(dev) if torch.cuda.is_available() else {}
@@ -620,6 +622,9 @@ def main():
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
     timer.enabled = False
+    if getattr(editor, "PASS_TIMES", None) is not None:
+        print("[bench] device time per pass over the timed edits (GD_PASS_TIMES=1; event pairs inside the stream: excludes host gaps between passes)\n"
+              + editor.pass_times_report(), file=sys.stderr, flush=True)
     # one line per rank on stderr: which device it drove and what its first edit cost (first contact with an N-GPU node)
     print(f"[bench rank {rank}/{world}] device {dev} ({torch.cuda.get_device_name(local)}), first warm-up edit "
           f"{(warm_s[0] if warm_s else float('nan')):.2f} s, timed region {elapsed:.3f} s for {args.steps} edit(s), cyclic-collector pauses "

@@ -933,7 +933,14 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
                 raise RuntimeError("ref_stash does not match this pass (query scaling / shape / dtype): disable GD_REF_FROM_OPT")
             q_base, k_base, v_base, van_base = ref
         q_edit, k_edit, v_edit = q[e0:e1], k[e0:e1], v[e0:e1]
-        segs = [(q[:cb], k[:cb], v[:cb], out_full[:cb], None)]
+        v0 = 0
+        if self.collect_ahead and k.shape[1] >= 4096 and cb > 1:
+            # the carried row (row 0, REF_AHEAD) as its own launch at 64^2 tokens and up: with it the launch below has 25 heads = 325-335
+            # units of 256 queries for 256 CUs — 120 us as one launch (two rounds, or the even split's three segments per workgroup)
+            # against 66 + 33 us for the one-round 20-head launch and the 5-head launch in unit parts (tools/attn_one.py FORM=cfg4n[_split])
+            ops.attn_fwd([(q[:1], k[:1], v[:1], out_full[:1], None)], scale, heads=heads, q_scaled=self.q_scaled_tok)
+            v0 = 1
+        segs = [(q[v0:cb], k[v0:cb], v[v0:cb], out_full[v0:cb], None)]
         replace_out = out_full[cb:]
         edit_out = ident_out = edit_act = None
         if PAIR_BLEND and FUSED_WARP and k.shape[1] <= 128 and q.shape[2] == heads * 64 and ((not remover and blend) or (remover and not blend)):

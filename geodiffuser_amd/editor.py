@@ -63,6 +63,40 @@ REF_AHEAD = os.environ.get("GD_REF_AHEAD", "1") == "1"
 REF_AHEAD_PASSES = 0        # optimisation passes that ran on the edit row alone so far
 
 
+PASS_TIMES = {} if os.environ.get("GD_PASS_TIMES", "0") == "1" else None      # kind -> [(start event, end event)]
+
+
+def _timed_passes(cfg_pass, opt_pass, controller):
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def cfg(lat, ctx, tt, ahead=None):
+        by_stash = controller.ref_stash_serial is not None and controller.ref_stash_t == int(tt)
+        kind = "cfg 2 rows (reference row from a stash)" if by_stash else ("cfg 4 rows (carries the next reference row)" if ahead is not None else "cfg 3 rows")
+        a = ev()
+        out = cfg_pass(lat, ctx, tt, ahead)
+        PASS_TIMES.setdefault(kind, []).append((a, ev()))
+        return out
+
+    class _Opt:
+        def grads(self, c, lat, ctx, t, edit_row_only=False):
+            a = ev()
+            out = opt_pass.grads(c, lat, ctx, t, edit_row_only=edit_row_only)
+            PASS_TIMES.setdefault("optimisation pass, edit row only" if edit_row_only else "optimisation pass, 2 rows", []).append((a, ev()))
+            return out
+
+    return cfg, _Opt()
+
+
+def pass_times_report() -> str:
+    torch.cuda.synchronize()
+    rows = [f"{k}: {len(v)} passes, {sum(a.elapsed_time(b) for a, b in v) / len(v):.2f} ms each" for k, v in sorted(PASS_TIMES.items())]
+    PASS_TIMES.clear()
+    return "\n".join(rows)
+
+
 def ref_from_opt_supported() -> bool:
     """Both passes hand the hooked layers queries that carry scale * log2(e) from the projection's epilogue (the same 16-bit values)."""
     from . import attention_processors as AP
@@ -257,6 +291,8 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
         return diffusion_step(model, controller, lat, ctx, tt, guidance_scale, transform_coords=transform_coordinates)
 
     opt_pass = GraphedOptPass(model, transform_coordinates, guidance_scale)
+    if PASS_TIMES is not None:          # development aid (GD_PASS_TIMES=1): device time per kind of pass, HIP events on the launch stream
+        cfg_pass, opt_pass = _timed_passes(cfg_pass, opt_pass, controller)
     first_optim_complete = False
     # :157-160 concatenates the same two tensors at every step; built ONCE here, so the context of a step is the same tensor OBJECT
     # until an optimisation pass replaces it — which is what the captured passes' text-row K / V cache keys on (graphs.GraphedUNet)

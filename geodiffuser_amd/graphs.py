@@ -204,6 +204,7 @@ class GraphedUNet:
 # Captured optimisation passes, shared by all edits of the process.  key -> dict(graph, lat, ctx, t, g_lat, g_ctx, loss, log)
 _OPT_GRAPHS: Dict[Hashable, dict] = {}
 _OPT_GRAPH_LIMIT = 10           # each holds the activations of a batch-1 or batch-2 forward + backward in its private pool
+_WARMED = set()                 # (uid, form) whose first pass has run eagerly (library warm-up outside any capture)
 _SEEN_LAYERS: Dict[tuple, tuple] = {}   # (id(unet), latent shape) -> (weakref, [(S, heads)] of the hooked layers), learnt from the first eager pass
 
 
@@ -297,6 +298,7 @@ class GraphedOptPass:
         seen = _SEEN_LAYERS.get(uid)
         if seen is not None and seen[0]() is not self.model.unet:              # a dead model's id was recycled
             seen = None
+            _WARMED.discard((uid, "edit_row_only"))
             for k in [k for k in _OPT_GRAPHS if k[0] == uid[0]]:
                 _OPT_GRAPHS.pop(k)["graph"].reset()
         if seen is None:                                                       # very first pass on this UNet: eager, learn the layers
@@ -304,6 +306,11 @@ class GraphedOptPass:
             _SEEN_LAYERS[uid] = (weakref.ref(self.model.unet),
                                  sorted((S, c["f"], c["D"]) for S, c in controller.masks_cache_dict.items() if "f" in c))
             return out + (lat, ctx)
+        if edit_row_only and (uid, "edit_row_only") not in _WARMED:
+            # the first pass of this FORM on this UNet runs eagerly too: forward + backward at batch 1 meet convolution / GEMM shapes no pass
+            # has run yet, and a solver search (MIOpen find) or a library workspace allocation inside a stream capture invalidates it
+            _WARMED.add((uid, "edit_row_only"))
+            return self._eager(controller, lat, ctx, t, edit_row_only=True) + (lat, ctx)
         layers = seen[1]
         if not all(S in controller.masks_cache_dict and "f" in controller.masks_cache_dict[S] for S, *_ in layers):
             q_like = torch.empty(1, device=lat.device, dtype=self.model.unet.dtype)

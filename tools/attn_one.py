@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from geodiffuser_amd import ops
 BH, N, M = int(os.environ.get("BH", "32")), 4096, 4096
 torch.manual_seed(0)
+if "ES" in os.environ:       # even split of the key tiles: 0 never, 1 where the launcher's cost model says so (default), 2 every launch that can be split
+    ops.ATTN_CFG.update(even_split=int(os.environ["ES"]))
 QS = os.environ.get("QS", "0") == "1"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 DT = torch.float16 if os.environ.get("DT", "bf16") == "fp16" else torch.bfloat16      # DT=fp16: the same launches in the reference's autocast dtype
@@ -22,6 +24,27 @@ if os.environ.get("FORM") == "cfg":
     segs = [(q[0:1], k[0:1], v[0:1], o[0], None), (q[1:2], k[1:2], v[1:2], o[1], None),
             (q[1:2], k[1:2], v[1:2], act, None, (idx, w, m), (rows_p, n_dev)), (q[2:3], k[1:2], v[1:2], o[2], None)]
     run = lambda: ops.attn_fwd(segs, 0.125, heads=heads, q_scaled=True)        # the product path: even-split workspace, parts for the row-list units
+elif os.environ.get("FORM") in ("cfg4n", "cfg4n_split"):
+    # the CFG pass's launch when it carries the next step's reference row (editor.REF_AHEAD): 3 vanilla rows + the row-list segment + the
+    # replace segment = 25 heads; cfg4n_split: the carried row as its own 5-head launch next to the 20-head launch of FORM=cfg
+    heads, K, C = 5, 15, 320
+    q = (torch.randn(4, N, C, device="cuda") * 0.2).to(DT); k = torch.randn(4, N, C, device="cuda").to(DT); v = torch.randn(4, N, C, device="cuda").to(DT)
+    yy, xx = torch.meshgrid(torch.arange(64), torch.arange(64), indexing="ij")
+    m = (((yy - 33) ** 2 + (xx - 33) ** 2) < 13 ** 2).float().reshape(-1).cuda()
+    idx = torch.full((N, K), -1, dtype=torch.int32, device="cuda"); w = torch.zeros(N, K, device="cuda")
+    for j in range(4):
+        idx[:, j] = torch.where(m > 0, (torch.arange(N, device="cuda") + 64 * 3 + 5 + j) % N, torch.full((N,), -1, device="cuda")).int(); w[:, j] = 0.25
+    rows = torch.nonzero(m > 0).reshape(-1).int(); R = rows.numel(); Rp = -(-R // 256) * 256
+    rows_p = torch.cat([rows, torch.zeros(Rp - R, dtype=torch.int32, device="cuda")]).contiguous(); n_dev = torch.tensor([R], dtype=torch.int32, device="cuda")
+    o = torch.empty_like(q); act = torch.empty(1, Rp, C, device="cuda", dtype=DT)
+    rl = (q[2:3], k[2:3], v[2:3], act, None, (idx, w, m), (rows_p, n_dev)); rep = (q[3:4], k[2:3], v[2:3], o[3:4], None)
+    if os.environ.get("FORM") == "cfg4n":
+        segs = [(q[0:3], k[0:3], v[0:3], o[0:3], None), rl, rep]
+        run = lambda: ops.attn_fwd(segs, 0.125, heads=heads, q_scaled=True)
+    else:
+        s1 = [(q[0:1], k[0:1], v[0:1], o[0:1], None)]; s2 = [(q[1:3], k[1:3], v[1:3], o[1:3], None), rl, rep]
+        def run():
+            ops.attn_fwd(s1, 0.125, heads=heads, q_scaled=True); ops.attn_fwd(s2, 0.125, heads=heads, q_scaled=True)
 elif os.environ.get("FORM") == "cfgb4":
     # the CFG pass's 64^2 launch of a BATCH of 4 edits (geodiffuser_amd/batch.py): the vanilla rows of all edits as one segment (8 rows x 5
     # heads), one warped / row-list segment per edit (own tables), the replace attention of all edits as one segment: 80 heads, 6 segments

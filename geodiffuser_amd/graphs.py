@@ -23,6 +23,7 @@ from . import ops
 
 ENABLED = os.environ.get("GD_GRAPHS", "1") == "1"
 OPT_PASS_ENABLED = os.environ.get("GD_OPT_GRAPH", "1") == "1"
+KV_REFRESH_GRAPH = os.environ.get("GD_KV_REFRESH_GRAPH", "1") == "1"
 KV_CACHE = os.environ.get("GD_KV_CACHE", "1") == "1"     # captured no-grad passes: text-row K / V projections outside the graph, per context
 
 
@@ -37,7 +38,7 @@ def wait_in_flight():
 
 
 class _Entry:
-    __slots__ = ("seen", "graph", "x", "t", "ctx", "out", "kv", "kv_src", "kv_ver", "ahead", "serial")
+    __slots__ = ("seen", "graph", "x", "t", "ctx", "out", "kv", "kv_src", "kv_ver", "kv_graph", "ahead", "serial")
 
     def __init__(self):
         self.seen = 0
@@ -45,6 +46,7 @@ class _Entry:
         self.kv = None
         self.kv_src = None
         self.kv_ver = -1
+        self.kv_graph = None     # the 16 projections of _refresh_kv as one captured launch (the context changes at every optimisation step)
         self.ahead = None        # reference rows this pass leaves for the NEXT step's optimisation pass (controller.collect_ahead)
         self.serial = None
 
@@ -77,6 +79,8 @@ class GraphedUNet:
         for e in self.entries.values():
             if e.graph is not None:
                 e.graph.reset()
+            if e.kv_graph is not None:
+                e.kv_graph.reset()
         self.entries.clear()
         torch.cuda.synchronize()
 
@@ -184,6 +188,11 @@ class GraphedUNet:
                 e.ahead, e.serial = controller._ahead, next(_SERIAL)       # (the list keeps the graph's tensors alive: never reused inside its pool)
                 controller._ahead = None
             e.graph = g
+            if e.kv and KV_REFRESH_GRAPH:                      # (same capture event as the pass: not counted separately)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    self._refresh_kv(e)
+                e.kv_graph = g2
             e.graph.replay()
             hand_over()
             return e.out, False                                # Python side effects DID run (during capture)
@@ -191,7 +200,14 @@ class GraphedUNet:
         e.ctx.copy_(ctx)
         src, ver = _src_version(ctx_src)
         if e.kv and (src is None or src is not e.kv_src or ver != e.kv_ver):
-            self._refresh_kv(e)
+            # Inside the optimisation window the edit row's embedding changes at every optimisation step and each of the step forms (2 / 3 /
+            # 4 rows) keeps its own K / V: ~35 refreshes per edit, 16 eagerly dispatched batched GEMMs each with ~20 us of host gap between
+            # them (profiles/r06_gap_causes.md, a traced run: 11.6 ms of idle device per edit; untraced the host is mostly ahead: 1-4 ms per edit).
+            # Captured once, right behind the pass's own capture.
+            if e.kv_graph is not None:
+                e.kv_graph.replay()
+            else:
+                self._refresh_kv(e)
             e.kv_src, e.kv_ver = src, ver
             self.kv_refreshes += 1
         self._fill_t(e.t, t)

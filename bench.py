@@ -446,6 +446,7 @@ def dry_run(args) -> int:
           f"{args.steps} edit(s)", file=sys.stderr, flush=True)
     per_rank = gdist.gather_over_ranks(elapsed, device="cpu")
     first = gdist.gather_over_ranks(warm, device="cpu")
+    cores_by_rank = _cores_by_rank(gdist, world, "cpu")
     elapsed = gdist.max_over_ranks(elapsed, device="cpu")
     if rank == 0:
         print(json.dumps({"metric": "DRY RUN - no edit executed (launcher / rendezvous / broadcast / reporting check)", "value": None,
@@ -453,8 +454,18 @@ def dry_run(args) -> int:
                           "config": {"edits_in_flight_per_gpu": ppg, "device_of_rank": [gdist.local_device_index(r) for r in range(world)],
                                      "weights_broadcast_bytes": nbytes, "per_rank_s": per_rank, "first_warmup_edit_s": first,
                                      "weights_equal_after_broadcast": all(abs(p - probes[0]) < 1e-9 for p in probes),
+                                     "host_cores_by_rank": cores_by_rank,
                                      "edits_by_rank": {str(r): [j * world + r for j in range(args.steps)] for r in range(world)}}}), flush=True)
     return 0
+
+
+def _cores_by_rank(gdist, world, device):
+    """[[first core, last core, count] per rank] of the host-core slices dist.pin_rank_to_cores gave the ranks ([] for an unpinned rank)."""
+    mine = gdist.PINNED_CORES or []
+    lo = gdist.gather_over_ranks(float(mine[0]) if mine else -1.0, device=device)
+    hi = gdist.gather_over_ranks(float(mine[-1]) if mine else -1.0, device=device)
+    cnt = gdist.gather_over_ranks(float(len(mine)), device=device)
+    return [[int(a), int(b), int(c)] if c else [] for a, b, c in zip(lo, hi, cnt)]
 
 
 def free_port() -> int:
@@ -631,6 +642,7 @@ def main():
           f"{gc_stat['pauses']} x, {gc_stat['ms']:.1f} ms in all, longest {gc_stat['max_ms']:.1f} ms", file=sys.stderr, flush=True)
     per_rank = gdist.gather_over_ranks(elapsed, device=dev)
     first_edit = gdist.gather_over_ranks(warm_s[0] if warm_s else 0.0, device=dev)
+    cores_by_rank = _cores_by_rank(gdist, world, dev)
     elapsed = gdist.max_over_ranks(elapsed, device=dev)
     if rank == 0:
         timer.replay()
@@ -654,7 +666,8 @@ def main():
                        "tiny_debug_model": bool(args.tiny),
                        # multi-GPU reporting: seconds of the timed region on every rank (value uses their max) and of each rank's
                        # FIRST warm-up edit (solver search unless the find-db has the shapes, graph captures, allocator growth)
-                       "per_rank_s": per_rank, "first_warmup_edit_s": first_edit,
+                       "per_rank_s": per_rank, "first_warmup_edit_s": first_edit, "host_cores_by_rank": cores_by_rank,
+                       "dist_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                        "graph_captures_in_timed_region": captures, "device_allocator_in_timed_region": alloc,
                        "gc": {"pauses": gc_stat["pauses"],
                               "pause_ms_per_edit": round(gc_stat["ms"] / max(1, args.steps), 2), "longest_ms": round(gc_stat["max_ms"], 2)},

@@ -897,8 +897,10 @@ def perform_geometric_edit_batch(edits: Sequence[dict], ldm_stable_model=None, t
         ahead = E.start_ahead(prepass)
         try:
             traj = ddim_inversion_batch(model, images, prompts, num_ddim_steps, guidance_scale, dev)
-        finally:
-            subs, coords, masks, dev_in, batch = ahead.result()
+        except BaseException:
+            E._drain_ahead(ahead)           # the inversion's exception is the one to report; the pre-pass's, if any, is logged
+            raise
+        subs, coords, masks, dev_in, batch = ahead.result()
         _tm("inversion + pre-pass + controllers")
         out, logs = text2image_ldm_stable_batch(
             model, prompts, batch, num_ddim_steps, guidance_scale, latent=traj[-1], ddim_latents=traj, masks_obj=[m[None, None] for m in masks],

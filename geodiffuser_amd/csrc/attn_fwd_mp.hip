@@ -1144,8 +1144,18 @@ k_attn_fwd_w64(const FwdArgs a) {
         const int others = w_last - w_first;
 #define W64_SLOT(W2) (a.sk_ws + (size_t)(2 * (W2) + ((!P && (W2) * a.sk_tpw < unit * TU) ? 1 : 0)) * (2 * GD_SK_SLOT_F4) + (size_t)wave * 18 * 64 + lane)
         bool merger = false, published = false;
+        // sk_mode 0 (gd_attn_cfg_t::handoff = 0): the same protocol under the memory model's terms — an agent-scope RELEASE fence between a
+        // part's stores and its ticket, an agent-scope ACQUIRE fence between the observation "every other part has arrived" and the loads of
+        // those parts.  Mode 1 (default) relies on the cache-policy bits alone (write-through sc0 sc1 stores drained with vmcnt(0) before
+        // the ticket, sc0 sc1 loads served by L2): bit-identical results (tests/test_hip_kernels.py), 2-3 us per launch cheaper.
         if (wg == w_first) {
-            if (tid == 0) sk_last = a.sk_mode != 2 && __hip_atomic_fetch_add(a.sk_cnt + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == others;
+            if (tid == 0) {
+                sk_last = a.sk_mode != 2 && __hip_atomic_fetch_add(a.sk_cnt + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == others;
+                if (sk_last && a.sk_mode == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
             __syncthreads();
             merger = sk_last != 0;
             __syncthreads();                                   // everyone has read the flag before the ticket below rewrites it
@@ -1165,8 +1175,16 @@ k_attn_fwd_w64(const FwdArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
+                if (a.sk_mode == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 const int ticket = a.sk_mode == 2 ? -1 : __hip_atomic_fetch_add(a.sk_cnt + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 sk_last = ticket == others;
+                if (sk_last && a.sk_mode == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
             }
             __syncthreads();
             merger = sk_last != 0;
@@ -1330,7 +1348,7 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
     // Few units (at most half the CUs: the 5-head inversion launch = 80 units): every unit in P equal runs, one per workgroup — one
     // prologue per workgroup and at most P - 1 parts to fetch for the merger (tools/w64_phases.py: with the linear range a quarter of the
     // workgroups walk two segments and a unit has up to five parts)
-    if (a.sk_ws && a.sk_mode >= 1 && a.nwg <= 128 && TU >= 48) {
+    if (a.sk_ws && a.nwg <= 128 && TU >= 48) {
         int P = 256 / a.nwg;
         if (P > 4) P = 4;
         const int tpp = (TU / P) & ~3;                 // parts 1 .. P-1; part 0 takes the rest (64 tiles in 3 parts: 24 + 20 + 20)
@@ -1346,7 +1364,7 @@ static int w64_launch(FwdArgs a, int tot, int pre, int dtype, hipStream_t st, bo
     // workgroups of that segment build warped queries in their prologue (dependent gathers, ~5 us) and then walk the same 64 tiles as
     // everyone else — they finish last and the launch waits for them.  Where the CUs left over allow it, only THEIR units are cut
     // into parts (two or three workgroups each, 20-32 tiles): prologue + hand-off then end long before the dense workgroups.
-    if (!sk && a.sk_ws && a.sk_mode >= 1 && a.cseg >= 0 && a.nwg <= 256 && TU >= 48 && !sk_force) {
+    if (!sk && a.sk_ws && a.cseg >= 0 && a.nwg <= 256 && TU >= 48 && !sk_force) {
         const int cu = a.nwg - a.units_full;                    // units of the row-list segment
         int P = cu > 0 ? 1 + (256 - a.nwg) / cu : 1;
         if (P > 3) P = 3;
@@ -1404,7 +1422,7 @@ int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st) 
         // below 160 units the 64-query kernel needs the even split's workspace (unit parts)
         const long long blocks = (long long)((a.N + 31) / 32) * tot;
         const int T = a.M / ATT_BN;
-        if (qb == 8 && blocks < 1280 && !(a.sk_ws && a.sk_mode >= 1)) {
+        if (qb == 8 && blocks < 1280 && !a.sk_ws) {
             qb = 4;
             ks = (blocks < 1280 && T % 4 == 0) ? 2 : 1;
         }
@@ -1439,7 +1457,7 @@ int gd_attn_fwd_mp_launch(FwdArgs a, int qb, int ks, int dtype, hipStream_t st) 
         a.n_order = n;
     }
     const int pre = a.q_prescaled ? 1 : 0;
-    if (qb == 8) return w64_launch(a, tot, pre, dtype, st, a.sk_mode >= 1 && a.sk_force);
+    if (qb == 8) return w64_launch(a, tot, pre, dtype, st, a.sk_force != 0);
     if (sk_plan(a, tot, qb, ks)) {
 #define GD_SK_LAUNCH(T_, PRE_) k_attn_fwd_mp<T_, 4, 1, 2, PRE_, true><<<a.nwg, 256, 0, st>>>(a)
         if (dtype == GD_F16) { if (pre) GD_SK_LAUNCH(f16_t, true); else GD_SK_LAUNCH(f16_t, false); }

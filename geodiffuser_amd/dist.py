@@ -35,12 +35,45 @@ def local_device_index(local_rank: int) -> int:
     return local_rank // procs_per_gpu()
 
 
-def init(backend: str = None) -> tuple:
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+PINNED_CORES = None      # the host cores this rank was pinned to (None: not pinned)
+
+
+def pin_rank_to_cores(local_rank: int = None, local_world: int = None, max_threads: int = 16):
+    """Give every rank of a node its own slice of the host cores — BEFORE the first GPU call, so that the runtime's helper threads inherit
+    the mask — and size torch's intra-op pool to it.  A rank is a launcher thread that must keep ~1,500-kernel graph launches and the
+    eager glue between them ahead of its GPU, plus the pre-pass worker (editor.start_ahead) and the folder driver's IO threads; left
+    unpinned, N ranks x (those + a torch pool as wide as the whole host each) migrate over each other's cores, and one edit at a time
+    already loses time to host gaps on a quiet box.  Contiguous slices of the cores the process may use (a two-socket
+    node numbers a socket's cores contiguously and hangs GPUs 0..N/2-1 off socket 0); no-op for a single rank per node, where
+    sched_setaffinity does not exist, or with GD_PIN_CORES=0.  -> the rank's cores (list) or None."""
+    global PINNED_CORES
+    if os.environ.get("GD_PIN_CORES", "1") != "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else local_rank
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if local_world is None else local_world
+    if local_world <= 1:
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // local_world
+    if per < 1:
+        return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(max_threads, per - 2 if per > 3 else per)))      # two cores stay with the launcher + the pre-pass worker
+    PINNED_CORES = mine
+    return mine
+
+
+def init(backend: str = None, force: bool = None) -> tuple:
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process, unless ``force`` / GD_DIST_FORCE=1 and a
+    rendezvous is configured: a one-rank group, so that RCCL's initialisation and the broadcast path can run on a one-GPU box)."""
     rank, world, local = env_rank_world()
     if procs_per_gpu() > 1 and backend is None:
         backend = "gloo"
-    if world > 1 and not dist.is_initialized():
+    pin_rank_to_cores()
+    if force is None:
+        force = os.environ.get("GD_DIST_FORCE", "0") == "1"
+    if (world > 1 or (force and "MASTER_PORT" in os.environ)) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
             # every rank must name the SAME port, so a rank cannot pick (or retry) one on its own: the launcher does
@@ -120,7 +153,9 @@ def shard(items: Sequence[T], rank: int, world: int) -> List[T]:
 def broadcast_model(modules: Iterable[torch.nn.Module], src: int = 0, bucket_bytes: int = 256 << 20) -> int:
     """One-off weight broadcast from ``src`` in large flat buckets (xGMI is point-to-point: few, large transfers).
     Returns the number of bytes sent."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    if dist.get_world_size() == 1 and os.environ.get("GD_DIST_FORCE", "0") != "1":        # (forced: a one-rank group really broadcasts, to itself)
         return 0
     total = 0
     bucket, size = [], 0

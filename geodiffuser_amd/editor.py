@@ -478,6 +478,17 @@ def side_stream():
     main.wait_stream(side)
 
 
+def _drain_ahead(ahead):
+    """The caller is already unwinding with an exception of its own: wait for the work started beside it (nothing may keep launching
+    behind the caller's back) and keep ITS exception out of the way — logged, not raised (`finally: ahead.result()` replaced
+    the inversion's exception with the pre-pass's when both failed)."""
+    try:
+        ahead.result()
+    except Exception as e:  # noqa: BLE001
+        import sys
+        print(f"[geodiffuser_amd] the pre-pass beside a failing inversion failed as well: {e!r}", file=sys.stderr, flush=True)
+
+
 PREPASS_THREAD = os.environ.get("GD_PREPASS_THREAD", "1") == "1"
 _WORKER = None
 
@@ -613,8 +624,10 @@ def _perform_geometric_edit(image, depth, image_mask, transform_in, prompt, ldm_
     try:
         (_, _), x_t, uncond_embeddings, ddim_latents, ddim_noise = null_inversion.invert(image, prompt, offsets=(0, 0, 0, 0), verbose=False,
                                                                                           perform_inversion=perform_inversion, image_2=None)
-    finally:
-        transform_coordinates, controller, image_dev, mask_dev = ahead.result()
+    except BaseException:
+        _drain_ahead(ahead)                 # the inversion's exception is the one to report; the pre-pass's, if any, is logged
+        raise
+    transform_coordinates, controller, image_dev, mask_dev = ahead.result()
     if return_attention_maps:
         controller.store_attention_maps = True
     if loss_weights_dict is not None:                                                                      # :636-638

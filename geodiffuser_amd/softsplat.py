@@ -41,14 +41,19 @@ _GUARD = {
 
 def softsplat(tenIn: torch.Tensor, tenFlow: torch.Tensor, tenMetric, strMode: str):
     """Contract of U/softsplat.py:231-272: ``strMode`` = ``sum | avg | linear | soft`` with an optional ``-addeps | -zeroeps | -clipeps``
-    suffix (default addeps); ``sum`` / ``avg`` take no metric, ``linear`` / ``soft`` need one.  One splat launch carries the features
+    suffix (default addeps; an unknown suffix: no guard, as in the reference); exactly ``sum`` / ``avg`` take no metric, ``linear`` / ``soft``
+    need one.  One splat launch carries the features
     scaled by the importance and the importance itself; the quotient of the two is the normalised splat."""
-    mode, _, guard = strMode.partition("-")
-    if mode not in _WEIGHTING or (guard and guard not in _GUARD):
+    parts = strMode.split("-")
+    mode, guard = parts[0], (parts[1] if len(parts) > 1 else "")
+    if mode not in _WEIGHTING:
         raise AssertionError(f"softsplat: unknown mode {strMode!r}")
-    needs_metric = mode in ("linear", "soft")
-    if needs_metric != (tenMetric is not None):
-        raise AssertionError(f"softsplat: mode {strMode!r} {'needs' if needs_metric else 'takes no'} metric")
+    # the reference's assertions, as it writes them (:235-238): the metric must be absent only for the EXACT strings 'sum' / 'avg' (with a
+    # suffix it is accepted and ignored), and present for linear / soft whatever the suffix
+    if strMode in ("sum", "avg") and tenMetric is not None:
+        raise AssertionError(f"softsplat: mode {strMode!r} takes no metric")
+    if mode in ("linear", "soft") and tenMetric is None:
+        raise AssertionError(f"softsplat: mode {strMode!r} needs a metric")
     weigh = _WEIGHTING[mode]
     if weigh is None:
         return softsplat_func.apply(tenIn, tenFlow)
@@ -60,4 +65,5 @@ def softsplat(tenIn: torch.Tensor, tenFlow: torch.Tensor, tenMetric, strMode: st
         importance = weigh(tenMetric, tenIn)
         carried = tenIn if mode == "avg" else tenIn * importance
         splatted = softsplat_func.apply(torch.cat([carried, importance], 1), tenFlow)
-    return splatted[:, :-1] / _GUARD[guard or "addeps"](splatted[:, -1:])
+    # (a suffix the reference does not know leaves the normaliser as it is, :254-266: a plain division)
+    return splatted[:, :-1] / _GUARD.get(guard or "addeps", lambda z: z)(splatted[:, -1:])

@@ -450,6 +450,44 @@ def test_attention_even_split_segments_warp_and_handoff(ops, cfg):
         lib.gd_attn_fwd_set_config(-1, 0); lib.gd_attn_fwd_set_even_split(1)
 
 
+@pytest.mark.parametrize("BH,even_split", [(5, 1), (12, 2), (20, 2)])
+def test_w64_handoff_with_fences_equals_the_default(ops, BH, even_split):
+    """gd_attn_cfg_t.handoff on the 64-query kernel (r06; until r05 only k_attn_fwd_mp honoured 0): the parts of a split unit handed over
+    under agent-scope release / acquire fences (0) give BIT FOR BIT what the default cache-policy hand-off (1: write-through stores
+    drained before a relaxed ticket, L2-served loads) gives — unit parts (5 heads: every unit in three parts; the first-part holder merges
+    without storing its own) and the linear even split — also under the queued stress of the hand-off test above: 90 launches with
+    alternating inputs into their own output buffers while a second stream keeps the chip unevenly busy, compared after ONE synchronize."""
+    dtype = torch.bfloat16
+    N = 4096
+    sets = []
+    for seed in (20, 21, 22):
+        g = torch.Generator(device=DEV).manual_seed(seed + BH)
+        sets.append(tuple((torch.randn(BH, N, 64, device=DEV, generator=g) * s_).to(dtype) for s_ in (1.5, 1.5, 1.0)))
+    side = torch.cuda.Stream()
+    junk = torch.randn(32 << 20, device=DEV)
+    res = {}
+    for handoff in (1, 0):
+        got = []
+        for it in range(90):
+            if it % 3 == 0:
+                with torch.cuda.stream(side):
+                    junk[: (1 + it % 7) << 21].mul_(1.0001)
+            i = (it * 5 + it // 4) % 3
+            qq, kk, vv = sets[i]
+            o = torch.full_like(qq, float("nan")); l = torch.full((BH, N), float("nan"), device=DEV)
+            ops.attn_fwd([(qq, kk, vv, o, l)], 0.125, nsplit=1, cfg=dict(qb=8, ks=1, even_split=even_split, handoff=handoff))
+            got.append((i, o, l))
+        torch.cuda.synchronize()
+        res[handoff] = got
+    for (i1, o1, l1), (i0, o0, l0) in zip(res[1], res[0]):
+        assert i1 == i0 and torch.equal(o1, o0) and torch.equal(l1, l0)
+    for i in range(3):                                        # ... and right: against the fp64 formulation on a row sample
+        o = next(o for j, o, _ in res[0] if j == i)
+        rows = torch.arange(11, N, 211)
+        ro, _, _ = _ref_attn(sets[i][0][:, rows].cpu(), sets[i][1].cpu(), sets[i][2].cpu(), 0.125)
+        assert rel_err(o[:, rows].float().cpu(), ro) < TOLBF
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("f,N,M,heads", [(3, 1024, 1024, 0), (2, 1024, 77, 0), (1, 1024, 1024, 5), (1, 256, 256, 4), (2, 4096, 4096, 0)])
 def test_fused_query_warp_is_bit_identical_to_two_launches(ops, dtype, f, N, M, heads):
@@ -1177,6 +1215,21 @@ def test_softsplat_forward_backward(ops, mode):
         ones = torch.ones(1, 1, H, W, device=DEV)
         inside = softsplat(ones, torch.zeros(1, 2, H, W, device=DEV), None, "sum")
         assert torch.allclose(inside, ones)
+
+
+def test_softsplat_mode_contract_is_the_reference_s(ops):
+    """U/softsplat.py:233-238,254-266 as written: a metric is refused only for the EXACT strings 'sum' / 'avg' (with a suffix it is accepted
+    and ignored), linear / soft need one whatever the suffix, and a suffix the reference does not know means a plain division."""
+    from geodiffuser_amd.softsplat import softsplat
+    torch.manual_seed(3)
+    x = torch.randn(1, 3, 9, 11, device=DEV); flow = torch.randn(1, 2, 9, 11, device=DEV) * 0.4; metric = torch.randn(1, 1, 9, 11, device=DEV) * 0.3
+    for mode, m in (("sum", metric), ("avg", metric), ("linear", None), ("soft-zeroeps", None), ("max", None)):
+        with pytest.raises(AssertionError):
+            softsplat(x, flow, m, mode)
+    for mode in ("sum-addeps", "avg-clipeps", "soft-unknownsuffix", "linear-zeroeps"):
+        want = O.softsplat(x.cpu(), flow.cpu(), metric.cpu(), mode)
+        got = softsplat(x, flow, metric, mode).cpu()
+        assert got.shape == want.shape and torch.allclose(torch.nan_to_num(got), torch.nan_to_num(want), rtol=1e-5, atol=1e-6), mode
 
 
 # ------------------------------------------------------------------------------------------------ R14 / N1 geometry pre-pass

@@ -276,6 +276,36 @@ def test_bench_gpus_2_dry_run_really_starts_two_ranks():
     assert cfg["edits_by_rank"] == {"0": [0, 2, 4], "1": [1, 3, 5]}      # edit j -> rank j mod W, every edit exactly once
     for r in (0, 1):
         assert f"[bench rank {r}/2] device cpu (dry run)" in p.stderr
+    # every rank of a node on its own slice of the host cores (dist.pin_rank_to_cores, set in-process before anything else starts threads)
+    if hasattr(os, "sched_getaffinity") and len(os.sched_getaffinity(0)) >= 2:
+        (a0, a1, na), (b0, b1, nb) = cfg["host_cores_by_rank"]
+        assert na >= 1 and nb >= 1 and a1 < b0, cfg["host_cores_by_rank"]
+
+
+def test_pin_rank_to_cores_partitions_the_visible_cores():
+    """dist.pin_rank_to_cores in a child process per rank (the mask is per process): contiguous, disjoint, equal slices of the cores the
+    process may use; torch's intra-op pool sized to the slice; nothing happens for a single rank per node or with GD_PIN_CORES=0."""
+    if not hasattr(os, "sched_getaffinity") or len(os.sched_getaffinity(0)) < 4:
+        pytest.skip("needs sched_setaffinity and >= 4 visible cores")
+    code = ("import os, json, torch; from geodiffuser_amd import dist; c = dist.pin_rank_to_cores(); "
+            "print(json.dumps([c, sorted(os.sched_getaffinity(0)), torch.get_num_threads()]))")
+    import json
+    allc = sorted(os.sched_getaffinity(0))
+    got = []
+    for r in range(4):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="4", PYTHONPATH=ROOT)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-1000:]
+        c, mask, nt = json.loads(out.stdout.strip().splitlines()[-1])
+        assert c == mask and 1 <= nt <= len(c)
+        got.append(c)
+    per = len(allc) // 4
+    assert [x for c in got for x in c] == allc[:4 * per] and all(len(c) == per for c in got)
+    for extra in (dict(LOCAL_WORLD_SIZE="1"), dict(LOCAL_WORLD_SIZE="4", GD_PIN_CORES="0")):
+        env = dict(os.environ, LOCAL_RANK="0", PYTHONPATH=ROOT, **extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        c, mask, _ = json.loads(out.stdout.strip().splitlines()[-1])
+        assert c is None and mask == allc
 
 
 def test_edits_in_flight_starts_p_ranks_per_gpu():

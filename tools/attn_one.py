@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from geodiffuser_amd import ops
 BH, N, M = int(os.environ.get("BH", "32")), 4096, 4096
 torch.manual_seed(0)
+if "HS" in os.environ:       # hand-off of split units: 0 = release / acquire fences, 1 = cache-policy bits only (default)
+    ops.ATTN_CFG.update(handoff=int(os.environ["HS"]))
 if "ES" in os.environ:       # even split of the key tiles: 0 never, 1 where the launcher's cost model says so (default), 2 every launch that can be split
     ops.ATTN_CFG.update(even_split=int(os.environ["ES"]))
 QS = os.environ.get("QS", "0") == "1"

@@ -200,11 +200,23 @@ def load_model(diffusion_model="stabilityai/stable-diffusion-2-1-base", unet_pat
     """diffusion.py:99-149.  ``prediction_type``: "epsilon" / "v_prediction"; default: the checkpoint's scheduler config when a
     pipeline is loaded ("stabilityai/stable-diffusion-2-1" at 768^2 is a v-prediction model, BASELINE configs[3]), else "epsilon".  With diffusers + weights available this would wrap ``StableDiffusionPipeline.from_pretrained``;
     in this environment neither exists (no network), so a seeded random-init model of the same shape is built.
+    A local directory of the diffusers layout (``unet/``, ``vae/``, ``text_encoder/`` with safetensors) is loaded into this package's own
+    modules (geodiffuser_amd/checkpoint.py); GD_USE_DIFFUSERS=1 prefers diffusers' modules where diffusers is installed.
     Returns (ldm_stable, tokenizer, scheduler) like the reference."""
     if os.environ.get("GD_MIOPEN_CACHE", "1") == "1":
         # before the first convolution of the process: committed find-db + no naive solvers in MIOpen's per-shape search (miopen_cache.py)
         from . import miopen_cache
         miopen_cache.configure()
+    # A checkpoint DIRECTORY of the diffusers layout on local disk: its weights into THIS package's modules (checkpoint.from_safetensors), so
+    # that the edit runs on the harness the benchmark measures — NHWC convolutions, fused norms, captured passes — with real weights.
+    local = unet_path or diffusion_model
+    if isinstance(local, str) and os.path.isdir(os.path.join(local, "unet")) and not random_init and os.environ.get("GD_USE_DIFFUSERS", "0") != "1":
+        from .checkpoint import from_safetensors
+        pipe = from_safetensors(local, device=device, dtype=dtype)
+        if prediction_type not in (None, pipe.scheduler.config.prediction_type):
+            pipe.scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                                           set_alpha_to_one=False, prediction_type=prediction_type)
+        return pipe, pipe.tokenizer, pipe.scheduler
     try:  # pragma: no cover
         import diffusers  # noqa: F401
         have_diffusers = True

@@ -129,6 +129,19 @@ class _VAttn(nn.Module):
         return x + self.o(a).transpose(1, 2).reshape(b, c, h, w)
 
 
+class _VDown(nn.Module):
+    """The VAE encoder's stride-2 convolution as the public AutoencoderKL computes it: zero padding on the right / bottom only
+    (``F.pad(x, (0, 1, 0, 1))``, then a 3x3 stride-2 convolution without padding) — with symmetric padding real weights would see every
+    feature map shifted by half a pixel."""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1)))
+
+
 class AutoencoderKL(nn.Module):
     def __init__(self, ch=(128, 256, 512, 512), latent=4, scaling_factor=0.18215):
         super().__init__()
@@ -138,7 +151,7 @@ class AutoencoderKL(nn.Module):
         for i, c in enumerate(ch):
             enc += [_VRes(cin, c), _VRes(c, c)]
             if i < len(ch) - 1:
-                enc.append(nn.Conv2d(c, c, 3, stride=2, padding=1))
+                enc.append(_VDown(c))
             cin = c
         enc += [_VRes(cin, cin), _VAttn(cin), _VRes(cin, cin)]
         self.encoder = nn.Sequential(*enc)

@@ -197,7 +197,15 @@ class AttnTimer:
                     m = ((((xx - 0.56 * side) / (0.17 * side)) ** 2 + ((yy - 0.47 * side) / (0.14 * side)) ** 2) <= 1.0).float().reshape(-1)   # compact object mask (~8 % of the map)
                     seg = seg + ((idx.contiguous(), w.contiguous(), m.contiguous()),)
                     if rows_len:                           # the rows inside the mask, padded to the launch's list length
-                        rows = torch.nonzero(m > 0).reshape(-1).to(torch.int32)[:rows_len]
+                        # (lists are padded to buckets of N / 16 rows: a list of this padded length holds rows_len - N/16 + 1 .. rows_len rows;
+                        #  the replay takes 3/4 of a bucket below the padded length — the object mask grown until it has that many)
+                        want = max(1, rows_len - n // 64)
+                        grow = 1.0
+                        while int((m > 0).sum()) < want and grow < 8:
+                            grow *= 1.15
+                            m = ((((xx - 0.56 * side) / (0.17 * side * grow)) ** 2 + ((yy - 0.47 * side) / (0.14 * side * grow)) ** 2) <= 1.0).float().reshape(-1)
+                        seg = seg[:5] + ((idx.contiguous(), w.contiguous(), m.contiguous()),)
+                        rows = torch.nonzero(m > 0).reshape(-1).to(torch.int32)[:want]
                         n_dev = torch.tensor([rows.numel()], dtype=torch.int32, device="cuda")
                         rows = torch.cat([rows, torch.zeros(rows_len - rows.numel(), dtype=torch.int32, device="cuda")]).contiguous()
                         seg = (q, k, v, torch.empty(qs[0], rows_len, qs[2], dtype=dt, device="cuda"), None, seg[5], (rows, n_dev))

@@ -15,7 +15,7 @@ GD_F16, GD_BF16, GD_F32 = 0, 1, 2
 GD_TOKEN_MAJOR, GD_CHANNEL_MAJOR = 0, 1
 GD_ATTN_MAX_SEGS = 12
 GD_ATTN_MAX_PAIRS = 8
-GD_ABI_VERSION = 5
+GD_ABI_VERSION = 6
 
 
 class GdAttnSeg(Structure):
@@ -59,7 +59,7 @@ class GdRemovalBwd(Structure):               # gd_removal_bwd_t
 
 
 class GdHeadsSplit(Structure):               # gd_heads_split_t
-    _fields_ = [("src", c_void_p * 3), ("dst", c_void_p * 3), ("rows", c_int32 * 3), ("n", c_int32), ("B", c_int32), ("heads", c_int32), ("D", c_int32)]
+    _fields_ = [("src", c_void_p * 6), ("dst", c_void_p * 6), ("rows", c_int32 * 6), ("n", c_int32), ("B", c_int32), ("heads", c_int32), ("D", c_int32)]
 
 
 class GdHeadsMerge(Structure):               # gd_heads_merge_t

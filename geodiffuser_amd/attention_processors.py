@@ -408,9 +408,13 @@ class _EditLayer(torch.autograd.Function):
         tok_shapes = None
         if ref is not None and not heads:
             raise _lib.GeodiffError("_EditLayer: reference rows handed in need the token-major layer form (64-wide heads, GD_TOK_OPT)")
+        ref_hm = None
         if heads:
             tok_shapes = (q.shape, k.shape)
-            q, k, v = ops.heads_split((q, k, v), heads)
+            if ref is not None and ref[0].shape[0] == q.shape[0] and ref[0].dtype == q.dtype and ref[0].shape[2] == q.shape[2]:
+                q, k, v, *ref_hm = ops.heads_split((q, k, v, ref[0], ref[1], ref[2]), heads)         # both rows' tensors in one launch (ABI 6)
+            else:
+                q, k, v = ops.heads_split((q, k, v), heads)
         remover = ctrl._is_remover
         (b0, b1), (e0, e1) = ctrl.coords_base, ctrl.coords_edit
         cb = ctrl.coords_base[-1] * f
@@ -425,7 +429,7 @@ class _EditLayer(torch.autograd.Function):
         if ref is not None:
             if ref[0].dtype != dt or ref[0].shape[1] != N or ref[0].shape[2] != heads * D or ref[1].shape[2] != heads * D:
                 raise _lib.GeodiffError("_EditLayer: the reference rows handed in do not match this layer (dtype / tokens / width)")
-            q_base, k_base, v_base = ops.heads_split((ref[0], ref[1], ref[2]), heads)
+            q_base, k_base, v_base = ref_hm if ref_hm is not None else ops.heads_split((ref[0], ref[1], ref[2]), heads)
             q_edit, k_edit, v_edit = q, k, v
             van_q, van_k, van_v = q_base, k_base, v_base
             (b0, b1), (e0, e1), cb, n_van_live = (0, 1), (0, 1), f, 0

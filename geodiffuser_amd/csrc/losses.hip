@@ -328,11 +328,14 @@ extern "C" int gd_blend_merge(const void* base, const void* act, const int32_t* 
 
 // ---- the layer's layout boundary: token-major [B, rows, heads*D] <-> head-major [B*heads, rows, D], one launch each way ----------------
 // one 16-byte chunk (8 x 16-bit) per thread, destination-linear (stores coalesced; loads are 128-byte row pieces)
-__global__ void k_heads_split(const gd_heads_split_t a, long long c0, long long c1, long long c2) {
+struct HeadsSplitCum { long long c[GD_HEADS_SPLIT_MAX]; };
+__global__ void k_heads_split(const gd_heads_split_t a, const HeadsSplitCum cum) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= c2) return;
-    const int i = gid < c0 ? 0 : (gid < c1 ? 1 : 2);
-    const long long l = gid - (i == 0 ? 0 : (i == 1 ? c0 : c1));
+    if (gid >= cum.c[GD_HEADS_SPLIT_MAX - 1]) return;
+    int i = 0;
+#pragma unroll
+    for (int j = 0; j < GD_HEADS_SPLIT_MAX - 1; ++j) i += gid >= cum.c[j] ? 1 : 0;
+    const long long l = gid - (i == 0 ? 0 : cum.c[i - 1]);
     const int D8 = a.D >> 3, rows = a.rows[i], heads = a.heads;
     const int c = (int)(l % D8);
     long long t = l / D8;
@@ -345,19 +348,20 @@ __global__ void k_heads_split(const gd_heads_split_t a, long long c0, long long 
 }
 
 extern "C" int gd_heads_split(const gd_heads_split_t* a, int dtype, void* stream) {
-    GD_REQUIRE(a && a->n >= 1 && a->n <= 3, GD_EINVAL, "gd_heads_split: 1..3 tensors");
+    GD_REQUIRE(a && a->n >= 1 && a->n <= GD_HEADS_SPLIT_MAX, GD_EINVAL, "gd_heads_split: 1..%d tensors", GD_HEADS_SPLIT_MAX);
     GD_REQUIRE(a->B > 0 && a->heads > 0 && a->D > 0 && a->D % 8 == 0, GD_EINVAL, "gd_heads_split: bad sizes (D must be a multiple of 8)");
     GD_REQUIRE(dtype == GD_F16 || dtype == GD_BF16, GD_EINVAL, "gd_heads_split: dtype must be f16/bf16");
-    long long cum[3] = {0, 0, 0}, tot = 0;
-    for (int i = 0; i < 3; ++i) {
+    HeadsSplitCum cum;
+    long long tot = 0;
+    for (int i = 0; i < GD_HEADS_SPLIT_MAX; ++i) {
         if (i < a->n) {
             GD_REQUIRE(a->src[i] && a->dst[i] && a->rows[i] > 0, GD_EINVAL, "gd_heads_split: null pointer / no rows");
             tot += (long long)a->B * a->rows[i] * a->heads * (a->D / 8);
         }
-        cum[i] = tot;
+        cum.c[i] = tot;
     }
     const int blocks = (int)((tot + 255) / 256);
-    k_heads_split<<<blocks, 256, 0, as_stream(stream)>>>(*a, cum[0], cum[1], cum[2]);
+    k_heads_split<<<blocks, 256, 0, as_stream(stream)>>>(*a, cum);
     GD_CHECK_LAUNCH("gd_heads_split");
     return GD_OK;
 }

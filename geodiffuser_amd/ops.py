@@ -600,13 +600,13 @@ def blend_merge(base, act, pos, ro, m, eo_out=None, out=None):
 
 
 def heads_split(tensors: Sequence[torch.Tensor], heads: int) -> List[torch.Tensor]:
-    """Token-major [B, rows_i, heads*D] -> head-major [B*heads, rows_i, D] for up to three tensors of one batch size in ONE launch
+    """Token-major [B, rows_i, heads*D] -> head-major [B*heads, rows_i, D] for up to six tensors of one batch size in ONE launch
     (head_to_batch_dim of q, k and v: U/attention_processors.py:118-120,201-203)."""
     lib = _lib.load()
     t0 = tensors[0]
     dt = _dt16(t0, "tensor 0")
-    if not 1 <= len(tensors) <= 3:
-        raise _lib.GeodiffError("heads_split: 1..3 tensors")
+    if not 1 <= len(tensors) <= 6:
+        raise _lib.GeodiffError("heads_split: 1..6 tensors")
     B, _, C = t0.shape
     if C % heads or (C // heads) % 8:
         raise _lib.GeodiffError("heads_split: channels must be heads x (a multiple of 8)")

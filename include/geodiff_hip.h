@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 5
+#define GD_ABI_VERSION 6
 
 enum { GD_F16 = 0, GD_BF16 = 1, GD_F32 = 2 };
 enum { GD_TOKEN_MAJOR = 0 /* [B, P, C] */, GD_CHANNEL_MAJOR = 1 /* [B, C, P] */ };
@@ -401,14 +401,17 @@ int gd_edit_dq_fold(const float* dq_part, int kchunks, int64_t chunk_stride, int
 /* The layer's layout boundary in ONE launch each way (U/attention_processors.py:118-120,201-203 head_to_batch_dim of q / k / v and
  * :124,213 batch_to_head_dim of the output, and their autograd): the projections hand over token-major [B, rows, heads*D] tensors, the
  * optimisation pass's kernels work on head-major [B*heads, rows, D] ones.
- *   gd_heads_split : n <= 3 tensors at once, dst[i][(b*heads + h), r, :] = src[i][b, r, h*D : (h+1)*D]   (rows[i] rows each; 16-bit)
+ *   gd_heads_split : n <= GD_HEADS_SPLIT_MAX tensors at once, dst[i][(b*heads + h), r, :] = src[i][b, r, h*D : (h+1)*D]   (rows[i] rows each;
+ *                    16-bit).  ABI 6: six tensors (was three) — the edit row's q / k / v and the reference row's q / k / v handed in from the
+ *                    previous step's CFG pass (the optimisation pass on the edit row alone) in ONE launch.
  *   gd_heads_merge : out[b, r, h*D:(h+1)*D] = src[b][h, r, :] for every batch row b < B (<= 16: the two roles of up to 8 edits) whose
  *                    source is non-NULL, zeros for a NULL source (the rows that receive no gradient); src_f32 != 0: the sources are f32
  *                    and are rounded once (the key gradient); blend_b[b] != NULL: row b is  src[b]*m[b] + blend_b[b]*(1-m[b])  op by op
  *                    in the tensor dtype, exactly gd_blend_merge's blend (U/attention_processors.py:502-508,617-622) — the blend and
  *                    the layout change in one pass (one mask per row: every edit of a batch blends with its own). */
+#define GD_HEADS_SPLIT_MAX 6
 typedef struct gd_heads_split {
-    const void* src[3]; void* dst[3]; int32_t rows[3];
+    const void* src[GD_HEADS_SPLIT_MAX]; void* dst[GD_HEADS_SPLIT_MAX]; int32_t rows[GD_HEADS_SPLIT_MAX];
     int32_t n, B, heads, D;
 } gd_heads_split_t;
 int gd_heads_split(const gd_heads_split_t* a, int dtype, void* stream);

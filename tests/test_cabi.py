@@ -31,7 +31,7 @@ def test_header_symbols_all_exported_and_bound(lib):
         assert hasattr(lib, s), f"{s} declared in the header but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.gd_version() == _lib.GD_ABI_VERSION == 5
+    assert lib.gd_version() == _lib.GD_ABI_VERSION == 6
     # stateless, re-entrant, no hidden state — no process-wide tuning hook may come back (ABI 5 moved the five of ABI <= 4 into
     # per-call arguments: gd_attn_cfg_t, gd_conv3x3_cfg_t, gd_group_norm_nhwc's single_launch)
     assert not [s for s in syms if re.match(r"gd_.*_set_.*", s)], "process-global setters are not part of the ABI"

@@ -1794,9 +1794,11 @@ def test_heads_split_and_merge_are_the_permutes(ops, dtype):
     C = heads * D
     q, k, v = (torch.randn(B, n, C, generator=g).to(dtype).to(DEV) for n in (N, M, M))
     hm = lambda t: t.view(B, t.shape[1], heads, D).permute(0, 2, 1, 3).reshape(B * heads, t.shape[1], D)
-    for tensors in ((q, k, v), (q,), (k, q)):
+    for tensors in ((q, k, v), (q,), (k, q), (q, k, v, k, v, q), (v, q, k, q)):          # up to six per launch (ABI 6)
         for got, src in zip(ops.heads_split(tensors, heads), tensors):
             assert torch.equal(got, hm(src))
+    with pytest.raises(Exception):
+        ops.heads_split((q,) * 7, heads)
     a, b = hm(q)[:heads].contiguous(), hm(q)[heads:2 * heads].contiguous()
     m = torch.rand(N, generator=g).to(DEV)
     m[:7] = 0.0; m[7:13] = 1.0

@@ -25,23 +25,23 @@ def _kw(pipe, kind, steps):
     return kw
 
 
-def _single(pipe, seed, kind="geometry_editor", steps=8, size=256, prompt=""):
+def _single(pipe, seed, kind="geometry_editor", steps=8, size=256, prompt="", **over):
     from geodiffuser_amd import editor
     from geodiffuser_amd.synthetic import make_edit
     image, depth, mask, T = make_edit(seed, size=size, kind="translate" if seed % 2 == 0 else "rotate")
-    images, log, lat = editor.run_geodiffuser(image, depth, mask, T, prompt, **_kw(pipe, kind, steps))
+    images, log, lat = editor.run_geodiffuser(image, depth, mask, T, prompt, **dict(_kw(pipe, kind, steps), **over))
     torch.cuda.synchronize()
     return images, log, lat.float().cpu()
 
 
-def _batch(pipe, seeds, kind="geometry_editor", steps=8, size=256, prompts=None):
+def _batch(pipe, seeds, kind="geometry_editor", steps=8, size=256, prompts=None, **over):
     from geodiffuser_amd.batch import perform_geometric_edit_batch
     from geodiffuser_amd.synthetic import make_edit
     edits = []
     for i, s in enumerate(seeds):
         image, depth, mask, T = make_edit(s, size=size, kind="translate" if s % 2 == 0 else "rotate")
         edits.append(dict(image=image, depth=depth, image_mask=mask, transform_in=T, prompt=prompts[i] if prompts else ""))
-    kw = _kw(pipe, kind, steps)
+    kw = dict(_kw(pipe, kind, steps), **over)
     kw.pop("edit_type")
     res = perform_geometric_edit_batch(edits, edit_type=kind, **kw)
     torch.cuda.synchronize()
@@ -107,6 +107,30 @@ def test_mixed_batch_every_edit_lands_on_its_own_single_run(pipe):
         assert torch.equal(lat[0], lat1[0]) or rel_l2(lat[0], lat1[0]) < 2e-3     # reference row = the inversion trajectory's last replacement
         d = rel_l2(lat[1], lat1[1])
         print(f"[batch] edit {s}: in a batch of 3 vs alone {d:.2e} (two runs alone: {noise:.2e})")
+        assert d < max(6 * noise, 5e-2)
+
+
+def test_self_replace_window_shorter_than_the_optimisation_window(pipe):
+    """self_replace_steps < optimize_steps <= cross_replace_steps (the API accepts it; the reference's stock configurations do not use it):
+    past the self-replace window an optimisation pass meets self-attention layers that are INACTIVE — plain attention with autograd, no
+    loss (U/attention_processors.py:646-647).  ADVICE r05: the batched controller sent them through the merged edit layer.  Both edits of a
+    batch land on their one-edit runs (same optimisation steps, first-pass terms, latents within the loop's spread), and the logged loss
+    of an optimisation step past the window has its self-attention terms at exactly 0 in both drivers."""
+    over = dict(self_replace_steps=0.3, optimize_steps=0.8)
+    seeds = [4, 7]
+    singles = [_single(pipe, s, steps=10, **over) for s in seeds]
+    again = _single(pipe, seeds[0], steps=10, **over)
+    noise = rel_l2(again[2], singles[0][2])
+    res = _batch(pipe, seeds, steps=10, **over)
+    for (im, log, lat), (im1, log1, lat1), s in zip(res, singles, seeds):
+        assert sorted(log) == sorted(log1)
+        late = [i for i in sorted(log) if i >= 3]                # int(10 * 0.3) = 3: the self-replace window is steps 0..2
+        assert late, sorted(log)
+        for i in late:
+            assert all(float(v) == 0.0 for v in log[i]["self"].values()) and all(float(v) == 0.0 for v in log1[i]["self"].values()), (i, log[i]["self"], log1[i]["self"])
+            assert any(float(v) != 0.0 for v in log[i]["cross"].values())
+        d = rel_l2(lat[1], lat1[1])
+        print(f"[batch] edit {s}, self-replace window < optimisation window: in a batch of 2 vs alone {d:.2e} (two runs alone: {noise:.2e})")
         assert d < max(6 * noise, 5e-2)
 
 

@@ -51,9 +51,11 @@ def test_graphed_pass_text_kv_cache_follows_the_context(pipe):
     width = next(m.to_k.in_features for m in p.unet.modules() if getattr(m, "is_cross_attention", False))
     a = torch.randn(2, 77, width, device="cuda", generator=g); b = torch.randn(2, 77, width, device="cuda", generator=g)
     runner = graphs.GraphedUNet(p.unet)
-    seen_refresh = []
-    orig = runner._refresh_kv
-    runner._refresh_kv = lambda e: (seen_refresh.append(1), orig(e))[1]
+
+    class _Count:                                   # refreshes so far (r06: a refresh is a replay of the entry's captured projections)
+        def __len__(self):
+            return runner.kv_refreshes
+    seen_refresh = _Count()
 
     def both(ctx, src):
         with torch.no_grad():
@@ -76,8 +78,8 @@ def test_graphed_pass_text_kv_cache_follows_the_context(pipe):
     w, o = both(a, None); assert rel_l2(o.cpu(), w.cpu()) < 2e-3 and len(seen_refresh) == n0 + 4   # no source named: always re-computed
     # this runner (and its captured graph) dies here, at a moment of OUR choosing: a graph collected by the garbage collector in the middle
     # of another test's stream capture aborts the process (the product keeps its runners for the life of the model)
-    runner._refresh_kv = orig
-    del runner, orig
+    runner.reset()
+    del runner
     torch.cuda.synchronize(); gc.collect(); torch.cuda.synchronize()
 
 
@@ -899,6 +901,38 @@ def test_removal_edit_768_full_width_v_prediction():
         assert d["num_layers"] == 20                       # 10 self + 10 cross layers with N >= 32^2 (96^2 and 48^2 levels)
         assert all(np.isfinite(v) for att in ("self", "cross") for v in d[att].values())
         assert d["self"]["removal"] != 0.0
+
+
+def test_return_attention_maps_through_the_driver(pipe):
+    """run_geodiffuser(return_attention_maps=True) with the defaults (REF_FROM_OPT / REF_AHEAD on).  The controller then
+    stores maps, the processors leave the token-major path the reference-row stashes live on, and the driver must fall back to the 3-row
+    CFG pass at every step instead of handing a 2-row batch to a layer that never takes its reference row.  The stored maps are the
+    reference's: N <= 16^2 layers only, one entry per such hooked call and step (U/attention_sharing.py:153-166)."""
+    from geodiffuser_amd import editor
+    n0, n1 = editor.REF_FROM_OPT_PASSES, editor.REF_AHEAD_PASSES
+    images, log, store, latents = _run_kw(pipe, return_attention_maps=True)
+    assert editor.REF_FROM_OPT_PASSES == n0 and editor.REF_AHEAD_PASSES == n1          # no pass ran on a stash
+    assert torch.isfinite(latents).all() and len(log) > 0
+    lists = {k: v for k, v in store.items() if isinstance(v, list)}                    # (the store also keeps "length_*" counts)
+    assert sum(len(v) for v in lists.values()) > 0
+    for key, maps in lists.items():
+        for m in maps:
+            assert m.shape[1] <= 16 ** 2
+    images2, log2, latents2 = _run(pipe)                                               # ... and the edit is the ordinary one
+    assert sorted(log) == sorted(log2)
+
+
+def _run_kw(pipe, kind="geometry_editor", steps=6, seed=0, size=256, **extra):
+    from geodiffuser_amd import editor
+    from geodiffuser_amd.synthetic import editor_kwargs, make_edit
+    p, tok, sched = pipe
+    image, depth, mask, T = make_edit(seed, size=size, kind="translate")
+    kw = editor_kwargs(kind)
+    kw.update(num_ddim_steps=steps, ldm_stable_model=p, tokenizer_model=tok, scheduler_in=sched, return_latents=True, return_loss_log_dict=True)
+    kw.update(extra)
+    out = editor.run_geodiffuser(image, depth, mask, T, **kw)
+    torch.cuda.synchronize()
+    return out[:-1] + (out[-1].float().cpu(),)
 
 
 def test_bench_one_rank_under_torchrun_initialises_rccl_and_broadcasts():

@@ -75,6 +75,7 @@ class GeodiffError(RuntimeError):
 SIGNATURES = {
     "gd_version": (c_int, []),
     "gd_stream_capture_id": (c_int, [c_void_p, c_void_p]),
+    "gd_copy_rows": (c_int, [c_void_p, c_int, c_int, ctypes.c_int64, c_void_p]),
     "gd_last_error": (c_char_p, []),
     "gd_error_string": (c_char_p, [c_int]),
     "gd_rasterize_workspace_bytes": (c_size_t, [c_int, c_int, c_float]),

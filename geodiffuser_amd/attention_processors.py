@@ -338,6 +338,7 @@ def _flat(m: torch.Tensor) -> torch.Tensor:
 
 # Device buffers that outlive a controller: a captured hipGraph of a CFG pass reads the per-resolution tables by address, so an
 # edit that wants to reuse the graphs of the previous edit copies its tables INTO these buffers instead of allocating new ones.
+_REF_SLOTS: Dict[tuple, dict] = {}       # see _GeometryControllerBase.ref_slots
 _PERSISTENT_TABLES: Dict[tuple, torch.Tensor] = {}
 # ... which makes them process-wide state: ONE controller at a time may own them (the reference is one edit at a time per process as well: its
 # model cache, DISTANCE_CLASS, SPLATTER and GAUSSIAN_FEATURE_SMOOTHER are module globals).  The owner is the controller that built
@@ -887,7 +888,14 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
     # call, that row's token-major (q, k, v, attention output) (collect_ahead -> ref_stash, same entry format as above; `out` is row 0
     # of the pass's vanilla segment).  The optimisation pass of step i+1 then runs forward + backward on the EDIT ROW ALONE with the
     # reference q / k / v handed to _EditLayer (use_ahead), and that step's CFG pass reads the same entries (use_ref_stash).
-    collect_ahead = False        # set by the driver around the CFG pass that carries the next step's reference row
+    # ALL REFERENCE ROWS OF AN EDIT IN ONE PASS (editor.REF_AHEAD = 1, the default): every optimisation step's reference sample is known once the
+    # inversion is done, so one no-grad pass runs them all as a batch of vanilla rows with their own timesteps right behind the inversion
+    # (collect_ahead = "all": every row of every hooked call is kept, plain attention for all of them).  Before optimisation step m, row m of
+    # every kept tensor is copied (one launch: ops.RowCopyTable) into persistent one-row tensors (ref_slots) — the addresses both the
+    # optimisation pass on the edit row alone and that step's 2-row CFG pass read, the same for every step and every edit: no captured pass
+    # depends on which pass produced the rows.  Against the carrying form above: no 4-row CFG passes (the UNet's GEMMs pick worse tiles at
+    # M = 16,384 than at 12,288) and the first optimisation step runs on the edit row alone as well.
+    collect_ahead = False        # set by the driver: True around the CFG pass that carries the next step's reference row, "all" around the batched pass
     use_ahead = False            # set by the driver around the optimisation pass that takes its reference rows from ref_stash
     _ahead = None
 
@@ -895,7 +903,26 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         if self.collect_ahead:
             if self.cur_att_layer == 0 or self._ahead is None:
                 self._ahead = []
-            self._ahead.append((q[0:1].detach(), k[0:1].detach(), v[0:1].detach(), out[0:1].detach()))
+            if self.collect_ahead == "all":
+                self._ahead.append((q.detach(), k.detach(), v.detach(), out.detach()))
+            else:
+                self._ahead.append((q[0:1].detach(), k[0:1].detach(), v[0:1].detach(), out[0:1].detach()))
+
+    def ref_slots(self, stash):
+        """Persistent one-row tensors for the reference row of the current optimisation step (one set per device / dtype / layer-shape list,
+        shared by all edits of the process: captured passes read them by address), the table that copies row m of ``stash`` into them, and
+        the serial number that names them in graph keys."""
+        sig = (str(stash[0][0].device), stash[0][0].dtype, tuple(tuple(t.shape[1:]) for e in stash for t in e))
+        ent = _REF_SLOTS.get(sig)
+        if ent is None:
+            from . import graphs
+            slots = [tuple(torch.empty(1, *t.shape[1:], dtype=t.dtype, device=t.device) for t in e) for e in stash]
+            ent = _REF_SLOTS[sig] = dict(slots=slots, serial=("slots", next(graphs._SERIAL)), table=None, stash_id=None)
+        sid = tuple(t.data_ptr() for e in stash for t in e)
+        if ent["stash_id"] != sid:                               # (a captured batched pass keeps its addresses: built once per process)
+            ent["table"] = ops.RowCopyTable([(t.contiguous() if not t.is_contiguous() else t, d) for e, se in zip(stash, ent["slots"]) for t, d in zip(e, se)])
+            ent["stash_id"] = sid
+        return ent
 
     supports_token_major = True
     heads_tok = 0
@@ -994,6 +1021,10 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
         active = is_cross or (self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1])
         heads = self.heads_tok
         if heads:
+            if self.collect_ahead == "all":      # the batched reference pass: vanilla rows only, every row kept
+                out = attention_tok(q, k, v, scale, heads, q_scaled=self.q_scaled_tok)
+                self._leave_ahead(q, k, v, out)
+                return out
             ref = self._take_ref() if self.use_ref_stash else None
             if not active:
                 out = attention_tok(q, k, v, scale, heads, q_scaled=self.q_scaled_tok)
@@ -1004,6 +1035,9 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             out = self._forward_tok(q, k, v, is_cross, transform_coords, float(scale), heads, ref=ref)
             self._leave_ahead(q, k, v, out)
             return out
+        if self.collect_ahead == "all":      # the batched reference pass on a layer off the token-major path (head dims 40 / 80 / 160): plain
+            self._ahead = None               # attention, nothing kept — the driver sees an incomplete set and falls back
+            return attention(q, k, v, scale)
         ho = self.heads_opt              # token-major q / k / v [B, N, heads*64] (EditProcessor, TOK_OPT)
         ref_in = None
         if self.use_ahead:               # the live batch is the edit row alone; this layer's reference row was left by the previous CFG pass

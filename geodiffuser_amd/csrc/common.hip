@@ -35,6 +35,27 @@ void gd_zero_async(void* ptr, size_t bytes, hipStream_t st) {
     k_zero_u32<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((uint32_t*)ptr, n);
 }
 
+// gd_copy_rows: blockIdx.y = entry, blockIdx.x strides over its 16-byte words
+__global__ void k_copy_rows(const gd_copy_rows_t* __restrict__ entries, int row) {
+    const gd_copy_rows_t e = entries[blockIdx.y];
+    const long long n16 = e.bytes >> 4;
+    const u32x4* __restrict__ src = (const u32x4*)((const char*)e.src + (long long)row * e.bytes);
+    u32x4* __restrict__ dst = (u32x4*)e.dst;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int gd_copy_rows(const gd_copy_rows_t* entries, int n, int row, int64_t max_bytes, void* stream) {
+    GD_REQUIRE(entries && n > 0 && n <= 65535 && row >= 0 && max_bytes > 0 && (max_bytes & 15) == 0, GD_EINVAL,
+               "gd_copy_rows: bad arguments (n=%d, row=%d, max_bytes=%lld)", n, row, (long long)max_bytes);
+    // enough blocks per entry for the largest one at 4 x 16 bytes per thread; smaller entries leave blocks idle (they exit at once)
+    long long bx = (max_bytes / 16 + 256 * 4 - 1) / (256 * 4);
+    if (bx > 512) bx = 512;
+    if (bx < 1) bx = 1;
+    k_copy_rows<<<dim3((unsigned)bx, (unsigned)n), 256, 0, as_stream(stream)>>>(entries, row);
+    GD_CHECK_LAUNCH("gd_copy_rows");
+    return GD_OK;
+}
+
 // Id of the capture sequence `stream` is recording (0: not capturing).  Host-side helper for ops.zeros_f32: a pre-zeroed chunk must not
 // be shared between two hipGraph captures (the fill belongs to one graph only).  Lives here so that it asks the HIP runtime this
 // library is bound to — dlopen("libamdhip64.so") from Python can map a SECOND runtime next to the one PyTorch bundles.

@@ -15,7 +15,7 @@ from .pipeline import build_random_sd21
 from .scheduler import DDIMScheduler
 
 
-def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None, ctx_src=None):
+def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None, ctx_src=None, learn=True):
     """UNet call of a no-grad pass, through a captured hipGraph when the controller's launch sequence is static.
 
     A replay runs no Python, and the captured kernels read the controller's per-resolution tables (masks, splat idx / w, inpaint
@@ -28,14 +28,29 @@ def _unet_nograd(model, controller, x, t, ctx, tag, transform_coords=None, ctx_s
     def eager():
         # (per-row timesteps arrive as a tuple; an eager pass leaves no reference rows a captured pass may read: see GraphedUNet)
         tt = torch.tensor([int(v) for v in t], device=x.device, dtype=torch.long) if isinstance(t, tuple) else t
+        collect = getattr(controller, "collect_ahead", False)
+        if collect:
+            controller._ahead = None
         out = model.unet(x, tt, encoder_hidden_states=ctx)["sample"]
-        if getattr(controller, "collect_ahead", False):
-            controller.ref_stash, controller.ref_stash_serial = None, None
+        if collect:
+            st = controller._ahead
+            ok = st is not None and len(st) == controller.num_att_layers and all(isinstance(a, tuple) for a in st)
+            controller.ref_stash, controller.ref_stash_serial, controller._ahead = (st if ok else None), None, None
         return out
 
     if not graphs.ENABLED or torch.is_grad_enabled() or key_fn is None or getattr(controller, "store_attention_maps", False) \
             or not getattr(controller, "persistent_tables", False):
         return eager()
+    if not learn:
+        # a pass that reads none of the controller's per-resolution tables (the batched reference rows: vanilla attention for every row): no
+        # table has to exist before a replay and the table shapes are not part of its key
+        runner = model.__dict__.get("_graphed")
+        if runner is None:
+            runner = model.__dict__["_graphed"] = graphs.GraphedUNet(model.unet)
+        out, replayed = runner((tag,) + key_fn(), x, t, ctx, ctx_src=ctx_src, controller=controller)
+        if replayed:
+            controller.after_graph_replay()
+        return out
     seen = model.__dict__.setdefault("_cfg_layers", {})
     # the hooked (resolution, heads, head dim) set is learnt per (latent size, controller type); a model whose hooks changed since is
     # caught by the `learnt() != layers` comparison below (the controller then holds a table the list does not know) and learns it again

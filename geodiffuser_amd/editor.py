@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from . import ops, vis_utils, warp_utils
 from .attention_processors import (AttentionGeometryEdit, AttentionGeometryRemover, VanillaAttentionProcessor,
                                    register_attention_control_diffusers, set_attn_processor_for_edit)
-from .diffusion import diffusion_step, encode_text, image2latent, latent2image, load_model
+from .diffusion import _unet_nograd, diffusion_step, encode_text, image2latent, latent2image, load_model
 from .generic_torch import binarize_tensor, norm_tensor, reshape_transform_coords, torch_erode
 from .image_processing import masked_histogram_matching
 from .inversion import NullInversion
@@ -59,7 +59,9 @@ REF_FROM_OPT_PASSES = 0     # CFG passes that ran without their reference row so
 # layers), so the optimisation pass runs forward + backward on the edit row alone (attention_processors "ONE STEP AHEAD").  Applies where
 # REF_FROM_OPT does, from the second optimisation step of an edit on (the first has no CFG pass in front of it) and where the pass in
 # front is the plain 3-row form; anything else falls back to the two-row optimisation pass.
-REF_AHEAD = os.environ.get("GD_REF_AHEAD", "1") == "1"
+# REF_AHEAD: 1 (default) = ALL reference rows of an edit in ONE batched vanilla pass behind the inversion, row m copied into persistent one-row
+# tensors before optimisation step m (attention_processors "ALL REFERENCE ROWS"); 2 = the carrying form described above; 0 = off.
+REF_AHEAD = int(os.environ.get("GD_REF_AHEAD", "1"))
 REF_AHEAD_PASSES = 0        # optimisation passes that ran on the edit row alone so far
 
 
@@ -95,6 +97,42 @@ def pass_times_report() -> str:
     rows = [f"{k}: {len(v)} passes, {sum(a.elapsed_time(b) for a, b in v) / len(v):.2f} ms each" for k, v in sorted(PASS_TIMES.items())]
     PASS_TIMES.clear()
     return "\n".join(rows)
+
+
+@torch.no_grad()
+def _reference_rows_pass(model, controller, steps, timesteps, latents, ddim_latents, ref_text, transform_coordinates):
+    """The reference sample of every optimisation step of an edit as ONE batch of vanilla rows (row m: the latent the driver will find in
+    batch row 0 at step steps[m] — the initial latent at step 0, the inversion trajectory's entry afterwards, U/editor.py:375-377 —, its
+    timestep, the reference's text row), through the hooked UNet with ``collect_ahead = "all"``.  -> ({step: row}, ref_slots entry) or
+    None when the pass left no complete set of tensors (a layer off the token-major path: the drivers then fall back)."""
+    if not steps:
+        return None
+    n = len(ddim_latents)
+    rows = [latents[0:1] if i == 0 else ddim_latents[n - 1 - i].type_as(latents) for i in steps]
+    if any(r.shape != latents[0:1].shape for r in rows):
+        return None
+    x = torch.cat([r.to(latents.dtype) for r in rows])
+    ctx = ref_text.expand(len(steps), -1, -1).contiguous()           # (cond_ref: context row 2 of every step, U/editor.py:157-160)
+    set_attn_processor_for_edit(model, coords_base=(0, 1), coords_edit=(1, 2), use_cfg=True, n_batch=len(steps))
+    controller.collect_ahead = "all"
+    controller.ref_stash = controller.ref_stash_serial = controller.ref_stash_t = None
+    step0, layer0 = controller.cur_step, controller.cur_att_layer
+    ev0 = None
+    if PASS_TIMES is not None:
+        ev0 = torch.cuda.Event(enable_timing=True); ev0.record()
+    try:
+        _unet_nograd(model, controller, x, tuple(int(timesteps[i]) for i in steps), ctx, "refs", transform_coordinates, ctx_src=None, learn=False)
+    finally:
+        controller.collect_ahead = False
+        controller.cur_step, controller.cur_att_layer = step0, layer0          # not a step of the edit: the counters stay where they were
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True); ev1.record()
+            PASS_TIMES.setdefault(f"reference rows of all optimisation steps, one pass of {len(steps)} rows", []).append((ev0, ev1))
+    stash = controller.ref_stash
+    controller.ref_stash = controller.ref_stash_serial = None
+    if stash is None or any(t.shape[0] != len(steps) for e in stash for t in e):
+        return None
+    return {i: m for m, i in enumerate(steps)}, controller.ref_slots(stash)
 
 
 def ref_from_opt_supported() -> bool:
@@ -252,7 +290,7 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
     ref_from_opt = (REF_FROM_OPT and skip_ref and is_geo and ref_from_opt_supported() and getattr(controller, "supports_token_major", False)
                     and not getattr(controller, "store_attention_maps", False))
 
-    ref_ahead = REF_AHEAD and ref_from_opt and fast_start_steps == 0.0 and hasattr(controller, "collect_ahead")
+    ref_ahead = int(REF_AHEAD) if (REF_AHEAD and ref_from_opt and fast_start_steps == 0.0 and hasattr(controller, "collect_ahead")) else 0
 
     def is_opt_step(j):
         return j < T and (j < optimize_steps * T) and (j % skip_optim_steps == 0) and (j >= fast_start_steps * T)      # :181
@@ -291,6 +329,12 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
         return diffusion_step(model, controller, lat, ctx, tt, guidance_scale, transform_coords=transform_coordinates)
 
     opt_pass = GraphedOptPass(model, transform_coordinates, guidance_scale)
+    # REF_AHEAD = 1: the reference rows of ALL optimisation steps in one no-grad pass, now (their latents are the inversion trajectory's,
+    # their text row never changes: the embedding update touches the edit row only, U/optimization.py:240-249)
+    ref_rows = None          # step -> row of the batched pass
+    if ref_ahead == 1:
+        ref_rows = _reference_rows_pass(model, controller, [i for i in range(T) if is_opt_step(i)], timesteps, latents, ddim_latents,
+                                        text_embeddings[0:1], transform_coordinates)
     if PASS_TIMES is not None:          # development aid (GD_PASS_TIMES=1): device time per kind of pass, HIP events on the launch stream
         cfg_pass, opt_pass = _timed_passes(cfg_pass, opt_pass, controller)
     first_optim_complete = False
@@ -310,12 +354,16 @@ def text2image_ldm_stable(model, prompt: List[str], controller, num_inference_st
         clear_controller_loss(controller)
         # the reference row of the NEXT step, if that step optimises (REF_AHEAD): the trajectory entry the end of this step puts in row 0
         ahead = None
-        if ref_ahead and is_opt_step(i + 1) and len(ddim_latents) - 2 - i >= 0:
+        if ref_ahead == 2 and is_opt_step(i + 1) and len(ddim_latents) - 2 - i >= 0:
             ahead = (ddim_latents[len(ddim_latents) - 2 - i].type_as(latents.detach()), timesteps[i + 1])
         if (i < optimize_steps * T) and (i % skip_optim_steps == 0) and (i >= fast_start_steps * T):      # :181
             l_eff = lr * (50 - i) * skip_optim_steps * (50 / (NUM_DDIM_STEPS + 1e-8))                      # :207
             set_attn_processor_for_edit(model, coords_base=(0, 1), coords_edit=(1, 2), use_cfg=False)    # :213
-            # this step's reference row already went through the UNet (the CFG pass of the step before): the edit row alone
+            # this step's reference row already went through the UNet (the batched pass / the CFG pass of the step before): the edit row alone
+            if ref_rows is not None and i in ref_rows[0]:
+                ent = ref_rows[1]
+                ent["table"].copy(ref_rows[0][i])                # row m of every kept tensor -> the persistent one-row tensors, one launch
+                controller.ref_stash, controller.ref_stash_serial, controller.ref_stash_t = ent["slots"], ent["serial"], int(t)
             edit_row_only = bool(ref_ahead and controller.ref_stash_serial is not None and controller.ref_stash_t == int(t)
                                  and latents.shape[0] == 2)
             controller.collect_ref = ref_from_opt and not edit_row_only

@@ -139,9 +139,13 @@ class GraphedUNet:
             return torch.tensor([int(v) for v in t], device=x.device, dtype=torch.long) if isinstance(t, tuple) else t
 
         def eager():
-            out = self.unet(x, t_tensor(), encoder_hidden_states=ctx)["sample"]
             if collect:
-                controller.ref_stash, controller.ref_stash_serial = None, None
+                controller._ahead = None
+            out = self.unet(x, t_tensor(), encoder_hidden_states=ctx)["sample"]
+            if collect:          # eager tensors: no serial (a captured pass must not bake their addresses); the batched form copies out of them at once
+                st = controller._ahead
+                ok = st is not None and len(st) == controller.num_att_layers and all(isinstance(a, tuple) for a in st)
+                controller.ref_stash, controller.ref_stash_serial, controller._ahead = (st if ok else None), None, None
             return out, False
 
         if not ENABLED or torch.is_grad_enabled():

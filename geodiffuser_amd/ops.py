@@ -326,6 +326,30 @@ def attn_fwd(segs: Sequence[tuple], scale: float, heads: int = 0, nsplit: Option
         check(lib.gd_attn_fwd(arr, n, N, M, D, scale, ctypes.byref(c), None, 0, dt, _stream()), "gd_attn_fwd")
 
 
+class RowCopyTable:
+    """``gd_copy_rows`` table: for every (src [rows, ...], dst [1, ...]) pair, dst <- src[row] in ONE launch (``copy(row)``).  The (src, dst, bytes)
+    triples live in device memory; built once per set of tensors (one upload)."""
+
+    def __init__(self, pairs):
+        ent, self.keep, self.max_bytes = [], [], 0
+        for src, dst in pairs:
+            _need(src, "copy_rows src"); _need(dst, "copy_rows dst", src.dtype)
+            nb = dst.numel() * dst.element_size()
+            if src.dim() < 1 or src.numel() % max(1, src.shape[0]) or src.numel() // src.shape[0] != dst.numel() or nb % 16 or src.data_ptr() % 16 or dst.data_ptr() % 16:
+                raise _lib.GeodiffError("copy_rows: dst must hold exactly one row of src, 16-byte multiples, 16-byte aligned")
+            ent.append((src.data_ptr(), dst.data_ptr(), nb))
+            self.keep.append((src, dst))
+            self.max_bytes = max(self.max_bytes, nb)
+        self.rows = min(src.shape[0] for src, _ in pairs)
+        self.n = len(ent)
+        self.table = torch.tensor(ent, dtype=torch.int64).to(pairs[0][0].device)
+
+    def copy(self, row: int) -> None:
+        if not 0 <= row < self.rows:
+            raise _lib.GeodiffError(f"copy_rows: row {row} outside 0..{self.rows - 1}")
+        check(_lib.load().gd_copy_rows(_p(self.table), self.n, int(row), self.max_bytes, _stream()), "gd_copy_rows")
+
+
 def rows_merge(base: torch.Tensor, act: torch.Tensor, pos: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[h, n] = act[h, pos[n]] where pos[n] >= 0, else base[h, n]  (base / out [H, N, D], act [H, R, D] 16-bit, pos [N] i32):
     gd_blend_merge without the blend."""

@@ -528,6 +528,13 @@ int gd_softsplat_fwd(const float* in, const float* flow, int N, int C, int H, in
 int gd_softsplat_bwd(const float* in, const float* flow, const float* outgrad, int N, int C, int H, int W, float* ingrad,
                      float* flowgrad, void* stream);
 
+/* R10 step glue (ABI 6) — many row copies in ONE launch: for every entry e < n, dst[e][0 .. bytes[e]) = src[e][row * bytes[e] ..): the
+ * reference row of optimisation step `row` out of the per-layer tensors one batched UNet pass left for ALL optimisation steps of an edit
+ * (editor.REF_AHEAD: ~128 tensors, 140 MB per row) into the persistent one-row tensors the captured passes read by address.
+ * `entries` lives in DEVICE memory (n x gd_copy_rows_t); every bytes[e] is a multiple of 16, pointers 16-byte aligned. */
+typedef struct gd_copy_rows { const void* src; void* dst; int64_t bytes; } gd_copy_rows_t;
+int gd_copy_rows(const gd_copy_rows_t* entries, int n, int row, int64_t max_bytes, void* stream);
+
 /* Host helper: *id = 1 + the runtime's id of the capture sequence `stream` is recording, 0 when it is not capturing (callers that hand
  * out pre-zeroed scratch must not share a chunk between two hipGraph captures). */
 int gd_stream_capture_id(void* stream, unsigned long long* id);

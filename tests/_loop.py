@@ -59,13 +59,14 @@ def make_controller(kind, c, inp, device="cuda:0"):
     return ctrl, lw
 
 
-def run_device_loop(kind_name, dtype, skip_refs=(False, "3rows", True, "ahead")):
+def run_device_loop(kind_name, dtype, skip_refs=(False, "3rows", True, "carry", "ahead")):
     """-> (fixture dict, fixture name, runs) with runs = [(latents f32 cpu, loss log, final removal weight, first latent update, weight
     trajectory, CFG passes that took their reference row from another pass, optimisation passes that ran on the edit row alone)] — one run
     per entry of ``skip_refs``: False = the reference's 4-row CFG batch; "3rows" = without the unused uncond_ref row; True = that, and at
-    steps with an optimisation pass the reference row's layer tensors come from that pass (editor.REF_FROM_OPT: 2 rows); "ahead" = the
-    product default (r06): additionally the reference row of an optimisation step goes through the UNet one step ahead, in the previous
-    step's CFG pass, and the optimisation pass runs forward + backward on the edit row alone (editor.REF_AHEAD)."""
+    steps with an optimisation pass the reference row's layer tensors come from that pass (editor.REF_FROM_OPT: 2 rows); "carry" (r06): the
+    reference row of an optimisation step additionally goes through the UNet one step ahead, carried by the previous step's CFG pass, and the
+    optimisation pass runs forward + backward on the edit row alone (editor.REF_AHEAD = 2); "ahead" = the product default: ALL reference
+    rows of the edit in one batched pass before the loop, every optimisation pass on the edit row alone (editor.REF_AHEAD = 1)."""
     from geodiffuser_amd import editor
     from geodiffuser_amd.attention_processors import VanillaAttentionProcessor
     fixture, cfgname, kind, full, name = LOOP_KINDS[kind_name]
@@ -97,8 +98,8 @@ def run_device_loop(kind_name, dtype, skip_refs=(False, "3rows", True, "ahead"))
     try:
         for skip_ref in skip_refs:
             editor.SKIP_UNCOND_REF = bool(skip_ref)
-            editor.REF_FROM_OPT = prev_rfo and skip_ref in (True, "ahead")
-            editor.REF_AHEAD = prev_ahead and skip_ref == "ahead"
+            editor.REF_FROM_OPT = prev_rfo and skip_ref in (True, "carry", "ahead")
+            editor.REF_AHEAD = 0 if not prev_ahead else {"carry": 2, "ahead": 1}.get(skip_ref, 0)
             n_rfo, n_ahead = editor.REF_FROM_OPT_PASSES, editor.REF_AHEAD_PASSES
             updates.clear()
             weights.clear()

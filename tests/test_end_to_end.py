@@ -405,14 +405,18 @@ def test_loop_matches_reference_driver_g18(kind, dtype):
     from geodiffuser_amd import editor as _ed, graphs as _gr
     assert [r[5] for r in runs[:2]] == [0, 0] and [r[6] for r in runs[:3]] == [0, 0, 0]
     if kind == "sd14":
-        assert runs[2][5] == 0 and runs[3][6] == 0     # 40 / 80 / 160-wide heads take the head-major layer, which leaves nothing: the 3-row pass runs
+        assert runs[2][5] == 0 and runs[3][6] == 0 and runs[4][6] == 0     # 40 / 80 / 160-wide heads take the head-major layer, which leaves nothing: the 3-row pass runs
     elif _ed.REF_FROM_OPT and _gr.ENABLED and _gr.OPT_PASS_ENABLED:
         assert runs[2][5] >= len(g["steps"]) - 1, runs[2][5]      # (an optimisation pass that ran eagerly — a UNet's very first — leaves nothing)
-        assert runs[3][5] >= len(g["steps"]) - 1, runs[3][5]
+        assert runs[3][5] >= len(g["steps"]) - 1 and runs[4][5] >= len(g["steps"]) - 1, (runs[3][5], runs[4][5])
         if _ed.REF_AHEAD and len(g["steps"]) >= 10:
-            # every optimisation step but the first has a CFG pass in front of it; a carrying pass whose graph key is new runs eagerly
-            # once (its tensors are not addresses a captured pass may read): the regimes of a 50-step loop are 2-3
+            # carrying form: every optimisation step but the first has a CFG pass in front of it; a carrying pass whose graph key is new runs
+            # eagerly once (its tensors are not addresses a captured pass may read): the regimes of a 50-step loop are 2-3
             assert runs[3][6] >= len(g["steps"]) - 5, runs[3][6]
+        if _ed.REF_AHEAD and kind != "geometry_remover" and kind != "remover_full" and kind != "rem768_t75":
+            assert runs[4][6] == len(g["steps"]), runs[4][6]      # batched form: EVERY optimisation pass on the edit row alone
+        elif _ed.REF_AHEAD:
+            assert runs[4][6] >= len(g["steps"]) - 1, runs[4][6]  # (a removal edit's first pass ties its two identical rows: two-row form)
     for lat, log, w_rm, first_update, w_traj, _, _ in runs:
         assert sorted(log) == list(g["steps"])                                          # optimisation ran at the same steps
         if "weights_self_removal" in g:                                           # G28 / G29: the adaptive schedule took the same branch at EVERY pass

@@ -9,6 +9,7 @@ cp gpurun_out/r06_attn_traffic.json $O/ 2>/dev/null; cp gpurun_out/pmc_r06_*.md 
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_20steps.json 2> /dev/null
 GD_REF_AHEAD=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp16-leg > $O/bench_20steps_no_ref_ahead.json 2> /dev/null
+GD_REF_AHEAD=2 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp16-leg > $O/bench_20steps_ref_carried.json 2> /dev/null
 GD_PASS_TIMES=1 python bench.py --steps 8 --warmup 5 --no-cpu-baseline --no-fp16-leg 2>&1 > /dev/null | grep -A7 "device time per pass" > $O/pass_times.log
 python bench.py --size 768 --steps 4 --warmup 3 --no-cpu-baseline --no-fp16-leg > $O/bench_768.json 2> /dev/null
 python bench.py --model sdxl --size 1024 --steps 4 --warmup 3 --no-cpu-baseline --no-fp16-leg > $O/bench_sdxl_1024.json 2> /dev/null

@@ -58,6 +58,8 @@ def test_argument_validation_without_gpu(lib):
     assert lib.gd_ddim_step(None, None, None, 1.0, 0.5, 0.5, None, 10, 2, None) == -1
     assert b"null" in lib.gd_last_error()
     assert lib.gd_attn_fwd(None, 1, 64, 64, 64, 0.125, None, None, 0, 0, None) == -1
+    assert lib.gd_copy_rows(None, 4, 0, 1024, None) == -1 and lib.gd_copy_rows(ctypes.c_void_p(16), 4, -1, 1024, None) == -1
+    assert lib.gd_copy_rows(ctypes.c_void_p(16), 4, 0, 1000, None) == -1                       # sizes are multiples of 16 bytes
     from geodiffuser_amd._lib import GdAttnCfg, GdAttnSeg
     seg = (GdAttnSeg * 1)(GdAttnSeg(1, 1, 1, 1, 0, 1, 0))
     assert lib.gd_attn_fwd(seg, 1, 64, 64, 40, 0.125, None, None, 0, 0, None) == -4          # head dim 40 unsupported

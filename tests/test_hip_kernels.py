@@ -1815,6 +1815,28 @@ def test_heads_split_and_merge_are_the_permutes(ops, dtype):
         ops.heads_merge([a, d32[:, :N]], heads, N, D, dtype, DEV)          # mixed 16-bit / f32 sources
 
 
+def test_copy_rows_is_the_row_copies(ops):
+    """gd_copy_rows (ops.RowCopyTable): row m of every source into its one-row destination in ONE launch — the reference row of an
+    optimisation step out of the batched reference pass's tensors (editor.REF_AHEAD).  Pure data movement: bit-exact for every row, every
+    dtype / size mix, nothing outside the destinations touched; a row outside the sources is refused."""
+    g = torch.Generator().manual_seed(4)
+    srcs = [torch.randn(17, 4096, 320, generator=g).bfloat16().to(DEV), torch.randn(17, 77, 320, generator=g).half().to(DEV),
+            torch.randn(17, 64, 1280, generator=g).bfloat16().to(DEV), torch.randn(17, 8, generator=g).to(DEV)]
+    guard = torch.full((4, 64), 7.0, device=DEV)
+    dsts = [torch.zeros(1, *t.shape[1:], dtype=t.dtype, device=DEV) for t in srcs]
+    tab = ops.RowCopyTable(list(zip(srcs, dsts)))
+    for m in (0, 5, 16):
+        tab.copy(m)
+        torch.cuda.synchronize()
+        for t, d in zip(srcs, dsts):
+            assert torch.equal(d[0], t[m])
+    assert bool((guard == 7.0).all())
+    with pytest.raises(Exception):
+        tab.copy(17)
+    with pytest.raises(Exception):
+        ops.RowCopyTable([(srcs[0], torch.zeros(1, 4096, 64, dtype=torch.bfloat16, device=DEV))])      # not one row of the source
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("form", ["cross64", "cross32_f16", "self8", "remover_cross16", "head_major"])
 def test_pair_launch_equals_two_segments_and_the_blend(ops, dtype, form):

@@ -50,7 +50,7 @@ def pin_rank_to_cores(local_rank: int = None, local_world: int = None, max_threa
     if os.environ.get("GD_PIN_CORES", "1") != "1" or not hasattr(os, "sched_setaffinity"):
         return None
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else local_rank
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if local_world is None else local_world
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1")) if local_world is None else local_world      # (set by torch.distributed.run)
     if local_world <= 1:
         return None
     cores = sorted(os.sched_getaffinity(0))
@@ -70,7 +70,6 @@ def init(backend: str = None, force: bool = None) -> tuple:
     rank, world, local = env_rank_world()
     if procs_per_gpu() > 1 and backend is None:
         backend = "gloo"
-    pin_rank_to_cores()
     if force is None:
         force = os.environ.get("GD_DIST_FORCE", "0") == "1"
     if (world > 1 or (force and "MASTER_PORT" in os.environ)) and not dist.is_initialized():
@@ -81,6 +80,7 @@ def init(backend: str = None, force: bool = None) -> tuple:
             raise RuntimeError("geodiffuser_amd.dist.init: WORLD_SIZE > 1 but MASTER_PORT is not set — start the ranks through "
                                "torchrun / `bench.py --gpus N` (they pass a port to every rank)")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        pin_rank_to_cores()              # (before the first GPU call of the rank: torch.cuda.is_available() below is one)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":

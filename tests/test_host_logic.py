@@ -417,8 +417,11 @@ def test_dist_init_needs_a_port_from_the_launcher(monkeypatch):
     """More than one rank without MASTER_PORT: a loud error, not a silent 29500 (the ranks cannot agree on a port among themselves)."""
     from geodiffuser_amd import dist
     monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "0"); monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setenv("GD_PIN_CORES", "0")          # (this is the test process itself: it must keep all of its cores)
+    before = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
     with pytest.raises(RuntimeError, match="MASTER_PORT"):
         dist.init("gloo")
+    assert before is None or sorted(os.sched_getaffinity(0)) == before
 
 
 def test_batch_driver_starts_its_own_ranks(monkeypatch):

@@ -60,7 +60,7 @@ class AttnTimer:
         def shares(i):
             for j in range(i):
                 a, b = segs[j][1], segs[i][1]
-                if a.data_ptr() <= b.data_ptr() < a.data_ptr() + a.numel() * a.element_size():
+                if tuple(a.shape[1:]) == tuple(b.shape[1:]) and a.data_ptr() <= b.data_ptr() < a.data_ptr() + a.numel() * a.element_size():
                     return j, (b.data_ptr() - a.data_ptr()) // max(1, b.shape[1] * b.shape[2] * b.element_size())
             return -1, 0
         return (tuple((tuple(s[0].shape), tuple(s[1].shape), s[4] is not None,
@@ -181,7 +181,9 @@ class AttnTimer:
                 elif abs(scale - 0.125) > 1e-9:            # the optimisation pass: queries pre-scaled by the projection, scale = ln 2 (head dim 64)
                     q = q * (0.125 / scale)                # same distribution of the scores: N(0, 1) nats
                 q = q.to(dt)
-                if kshare >= 0:                            # the keys / values of an earlier segment (rows krow .. of its batch), as in the edit
+                base_k = segs[kshare][1] if 0 <= kshare < len(segs) else None
+                if base_k is not None and krow + ks[0] <= base_k.shape[0] and tuple(base_k.shape[1:]) == tuple(ks[1:]):
+                    # the keys / values of an earlier segment (rows krow .. of its batch), as in the edit
                     k, v = segs[kshare][1][krow:krow + ks[0]], segs[kshare][2][krow:krow + ks[0]]
                 else:
                     k = torch.randn(ks, device="cuda").to(dt); v = torch.randn(ks, device="cuda").to(dt)
@@ -245,7 +247,8 @@ class AttnTimer:
         rows.sort(key=lambda r: -r["launches"])
         # launch-count-weighted mean over the configurations, like `achieved`
         try:
-            tw = [(r["launches"], tab.get(str(r["heads"]))) for r in rows]
+            # (many plain heads — the batched reference pass of an edit, 85 — scale from the 32-head measurement: every head's Q / K / V / O once)
+            tw = [(r["launches"], tab.get(str(r["heads"])) if r["heads"] <= 32 or r["warp_row_list"] else int(tab["32"] * r["heads"] / 32.0)) for r in rows]
             if all(t is not None for _, t in tw):
                 traffic = int(sum(c * t for c, t in tw) / sum(c for c, _ in tw))
         except Exception:  # noqa: BLE001

@@ -904,7 +904,9 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             if self.cur_att_layer == 0 or self._ahead is None:
                 self._ahead = []
             if self.collect_ahead == "all":
-                self._ahead.append((q.detach(), k.detach(), v.detach(), out.detach()))
+                # (row copies address the kept tensors in place, replay after replay: a non-contiguous one voids the set -> the drivers fall back)
+                ok = all(t.is_contiguous() for t in (q, k, v, out))
+                self._ahead.append((q.detach(), k.detach(), v.detach(), out.detach()) if ok else False)
             else:
                 self._ahead.append((q[0:1].detach(), k[0:1].detach(), v[0:1].detach(), out[0:1].detach()))
 
@@ -920,7 +922,7 @@ class _GeometryControllerBase(AttentionStore, abc.ABC):
             ent = _REF_SLOTS[sig] = dict(slots=slots, serial=("slots", next(graphs._SERIAL)), table=None, stash_id=None)
         sid = tuple(t.data_ptr() for e in stash for t in e)
         if ent["stash_id"] != sid:                               # (a captured batched pass keeps its addresses: built once per process)
-            ent["table"] = ops.RowCopyTable([(t.contiguous() if not t.is_contiguous() else t, d) for e, se in zip(stash, ent["slots"]) for t, d in zip(e, se)])
+            ent["table"] = ops.RowCopyTable([(t, d) for e, se in zip(stash, ent["slots"]) for t, d in zip(e, se)])
             ent["stash_id"] = sid
         return ent
 

@@ -13,8 +13,13 @@ checkpoints.  Edits are independent, so N ranks run N different edits concurrent
 the model is broadcast once from rank 0 over RCCL at start-up).
 
 Besides the contract's fields the JSON line carries
-  roofline     : the dominant kernel (k_attn_fwd, MFMA-bound) — algorithmic FLOPs / launch duration measured live with
-                 HIP events on the launch stream during the timed region, for the 64^2 self-attention launches;
+  roofline     : the dominant kernel (k_attn_fwd_w64, MFMA-bound) — executed and algorithmic FLOPs / launch duration for the 64^2
+                 self-attention launches of the timed region: every launch configuration is counted (eager launches directly,
+                 captured ones through their graph's replays) and re-issued un-captured inside HIP-event brackets on the launch
+                 stream, rotating over tensor sets larger than the last-level cache; `traffic` = PMC-measured HBM bytes per launch at
+                 HEAD (profiles/r06_attn_traffic.json);
+  fp16         : the same workload with the weights in fp16 (the dtype inside the north star's 1e-3), same warm-ups and timed edits,
+                 run after the timed region in a child process — never part of ms_per_step;
   cpu_baseline : the oracle (CPU restatement of the reference's formulation) timed on this box's host cores on a bounded
                  sample of the same workload.
 """

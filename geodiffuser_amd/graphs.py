@@ -318,19 +318,22 @@ class GraphedOptPass:
         seen = _SEEN_LAYERS.get(uid)
         if seen is not None and seen[0]() is not self.model.unet:              # a dead model's id was recycled
             seen = None
-            _WARMED.discard((uid, "edit_row_only"))
+            _WARMED.discard((uid, "edit_row_only")); _WARMED.discard((uid, "rows"))
             for k in [k for k in _OPT_GRAPHS if k[0] == uid[0]]:
                 _OPT_GRAPHS.pop(k)["graph"].reset()
+        form = "edit_row_only" if edit_row_only else "rows"
         if seen is None:                                                       # very first pass on this UNet: eager, learn the layers
+            _WARMED.add((uid, form))
             out = self._eager(controller, lat, ctx, t, edit_row_only=edit_row_only)
             _SEEN_LAYERS[uid] = (weakref.ref(self.model.unet),
                                  sorted((S, c["f"], c["D"]) for S, c in controller.masks_cache_dict.items() if "f" in c))
             return out + (lat, ctx)
-        if edit_row_only and (uid, "edit_row_only") not in _WARMED:
-            # the first pass of this FORM on this UNet runs eagerly too: forward + backward at batch 1 meet convolution / GEMM shapes no pass
-            # has run yet, and a solver search (MIOpen find) or a library workspace allocation inside a stream capture invalidates it
-            _WARMED.add((uid, "edit_row_only"))
-            return self._eager(controller, lat, ctx, t, edit_row_only=True) + (lat, ctx)
+        if (uid, form) not in _WARMED:
+            # the first pass of each FORM (the rows beside the edit row: with or without the reference row) on this UNet runs eagerly too:
+            # forward + backward at another batch size meet convolution / GEMM shapes no pass has run yet, and a solver search (MIOpen find)
+            # or a library workspace allocation inside a stream capture invalidates it
+            _WARMED.add((uid, form))
+            return self._eager(controller, lat, ctx, t, edit_row_only=edit_row_only) + (lat, ctx)
         layers = seen[1]
         if not all(S in controller.masks_cache_dict and "f" in controller.masks_cache_dict[S] for S, *_ in layers):
             q_like = torch.empty(1, device=lat.device, dtype=self.model.unet.dtype)

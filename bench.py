@@ -41,7 +41,12 @@ import torch  # noqa: E402
 
 PEAK_MFMA_16BIT = 2.5e15     # dense bf16/fp16 MFMA peak of MI355X, /opt/skills/guides/MI355X_MICROARCH.md
 TRAFFIC_TABLE = "r06_attn_traffic.json"   # PMC-measured HBM bytes per launch of the attention kernel AT HEAD, by launch form (profiles/; tools/traffic_at_head.sh)
-REPLAY_FOOTPRINT = 320 << 20              # bytes of q / k / v / out the replay of one configuration cycles through (> the 256 MB last-level cache)
+# bytes of q / k / v / out the replay of one configuration cycles through: several times what the L2s hold (8 x 4 MB), so that a launch does
+# not find its own previous run's data there, but inside the 256 MB last-level cache, where a launch inside an edit finds the tensors its
+# producer GEMM has just written.  Calibrated against rocprofv3's in-situ durations of the same run (profiles/r06_replay_calibration.log):
+# 96 / 160 / 320 MB -> replay average 55.3 / 56.0 / 57.5 us against 56.2 in situ; per configuration within 3 % at 160 MB except the 5-head
+# inversion launch (-5 %: in situ it sits in a launch-bound batch-1 pass) and the 85-head launch (+5 %).  GD_REPLAY_MB overrides.
+REPLAY_FOOTPRINT = int(os.environ.get("GD_REPLAY_MB", "160")) << 20
 
 
 class AttnTimer:

@@ -12,4 +12,5 @@ cd $ROOT
 TR=$(find $OUT -name "*kernel_trace.csv" | head -1)
 GD_PROF_EDITS=${STEPS:-2} python3 tools/prof_summary.py $TR gpurun_out/${TAG}_bench_summary.md gpurun_out/${TAG}_bench_kernel_stats.csv "$TAG - rocprofv3 --kernel-trace --stats of bench.py --steps ${STEPS:-2} --warmup ${WARMUP:-3} --no-cpu-baseline (MI355X, bf16)"
 rm -f $TR   # hundreds of MB
+cp $OUT/bench.json gpurun_out/${TAG}_bench_traced.json 2>/dev/null   # the bench line of the SAME (traced) run: its replay times beside the in-situ ones above
 head -60 gpurun_out/${TAG}_bench_summary.md

@@ -454,6 +454,54 @@ def test_cfg_layer_with_the_reference_row_handed_in_equals_the_three_row_layer(k
             c2(q[rows].contiguous(), k[rows].contiguous(), v[rows].contiguous(), is_cross=cross, place_in_unet="up", transform_coords=coords, scale=0.125)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("kind", ["edit", "remover"])
+@pytest.mark.parametrize("cross", [False, True])
+@pytest.mark.parametrize("S", [32, 64])
+def test_optimisation_layer_with_the_reference_row_handed_in_equals_the_two_row_layer(dtype, kind, cross, S):
+    """editor.REF_AHEAD at layer level: one hooked call of an optimisation pass on the EDIT ROW ALONE, the reference row's token-major
+    q / k / v handed in (what the batched reference pass left and gd_copy_rows put into the persistent one-row tensors), against the same call
+    on the two-row batch [reference, edit] — the same launches on the same values: the edit row's output, the layer's loss and logged terms
+    and the gradients to the edit row's q (and k, cross-attention) are BIT-IDENTICAL.  Unsuitable state is refused, not mis-computed."""
+    mask = cases.ellipse_mask()
+    coords = torch.from_numpy(cases.make_coords("translate", mask))
+    H = 5
+    N, M = S * S, (77 if cross else S * S)
+    torch.manual_seed(S + 7)
+    q = (torch.randn(2, N, H * 64, device=DEV) * (1.2 * 0.125 * 1.4427)).to(dtype)      # queries as the projections hand them over: scale * log2(e) folded in
+    k = (torch.randn(2, M, H * 64, device=DEV) * 1.2).to(dtype)
+    v = torch.randn(2, M, H * 64, device=DEV).to(dtype)
+    gout = (torch.randn(2, N, H * 64, device=DEV) * 0.01).to(dtype)
+
+    def run(ref_in):
+        c = _make_hip_controller(dict(kind=kind, coords="translate", cur_step=3, quant=True, cfg=False), mask)
+        c.num_att_layers, c.cur_step, c.use_cfg = 32, 3, False
+        c.heads_opt, c.q_scaled_hm = H, True
+        rows = slice(1, 2) if ref_in else slice(0, 2)
+        qq, kk = q[rows].clone().requires_grad_(True), k[rows].clone().requires_grad_(True)
+        if ref_in:
+            c.ref_stash, c.use_ahead, c._ref_pos = [(q[0:1], k[0:1], v[0:1], None)], True, 0
+        with torch.enable_grad():
+            out = c(qq, kk, v[rows], is_cross=cross, place_in_unet="up", transform_coords=coords, scale=0.125)
+            tot = (out.float() * gout[rows].float()).sum() + (c.loss if torch.is_tensor(c.loss) else 0.0)
+            dq, dk = torch.autograd.grad(tot, [qq, kk], allow_unused=True)
+        log = {a: {kk_: float(vv) for kk_, vv in c.loss_log_dict[a].items()} for a in ("self", "cross")}
+        return out.detach(), (c.loss.detach() if torch.is_tensor(c.loss) else None), dq, dk, log, c
+
+    o2, l2, dq2, dk2, log2, _ = run(False)
+    o1, l1, dq1, dk1, log1, c1 = run(True)
+    assert o1.shape == (1, N, H * 64) and c1._ref_pos == 1
+    assert torch.equal(o1[0], o2[1])
+    assert (l1 is None) == (l2 is None) and (l1 is None or torch.equal(l1, l2)) and log1 == log2
+    assert torch.equal(dq1[0], dq2[1]) and float(dq2[0].float().abs().max()) == 0.0          # (the reference row never received a gradient)
+    assert (dk1 is None) == (dk2 is None)
+    if dk1 is not None:
+        assert torch.equal(dk1[0], dk2[1])
+    c1.q_scaled_hm, c1._ref_pos, c1.use_ahead, c1.heads_opt = False, 0, True, H              # unscaled queries must not take the handed-in row
+    with pytest.raises(Exception), torch.enable_grad():
+        c1(q[1:2].clone().requires_grad_(True), k[1:2], v[1:2], is_cross=cross, place_in_unet="up", transform_coords=coords, scale=0.125)
+
+
 def test_store_attention_maps_slow_path():
     """N4: with store_attention_maps the HIP controller keeps the edit row's probability maps of the N <= 16^2 layers exactly where
     the reference keeps them (oracle pinned by G17), at head dim 64."""

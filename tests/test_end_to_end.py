@@ -963,3 +963,34 @@ def test_bench_one_rank_under_torchrun_initialises_rccl_and_broadcasts():
     cfg = line["config"]
     assert line["n_gpus"] == 1 and cfg["dist_backend"] == "nccl" and cfg["weights_broadcast_bytes"] > 0 and cfg["tiny_debug_model"] is True
     assert line["value"] > 0 and len(cfg["per_rank_s"]) == 1
+
+
+def test_two_ranks_on_the_one_gpu_run_sharded_edits():
+    """The multi-rank path with two REAL ranks on the hardware that is here: ``bench.py --gpus 1 --edits-in-flight 2`` starts two ranks
+    through torch.distributed.run, both drive device 0 (control plane on gloo, the weight broadcast staged through the host: RCCL takes
+    one rank per device), each pins itself to its own slice of the host cores, runs ITS shard of the edits (edit j -> rank j mod 2) with
+    the full machinery (captures, the batched reference pass, replays), and rank 0 alone prints the line with one entry per rank.
+    Narrow model, 256^2, 6 steps: plumbing, not a number."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR",
+                                                            "GD_EDITS_IN_FLIGHT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--edits-in-flight", "2", "--steps", "2", "--warmup", "2", "--tiny", "--size",
+           "256", "--ddim-steps", "6", "--no-cpu-baseline", "--no-fp16-leg"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and cfg["edits_in_flight_per_gpu"] == 2 and cfg["dist_backend"] == "gloo" and cfg["weights_broadcast_bytes"] > 0
+    assert len(cfg["per_rank_s"]) == 2 and line["value"] > 0 and cfg["graph_captures_in_timed_region"] == {"unet": 0, "opt": 0}
+    cores = cfg["host_cores_by_rank"]
+    if hasattr(os, "sched_getaffinity") and len(os.sched_getaffinity(0)) >= 2:
+        assert len(cores) == 2 and cores[0] and cores[1] and cores[0][1] < cores[1][0], cores
+    for r in (0, 1):
+        assert f"[bench rank {r}/2] device cuda:0" in p.stderr

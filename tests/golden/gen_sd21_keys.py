@@ -155,5 +155,5 @@ if __name__ == "__main__":
     out["_counts"] = counts
     out["_source"] = "tests/golden/gen_sd21_keys.py (public configs of stabilityai/stable-diffusion-2-1-base; unpinned against diffusers / transformers)"
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sd21_base_keys.json")
-    json.dump(out, open(path, "w"), indent=0, sort_keys=True)
+    json.dump(out, open(path, "w"), sort_keys=True, separators=(",", ":"))
     print(path, counts, {k: len(v) for k, v in out.items() if not k.startswith("_")})

@@ -61,7 +61,7 @@ REF_FROM_OPT_PASSES = 0     # CFG passes that ran without their reference row so
 # front is the plain 3-row form; anything else falls back to the two-row optimisation pass.
 # REF_AHEAD: 1 (default) = ALL reference rows of an edit in ONE batched vanilla pass behind the inversion, row m copied into persistent one-row
 # tensors before optimisation step m (attention_processors "ALL REFERENCE ROWS"); 2 = the carrying form described above; 0 = off.
-REF_AHEAD = int(os.environ.get("GD_REF_AHEAD", "1"))
+REF_AHEAD = {"0": 0, "1": 1, "2": 2}.get(os.environ.get("GD_REF_AHEAD", "1").strip(), 1)
 REF_AHEAD_PASSES = 0        # optimisation passes that ran on the edit row alone so far
 
 
